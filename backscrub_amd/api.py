@@ -1,0 +1,298 @@
+"""ctypes binding of libbsx.so and the Python mirror of the reference interface.
+
+Reference interface mirrored here (same names / argument meaning / error behaviour):
+  lib/libbackscrub.h:13   bs_tensorflow_version()
+  lib/libbackscrub.h:16   bs_maskgen_new(modelname, threads, width, height, ondebug, onprep, oninfer, onmask, caller_ctx)
+  lib/libbackscrub.h:36   bs_maskgen_delete(context)
+  lib/libbackscrub.h:39   bs_maskgen_process(context, frame, mask) -> bool
+  app/deepseg.cc:108      alpha_blend(srca, srcb, mask)
+
+PyTorch is used only as the owner of device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_u8p = C.POINTER(C.c_uint8)
+DEBUG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+STAGE_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class BsxError(RuntimeError):
+    pass
+
+
+class _Info(C.Structure):
+    _fields_ = [("model_type", C.c_int), ("width", C.c_int), ("height", C.c_int), ("n_streams", C.c_int),
+                ("in_w", C.c_int), ("in_h", C.c_int), ("in_c", C.c_int), ("out_w", C.c_int), ("out_h", C.c_int),
+                ("out_c", C.c_int), ("roi", C.c_int * 4), ("in_roi", C.c_int * 4), ("n_ops", C.c_int), ("n_steps", C.c_int),
+                ("device", C.c_int), ("norm_scale", C.c_float), ("norm_offset", C.c_float), ("nn_flops_per_frame", C.c_double),
+                ("act_bytes_per_stream", C.c_size_t)]
+
+
+class LaunchStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("avg_ms", C.c_double), ("bytes", C.c_double), ("flops", C.c_double)]
+
+
+# every symbol include/bsx.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("bsx_version", C.c_char_p, []),
+    ("bsx_device_count", C.c_int, []),
+    ("bsx_new", C.c_void_p, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, DEBUG_FN, STAGE_FN, STAGE_FN, STAGE_FN, C.c_void_p]),
+    ("bsx_delete", None, [C.c_void_p]),
+    ("bsx_get_info", C.c_int, [C.c_void_p, C.POINTER(_Info)]),
+    ("bsx_last_error", C.c_char_p, [C.c_void_p]),
+    ("bsx_reset", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("bsx_process_host", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    ("bsx_process_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("bsx_masks_device", C.c_void_p, [C.c_void_p]),
+    ("bsx_composite_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("bsx_step_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    ("bsx_resize_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("bsx_bgr_to_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("bsx_debug_buffer", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("bsx_debug_run_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    ("bsx_plan_describe", C.c_char_p, [C.c_void_p]),
+    ("bsx_debug_tensor", C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_long]),
+    ("bsx_profile_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.c_void_p]),
+]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libbsx.so")
+
+
+def lib():
+    """Load libbsx.so.  Fails loudly (no fallback) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        # torch bundles its own HIP runtime under the same SONAME as /opt/rocm's; importing it first makes the
+        # whole process (torch allocations + our launches) use ONE runtime instance.
+        import torch  # noqa: F401
+        p = lib_path()
+        if not os.path.exists(p):
+            raise BsxError("libbsx.so is missing (%s): run `python -m backscrub_amd.build` — there is no CPU fallback" % p)
+        L = C.CDLL(p)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)  # AttributeError if the library does not export it
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, ctx=None, what=""):
+    if rc != 0:
+        msg = lib().bsx_last_error(ctx) or b""
+        raise BsxError("%s failed (%d): %s" % (what, rc, msg.decode(errors="replace").strip()))
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class MaskGen:
+    """Batched mask generator: n_streams independent camera streams on one GPU."""
+
+    def __init__(self, model_path, width, height, n_streams=1, device=0, threads=2, ondebug=None, onprep=None, oninfer=None,
+                 onmask=None, caller_ctx=None):
+        L = lib()
+        self._cbs = (DEBUG_FN(ondebug) if ondebug else DEBUG_FN(), STAGE_FN(onprep) if onprep else STAGE_FN(),
+                     STAGE_FN(oninfer) if oninfer else STAGE_FN(), STAGE_FN(onmask) if onmask else STAGE_FN())
+        self.h = L.bsx_new(os.fsencode(model_path), threads, width, height, n_streams, device, *self._cbs, caller_ctx)
+        if not self.h:
+            raise BsxError("bsx_new failed: %s" % (L.bsx_last_error(None) or b"").decode(errors="replace").strip())
+        info = _Info()
+        _check(L.bsx_get_info(self.h, C.byref(info)), self.h, "bsx_get_info")
+        self.info = {k: (list(getattr(info, k)) if k in ("roi", "in_roi") else getattr(info, k)) for k, _ in _Info._fields_}
+        self.width, self.height, self.n_streams, self.device = width, height, n_streams, device
+
+    # ---- batched device path -----------------------------------------------------------------
+    def process_batch(self, frames, masks_out=None):
+        """frames: torch u8 cuda [n,H,W,3] contiguous.  Returns a torch view [n,H,W] of the persistent masks."""
+        n = self._n(frames)
+        mo = C.c_void_p(masks_out.data_ptr()) if masks_out is not None else None
+        _check(lib().bsx_process_batch(self.h, C.c_void_p(frames.data_ptr()), n, mo, _stream_ptr()), self.h, "bsx_process_batch")
+        return self.masks()[:n]
+
+    def composite(self, bg, frames, masks=None, out=None):
+        torch = _torch()
+        n = self._n(frames)
+        if out is None:
+            out = torch.empty_like(frames)
+        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        mp = C.c_void_p(masks.data_ptr()) if masks is not None else None
+        _check(lib().bsx_composite_batch(self.h, C.c_void_p(bg.data_ptr()), stride, C.c_void_p(frames.data_ptr()), mp,
+                                         C.c_void_p(out.data_ptr()), n, _stream_ptr()), self.h, "bsx_composite_batch")
+        return out
+
+    def step(self, frames, bg, out):
+        n = self._n(frames)
+        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        _check(lib().bsx_step_batch(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride,
+                                    C.c_void_p(out.data_ptr()), n, _stream_ptr()), self.h, "bsx_step_batch")
+        return out
+
+    def profile(self, frames, bg, out, iters=5):
+        """per-launch hipEvent timings of the whole per-batch sequence → list of dicts"""
+        n = self._n(frames)
+        cap = self.info["n_steps"] + 8
+        arr = (LaunchStat * cap)()
+        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        k = lib().bsx_profile_batch(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride, C.c_void_p(out.data_ptr()),
+                                    n, iters, arr, cap, _stream_ptr())
+        if k < 0:
+            _check(k, self.h, "bsx_profile_batch")
+        return [dict(name=arr[i].name.decode(), avg_ms=arr[i].avg_ms, bytes=arr[i].bytes, flops=arr[i].flops) for i in range(k)]
+
+    def masks(self):
+        """torch u8 view [n_streams,H,W] of the lib-owned persistent masks (cf. `mask = ctx.mask`, libbackscrub.cc:374)."""
+        return self._view(3, "uint8", (self.n_streams, self.height, self.width))
+
+    def reset(self):
+        _check(lib().bsx_reset(self.h, _stream_ptr()), self.h, "bsx_reset")
+
+    def resize_bgr(self, src, dw, dh):
+        torch = _torch()
+        n, sh, sw, _ = src.shape
+        dst = torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=src.device)
+        _check(lib().bsx_resize_bgr(self.h, C.c_void_p(src.data_ptr()), sw, sh, C.c_void_p(dst.data_ptr()), dw, dh, n, _stream_ptr()),
+               self.h, "bsx_resize_bgr")
+        return dst
+
+    def bgr_to_yuyv(self, bgr):
+        torch = _torch()
+        n, h, w, _ = bgr.shape
+        out = torch.empty((n, h, w, 2), dtype=torch.uint8, device=bgr.device)
+        _check(lib().bsx_bgr_to_yuyv(self.h, C.c_void_p(bgr.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, _stream_ptr()),
+               self.h, "bsx_bgr_to_yuyv")
+        return out
+
+    # ---- drop-in single frame path (host buffers) -----------------------------------------------
+    def process_host(self, frame: np.ndarray, stream_idx=0, mask_out: np.ndarray | None = None) -> np.ndarray:
+        if frame.dtype != np.uint8 or frame.ndim != 3 or frame.shape[2] != 3 or frame.shape[0] != self.height or frame.shape[1] != self.width:
+            raise BsxError("frame must be uint8 [%d,%d,3]" % (self.height, self.width))
+        if frame.strides[2] != 1 or frame.strides[1] != 3:
+            frame = np.ascontiguousarray(frame)
+        if mask_out is None:
+            mask_out = np.empty((self.height, self.width), np.uint8)
+        _check(lib().bsx_process_host(self.h, stream_idx, frame.ctypes.data, frame.strides[0], mask_out.ctypes.data, mask_out.strides[0]),
+               self.h, "bsx_process_host")
+        return mask_out
+
+    # ---- introspection (tests) --------------------------------------------------------------------
+    def run_stage(self, stage, frames=None, n=None):
+        n = n if n is not None else (self._n(frames) if frames is not None else self.n_streams)
+        fp = C.c_void_p(frames.data_ptr()) if frames is not None else None
+        _check(lib().bsx_debug_run_stage(self.h, stage, fp, n, _stream_ptr()), self.h, "bsx_debug_run_stage")
+
+    def input_tensor(self):
+        i = self.info
+        return self._view(0, "float32", (self.n_streams, i["in_h"], i["in_w"], i["in_c"]))
+
+    def output_tensor(self):
+        i = self.info
+        return self._view(1, "float32", (self.n_streams, i["out_h"], i["out_w"], i["out_c"]))
+
+    def ofinal(self):
+        i = self.info
+        return self._view(2, "uint8", (self.n_streams, i["out_h"], i["out_w"]))
+
+    def plan(self) -> str:
+        return lib().bsx_plan_describe(self.h).decode()
+
+    def graph_tensor(self, idx) -> np.ndarray:
+        n = lib().bsx_debug_tensor(self.h, idx, None, 0)
+        if n < 0:
+            raise BsxError("tensor %d not materialised" % idx)
+        _torch().cuda.synchronize()
+        a = np.empty(n, np.float32)
+        lib().bsx_debug_tensor(self.h, idx, a.ctypes.data_as(C.POINTER(C.c_float)), n)
+        return a
+
+    def _view(self, which, dtype, shape):
+        torch = _torch()
+        p, b = C.c_void_p(), C.c_size_t()
+        _check(lib().bsx_debug_buffer(self.h, which, C.byref(p), C.byref(b)), self.h, "bsx_debug_buffer")
+        return _as_torch(p.value, b.value, dtype, shape, self.device)
+
+    def _n(self, frames):
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (self.height, self.width, 3) or not frames.is_contiguous() or not frames.is_cuda:
+            raise BsxError("frames must be a contiguous cuda uint8 tensor [n,%d,%d,3]" % (self.height, self.width))
+        if frames.shape[0] > self.n_streams:
+            raise BsxError("batch larger than n_streams")
+        return int(frames.shape[0])
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bsx_delete(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _CudaArray:
+    """__cuda_array_interface__ holder so torch can alias lib-owned device memory without copying."""
+
+    def __init__(self, ptr, nbytes, typestr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+        self._nbytes = nbytes
+
+
+def _as_torch(ptr, nbytes, dtype, shape, device):
+    torch = _torch()
+    typestr = {"uint8": "|u1", "float32": "<f4"}[dtype]
+    return torch.as_tensor(_CudaArray(ptr, nbytes, typestr, shape), device="cuda:%d" % device)
+
+
+# ---- reference-named entry points -----------------------------------------------------------------
+def bs_tensorflow_version() -> str:
+    return lib().bsx_version().decode()
+
+
+def bs_maskgen_new(modelname, threads, width, height, ondebug=None, onprep=None, oninfer=None, onmask=None, caller_ctx=None):
+    """Returns a context, or None on failure (after a message through ondebug/stderr) — like lib/libbackscrub.cc:161-259."""
+    try:
+        return MaskGen(modelname, width, height, n_streams=1, threads=threads, ondebug=ondebug, onprep=onprep, oninfer=oninfer,
+                       onmask=onmask, caller_ctx=caller_ctx)
+    except BsxError:
+        return None
+
+
+def bs_maskgen_delete(context):
+    if context is not None:  # NULL-safe like :262
+        context.close()
+
+
+def bs_maskgen_process(context, frame: np.ndarray, mask: np.ndarray) -> bool:
+    """frame: BGR uint8 [H,W,3]; mask: uint8 [H,W] written in place.  False on a null context / failure (:280)."""
+    if context is None or getattr(context, "h", None) is None:
+        return False
+    try:
+        context.process_host(frame, 0, mask)
+        return True
+    except BsxError:
+        return False
+
+
+def alpha_blend(srca, srcb, mask, context: MaskGen):
+    """GPU alpha_blend (app/deepseg.cc:108-134): srca=background, srcb=frame, mask 255⇒srca. Torch cuda u8 tensors."""
+    if srcb.dim() == 3:
+        return context.composite(srca, srcb[None], mask[None])[0]
+    return context.composite(srca, srcb, mask)

@@ -1,0 +1,478 @@
+// bsx_api.hip — the C ABI of libbsx.so (include/bsx.h): context, geometry, per-batch launch
+// sequence.  Host-side mirror of lib/libbackscrub.cc (bs_maskgen_new :161-259,
+// bs_maskgen_process :279-376, bs_maskgen_delete :261-277) and of the compositing step of
+// app/deepseg.cc (:108-134, :649-661), re-designed for batches of independent streams
+// resident in HBM.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bsx.h"
+#include "kernels.hpp"
+#include "plan.hpp"
+#include "tflite_model.hpp"
+
+using namespace bsx;
+
+namespace {
+thread_local std::string g_last_error;
+
+struct HostResizeTab {
+  std::vector<int> xofs, yofs;
+  std::vector<short> xa, ya;
+  int sw = 0, sh = 0, dw = 0, dh = 0, mode = 0;
+};
+
+inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
+inline short sat_short(long v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+// Coefficient tables of cv::resize(INTER_LINEAR) for 8-bit images (OpenCV imgproc resize.cpp):
+// scale = 1/(dst/src) in double; fx = (float)((dx+0.5)*scale-0.5); sx = floor(fx); fx -= sx;
+// left/right clamps zero the fraction; coefficients = saturate_cast<short>(w*2048) (round-half-even).
+HostResizeTab make_resize_tab(int sw, int sh, int dw, int dh) {
+  HostResizeTab t;
+  t.sw = sw; t.sh = sh; t.dw = dw; t.dh = dh;
+  if (sw == dw && sh == dh) { t.mode = 1; return t; }
+  double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+  double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+  long isx = lrint(scale_x), isy = lrint(scale_y);
+  bool area_fast = std::fabs(scale_x - (double)isx) < 2.220446049250313e-16 && std::fabs(scale_y - (double)isy) < 2.220446049250313e-16;
+  if (area_fast && isx == 2 && isy == 2) { t.mode = 2; return t; }
+  t.xofs.resize(dw); t.xa.resize(2 * (size_t)dw); t.yofs.resize(dh); t.ya.resize(2 * (size_t)dh);
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    t.xofs[dx] = sx;
+    t.xa[2 * dx] = sat_short(lrintf((1.f - fx) * 2048.f));
+    t.xa[2 * dx + 1] = sat_short(lrintf(fx * 2048.f));
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor(fy);
+    fy -= sy;
+    t.yofs[dy] = sy;
+    t.ya[2 * dy] = sat_short(lrintf((1.f - fy) * 2048.f));
+    t.ya[2 * dy + 1] = sat_short(lrintf(fy * 2048.f));
+  }
+  return t;
+}
+
+struct DevResizeTab {
+  ResizeTab tab;
+  void* mem = nullptr;
+};
+
+}  // namespace
+
+struct bsx_ctx {
+  // callbacks (lib/libbackscrub.cc:37-41)
+  bsx_debug_fn ondebug = nullptr;
+  bsx_stage_fn onprep = nullptr, oninfer = nullptr, onmask = nullptr;
+  void* caller_ctx = nullptr;
+  // model
+  Graph graph;
+  Plan plan;
+  int model_type = BSX_MODEL_UNKNOWN;
+  float norm_scale = 0, norm_offset = 0;
+  // geometry
+  int width = 0, height = 0, n_streams = 0, device = 0;
+  int inW = 0, inH = 0, inC = 0, outW = 0, outH = 0, outC = 0;
+  Rect4 roi{}, in_roi{};
+  size_t threads = 0;
+  // device state
+  hipStream_t own_stream = nullptr;
+  float* d_arena = nullptr;
+  float* d_weights = nullptr;
+  uint32_t* d_canvas = nullptr;
+  uint8_t* d_ofinal = nullptr;
+  uint8_t* d_masks = nullptr;
+  uint8_t* d_host_frame = nullptr;  // staging for bsx_process_host
+  float* d_color_lut = nullptr;
+  BilateralParams bilateral{};
+  DevResizeTab tab_down, tab_up;
+  std::map<std::pair<std::pair<int, int>, std::pair<int, int>>, DevResizeTab> bg_tabs;
+  std::string last_error, plan_text;
+
+  float* tensor_ptr(int t) const { return d_arena + (size_t)plan.tensor_off[t] * (size_t)n_streams; }
+};
+
+namespace {
+
+void report(bsx_ctx* c, bsx_debug_fn fn, void* user, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->last_error = buf;
+  g_last_error = buf;
+  if (fn) fn(user, buf); else fputs(buf, stderr);   // same routing as _dbg(), lib/libbackscrub.cc:72-83
+}
+
+#define BSX_HIP(c, expr)                                                                                    \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess) {                                                                                 \
+      report((c), (c) ? (c)->ondebug : nullptr, (c) ? (c)->caller_ctx : nullptr, "error: HIP %s at %s:%d (%s)\n", \
+             hipGetErrorString(e_), __FILE__, __LINE__, #expr);                                             \
+      return BSX_EDEVICE;                                                                                   \
+    }                                                                                                       \
+  } while (0)
+
+int upload_tab(bsx_ctx* c, const HostResizeTab& h, DevResizeTab* d) {
+  d->tab.sw = h.sw; d->tab.sh = h.sh; d->tab.dw = h.dw; d->tab.dh = h.dh; d->tab.mode = h.mode;
+  if (h.mode != 0) return BSX_OK;
+  size_t b_xofs = h.xofs.size() * 4, b_yofs = h.yofs.size() * 4, b_xa = h.xa.size() * 2, b_ya = h.ya.size() * 2;
+  auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
+  size_t total = up16(b_xofs) + up16(b_yofs) + up16(b_xa) + up16(b_ya);
+  BSX_HIP(c, hipMalloc(&d->mem, total));
+  char* p = (char*)d->mem;
+  BSX_HIP(c, hipMemcpy(p, h.xofs.data(), b_xofs, hipMemcpyHostToDevice)); d->tab.xofs = (const int*)p; p += up16(b_xofs);
+  BSX_HIP(c, hipMemcpy(p, h.yofs.data(), b_yofs, hipMemcpyHostToDevice)); d->tab.yofs = (const int*)p; p += up16(b_yofs);
+  BSX_HIP(c, hipMemcpy(p, h.xa.data(), b_xa, hipMemcpyHostToDevice)); d->tab.xa = (const short*)p; p += up16(b_xa);
+  BSX_HIP(c, hipMemcpy(p, h.ya.data(), b_ya, hipMemcpyHostToDevice)); d->tab.ya = (const short*)p;
+  return BSX_OK;
+}
+
+int model_type_from_name(const std::string& n) {  // lib/libbackscrub.cc:116-130 (same precedence)
+  if (n.find("body-pix") != n.npos) return BSX_MODEL_BODYPIX;
+  if (n.find("deeplab") != n.npos) return BSX_MODEL_DEEPLAB;
+  if (n.find("segm_") != n.npos) return BSX_MODEL_MEET;
+  if (n.find("selfie") != n.npos) return BSX_MODEL_MLKIT;
+  return BSX_MODEL_UNKNOWN;
+}
+
+int init_device_state(bsx_ctx* c) {
+  BSX_HIP(c, hipSetDevice(c->device));
+  BSX_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  const size_t N = (size_t)c->n_streams;
+  BSX_HIP(c, hipMalloc(&c->d_arena, c->plan.arena_floats_per_stream * N * sizeof(float)));
+  BSX_HIP(c, hipMalloc(&c->d_weights, std::max<size_t>(c->plan.weights.size(), 4) * sizeof(float)));
+  BSX_HIP(c, hipMemcpy(c->d_weights, c->plan.weights.data(), c->plan.weights.size() * sizeof(float), hipMemcpyHostToDevice));
+  BSX_HIP(c, hipMalloc(&c->d_canvas, N * c->inW * c->inH * sizeof(uint32_t)));
+  BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
+  BSX_HIP(c, hipMalloc(&c->d_masks, N * c->width * c->height));
+  BSX_HIP(c, hipMemset(c->d_ofinal, 0, N * c->outW * c->outH));            // :257 leaves it uninitialised; defined as 0
+  BSX_HIP(c, hipMemset(c->d_masks, 255, N * c->width * c->height));        // :248
+  // bilateralFilter(d=5, sigmaColor=100, sigmaSpace=100) tables (OpenCV bilateral_filter):
+  {
+    const double sigma_color = 100.0, sigma_space = 100.0;
+    const double gc = -0.5 / (sigma_color * sigma_color), gs = -0.5 / (sigma_space * sigma_space);
+    const int radius = 2;
+    std::vector<float> lut(768);
+    for (int i = 0; i < 768; i++) lut[i] = (float)std::exp(i * i * gc);
+    BSX_HIP(c, hipMalloc(&c->d_color_lut, 768 * sizeof(float)));
+    BSX_HIP(c, hipMemcpy(c->d_color_lut, lut.data(), 768 * sizeof(float), hipMemcpyHostToDevice));
+    int k = 0;
+    for (int i = -radius; i <= radius; i++) for (int j = -radius; j <= radius; j++) {
+      double r = std::sqrt((double)i * i + (double)j * j);
+      if (r > radius) continue;
+      c->bilateral.space_w[k] = (float)std::exp(r * r * gs);
+      c->bilateral.off_y[k] = i; c->bilateral.off_x[k] = j;
+      k++;
+    }
+    c->bilateral.color_lut = c->d_color_lut;
+    c->bilateral.scale = c->norm_scale; c->bilateral.offset = c->norm_offset;
+  }
+  int rc = upload_tab(c, make_resize_tab(c->roi.w, c->roi.h, c->in_roi.w, c->in_roi.h), &c->tab_down);
+  if (rc) return rc;
+  rc = upload_tab(c, make_resize_tab(c->in_roi.w, c->in_roi.h, c->roi.w, c->roi.h), &c->tab_up);
+  if (rc) return rc;
+  // canvas outside in_roi is written as 0 by the prep kernel on every frame (the reference keeps a
+  // persistent zeroed in_u8_bgr, :251); nothing else to initialise.
+  return BSX_OK;
+}
+
+// NULL means the HIP default (null) stream, exactly as in every HIP API; the context's own
+// non-blocking stream is only used by the synchronous host path.
+hipStream_t pick(bsx_ctx*, void* s) { return (hipStream_t)s; }
+
+int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s) {
+  BSX_HIP(c, launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
+  BSX_HIP(c, launch_prep_bilateral(c->d_canvas, c->tensor_ptr(c->plan.input), c->inW, c->inH, c->bilateral, n, s));
+  return BSX_OK;
+}
+int run_infer(bsx_ctx* c, int n, hipStream_t s) {
+  for (const Step& st : c->plan.steps) BSX_HIP(c, launch_step(st, c->plan, c->d_arena, c->d_weights, n, c->n_streams, s));
+  return BSX_OK;
+}
+int run_decode(bsx_ctx* c, int n, hipStream_t s) {
+  BSX_HIP(c, launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
+  return BSX_OK;
+}
+int run_mask(bsx_ctx* c, int n, hipStream_t s) {
+  BSX_HIP(c, launch_mask_upscale_blur(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, n, s));
+  return BSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bsx_version(void) { return "bsx 0.1 (HIP gfx950, f32 NHWC)"; }
+
+int bsx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* bsx_last_error(const bsx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t height, int n_streams, int device, bsx_debug_fn ondebug,
+                 bsx_stage_fn onprep, bsx_stage_fn oninfer, bsx_stage_fn onmask, void* caller_ctx) {
+  if (!model_path || !width || !height || n_streams <= 0) { report(nullptr, ondebug, caller_ctx, "error: bad arguments to bsx_new\n"); return nullptr; }
+  std::unique_ptr<bsx_ctx> c(new bsx_ctx);
+  c->ondebug = ondebug; c->onprep = onprep; c->oninfer = oninfer; c->onmask = onmask; c->caller_ctx = caller_ctx;
+  c->threads = threads; c->width = (int)width; c->height = (int)height; c->n_streams = n_streams; c->device = device;
+  std::string err;
+  if (!load_tflite(model_path, &c->graph, &err)) { report(nullptr, ondebug, caller_ctx, "error: %s\n", err.c_str()); return nullptr; }
+  c->model_type = model_type_from_name(model_path);
+  if (c->model_type == BSX_MODEL_UNKNOWN) { report(nullptr, ondebug, caller_ctx, "error: unknown model type '%s'.\n", model_path); return nullptr; }
+  // normalisation (lib/libbackscrub.cc:132-148)
+  if (c->model_type == BSX_MODEL_DEEPLAB) { c->norm_scale = (float)(1 / 127.5); c->norm_offset = -1.f; }
+  else { c->norm_scale = (float)(1 / 255.0); c->norm_offset = 0.f; }
+  const TensorInfo& ti = c->graph.tensors[c->graph.input];
+  const TensorInfo& to = c->graph.tensors[c->graph.output];
+  if (ti.shape.size() != 4 || to.shape.size() != 4 || ti.dims[0] != 1) {  // cf. getTensorMat, :85-112
+    report(nullptr, ondebug, caller_ctx, "error: model input/output is not a single 4-D float tensor\n");
+    return nullptr;
+  }
+  c->inH = ti.dims[1]; c->inW = ti.dims[2]; c->inC = ti.dims[3];
+  c->outH = to.dims[1]; c->outW = to.dims[2]; c->outC = to.dims[3];
+  if (c->inC != 3) { report(nullptr, ondebug, caller_ctx, "error: model input must have 3 channels\n"); return nullptr; }
+  if ((c->model_type == BSX_MODEL_MEET && c->outC != 2) || (c->model_type == BSX_MODEL_DEEPLAB && c->outC < 16)) {
+    report(nullptr, ondebug, caller_ctx, "error: model output has %d channels, unexpected for this model type\n", c->outC);
+    return nullptr;
+  }
+  bool no_reuse = getenv("BSX_ARENA_NO_REUSE") != nullptr;
+  if (!build_plan(c->graph, &c->plan, &err, !no_reuse)) { report(nullptr, ondebug, caller_ctx, "error: unable to build GPU plan: %s\n", err.c_str()); return nullptr; }
+  // ROI geometry, float arithmetic truncated to int exactly as lib/libbackscrub.cc:230-246
+  float ratio = (float)c->inH / (float)c->inW;
+  float frameratio = (float)height / (float)width;
+  if (frameratio < ratio) {
+    c->roi = Rect4{(int)((width - height / ratio) / 2), 0, (int)(height / ratio), (int)height};
+    c->in_roi = Rect4{0, 0, c->inW, c->inH};
+  } else {
+    c->roi = Rect4{0, 0, (int)width, (int)height};
+    c->in_roi = Rect4{(int)((c->inW - c->inH / frameratio) / 2), 0, (int)(c->inH / frameratio), c->inH};
+  }
+  if (c->roi.w <= 0 || c->roi.h <= 0 || c->roi.x < 0 || c->roi.x + c->roi.w > c->width || c->in_roi.w <= 0 || c->in_roi.x < 0 ||
+      c->in_roi.x + c->in_roi.w > c->inW || c->in_roi.x + c->in_roi.w > c->outW || c->in_roi.h > c->outH) {
+    report(nullptr, ondebug, caller_ctx, "error: frame/model geometry yields an empty or out-of-range ROI\n");
+    return nullptr;
+  }
+  if (init_device_state(c.get()) != BSX_OK) { bsx_ctx* raw = c.release(); bsx_delete(raw); return nullptr; }
+  c->plan_text = c->plan.describe();
+  return c.release();
+}
+
+void bsx_delete(bsx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  void* ptrs[] = {c->d_arena, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_color_lut, c->tab_down.mem, c->tab_up.mem};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int bsx_get_info(const bsx_ctx* c, bsx_info* o) {
+  if (!c || !o) return BSX_EINVAL;
+  memset(o, 0, sizeof *o);
+  o->model_type = c->model_type; o->width = c->width; o->height = c->height; o->n_streams = c->n_streams;
+  o->in_w = c->inW; o->in_h = c->inH; o->in_c = c->inC; o->out_w = c->outW; o->out_h = c->outH; o->out_c = c->outC;
+  int r[4] = {c->roi.x, c->roi.y, c->roi.w, c->roi.h}, q[4] = {c->in_roi.x, c->in_roi.y, c->in_roi.w, c->in_roi.h};
+  memcpy(o->roi, r, sizeof r); memcpy(o->in_roi, q, sizeof q);
+  o->n_ops = c->graph.n_file_ops; o->n_steps = (int)c->plan.steps.size(); o->device = c->device;
+  o->norm_scale = c->norm_scale; o->norm_offset = c->norm_offset;
+  o->nn_flops_per_frame = 2.0 * c->plan.macs_per_frame;
+  o->act_bytes_per_stream = c->plan.arena_floats_per_stream * sizeof(float);
+  return BSX_OK;
+}
+
+int bsx_reset(bsx_ctx* c, void* stream) {
+  if (!c) return BSX_EINVAL;
+  hipStream_t s = pick(c, stream);
+  const size_t N = (size_t)c->n_streams;
+  BSX_HIP(c, hipMemsetAsync(c->d_ofinal, 0, N * c->outW * c->outH, s));
+  BSX_HIP(c, hipMemsetAsync(c->d_masks, 255, N * c->width * c->height, s));
+  return BSX_OK;
+}
+
+uint8_t* bsx_masks_device(bsx_ctx* c) { return c ? c->d_masks : nullptr; }
+
+int bsx_process_batch(bsx_ctx* c, const uint8_t* d_frames, int n, uint8_t* d_masks, void* stream) {
+  if (!c || !d_frames || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  hipStream_t s = pick(c, stream);
+  int rc;
+  if ((rc = run_prep(c, d_frames, n, s))) return rc;
+  if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }   // :303
+  if ((rc = run_infer(c, n, s))) return rc;
+  if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); } // :311
+  if ((rc = run_decode(c, n, s))) return rc;
+  if (c->onmask) { BSX_HIP(c, hipStreamSynchronize(s)); c->onmask(c->caller_ctx); }   // :363
+  if ((rc = run_mask(c, n, s))) return rc;
+  if (d_masks) BSX_HIP(c, hipMemcpyAsync(d_masks, c->d_masks, (size_t)n * c->width * c->height, hipMemcpyDeviceToDevice, s));
+  return BSX_OK;
+}
+
+int bsx_process_host(bsx_ctx* c, int stream_idx, const uint8_t* h_bgr, size_t bgr_stride, uint8_t* h_mask, size_t mask_stride) {
+  if (!c || !h_bgr || !h_mask || stream_idx < 0 || stream_idx >= c->n_streams) return BSX_EINVAL;
+  if (bgr_stride < (size_t)c->width * 3 || mask_stride < (size_t)c->width) return BSX_ESIZE;
+  hipStream_t s = c->own_stream;
+  const size_t fbytes = (size_t)c->width * c->height * 3;
+  if (!c->d_host_frame) BSX_HIP(c, hipMalloc(&c->d_host_frame, fbytes));
+  BSX_HIP(c, hipMemcpy2DAsync(c->d_host_frame, (size_t)c->width * 3, h_bgr, bgr_stride, (size_t)c->width * 3, c->height, hipMemcpyHostToDevice, s));
+  // run the single stream in its own state slot: temporarily view slot `stream_idx` as slot 0
+  uint8_t* ofinal0 = c->d_ofinal; uint8_t* masks0 = c->d_masks;
+  c->d_ofinal += (size_t)stream_idx * c->outW * c->outH;
+  c->d_masks += (size_t)stream_idx * c->width * c->height;
+  int rc = bsx_process_batch(c, c->d_host_frame, 1, nullptr, s);
+  uint8_t* my_mask = c->d_masks;
+  c->d_ofinal = ofinal0; c->d_masks = masks0;
+  if (rc) return rc;
+  BSX_HIP(c, hipMemcpy2DAsync(h_mask, mask_stride, my_mask, (size_t)c->width, (size_t)c->width, c->height, hipMemcpyDeviceToHost, s));
+  BSX_HIP(c, hipStreamSynchronize(s));
+  return BSX_OK;
+}
+
+int bsx_composite_batch(bsx_ctx* c, const uint8_t* d_bg, size_t bg_frame_stride, const uint8_t* d_frames, const uint8_t* d_masks, uint8_t* d_out,
+                        int n, void* stream) {
+  if (!c || !d_bg || !d_frames || !d_out || n <= 0) return BSX_EINVAL;
+  if (!d_masks) { if (n > c->n_streams) return BSX_EINVAL; d_masks = c->d_masks; }
+  BSX_HIP(c, launch_blend(d_bg, bg_frame_stride, d_frames, d_masks, d_out, (size_t)c->width * c->height, n, pick(c, stream)));
+  return BSX_OK;
+}
+
+int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream) {
+  int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
+  if (rc) return rc;
+  return bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, d_out, n, stream);
+}
+
+int bsx_resize_bgr(bsx_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream) {
+  if (!c || !d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || n <= 0) return BSX_EINVAL;
+  auto key = std::make_pair(std::make_pair(sw, sh), std::make_pair(dw, dh));
+  auto it = c->bg_tabs.find(key);
+  if (it == c->bg_tabs.end()) {
+    DevResizeTab d;
+    int rc = upload_tab(c, make_resize_tab(sw, sh, dw, dh), &d);
+    if (rc) return rc;
+    it = c->bg_tabs.emplace(key, d).first;
+  }
+  BSX_HIP(c, launch_resize_bgr(d_src, d_dst, it->second.tab, n, pick(c, stream)));
+  return BSX_OK;
+}
+
+int bsx_bgr_to_yuyv(bsx_ctx* c, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, int h, int n, void* stream) {
+  if (!c || !d_bgr || !d_yuyv || w <= 0 || h <= 0 || n <= 0) return BSX_EINVAL;
+  BSX_HIP(c, launch_bgr_to_yuyv(d_bgr, d_yuyv, w, h, n, pick(c, stream)));
+  return BSX_OK;
+}
+
+int bsx_debug_buffer(bsx_ctx* c, int which, void** d_ptr, size_t* bytes) {
+  if (!c || !d_ptr || !bytes) return BSX_EINVAL;
+  const size_t N = (size_t)c->n_streams;
+  switch (which) {
+    case 0: *d_ptr = c->tensor_ptr(c->plan.input); *bytes = N * c->inW * c->inH * c->inC * 4; break;
+    case 1: *d_ptr = c->tensor_ptr(c->plan.output); *bytes = N * c->outW * c->outH * c->outC * 4; break;
+    case 2: *d_ptr = c->d_ofinal; *bytes = N * c->outW * c->outH; break;
+    case 3: *d_ptr = c->d_masks; *bytes = N * c->width * c->height; break;
+    default: return BSX_EINVAL;
+  }
+  return BSX_OK;
+}
+
+int bsx_debug_run_stage(bsx_ctx* c, int stage, const uint8_t* d_frames, int n, void* stream) {
+  if (!c || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  hipStream_t s = pick(c, stream);
+  switch (stage) {
+    case 0: if (!d_frames) return BSX_EINVAL; return run_prep(c, d_frames, n, s);
+    case 1: return run_infer(c, n, s);
+    case 2: return run_decode(c, n, s);
+    case 3: return run_mask(c, n, s);
+    default: return BSX_EINVAL;
+  }
+}
+
+int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_stride, uint8_t* d_out, int n, int iters,
+                      bsx_launch_stat* out, int cap, void* stream) {
+  if (!c || !d_frames || !d_bg || !d_out || !out || n <= 0 || n > c->n_streams || iters <= 0) return BSX_EINVAL;
+  hipStream_t s = pick(c, stream);
+  const int L = 2 + (int)c->plan.steps.size() + 3;
+  if (cap < L) return BSX_EINVAL;
+  std::vector<hipEvent_t> ev((size_t)2 * L);
+  for (auto& e : ev) BSX_HIP(c, hipEventCreate(&e));
+  std::vector<double> sum(L, 0.0);
+  const double N = n, px = (double)c->width * c->height;
+  for (int it = 0; it < iters; it++) {
+    int k = 0;
+#define BSX_TIMED(call)                                    \
+    do {                                                   \
+      BSX_HIP(c, hipEventRecord(ev[2 * k], s));            \
+      BSX_HIP(c, (call));                                  \
+      BSX_HIP(c, hipEventRecord(ev[2 * k + 1], s));        \
+      k++;                                                 \
+    } while (0)
+    BSX_TIMED(launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
+    BSX_TIMED(launch_prep_bilateral(c->d_canvas, c->tensor_ptr(c->plan.input), c->inW, c->inH, c->bilateral, n, s));
+    for (const Step& st : c->plan.steps) BSX_TIMED(launch_step(st, c->plan, c->d_arena, c->d_weights, n, c->n_streams, s));
+    BSX_TIMED(launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
+    BSX_TIMED(launch_mask_upscale_blur(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, n, s));
+    BSX_TIMED(launch_blend(d_bg, bg_stride, d_frames, c->d_masks, d_out, (size_t)c->width * c->height, n, s));
+#undef BSX_TIMED
+    BSX_HIP(c, hipStreamSynchronize(s));
+    for (int j = 0; j < L; j++) { float ms = 0; BSX_HIP(c, hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1])); sum[j] += ms; }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  auto put = [&](int j, const std::string& name, double bytes, double flops) {
+    memset(&out[j], 0, sizeof out[j]);
+    snprintf(out[j].name, sizeof out[j].name, "%s", name.c_str());
+    out[j].avg_ms = sum[j] / iters; out[j].bytes = bytes; out[j].flops = flops;
+  };
+  int j = 0;
+  const double canvas = (double)c->inW * c->inH;
+  // prep_resize: reads the touched part of the ROI (<= 3 B/px of the ROI), writes the 4 B/px canvas
+  put(j++, "prep_resize", N * (3.0 * c->roi.w * c->roi.h + 4.0 * canvas), 0);
+  put(j++, "prep_bilateral", N * (4.0 * canvas + 12.0 * canvas), 0);
+  for (const Step& st : c->plan.steps) {
+    double in = (double)st.H * st.W * st.Cin, o = (double)st.OH * st.OW * st.Cout, b = 0;
+    switch (st.kind) {
+      case StepKind::Eltwise: b = in + o + (st.elt == kEltUnary ? 0 : (st.bcast1 ? st.Cin : in)) + (st.elt == kEltMulAdd ? in : 0); break;
+      case StepKind::Concat: b = 2 * o; break;
+      case StepKind::Gap: b = in + st.Cin; break;
+      default: b = in + o + (st.residual >= 0 ? o : 0) + (st.in_scale >= 0 ? st.Cin : 0); break;
+    }
+    put(j++, st.label, N * b * 4.0, N * 2.0 * st.macs);
+  }
+  put(j++, "decode_iir", N * ((double)c->outW * c->outH * c->outC * 4.0 + 2.0 * c->outW * c->outH), 0);
+  put(j++, "mask_upscale_blur", N * ((double)c->in_roi.w * c->in_roi.h + (double)c->roi.w * c->roi.h), 0);
+  put(j++, "blend", N * 10.0 * px, 0);
+  return j;
+}
+
+const char* bsx_plan_describe(bsx_ctx* c) { return c ? c->plan_text.c_str() : ""; }
+
+long bsx_debug_tensor(bsx_ctx* c, int t, float* h_out, long cap) {
+  if (!c || t < 0 || t >= (int)c->graph.tensors.size() || c->plan.tensor_off[t] < 0) return BSX_EINVAL;
+  long n = (long)c->graph.tensors[t].elems();
+  if (!h_out) return n;
+  if (hipDeviceSynchronize() != hipSuccess) return BSX_EDEVICE;
+  if (hipMemcpy(h_out, c->tensor_ptr(t), sizeof(float) * (size_t)std::min(n, cap), hipMemcpyDeviceToHost) != hipSuccess) return BSX_EDEVICE;
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// kernels.hpp — launch interface of the hand-written gfx950 kernels (kernels_nn.hip,
+// kernels_img.hip).  Host-only declarations; everything takes an explicit hipStream_t.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.hpp"
+
+namespace bsx {
+
+// ---- network -------------------------------------------------------------------------
+// Executes one fused step for `n` streams.  `arena` holds every activation tensor at
+// arena + plan.tensor_off[t] * n_cap (frame i of tensor t at + i * elems(t)).
+hipError_t launch_step(const Step& st, const Plan& plan, float* arena, const float* weights, int n, int n_cap, hipStream_t s);
+
+// ---- image path ----------------------------------------------------------------------
+// Fixed-point bilinear tables of cv::resize(INTER_LINEAR, 8u) for one (src,dst) size pair
+// (device arrays; built on the host with the same float/double arithmetic OpenCV uses).
+struct ResizeTab {
+  const int* xofs = nullptr;     // [dw]  source column (already clamped)
+  const short* xa = nullptr;     // [2*dw] horizontal coefficients (a0,a1), sum 2048
+  const int* yofs = nullptr;     // [dh]  source row before clamping
+  const short* ya = nullptr;     // [2*dh] vertical coefficients (b0,b1)
+  int sw = 0, sh = 0, dw = 0, dh = 0;
+  int mode = 0;                  // 0 linear, 1 copy (same size), 2 INTER_AREA 2x2 (both scales exactly 2)
+};
+
+struct Rect4 { int x, y, w, h; };
+
+struct BilateralParams {
+  float space_w[13];
+  int off_y[13], off_x[13];
+  const float* color_lut;        // [768] device
+  float scale, offset;
+};
+
+// frame ROI ↓ → model canvas (packed RGBX u32, bars = 0).  libbackscrub.cc:285-290
+hipError_t launch_prep_resize(const uint8_t* frames, int W, int H, Rect4 roi, uint32_t* canvas, int inW, int inH, Rect4 in_roi,
+                              ResizeTab tab, int n, hipStream_t s);
+// bilateral(5,100,100) + convertTo f32 → network input [n][inH][inW][3].  libbackscrub.cc:295-302
+hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, int inW, int inH, BilateralParams bp, int n, hipStream_t s);
+// decode + temporal IIR on the model-resolution mask.  libbackscrub.cc:317-357
+hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, int npix, int nch, int n, hipStream_t s);
+// ofinal(in_roi) ↑ roi size, 5x5 box blur (REFLECT_101 on the ROI), write into mask(roi).  libbackscrub.cc:367-371
+hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H,
+                                    Rect4 roi, int n, hipStream_t s);
+// alpha blend.  deepseg.cc:108-134
+hipError_t launch_blend(const uint8_t* bg, size_t bg_stride, const uint8_t* frames, const uint8_t* masks, uint8_t* out, size_t npix,
+                        int n, hipStream_t s);
+// generic BGR resize (background → frame size).  background.cc:186,190
+hipError_t launch_resize_bgr(const uint8_t* src, uint8_t* dst, ResizeTab tab, int n, hipStream_t s);
+// BGR → YUYV.  deepseg.cc:87-106
+hipError_t launch_bgr_to_yuyv(const uint8_t* bgr, uint8_t* yuyv, int w, int h, int n, hipStream_t s);
+// fill
+hipError_t launch_fill_u8(uint8_t* p, uint8_t v, size_t bytes, hipStream_t s);
+
+}  // namespace bsx

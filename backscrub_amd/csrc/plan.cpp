@@ -1,0 +1,346 @@
+// plan.cpp — graph → fused step list + weight packing + activation arena layout.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <map>
+
+namespace bsx {
+namespace {
+
+// TFLite SAME/VALID geometry (ComputeOutSize / ComputePaddingHeightWidth): SAME → ceil(in/s),
+// total pad = max(0,(out-1)s + (k-1)d + 1 - in), leading pad = total/2 (extra goes bottom/right).
+void conv_geometry(int in, int k, int s, int d, bool same, int* out, int* pad) {
+  int eff = (k - 1) * d + 1;
+  *out = same ? (in + s - 1) / s : (in + s - eff) / s;
+  int total = (*out - 1) * s + eff - in;
+  *pad = total > 0 ? total / 2 : 0;
+}
+
+bool is_unary(OpType t) { return t == OpType::Relu || t == OpType::Relu6 || t == OpType::HardSwish || t == OpType::Logistic; }
+int unary_act(OpType t) {
+  switch (t) {
+    case OpType::Relu: return kActRelu;
+    case OpType::Relu6: return kActRelu6;
+    case OpType::HardSwish: return kActHswish;
+    case OpType::Logistic: return kActSigmoid;
+    default: return kActNone;
+  }
+}
+const char* act_name(int a) {
+  switch (a) { case kActRelu: return "relu"; case kActRelu6: return "relu6"; case kActHswish: return "hswish"; case kActSigmoid: return "sigmoid"; default: return "-"; }
+}
+bool same_dims(const TensorInfo& a, const TensorInfo& b) { for (int i = 0; i < 4; i++) if (a.dims[i] != b.dims[i]) return false; return true; }
+bool is_chan_vec(const TensorInfo& v, const TensorInfo& full) { return v.dims[1] == 1 && v.dims[2] == 1 && v.dims[3] == full.dims[3] && (full.dims[1] * full.dims[2] > 1); }
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+std::string Plan::describe() const {
+  static const char* kn[] = {"conv", "pwconv", "dwconv", "gap", "eltwise", "resize", "concat", "tconv"};
+  std::string s;
+  char line[512];
+  int i = 0;
+  for (const Step& st : steps) {
+    snprintf(line, sizeof line, "%3d %-7s %-26s in %dx%dx%d -> out %dx%dx%d k%dx%d s%d d%d act=%s res=%d scale=%d macs=%.0f\n", i++,
+             kn[(int)st.kind], st.label.c_str(), st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.kh, st.kw, st.sh, st.dh, act_name(st.act),
+             st.residual, st.in_scale, st.macs);
+    s += line;
+  }
+  return s;
+}
+
+bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena) {
+  auto fail = [&](const std::string& m) { if (err) *err = m; return false; };
+  const int NT = (int)g.tensors.size();
+  const int NN = (int)g.nodes.size();
+
+  // consumers of each tensor
+  std::vector<std::vector<int>> users(NT);
+  for (int i = 0; i < NN; i++) for (int t : g.nodes[i].inputs) if (t >= 0 && !g.tensors[t].is_const) users[t].push_back(i);
+  auto single_user = [&](int t) -> int { return (t != g.output && users[t].size() == 1) ? users[t][0] : -1; };
+
+  std::vector<char> fused(NN, 0);
+  std::vector<Step> steps;
+  std::vector<float>& W = plan->weights;
+  W.clear();
+  auto align_w = [&]() { while (W.size() % 4) W.push_back(0.f); };
+
+  for (int i = 0; i < NN; i++) {
+    if (fused[i]) continue;
+    const Node& n = g.nodes[i];
+    const TensorInfo& out_t = g.tensors[n.output];
+    Step st;
+    st.last_node = n.index;
+    auto T = [&](int k) -> const TensorInfo& { return g.tensors[n.inputs[k]]; };
+
+    auto chain_epilogue = [&](int cur) -> int {
+      // fold [unary act] then [residual ADD] that solely consume the running output
+      for (;;) {
+        int u = single_user(cur);
+        if (u < 0 || fused[u]) break;
+        const Node& y = g.nodes[u];
+        if (is_unary(y.type) && st.act == kActNone && st.residual < 0) {
+          st.act = unary_act(y.type); fused[u] = 1; cur = y.output; st.last_node = y.index; continue;
+        }
+        if (y.type == OpType::Add && y.act == kActNone && st.residual < 0 && y.inputs.size() == 2) {
+          int other = y.inputs[0] == cur ? y.inputs[1] : y.inputs[0];
+          if (other >= 0 && other != cur && !g.tensors[other].is_const && same_dims(g.tensors[other], g.tensors[cur])) {
+            st.residual = other; fused[u] = 1; cur = y.output; st.last_node = y.index; continue;
+          }
+        }
+        break;
+      }
+      return cur;
+    };
+
+    switch (n.type) {
+      case OpType::Conv:
+      case OpType::FullyConnected: {
+        if (n.inputs.size() < 2) return fail("conv without weights");
+        const TensorInfo& x = T(0);
+        const TensorInfo& w = T(1);
+        if (!w.is_const) return fail("non-constant conv weights unsupported");
+        const TensorInfo* b = (n.inputs.size() > 2 && n.inputs[2] >= 0) ? &T(2) : nullptr;
+        if (b && !b->is_const) return fail("non-constant bias unsupported");
+        bool fc = n.type == OpType::FullyConnected;
+        st.in0 = n.inputs[0];
+        st.H = x.dims[1]; st.W = x.dims[2]; st.Cin = x.dims[3];
+        if (fc) {
+          st.Cout = w.dims[2]; st.kh = st.kw = 1;
+          if (w.dims[3] != st.Cin) return fail("FULLY_CONNECTED depth mismatch");
+          st.OH = st.H; st.OW = st.W;
+        } else {
+          st.Cout = w.dims[0]; st.kh = w.dims[1]; st.kw = w.dims[2];
+          if (w.dims[3] != st.Cin) return fail("CONV_2D depth mismatch");
+          st.sh = n.stride_h; st.sw = n.stride_w; st.dh = n.dil_h; st.dw = n.dil_w;
+          conv_geometry(st.H, st.kh, st.sh, st.dh, n.same_padding, &st.OH, &st.pad_t);
+          conv_geometry(st.W, st.kw, st.sw, st.dw, n.same_padding, &st.OW, &st.pad_l);
+        }
+        if (st.OH != out_t.dims[1] || st.OW != out_t.dims[2] || st.Cout != out_t.dims[3]) return fail("conv output shape mismatch at op #" + std::to_string(n.index));
+        bool pw = st.kh == 1 && st.kw == 1 && st.sh == 1 && st.sw == 1;
+        st.kind = pw ? StepKind::PwConv : StepKind::Conv;
+        st.act = n.act;
+        // squeeze-excite fold: input = MUL(x, s[N,1,1,C]) consumed only here → scale on load
+        if (pw) {
+          int prod = -1;
+          for (int j = 0; j < i; j++) if (!fused[j] && g.nodes[j].output == st.in0) prod = j;
+          if (prod >= 0 && g.nodes[prod].type == OpType::Mul && g.nodes[prod].act == kActNone && single_user(st.in0) == i) {
+            const Node& m = g.nodes[prod];
+            int a = m.inputs[0], s2 = m.inputs[1];
+            if (a >= 0 && s2 >= 0 && !g.tensors[a].is_const && !g.tensors[s2].is_const) {
+              if (is_chan_vec(g.tensors[a], g.tensors[s2])) std::swap(a, s2);
+              if (is_chan_vec(g.tensors[s2], g.tensors[a])) {
+                // the MUL step was already emitted (it precedes us); remove it
+                for (size_t k = 0; k < steps.size(); k++)
+                  if (steps[k].kind == StepKind::Eltwise && steps[k].out == st.in0) { steps.erase(steps.begin() + k); break; }
+                st.in0 = a; st.in_scale = s2;
+              }
+            }
+          }
+        }
+        // pack weights [kh][kw][ci][co_pad]
+        int ct = st.Cout <= 8 ? 8 : (st.Cout <= 16 ? 16 : 32);
+        if (!pw) ct = 16;
+        st.cout_tile = ct;
+        st.cout_pad = round_up(st.Cout, ct);
+        align_w();
+        st.w_off = W.size();
+        W.resize(W.size() + (size_t)st.kh * st.kw * st.Cin * st.cout_pad, 0.f);
+        for (int o = 0; o < st.Cout; o++) for (int fy = 0; fy < st.kh; fy++) for (int fx = 0; fx < st.kw; fx++) for (int c = 0; c < st.Cin; c++) {
+          size_t src = fc ? ((size_t)o * st.Cin + c) : ((((size_t)o * st.kh + fy) * st.kw + fx) * st.Cin + c);
+          W[st.w_off + (((size_t)fy * st.kw + fx) * st.Cin + c) * st.cout_pad + o] = w.f32[src];
+        }
+        align_w();
+        st.b_off = W.size();
+        W.resize(W.size() + st.cout_pad, 0.f);
+        if (b) for (int o = 0; o < st.Cout; o++) W[st.b_off + o] = b->f32[o];
+        st.macs = (double)st.OH * st.OW * st.Cout * st.kh * st.kw * st.Cin;
+        st.out = chain_epilogue(n.output);
+        st.label = (fc ? "fc#" : "conv#") + std::to_string(n.index);
+        break;
+      }
+      case OpType::DwConv: {
+        const TensorInfo& x = T(0);
+        const TensorInfo& w = T(1);
+        if (!w.is_const) return fail("non-constant depthwise weights unsupported");
+        if (n.depth_mult != 1) return fail("depth_multiplier != 1 unsupported");
+        const TensorInfo* b = (n.inputs.size() > 2 && n.inputs[2] >= 0) ? &T(2) : nullptr;
+        st.kind = StepKind::DwConv;
+        st.in0 = n.inputs[0];
+        st.H = x.dims[1]; st.W = x.dims[2]; st.Cin = st.Cout = x.dims[3];
+        st.kh = w.dims[1]; st.kw = w.dims[2];
+        if (w.dims[3] != st.Cin) return fail("depthwise channel mismatch");
+        if (st.Cin % 4) return fail("depthwise channels must be a multiple of 4");
+        st.sh = n.stride_h; st.sw = n.stride_w; st.dh = n.dil_h; st.dw = n.dil_w;
+        conv_geometry(st.H, st.kh, st.sh, st.dh, n.same_padding, &st.OH, &st.pad_t);
+        conv_geometry(st.W, st.kw, st.sw, st.dw, n.same_padding, &st.OW, &st.pad_l);
+        if (st.OH != out_t.dims[1] || st.OW != out_t.dims[2]) return fail("depthwise output shape mismatch at op #" + std::to_string(n.index));
+        st.act = n.act;
+        st.cout_pad = st.Cout;
+        align_w();
+        st.w_off = W.size();
+        W.insert(W.end(), w.f32.begin(), w.f32.end());  // already [kh][kw][C]
+        align_w();
+        st.b_off = W.size();
+        W.resize(W.size() + st.Cout, 0.f);
+        if (b) for (int o = 0; o < st.Cout; o++) W[st.b_off + o] = b->f32[o];
+        st.macs = (double)st.OH * st.OW * st.Cout * st.kh * st.kw;
+        st.out = chain_epilogue(n.output);
+        st.label = "dw#" + std::to_string(n.index);
+        break;
+      }
+      case OpType::TransposeConvBias: {
+        const TensorInfo& x = T(0);
+        const TensorInfo& w = T(1);
+        const TensorInfo& b = T(2);
+        if (!w.is_const || !b.is_const) return fail("non-constant transpose-conv weights unsupported");
+        st.kind = StepKind::TConv;
+        st.in0 = n.inputs[0];
+        st.H = x.dims[1]; st.W = x.dims[2]; st.Cin = x.dims[3];
+        st.Cout = w.dims[0]; st.kh = w.dims[1]; st.kw = w.dims[2];
+        st.sh = n.tconv_stride_h; st.sw = n.tconv_stride_w;
+        // lib/transpose_conv_bias.cc:171-181: SAME pad = max(0, k-(in-1)%s-1); out = s*(in-1)+k-pad
+        int pad_h = n.tconv_padding_same ? std::max(0, st.kh - (st.H - 1) % st.sh - 1) : 0;
+        int pad_w = n.tconv_padding_same ? std::max(0, st.kw - (st.W - 1) % st.sw - 1) : 0;
+        st.OH = st.sh * (st.H - 1) + st.kh - pad_h; st.OW = st.sw * (st.W - 1) + st.kw - pad_w;
+        st.pad_t = pad_h / 2; st.pad_l = pad_w / 2;
+        if (st.kh != st.sh || st.kw != st.sw || st.pad_t || st.pad_l)
+          return fail("Convolution2DTransposeBias: only kernel==stride, zero-pad geometry is implemented");
+        if (st.OH != out_t.dims[1] || st.OW != out_t.dims[2] || st.Cout != out_t.dims[3]) return fail("tconv output shape mismatch");
+        if (st.Cin % 4) return fail("tconv input channels must be a multiple of 4");
+        align_w();
+        st.w_off = W.size();  // [fy][fx][oc][ic]
+        W.resize(W.size() + (size_t)st.kh * st.kw * st.Cout * st.Cin);
+        for (int o = 0; o < st.Cout; o++) for (int fy = 0; fy < st.kh; fy++) for (int fx = 0; fx < st.kw; fx++) for (int c = 0; c < st.Cin; c++)
+          W[st.w_off + (((size_t)fy * st.kw + fx) * st.Cout + o) * st.Cin + c] = w.f32[(((size_t)o * st.kh + fy) * st.kw + fx) * st.Cin + c];
+        align_w();
+        st.b_off = W.size();
+        W.insert(W.end(), b.f32.begin(), b.f32.begin() + st.Cout);
+        st.macs = (double)st.OH * st.OW * st.Cout * st.Cin;
+        st.out = chain_epilogue(n.output);
+        if (st.residual >= 0) return fail("residual after tconv unsupported");
+        st.label = "tconv#" + std::to_string(n.index);
+        break;
+      }
+      case OpType::AvgPool: {
+        const TensorInfo& x = T(0);
+        if (n.filter_h != x.dims[1] || n.filter_w != x.dims[2] || out_t.dims[1] != 1 || out_t.dims[2] != 1)
+          return fail("only global AVERAGE_POOL_2D is implemented (op #" + std::to_string(n.index) + ")");
+        if (n.act != kActNone) return fail("fused activation on AVERAGE_POOL_2D unsupported");
+        st.kind = StepKind::Gap;
+        st.in0 = n.inputs[0]; st.out = n.output;
+        st.H = x.dims[1]; st.W = x.dims[2]; st.Cin = st.Cout = x.dims[3];
+        st.label = "gap#" + std::to_string(n.index);
+        break;
+      }
+      case OpType::Relu: case OpType::Relu6: case OpType::HardSwish: case OpType::Logistic: {
+        const TensorInfo& x = T(0);
+        st.kind = StepKind::Eltwise; st.elt = kEltUnary; st.act = unary_act(n.type);
+        st.in0 = n.inputs[0]; st.out = n.output;
+        st.H = st.OH = x.dims[1]; st.W = st.OW = x.dims[2]; st.Cin = st.Cout = x.dims[3];
+        st.label = "act#" + std::to_string(n.index);
+        break;
+      }
+      case OpType::Add: case OpType::Mul: {
+        if (n.inputs.size() != 2) return fail("binary op arity");
+        int a = n.inputs[0], b = n.inputs[1];
+        if (g.tensors[a].is_const || g.tensors[b].is_const) return fail("constant operand in ADD/MUL unsupported");
+        if (is_chan_vec(g.tensors[a], g.tensors[b])) std::swap(a, b);
+        const TensorInfo& x = g.tensors[a];
+        st.kind = StepKind::Eltwise; st.elt = n.type == OpType::Add ? kEltAdd : kEltMul;
+        st.in0 = a; st.in1 = b; st.out = n.output; st.act = n.act;
+        st.bcast1 = is_chan_vec(g.tensors[b], x);
+        if (!st.bcast1 && !same_dims(g.tensors[b], x)) return fail("unsupported broadcast in ADD/MUL at op #" + std::to_string(n.index));
+        st.H = st.OH = x.dims[1]; st.W = st.OW = x.dims[2]; st.Cin = st.Cout = x.dims[3];
+        st.label = std::string(n.type == OpType::Add ? "add#" : "mul#") + std::to_string(n.index);
+        // gate*skip + up  →  one pass
+        if (n.type == OpType::Mul && st.bcast1 && n.act == kActNone) {
+          int u = single_user(n.output);
+          if (u >= 0 && !fused[u] && g.nodes[u].type == OpType::Add && g.nodes[u].act == kActNone) {
+            const Node& y = g.nodes[u];
+            int other = y.inputs[0] == n.output ? y.inputs[1] : y.inputs[0];
+            if (other >= 0 && !g.tensors[other].is_const && same_dims(g.tensors[other], x)) {
+              st.elt = kEltMulAdd; st.in2 = other; st.out = y.output; fused[u] = 1; st.last_node = y.index;
+              st.label = "muladd#" + std::to_string(n.index);
+            }
+          }
+        }
+        break;
+      }
+      case OpType::ResizeBilinear: {
+        const TensorInfo& x = T(0);
+        st.kind = StepKind::Resize;
+        st.in0 = n.inputs[0]; st.out = n.output;
+        st.H = x.dims[1]; st.W = x.dims[2]; st.Cin = st.Cout = x.dims[3];
+        st.OH = out_t.dims[1]; st.OW = out_t.dims[2];
+        if (n.inputs.size() > 1 && n.inputs[1] >= 0) {
+          const TensorInfo& sz = T(1);
+          if (sz.i32.size() >= 2 && (sz.i32[0] != st.OH || sz.i32[1] != st.OW)) return fail("RESIZE_BILINEAR size disagrees with output shape");
+        }
+        st.align_corners = n.align_corners; st.half_pixel = n.half_pixel;
+        st.label = "resize#" + std::to_string(n.index);
+        break;
+      }
+      case OpType::Concat: {
+        int ax = n.axis < 0 ? n.axis + 4 : n.axis + (4 - (int)out_t.shape.size());
+        if (ax != 3) return fail("only channel-axis CONCATENATION is implemented");
+        st.kind = StepKind::Concat;
+        st.out = n.output;
+        st.H = st.OH = out_t.dims[1]; st.W = st.OW = out_t.dims[2]; st.Cout = out_t.dims[3];
+        for (int t : n.inputs) { if (g.tensors[t].is_const) return fail("constant CONCATENATION input unsupported"); if (g.tensors[t].dims[3] % 4) return fail("concat channels must be multiples of 4"); st.concat_in.push_back(t); st.concat_c.push_back(g.tensors[t].dims[3]); }
+        st.in0 = st.concat_in[0];
+        st.label = "concat#" + std::to_string(n.index);
+        break;
+      }
+      default:
+        return fail("operator #" + std::to_string(n.index) + " has no GPU implementation");
+    }
+    steps.push_back(std::move(st));
+  }
+  // a fused group executes where its LAST op stood, so every external input already exists
+  std::stable_sort(steps.begin(), steps.end(), [](const Step& a, const Step& b) { return a.last_node < b.last_node; });
+
+  // ---- activation arena: first-fit over [first def, last use] intervals, in per-stream float units
+  plan->tensor_off.assign(NT, -1);
+  std::vector<int> first(NT, -1), last(NT, -1);
+  auto touch = [&](int t, int s) { if (t < 0) return; if (first[t] < 0) first[t] = s; last[t] = s; };
+  const int NS = (int)steps.size();
+  touch(g.input, -1);
+  for (int s = 0; s < NS; s++) {
+    const Step& st = steps[s];
+    touch(st.in0, s); touch(st.in1, s); touch(st.in2, s); touch(st.residual, s); touch(st.in_scale, s);
+    for (int t : st.concat_in) touch(t, s);
+    touch(st.out, s);
+  }
+  first[g.input] = -1;
+  last[g.output] = NS + 1;  // keep the network output alive for the decode stage
+  last[g.input] = std::max(last[g.input], 0);
+  struct Block { size_t off, len; int until; };
+  std::vector<Block> live;
+  size_t high = 0;
+  std::vector<int> order;
+  for (int t = 0; t < NT; t++) if (first[t] >= -1 && last[t] >= 0 && !g.tensors[t].is_const && (t == g.input || first[t] >= 0)) order.push_back(t);
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+  for (int t : order) {
+    size_t len = (g.tensors[t].elems() + 63) / 64 * 64;  // 256-byte granules
+    int start = first[t];
+    if (reuse_arena) live.erase(std::remove_if(live.begin(), live.end(), [&](const Block& b) { return b.until < start; }), live.end());
+    std::sort(live.begin(), live.end(), [](const Block& a, const Block& b) { return a.off < b.off; });
+    size_t pos = 0;
+    for (const Block& b : live) { if (pos + len <= b.off) break; pos = std::max(pos, b.off + b.len); }
+    plan->tensor_off[t] = (long)pos;
+    live.push_back({pos, len, last[t]});
+    high = std::max(high, pos + len);
+  }
+  plan->arena_floats_per_stream = high;
+  plan->input = g.input;
+  plan->output = g.output;
+  plan->macs_per_frame = 0;
+  for (const Step& st : steps) plan->macs_per_frame += st.macs;
+  plan->steps = std::move(steps);
+  return true;
+}
+
+}  // namespace bsx

@@ -1,0 +1,58 @@
+// plan.hpp — fused GPU execution plan for one segmentation network.
+//
+// The reference runs the graph op by op through tflite::Interpreter::Invoke()
+// (/root/reference/lib/libbackscrub.cc:307).  Here the graph is compiled once, at
+// bsx_new(), into a short list of batched kernel launches ("steps"): activations and
+// residual adds are folded into the producing convolution, the squeeze-excite MUL is
+// folded into the consuming 1x1 convolution, gate*skip+up becomes one pass, and all
+// activation tensors live in one arena with liveness-based reuse so a batch of streams
+// stays resident in the Infinity Cache between layers.
+#pragma once
+#include <cstddef>
+#include <string>
+#include <vector>
+
+#include "tflite_model.hpp"
+
+namespace bsx {
+
+enum class StepKind : int { Conv = 0, PwConv, DwConv, Gap, Eltwise, Resize, Concat, TConv };
+enum EltOp : int { kEltAdd = 0, kEltMul = 1, kEltUnary = 2, kEltMulAdd = 3 };
+
+struct Step {
+  StepKind kind = StepKind::Conv;
+  std::string label;
+  int in0 = -1, in1 = -1, in2 = -1;   // graph tensor ids
+  int out = -1;
+  int residual = -1;                  // tensor added after the activation (conv-type steps)
+  int in_scale = -1;                  // [N,1,1,Cin] tensor multiplied into the input (PwConv only)
+  int H = 1, W = 1, Cin = 1, OH = 1, OW = 1, Cout = 1;
+  int kh = 1, kw = 1, sh = 1, sw = 1, dh = 1, dw = 1, pad_t = 0, pad_l = 0;
+  int act = kActNone;
+  int elt = kEltAdd;
+  bool bcast1 = false;                // in1 is [N,1,1,C]
+  bool align_corners = false, half_pixel = false;
+  int cout_pad = 0;                   // padded Cout of the packed weights
+  int cout_tile = 16;                 // output channels per thread in the conv kernels
+  size_t w_off = 0, b_off = 0;        // float offsets into the weight arena
+  std::vector<int> concat_in;         // Concat: all inputs
+  std::vector<int> concat_c;          // Concat: channels of each input
+  double macs = 0;                    // per frame
+  int last_node = -1;                 // file operator index of the last fused op
+};
+
+struct Plan {
+  std::vector<Step> steps;
+  std::vector<float> weights;         // packed weight arena (host copy)
+  std::vector<long> tensor_off;       // per graph tensor: float offset per stream-slot unit, -1 if not materialised
+  size_t arena_floats_per_stream = 0; // arena size = this * n_streams
+  int input = -1, output = -1;
+  double macs_per_frame = 0;
+  std::string describe() const;
+};
+
+// Build the plan.  Returns false with `err` for unsupported graph features.
+// `reuse_arena=false` gives every tensor its own slot (layer-by-layer debugging).
+bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena = true);
+
+}  // namespace bsx

@@ -1,0 +1,161 @@
+/* bsx.h — C ABI of libbsx.so, the MI355X-native backscrub hot path.
+ *
+ * Plain C: opaque handle, raw pointers, sizes.  No C++ / OpenCV / torch types cross this
+ * boundary.  `d_` pointers are HIP device pointers on the context's GPU; `h_` pointers are
+ * host memory.  `stream` is a hipStream_t passed as void* (NULL = the HIP default stream, as in every HIP API).
+ * All functions return 0 on success or a negative BSX_E* code; nothing throws.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *
+ *   bsx_version            bs_tensorflow_version()        lib/libbackscrub.h:13,  .cc:150-152
+ *   bsx_new                bs_maskgen_new()               lib/libbackscrub.h:16-33, .cc:161-259
+ *   bsx_delete             bs_maskgen_delete()            lib/libbackscrub.h:36,  .cc:261-277
+ *   bsx_process_host       bs_maskgen_process()           lib/libbackscrub.h:39,  .cc:279-376
+ *                          (one stream, host frame in, host mask out — what the C++ shim
+ *                          csrc/bs_maskgen_shim.cpp forwards cv::Mat data to)
+ *   bsx_process_batch      the same function for n_streams device-resident frames at once
+ *   bsx_composite_batch    alpha_blend()                  app/deepseg.cc:108-134 (file-static)
+ *   bsx_step_batch         one main-loop iteration        app/deepseg.cc:634-661
+ *                          (set_input_frame → mask → alpha_blend), batched
+ *   bsx_resize_bgr         grab_background() cv::resize   app/background.cc:178-194
+ *   bsx_bgr_to_yuyv        convert_rgb_to_yuyv()          app/deepseg.cc:87-106
+ *   bsx_profile_batch      the per-stage timers           app/deepseg.cc:137-156,701-720 (timinginfo_t)
+ *   bsx_get_info           the geometry of backscrub_ctx_t lib/libbackscrub.cc:28-54,234-246
+ *
+ * Threading: a context is NOT thread-safe (same as the reference: one context per caller
+ * thread, lib/libbackscrub.cc has no locks).  Callbacks fire synchronously on the calling
+ * thread in the order prep → infer → mask, once per process call (per batch for the batched
+ * calls), see lib/libbackscrub.cc:303,311,363.
+ */
+#ifndef BSX_H_
+#define BSX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bsx_ctx bsx_ctx;
+
+typedef void (*bsx_debug_fn)(void* caller_ctx, const char* msg);
+typedef void (*bsx_stage_fn)(void* caller_ctx);
+
+enum {
+  BSX_OK = 0,
+  BSX_EINVAL = -1,   /* NULL context / bad argument (reference: `return false`, .cc:280) */
+  BSX_EMODEL = -2,   /* model file unreadable / unsupported op / unknown model type (.cc:191-203) */
+  BSX_EDEVICE = -3,  /* HIP error (message via ondebug or stderr) */
+  BSX_ESIZE = -4     /* frame geometry does not match the one given to bsx_new */
+};
+
+/* model types, as sniffed from the file name by the reference (lib/libbackscrub.cc:116-130) */
+enum { BSX_MODEL_UNKNOWN = 0, BSX_MODEL_DEEPLAB = 1, BSX_MODEL_MLKIT = 2, BSX_MODEL_MEET = 3, BSX_MODEL_BODYPIX = 4 };
+
+typedef struct bsx_info {
+  int model_type;
+  int width, height;              /* frame geometry */
+  int n_streams;                  /* batch capacity */
+  int in_w, in_h, in_c;           /* model input tensor */
+  int out_w, out_h, out_c;        /* model output tensor */
+  int roi[4];                     /* roidim   x,y,w,h in the frame       (.cc:234-246) */
+  int in_roi[4];                  /* in_roidim x,y,w,h in the model canvas */
+  int n_ops, n_steps;             /* graph operators / fused GPU launches per batch */
+  int device;
+  float norm_scale, norm_offset;  /* .cc:132-148 */
+  double nn_flops_per_frame;      /* 2*MAC of the loaded graph */
+  size_t act_bytes_per_stream;    /* activation arena per stream */
+} bsx_info;
+
+/* "bsx <ver> (HIP gfx950)"; static storage. */
+const char* bsx_version(void);
+
+/* Number of visible HIP devices (0 if none / runtime missing). */
+int bsx_device_count(void);
+
+/* Create a mask generator for `n_streams` independent camera streams of width x height BGR
+ * frames on HIP device `device`.  `threads` is accepted for signature parity with
+ * bs_maskgen_new (intra-op CPU threads there) and recorded only.  Callbacks may be NULL.
+ * Returns NULL on failure after reporting through ondebug (or stderr), like the reference. */
+bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t height,
+                 int n_streams, int device,
+                 bsx_debug_fn ondebug, bsx_stage_fn onprep, bsx_stage_fn oninfer, bsx_stage_fn onmask,
+                 void* caller_ctx);
+
+/* NULL-safe. */
+void bsx_delete(bsx_ctx* ctx);
+
+int bsx_get_info(const bsx_ctx* ctx, bsx_info* out);
+
+/* Last error text for this context (or the global one if ctx==NULL); static/ctx storage. */
+const char* bsx_last_error(const bsx_ctx* ctx);
+
+/* Reset the per-stream temporal state (`ofinal` → 0, `mask` → 255) of all streams. */
+int bsx_reset(bsx_ctx* ctx, void* stream);
+
+/* Drop-in single-frame path.  h_bgr: height rows of width*3 bytes, `bgr_stride` bytes apart
+ * (CV_8UC3 cv::Mat data/step).  h_mask: height rows of width bytes, `mask_stride` apart;
+ * receives the full-frame mask (255 = background).  Uses stream slot `stream_idx`.
+ * Synchronous: returns after the mask is in h_mask. */
+int bsx_process_host(bsx_ctx* ctx, int stream_idx, const uint8_t* h_bgr, size_t bgr_stride,
+                     uint8_t* h_mask, size_t mask_stride);
+
+/* Batched device path: frames [n][height][width][3] u8 contiguous (n <= n_streams; frame i
+ * belongs to stream i).  Updates each stream's temporal state and its persistent full-frame
+ * mask.  If d_masks != NULL the masks are also copied there ([n][height][width]).
+ * Asynchronous on `stream` unless callbacks are set (each callback needs a stream sync). */
+int bsx_process_batch(bsx_ctx* ctx, const uint8_t* d_frames, int n, uint8_t* d_masks, void* stream);
+
+/* Device pointer of the persistent masks [n_streams][height][width] (valid until bsx_delete;
+ * contents valid after the process call that produced them has completed on its stream) —
+ * the analogue of `mask = ctx.mask` aliasing the lib-owned buffer (lib/libbackscrub.cc:374). */
+uint8_t* bsx_masks_device(bsx_ctx* ctx);
+
+/* out = (bg*m + frame*(255-m))/255 per byte (C truncating divide).  d_bg is one
+ * [height][width][3] image shared by all frames when bg_frame_stride == 0, else frame i uses
+ * d_bg + i*bg_frame_stride.  d_masks == NULL means "use the context's persistent masks". */
+int bsx_composite_batch(bsx_ctx* ctx, const uint8_t* d_bg, size_t bg_frame_stride,
+                        const uint8_t* d_frames, const uint8_t* d_masks, uint8_t* d_out, int n, void* stream);
+
+/* bsx_process_batch followed by bsx_composite_batch on the same stream. */
+int bsx_step_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
+                   uint8_t* d_out, int n, void* stream);
+
+/* cv::resize(src, dst, Size(dw,dh)) with INTER_LINEAR on packed BGR u8 (device pointers, n images). */
+int bsx_resize_bgr(bsx_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream);
+
+/* BGR u8 [n][h][w][3] -> YUYV 4:2:2 [n][h][w][2] exactly as convert_rgb_to_yuyv (byte order Y0 V Y1 U). */
+int bsx_bgr_to_yuyv(bsx_ctx* ctx, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, int h, int n, void* stream);
+
+/* ---- introspection used by the parity tests and the bench (stage-by-stage checks) ---- */
+/* Device pointer + element count of: 0 = model input tensor [n_streams][in_h][in_w][in_c] f32,
+ * 1 = model output tensor f32, 2 = ofinal u8 [n_streams][out_h][out_w], 3 = masks u8. */
+int bsx_debug_buffer(bsx_ctx* ctx, int which, void** d_ptr, size_t* bytes);
+/* Run single stages on the current buffers (n streams): 0 = prep, 1 = infer, 2 = decode+IIR, 3 = upscale+blur. */
+int bsx_debug_run_stage(bsx_ctx* ctx, int stage, const uint8_t* d_frames, int n, void* stream);
+/* Per-launch description of the fused plan, one line per GPU launch; returned string is owned by ctx. */
+const char* bsx_plan_describe(bsx_ctx* ctx);
+/* Copy out the value of graph tensor `tensor_idx` for stream 0 after an infer (only tensors that survive
+ * fusion are available); returns element count or negative error.  h_out may be NULL to query the size. */
+long bsx_debug_tensor(bsx_ctx* ctx, int tensor_idx, float* h_out, long cap);
+
+/* ---- measurement ---- */
+typedef struct bsx_launch_stat {
+  char name[64];      /* kernel / fused step label */
+  double avg_ms;      /* mean hipEvent-bracketed duration of this launch over `iters` repetitions */
+  double bytes;       /* ALGORITHMIC bytes this launch must move for n streams (inputs once + outputs once) */
+  double flops;       /* 2*MAC for n streams (0 for byte kernels) */
+} bsx_launch_stat;
+
+/* Runs the whole per-batch sequence (prep, every fused network step, decode, upscale+blur, blend)
+ * `iters` times, bracketing EVERY launch with hipEvents on `stream`, and writes one record per
+ * launch (in launch order) into out[0..cap).  Returns the number of launches, or a negative error.
+ * The temporal state advances exactly as `iters` calls of bsx_step_batch would. */
+int bsx_profile_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out,
+                      int n, int iters, bsx_launch_stat* out, int cap, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSX_H_ */

@@ -1,0 +1,303 @@
+"""GPU parity tests: the HIP path (through the C ABI of libbsx.so) against the CPU oracle.
+
+Bars (BASELINE.json north_star): integer/byte stages bit-exact; network logits within
+float tolerance; end to end mask IoU >= 0.999 and composited frame max-abs <= 1 LSB.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODEL_KEYS, model_path, synthetic_model_path
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+VGA, HD = (640, 480), (1280, 720)
+
+
+@pytest.fixture(scope="module")
+def bs():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    import backscrub_amd
+    backscrub_amd.lib()  # raises if libbsx.so is missing: no silent fallback
+    return backscrub_amd
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _iou_fg(a, b):
+    """IoU of the person region (mask < 128) — 1.0 when both are empty"""
+    fa, fb = a < 128, b < 128
+    union = np.logical_or(fa, fb).sum()
+    return 1.0 if union == 0 else np.logical_and(fa, fb).sum() / union
+
+
+# --------------------------------------------------------------------------------------------
+# alpha blend (deepseg.cc:108-134): bit exact, including every (a, b, m) byte combination
+# --------------------------------------------------------------------------------------------
+def test_blend_exhaustive_identity(bs, oracle):
+    m, a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    W, H = 4096, 4096  # 2^24 pixels = all (m,a,b) triples, one per pixel
+    mask = m.reshape(H, W)
+    bg = np.repeat(a.reshape(H, W, 1), 3, 2)
+    fr = np.repeat(b.reshape(H, W, 1), 3, 2)
+    mg = bs.MaskGen(synthetic_model_path("lite"), W, H, n_streams=1)
+    out = mg.composite(_dev(bg), _dev(fr[None]), _dev(mask[None]))[0].cpu().numpy()
+    want = ((bg.astype(np.int32) * mask[..., None] + fr.astype(np.int32) * (255 - mask[..., None].astype(np.int32))) // 255).astype(np.uint8)
+    assert np.array_equal(out, want)
+    assert np.array_equal(want[:64], oracle.alpha_blend(bg[:64], fr[:64], mask[:64]))
+    mg.close()
+
+
+@pytest.mark.parametrize("res,n,shared_bg", [(VGA, 5, True), (HD, 2, False), ((322, 243), 3, True)])
+def test_blend_matches_oracle(bs, oracle, res, n, shared_bg):
+    from backscrub_amd import synth
+    W, H = res
+    fr = synth.random_u8((n, H, W, 3), 1)
+    bg = synth.random_u8((H, W, 3) if shared_bg else (n, H, W, 3), 2)
+    mask = synth.random_u8((n, H, W), 3)
+    mask[0, :8] = 255
+    mask[0, 8:16] = 0
+    mg = bs.MaskGen(synthetic_model_path("lite"), W, H, n_streams=n)
+    out = mg.composite(_dev(bg), _dev(fr), _dev(mask)).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[i], oracle.alpha_blend(bg if shared_bg else bg[i], fr[i], mask[i])), "frame %d" % i
+    mg.close()
+
+
+# --------------------------------------------------------------------------------------------
+# stage-by-stage parity on identical inputs
+# --------------------------------------------------------------------------------------------
+CASES = [("lite", VGA), ("lite", HD), ("full", HD), ("full", VGA), ("mlkit", VGA), ("mlkit", HD), ("deeplab", VGA)]
+
+
+@pytest.mark.parametrize("key,res", CASES)
+@pytest.mark.parametrize("real", [True, False])
+def test_stages_match_oracle(bs, oracle, key, res, real):
+    from backscrub_amd import synth
+    path = model_path(key, prefer_real=real)
+    if real and "synthetic" in os.path.basename(path):
+        pytest.skip("reference model not staged on this box")
+    W, H = res
+    n = 3
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    oc = [oracle.Ctx(path, W, H) for _ in range(n)]
+    info = mg.info
+    assert tuple(info["roi"]) == oc[0].roidim and tuple(info["in_roi"]) == oc[0].in_roidim
+    frames = np.stack([synth.frame(W, H, s) for s in range(n)])
+    frames[2] = synth.random_u8((H, W, 3), 7)  # one pure-noise stream stresses the integer paths
+    d_frames = _dev(frames)
+
+    # (0) prep: resize + BGR2RGB + bilateral + normalise — bit exact
+    mg.run_stage(0, d_frames)
+    got_in = mg.input_tensor().cpu().numpy()
+    for i in range(n):
+        want = oc[i].prep(frames[i])
+        assert np.array_equal(got_in[i], want), "prep mismatch stream %d: %d px differ, max %g" % (
+            i, (got_in[i] != want).sum(), np.abs(got_in[i] - want).max())
+
+    # (1) network: float tolerance (different summation order / FMA)
+    mg.run_stage(1, n=n)
+    got_out = mg.output_tensor().cpu().numpy()
+    for i in range(n):
+        want = oc[i].infer()
+        scale = max(1.0, float(np.abs(want).max()))
+        err = float(np.abs(got_out[i] - want).max()) / scale
+        assert err < 1e-4, "logits rel err %g (stream %d)" % (err, i)
+
+    # (2) decode + IIR on the ORACLE's logits, from a non-trivial previous state — bit exact
+    prev = synth.random_u8((n, info["out_h"], info["out_w"]), 11)
+    mg.output_tensor().copy_(_dev(np.stack([c.output() for c in oc])))
+    mg.ofinal().copy_(_dev(prev))
+    mg.run_stage(2, n=n)
+    got_of = mg.ofinal().cpu().numpy()
+    for i in range(n):
+        oc[i].set_ofinal(prev[i])
+        oc[i].post()
+        assert np.array_equal(got_of[i], oc[i].ofinal()), "decode mismatch stream %d" % i
+
+    # (3) upscale + blur into the persistent mask — bit exact
+    mg.run_stage(3, n=n)
+    got_m = mg.masks().cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got_m[i], oc[i].mask()), "mask mismatch stream %d: %d px" % (i, (got_m[i] != oc[i].mask()).sum())
+    for c in oc:
+        c.close()
+    mg.close()
+
+
+# --------------------------------------------------------------------------------------------
+# end to end: several frames per stream, temporal state carried on the GPU
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", HD), ("full", HD), ("deeplab", VGA)])
+@pytest.mark.parametrize("real", [True, False])
+def test_end_to_end_iou_and_composite(bs, oracle, key, res, real):
+    from backscrub_amd import synth
+    path = model_path(key, prefer_real=real)
+    if real and "synthetic" in os.path.basename(path):
+        pytest.skip("reference model not staged on this box")
+    W, H = res
+    n, T = (4, 4) if key != "deeplab" else (2, 3)
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    oc = [oracle.Ctx(path, W, H) for _ in range(n)]
+    bg = synth.background(W, H)
+    d_bg = _dev(bg)
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    for t in range(T):
+        frames = np.stack([synth.frame(W, H, s, t) for s in range(n)])
+        d_frames = _dev(frames)
+        mg.step(d_frames, d_bg, out)
+        got_mask = mg.masks().cpu().numpy()
+        got_out = out.cpu().numpy()
+        for i in range(n):
+            want_mask = oc[i].process(frames[i])
+            want_out = oracle.alpha_blend(bg, frames[i], want_mask)
+            iou = _iou_fg(got_mask[i], want_mask)
+            assert iou >= 0.999, "t=%d stream %d IoU %.5f" % (t, i, iou)
+            if np.array_equal(got_mask[i], want_mask):
+                assert np.array_equal(got_out[i], want_out)
+            # composite: <= 1 LSB except where a decision pixel flipped (bounded by the IoU bar)
+            diff = np.abs(got_out[i].astype(np.int16) - want_out.astype(np.int16)).max(-1)
+            assert (diff > 1).mean() <= 1e-3, "t=%d stream %d: %.5f of pixels differ by > 1 LSB" % (t, i, (diff > 1).mean())
+    for c in oc:
+        c.close()
+    mg.close()
+
+
+def test_deeplab_argmax_agreement(bs, oracle):
+    """DeepLab rarely fires 'person' on synthetic frames, so also compare the full 21-way argmax map."""
+    from backscrub_amd import synth
+    path = model_path("deeplab")
+    W, H = VGA
+    mg = bs.MaskGen(path, W, H, n_streams=1)
+    oc = oracle.Ctx(path, W, H)
+    f = synth.frame(W, H, 3)
+    mg.process_batch(_dev(f[None]))
+    got = mg.output_tensor().cpu().numpy()[0].argmax(-1)
+    oc.process(f)
+    want = oc.output().argmax(-1)
+    assert (got == want).mean() >= 0.999
+    oc.close()
+    mg.close()
+
+
+# --------------------------------------------------------------------------------------------
+# the drop-in single-frame host path and its reference-style error behaviour
+# --------------------------------------------------------------------------------------------
+def test_bs_maskgen_host_path_and_callbacks(bs, oracle):
+    from backscrub_amd import synth
+    path = model_path("lite")
+    W, H = VGA
+    events = []
+    ctx = bs.bs_maskgen_new(path, 2, W, H, None, lambda c: events.append("prep"), lambda c: events.append("infer"),
+                            lambda c: events.append("mask"), None)
+    assert ctx is not None
+    oc = oracle.Ctx(path, W, H)
+    mask = np.zeros((H, W), np.uint8)
+    for t in range(3):
+        f = synth.frame(W, H, 0, t)
+        assert bs.bs_maskgen_process(ctx, f, mask) is True
+        assert _iou_fg(mask, oc.process(f)) >= 0.999
+    assert events == ["prep", "infer", "mask"] * 3   # lib/libbackscrub.cc:303,311,363
+    bs.bs_maskgen_delete(ctx)
+    bs.bs_maskgen_delete(None)                        # NULL-safe, :262
+    assert bs.bs_maskgen_process(None, f, mask) is False  # :280
+    msgs = []
+    assert bs.bs_maskgen_new("/nonexistent/segm_x.tflite", 2, W, H, lambda c, m: msgs.append(m)) is None  # :191-195
+    assert msgs and b"unable to load model" in msgs[0]
+    assert bs.bs_maskgen_new(synthetic_model_path("lite").replace("segm_", "xx_") + ".missing", 2, W, H, lambda c, m: None) is None
+    oc.close()
+
+
+def test_unknown_model_type_rejected(bs, tmp_path):
+    import shutil
+    p = tmp_path / "mystery.tflite"
+    shutil.copy(synthetic_model_path("lite"), p)
+    msgs = []
+    assert bs.bs_maskgen_new(str(p), 2, 640, 480, lambda c, m: msgs.append(m)) is None   # :199-203
+    assert b"unknown model type" in msgs[0]
+
+
+def test_roi_border_stays_background(bs):
+    """Mask pixels outside roidim stay 255 forever (libbackscrub.cc:248-249)."""
+    from backscrub_amd import synth
+    W, H = VGA
+    mg = bs.MaskGen(model_path("mlkit"), W, H, n_streams=1)   # roi = (80,0,480,480)
+    for t in range(3):
+        m = mg.process_batch(_dev(synth.frame(W, H, 0, t)[None])).cpu().numpy()[0]
+    x, _, w, _ = mg.info["roi"]
+    assert (m[:, :x] == 255).all() and (m[:, x + w:] == 255).all()
+    mg.close()
+
+
+# --------------------------------------------------------------------------------------------
+# "next" rows already on the GPU: background resize and the YUYV packer — bit exact
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src,dst", [((1280, 720), (640, 480)), ((1200, 859), (640, 480)), ((480, 360), (1280, 720)),
+                                     ((1280, 960), (640, 480)), ((640, 480), (640, 480)), ((33, 17), (640, 480))])
+def test_resize_bgr_matches_oracle(bs, oracle, src, dst):
+    from backscrub_amd import synth
+    img = synth.random_u8((2, src[1], src[0], 3), 5)
+    mg = bs.MaskGen(synthetic_model_path("lite"), 640, 480, n_streams=1)
+    got = mg.resize_bgr(_dev(img), dst[0], dst[1]).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.resize_linear(img[i], dst[0], dst[1]))
+    mg.close()
+
+
+def test_yuyv_matches_oracle(bs, oracle):
+    from backscrub_amd import synth
+    img = synth.random_u8((2, 480, 640, 3), 9)
+    mg = bs.MaskGen(synthetic_model_path("lite"), 640, 480, n_streams=1)
+    got = mg.bgr_to_yuyv(_dev(img)).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.bgr_to_yuyv(img[i]))
+    mg.close()
+
+
+# --------------------------------------------------------------------------------------------
+# size-independent properties at the BASELINE batch size (256 VGA streams, segm_lite)
+# --------------------------------------------------------------------------------------------
+def test_full_batch_properties(bs, oracle):
+    from backscrub_amd import synth
+    W, H = VGA
+    n = 256
+    path = model_path("lite")
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    base = synth.frames(8, W, H)
+    frames = np.concatenate([base] * (n // 8))           # stream i carries scene i % 8
+    d_frames = _dev(frames)
+    bg = synth.background(W, H)
+    d_bg = _dev(bg)
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(4):
+        mg.step(d_frames, d_bg, out)
+    masks = mg.masks().cpu().numpy()
+    # streams are independent and deterministic: identical inputs → identical state, wherever they sit in the batch
+    for i in range(8, n):
+        assert np.array_equal(masks[i], masks[i % 8]), "stream %d differs from its twin" % i
+    # IIR steady state after >= 3 identical frames: model-resolution mask is exactly 0x00 / 0xFF
+    of = mg.ofinal().cpu().numpy()
+    assert set(np.unique(of).tolist()) <= {0, 255}
+    # idempotence at steady state
+    before = masks.copy()
+    mg.step(d_frames, d_bg, out)
+    assert np.array_equal(mg.masks().cpu().numpy(), before)
+    # blend endpoints: mask 255 → background, mask 0 → camera frame
+    o = out.cpu().numpy()
+    m = mg.masks().cpu().numpy()
+    assert np.array_equal(o[m == 255], np.broadcast_to(bg, o.shape)[m == 255])
+    assert np.array_equal(o[m == 0], frames[m == 0])
+    # and the oracle agrees on the 8 distinct scenes
+    for i in range(8):
+        oc = oracle.Ctx(path, W, H)
+        for _ in range(5):
+            want = oc.process(frames[i])
+        assert _iou_fg(m[i], want) >= 0.999
+        oc.close()
+    mg.close()
