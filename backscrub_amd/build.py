@@ -58,7 +58,31 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_shim_demo(force or bool(procs), verbose)
     return LIB
+
+
+DEMO = os.path.join(HERE, "bsx_demo")
+
+
+def build_shim_demo(force=False, verbose=False):
+    """C++ drop-in shim (bs_maskgen_* over the C ABI) + the demo application, compiled with plain g++
+    against tests/cv_stub (OpenCV is not installed in this image)."""
+    root = os.path.dirname(HERE)
+    shim = os.path.join(CSRC, "bs_maskgen_shim.cpp")
+    demo_src = os.path.join(root, "tools", "bsx_demo.cpp")
+    deps = [shim, demo_src, os.path.join(root, "include", "bsx.h"), os.path.join(root, "include", "bs_maskgen.h"), LIB]
+    if not (force or _stale(DEMO, deps)):
+        return DEMO
+    inc = ["-I", os.path.join(root, "include"), "-I", os.path.join(root, "tests", "cv_stub")]
+    obj = os.path.join(OBJ, "bs_maskgen_shim.o")
+    cmds = [["g++", "-std=c++17", "-O2", "-fPIC"] + inc + ["-c", shim, "-o", obj],
+            ["g++", "-std=c++17", "-O2"] + inc + [demo_src, obj, "-L", HERE, "-lbsx", "-Wl,-rpath,$ORIGIN", "-o", DEMO]]
+    for c in cmds:
+        if verbose:
+            print(" ".join(c))
+        subprocess.check_call(c)
+    return DEMO
 
 
 if __name__ == "__main__":

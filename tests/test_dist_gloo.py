@@ -1,0 +1,52 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercising the same sharding + counter all-reduce
+bench.py uses on RCCL (the compute itself has no CPU path and is not run here)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from backscrub_amd.dist import reduce_counters, shard_streams
+
+
+def test_shard_streams_partitions_exactly():
+    for total in (1, 7, 256, 8192, 8195):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_streams(total, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            for a, b in zip(blocks, blocks[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    start, end = shard_streams(513, world, rank)
+    frames = (end - start) * 10
+    elapsed = 1.0 + 0.5 * rank
+    out = reduce_counters(frames, elapsed, 1000 + rank)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_counter_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, (frames, elapsed, checksum) in res:
+        assert frames == 5130.0 and elapsed == 1.5 and checksum == 2001
+
+
+def test_reduce_counters_without_group():
+    assert reduce_counters(5, 2.0, 7) == (5.0, 2.0, 7)
