@@ -9,5 +9,5 @@ is missing or no GPU is visible, calls raise.
 """
 from .api import (  # noqa: F401
     BsxError, MaskGen, alpha_blend, bs_maskgen_delete, bs_maskgen_new, bs_maskgen_process, bs_tensorflow_version, lib,
-    lib_path,
+    lib_path, model_describe,
 )

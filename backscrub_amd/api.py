@@ -60,6 +60,7 @@ SYMBOLS = [
     ("bsx_debug_run_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_plan_describe", C.c_char_p, [C.c_void_p]),
     ("bsx_debug_tensor", C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_long]),
+    ("bsx_model_describe", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("bsx_profile_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.c_void_p]),
 ]
 
@@ -259,6 +260,15 @@ def _as_torch(ptr, nbytes, dtype, shape, device):
     torch = _torch()
     typestr = {"uint8": "|u1", "float32": "<f4"}[dtype]
     return torch.as_tensor(_CudaArray(ptr, nbytes, typestr, shape), device="cuda:%d" % device)
+
+
+def model_describe(path: str) -> str:
+    """Parse + plan a model on the host only (no GPU needed); raises BsxError with the loader's message."""
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib().bsx_model_describe(os.fsencode(path), buf, len(buf))
+    if rc != 0:
+        raise BsxError(buf.value.decode(errors="replace"))
+    return buf.value.decode()
 
 
 # ---- reference-named entry points -----------------------------------------------------------------

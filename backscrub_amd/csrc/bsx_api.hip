@@ -464,6 +464,21 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   return j;
 }
 
+int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
+  if (!model_path || !buf || !cap) return BSX_EINVAL;
+  Graph g; Plan p; std::string err, out;
+  int rc = BSX_OK;
+  if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { out = err; rc = BSX_EMODEL; }
+  else {
+    char head[256];
+    snprintf(head, sizeof head, "ops=%d nodes=%d steps=%d macs=%.0f arena_floats=%zu\n", g.n_file_ops, (int)g.nodes.size(), (int)p.steps.size(),
+             p.macs_per_frame, p.arena_floats_per_stream);
+    out = head + p.describe();
+  }
+  snprintf(buf, cap, "%s", out.c_str());
+  return rc;
+}
+
 const char* bsx_plan_describe(bsx_ctx* c) { return c ? c->plan_text.c_str() : ""; }
 
 long bsx_debug_tensor(bsx_ctx* c, int t, float* h_out, long cap) {

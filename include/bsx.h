@@ -140,6 +140,11 @@ const char* bsx_plan_describe(bsx_ctx* ctx);
  * fusion are available); returns element count or negative error.  h_out may be NULL to query the size. */
 long bsx_debug_tensor(bsx_ctx* ctx, int tensor_idx, float* h_out, long cap);
 
+/* Parse a .tflite file and build the fused plan WITHOUT touching a GPU; writes a text description
+ * ("ops=<n> nodes=<n> steps=<n> macs=<per frame> arena_floats=<per stream>" then one line per launch)
+ * into buf (NUL-terminated, truncated to cap).  Returns 0, or BSX_EMODEL with the reason in buf. */
+int bsx_model_describe(const char* model_path, char* buf, size_t cap);
+
 /* ---- measurement ---- */
 typedef struct bsx_launch_stat {
   char name[64];      /* kernel / fused step label */

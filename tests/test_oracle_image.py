@@ -1,0 +1,191 @@
+"""Pins for the CPU oracle's integer / image stages: independent numpy re-derivations of the published
+OpenCV 8-bit formulas, exhaustive integer identities, the geometry table of SURVEY.md §8, and the
+edge cases the domain has (tiny / ragged sizes, identity resize, exact 2x area case, IIR steady state)."""
+import numpy as np
+import pytest
+
+from conftest import MODEL_KEYS, model_path
+
+
+# ---- geometry (lib/libbackscrub.cc:234-246) ------------------------------------------------------
+GEOMETRY = [  # frame, model key, roidim, in_roidim  — SURVEY.md §8 table
+    ((640, 480), "mlkit", (80, 0, 480, 480), (0, 0, 256, 256)),
+    ((640, 480), "lite", (0, 0, 640, 480), (16, 0, 128, 96)),
+    ((640, 480), "deeplab", (80, 0, 480, 480), (0, 0, 257, 257)),
+    ((1280, 720), "mlkit", (280, 0, 720, 720), (0, 0, 256, 256)),
+    ((1280, 720), "full", (0, 0, 1280, 720), (0, 0, 256, 144)),
+    ((1280, 720), "lite", (40, 0, 1200, 720), (0, 0, 160, 96)),
+    ((640, 480), "full", (0, 0, 640, 480), (32, 0, 192, 144)),
+]
+
+
+@pytest.mark.parametrize("res,key,roi,in_roi", GEOMETRY)
+def test_geometry_table(oracle, res, key, roi, in_roi):
+    c = oracle.Ctx(model_path(key), *res)
+    assert c.roidim == roi and c.in_roidim == in_roi
+    assert c.mask().min() == 255          # :248 mask starts all-background
+    c.close()
+
+
+# ---- resize: independent vectorised numpy statement of OpenCV's 8u INTER_LINEAR -------------------
+def _np_resize(src, dw, dh):
+    sh, sw = src.shape[:2]
+    if (sw, sh) == (dw, dh):
+        return src.copy()
+    s = src.astype(np.int64).reshape(sh, sw, -1)
+    sx_, sy_ = 1.0 / (dw / sw), 1.0 / (dh / sh)
+    if sx_ == 2.0 and sy_ == 2.0:
+        out = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+        return out.astype(np.uint8).reshape((dh, dw) + src.shape[2:])
+
+    def coeffs(d, sc, n, clamp):
+        f = ((np.arange(d) + 0.5) * sc - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        f = (f - i.astype(np.float32)).astype(np.float32)
+        if clamp:
+            lo, hi = i < 0, i >= n - 1
+            f[lo | hi] = 0
+            i[lo] = 0
+            i[hi] = n - 1
+        a1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        return i, a0, a1
+
+    xi, xa0, xa1 = coeffs(dw, sx_, sw, True)
+    yi, yb0, yb1 = coeffs(dh, sy_, sh, False)
+    xi1 = np.minimum(xi + 1, sw - 1)
+    y0, y1 = np.clip(yi, 0, sh - 1), np.clip(yi + 1, 0, sh - 1)
+    h = s[:, xi] * xa0[None, :, None] + s[:, xi1] * xa1[None, :, None]
+    r0, r1 = h[y0], h[y1]
+    out = (((yb0[:, None, None] * (r0 >> 4)) >> 16) + ((yb1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8).reshape((dh, dw) + src.shape[2:])
+
+
+@pytest.mark.parametrize("src,dst,cn", [((480, 480), (256, 256), 3), ((640, 480), (128, 96), 3), ((128, 96), (640, 480), 1),
+                                        ((256, 144), (1280, 720), 1), ((1200, 859), (640, 480), 3), ((1280, 960), (640, 480), 3),
+                                        ((7, 5), (31, 17), 1), ((31, 17), (7, 5), 3), ((2, 2), (9, 9), 1), ((64, 48), (64, 48), 3)])
+def test_resize_matches_numpy_restatement(oracle, src, dst, cn):
+    rng = np.random.default_rng(src[0] * 131 + dst[0])
+    img = rng.integers(0, 256, (src[1], src[0], cn) if cn > 1 else (src[1], src[0]), dtype=np.uint8)
+    got = oracle.resize_linear(img, dst[0], dst[1])
+    assert np.array_equal(got, _np_resize(img, dst[0], dst[1]))
+
+
+def test_resize_constant_image_stays_constant(oracle):
+    for v in (0, 1, 127, 254, 255):
+        img = np.full((37, 53, 3), v, np.uint8)
+        assert (oracle.resize_linear(img, 200, 150) == v).all()
+        assert (oracle.resize_linear(img, 11, 9) == v).all()
+
+
+# ---- blur 5x5: (s+12)/25 with REFLECT_101 ------------------------------------------------------------
+def test_blur_is_rounded_box_mean(oracle):
+    rng = np.random.default_rng(5)
+    for shape in ((480, 640), (5, 7), (9, 3), (64, 64)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        p = np.pad(img.astype(np.int64), 2, mode="reflect")
+        s = sum(p[j:j + shape[0], i:i + shape[1]] for j in range(5) for i in range(5))
+        assert np.array_equal(oracle.blur5(img), ((s + 12) // 25).astype(np.uint8))
+    # the identity round(s/25) == (s+12)//25 over the whole range (no ties: 25 is odd)
+    s = np.arange(0, 25 * 255 + 1)
+    assert np.array_equal(np.rint(s * (1.0 / 25)).astype(np.int64), (s + 12) // 25)
+
+
+# ---- alpha blend (app/deepseg.cc:108-134) --------------------------------------------------------------
+def test_blend_truncating_divide_and_endpoints(oracle):
+    rng = np.random.default_rng(1)
+    bg, fr = rng.integers(0, 256, (2, 33, 47, 3), dtype=np.uint8)
+    m = rng.integers(0, 256, (33, 47), dtype=np.uint8)
+    m[0] = 255
+    m[1] = 0
+    out = oracle.alpha_blend(bg, fr, m)
+    want = (bg.astype(np.int64) * m[..., None] + fr.astype(np.int64) * (255 - m[..., None].astype(np.int64))) // 255
+    assert np.array_equal(out, want.astype(np.uint8))
+    assert np.array_equal(out[0], bg[0]) and np.array_equal(out[1], fr[1])   # 255 ⇒ background, 0 ⇒ camera
+
+
+# ---- decode + IIR (lib/libbackscrub.cc:317-357) -----------------------------------------------------------
+def test_iir_reaches_steady_state_in_three_frames(oracle):
+    prob = np.full((4, 4, 1), 0.1, np.float32)          # "not a person" → val 255
+    o = np.zeros((4, 4), np.uint8)
+    seq = []
+    for _ in range(4):
+        o = oracle.decode_iir(2, prob, o)
+        seq.append(int(o[0, 0]))
+    assert seq == [0xE0, 0xFC, 0xFF, 0xFF]
+    prob[:] = 0.9                                        # person → val 0
+    seq = []
+    for _ in range(4):
+        o = oracle.decode_iir(2, prob, o)
+        seq.append(int(o[0, 0]))
+    assert seq == [0x1F, 0x03, 0x00, 0x00]
+
+
+def test_decode_rules(oracle):
+    z = np.zeros((1, 6), np.uint8)
+    # MLKit: strictly greater than the DOUBLE literal 0.65 (float32(0.65) < 0.65 → background)
+    p = np.array([[0.65, np.nextafter(np.float32(0.65), np.float32(1)), 0.6499, 0.66, np.nan, 1.0]], np.float32)[..., None]
+    assert (oracle.decode_iir(2, p, z)[0] >> 5).tolist() == [7, 0, 7, 0, 7, 0]
+    # Meet: softmax-2 compare; ties, overflow (inf/inf = NaN → background) and NaN go to 255
+    l = np.array([[[0, 1], [1, 0], [2, 2], [100, 101], [-200, -201], [np.nan, 1]]], np.float32)
+    assert (oracle.decode_iir(3, l, z)[0] >> 5).tolist() == [0, 7, 7, 7, 7, 7]
+    # DeepLab: first maximum wins, person = class 15, everything below -10000 selects class 0
+    d = np.zeros((1, 3, 21), np.float32)
+    d[0, 0, 15] = 1
+    d[0, 1, 15] = 1
+    d[0, 1, 3] = 1          # earlier class with the same value wins
+    d[0, 2, :] = -20000      # nothing beats the initial -10000 → maxpos stays 0
+    assert (oracle.decode_iir(1, d, np.zeros((1, 3), np.uint8))[0] >> 5).tolist() == [0, 7, 7]
+
+
+# ---- bilateral: independent float32 numpy statement in the same tap order -------------------------------------
+def test_bilateral_matches_numpy_restatement(oracle):
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8)
+    img[:8] = (rng.integers(0, 256, (8, 31, 1)) // 8 * 8).astype(np.uint8)   # smooth-ish part
+    got = oracle.bilateral(img)
+    lut = np.exp(np.arange(768, dtype=np.float64) ** 2 * (-0.5 / 100.0 ** 2)).astype(np.float32)
+    taps = [(i, j) for i in range(-2, 3) for j in range(-2, 3) if np.sqrt(i * i + j * j) <= 2]
+    assert len(taps) == 13
+    p = np.pad(img, ((2, 2), (2, 2), (0, 0)), mode="reflect").astype(np.int32)
+    c = img.astype(np.int32)
+    acc = np.zeros(img.shape, np.float32)
+    ws = np.zeros(img.shape[:2], np.float32)
+    for i, j in taps:
+        nb = p[2 + i:2 + i + img.shape[0], 2 + j:2 + j + img.shape[1]]
+        w = np.float32(np.exp((i * i + j * j) * (-0.5 / 100.0 ** 2))) * lut[np.abs(nb - c).sum(-1)]
+        acc = acc + nb.astype(np.float32) * w[..., None]
+        ws = ws + w
+    want = np.rint(acc * (np.float32(1) / ws)[..., None]).astype(np.uint8)
+    assert np.array_equal(got, want)
+    flat = np.full((9, 9, 3), 77, np.uint8)
+    assert np.array_equal(oracle.bilateral(flat), flat)
+
+
+# ---- YUYV packer (app/deepseg.cc:87-106) --------------------------------------------------------------------------
+def test_yuyv_layout_and_formula(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (4, 8, 3), dtype=np.uint8)
+    out = oracle.bgr_to_yuyv(img).reshape(-1, 4)
+    a = img.reshape(-1, 3).astype(np.int64)
+    R, G, B = a[:, 0], a[:, 1], a[:, 2]                    # RGB2YUV applied to BGR-ordered bytes
+    Y = (R * 4899 + G * 9617 + B * 1868 + 8192) >> 14
+    U = np.clip(((B - Y) * 8061 + (128 << 14) + 8192) >> 14, 0, 255)
+    V = np.clip(((R - Y) * 14369 + (128 << 14) + 8192) >> 14, 0, 255)
+    assert np.array_equal(out[:, 0], Y[0::2]) and np.array_equal(out[:, 2], Y[1::2])
+    assert np.array_equal(out[:, 1], (V[0::2] + V[1::2]) // 2) and np.array_equal(out[:, 3], (U[0::2] + U[1::2]) // 2)
+
+
+# ---- whole context: persistent border, determinism ------------------------------------------------------------------
+def test_context_is_deterministic_and_border_persists(oracle):
+    from backscrub_amd import synth
+    path = model_path("mlkit")
+    a, b = oracle.Ctx(path, 640, 480), oracle.Ctx(path, 640, 480)
+    for t in range(3):
+        f = synth.frame(640, 480, 1, t)
+        ma, mb = a.process(f), b.process(f)
+        assert np.array_equal(ma, mb)
+    x, _, w, _ = a.roidim
+    assert (ma[:, :x] == 255).all() and (ma[:, x + w:] == 255).all()
+    a.close()
+    b.close()

@@ -1,0 +1,75 @@
+"""The product's C++ .tflite loader + planner, exercised on the host only (bsx_model_describe needs no GPU)."""
+import os
+import re
+
+import pytest
+
+from conftest import MODEL_KEYS, ROOT, model_path, synthetic_model_path
+
+# MMAC per frame of the four shipped graphs
+MACS = {"lite": 14.0e6, "full": 33.5e6, "mlkit": 59.2e6, "deeplab": 725.8e6}
+
+
+@pytest.fixture(scope="module")
+def bs():
+    from backscrub_amd import build
+    build.build()
+    import backscrub_amd
+    return backscrub_amd
+
+
+@pytest.mark.parametrize("key", list(MODEL_KEYS))
+@pytest.mark.parametrize("real", [True, False])
+def test_loader_and_planner_agree_with_python_reader(bs, key, real):
+    from backscrub_amd import tflite_io
+    path = model_path(key, prefer_real=real)
+    m = tflite_io.load(path)
+    txt = bs.model_describe(path)
+    head = dict(kv.split("=") for kv in txt.splitlines()[0].split())
+    assert int(head["ops"]) == len(m.ops)
+    assert int(head["nodes"]) == sum(1 for o in m.ops if o.name != "DEQUANTIZE")
+    assert abs(float(head["macs"]) - MACS[key]) / MACS[key] < 0.01
+    steps = txt.splitlines()[1:]
+    assert int(head["steps"]) == len(steps) < int(head["nodes"])       # fusion happened
+    # every activation op was folded into its producer in the Meet/MLKit graphs
+    if key != "deeplab":
+        assert not any(re.search(r"\bact#", s) for s in steps)
+        assert sum("scale=-1" not in s for s in steps) >= 5            # SE multiplies folded into the projection convs
+
+
+def test_unknown_or_corrupt_files_fail_cleanly(bs, tmp_path):
+    good = open(synthetic_model_path("lite"), "rb").read()
+    with pytest.raises(bs.BsxError, match="unable to load model"):
+        bs.model_describe(str(tmp_path / "missing.tflite"))
+    for cut in (0, 3, 15, 64, 1000, len(good) // 2, len(good) - 1):
+        p = tmp_path / ("cut%d.tflite" % cut)
+        p.write_bytes(good[:cut])
+        with pytest.raises(bs.BsxError):
+            bs.model_describe(str(p))
+    # flipped bytes in the header region must never crash the process
+    import random
+    rnd = random.Random(1)
+    for k in range(40):
+        b = bytearray(good)
+        for _ in range(8):
+            b[rnd.randrange(0, 4096)] = rnd.randrange(256)
+        p = tmp_path / ("fuzz%d.tflite" % k)
+        p.write_bytes(bytes(b))
+        try:
+            bs.model_describe(str(p))
+        except bs.BsxError:
+            pass
+
+
+def test_unsupported_operator_is_reported(bs, tmp_path):
+    from backscrub_amd import tflite_io as T
+    from tools import make_synthetic_model as S
+    m = S.build("lite")
+    for op in m.ops:
+        if op.name == "HARD_SWISH":
+            op.code, op.name = 25, "SOFTMAX"   # a builtin the path does not implement
+            break
+    p = tmp_path / "segm_softmax.tflite"
+    T.save(m, str(p))
+    with pytest.raises(bs.BsxError, match="unsupported builtin operator code 25"):
+        bs.model_describe(str(p))
