@@ -93,18 +93,28 @@ struct bsx_ctx {
   // device state
   hipStream_t own_stream = nullptr;
   float* d_arena = nullptr;
+  float* d_net_in = nullptr;        // network input  [n][inH][inW][inC] f32 (written by the prep kernels)
+  float* d_net_out = nullptr;       // network output [n][outH][outW][outC] f32 (read by the decode kernel)
   float* d_weights = nullptr;
   uint32_t* d_canvas = nullptr;
   uint8_t* d_ofinal = nullptr;
   uint8_t* d_masks = nullptr;
   uint8_t* d_host_frame = nullptr;  // staging for bsx_process_host
   float* d_color_lut = nullptr;
+  MicroOp* d_program = nullptr;     // per-frame network program (kernels_frame.hip)
+  bool use_program = false;
   BilateralParams bilateral{};
   DevResizeTab tab_down, tab_up;
   std::map<std::pair<std::pair<int, int>, std::pair<int, int>>, DevResizeTab> bg_tabs;
   std::string last_error, plan_text;
 
-  float* tensor_ptr(int t) const { return d_arena + (size_t)plan.tensor_off[t] * (size_t)n_streams; }
+  // stream-0 view of a graph tensor (network input/output have dedicated buffers; intermediates are batch-major in
+  // the per-launch path and frame-major — frame 0 first — in the per-frame program)
+  float* tensor_ptr(int t) const {
+    if (t == plan.input) return d_net_in;
+    if (t == plan.output) return d_net_out;
+    return use_program ? d_arena + plan.tensor_off[t] : d_arena + (size_t)plan.tensor_off[t] * (size_t)n_streams;
+  }
 };
 
 namespace {
@@ -158,8 +168,16 @@ int init_device_state(bsx_ctx* c) {
   BSX_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   const size_t N = (size_t)c->n_streams;
   BSX_HIP(c, hipMalloc(&c->d_arena, c->plan.arena_floats_per_stream * N * sizeof(float)));
+  BSX_HIP(c, hipMalloc(&c->d_net_in, N * c->inW * c->inH * c->inC * sizeof(float)));
+  BSX_HIP(c, hipMalloc(&c->d_net_out, N * c->outW * c->outH * c->outC * sizeof(float)));
   BSX_HIP(c, hipMalloc(&c->d_weights, std::max<size_t>(c->plan.weights.size(), 4) * sizeof(float)));
   BSX_HIP(c, hipMemcpy(c->d_weights, c->plan.weights.data(), c->plan.weights.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->use_program = !c->plan.program.empty() && getenv("BSX_NO_FRAME_PROGRAM") == nullptr;
+  if (c->use_program) {
+    BSX_HIP(c, hipMalloc(&c->d_program, c->plan.program.size() * sizeof(MicroOp)));
+    BSX_HIP(c, hipMemcpy(c->d_program, c->plan.program.data(), c->plan.program.size() * sizeof(MicroOp), hipMemcpyHostToDevice));
+    BSX_HIP(c, frame_program_prepare(c->plan.program_lds_floats));
+  }
   BSX_HIP(c, hipMalloc(&c->d_canvas, N * c->inW * c->inH * sizeof(uint32_t)));
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
   BSX_HIP(c, hipMalloc(&c->d_masks, N * c->width * c->height));
@@ -204,7 +222,12 @@ int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s) {
   return BSX_OK;
 }
 int run_infer(bsx_ctx* c, int n, hipStream_t s) {
-  for (const Step& st : c->plan.steps) BSX_HIP(c, launch_step(st, c->plan, c->d_arena, c->d_weights, n, c->n_streams, s));
+  if (c->use_program) {
+    BSX_HIP(c, launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena,
+                                    (long)c->plan.arena_floats_per_stream, c->d_net_in, c->d_net_out, c->d_weights, n, s));
+    return BSX_OK;
+  }
+  for (const Step& st : c->plan.steps) BSX_HIP(c, launch_step(st, c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s));
   return BSX_OK;
 }
 int run_decode(bsx_ctx* c, int n, hipStream_t s) {
@@ -275,6 +298,13 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
   }
   if (init_device_state(c.get()) != BSX_OK) { bsx_ctx* raw = c.release(); bsx_delete(raw); return nullptr; }
   c->plan_text = c->plan.describe();
+  {
+    char line[256];
+    snprintf(line, sizeof line, "frame program: %s, %zu micro-ops, LDS %d floats (%.1f KiB), %d tensors in LDS, %d in HBM\n",
+             c->use_program ? "ON" : "off", c->plan.program.size(), c->plan.program_lds_floats, c->plan.program_lds_floats / 256.0,
+             c->plan.program_lds_tensors, c->plan.program_global_tensors);
+    c->plan_text += line;
+  }
   return c.release();
 }
 
@@ -282,7 +312,7 @@ void bsx_delete(bsx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* ptrs[] = {c->d_arena, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_color_lut, c->tab_down.mem, c->tab_up.mem};
+  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -296,7 +326,7 @@ int bsx_get_info(const bsx_ctx* c, bsx_info* o) {
   o->in_w = c->inW; o->in_h = c->inH; o->in_c = c->inC; o->out_w = c->outW; o->out_h = c->outH; o->out_c = c->outC;
   int r[4] = {c->roi.x, c->roi.y, c->roi.w, c->roi.h}, q[4] = {c->in_roi.x, c->in_roi.y, c->in_roi.w, c->in_roi.h};
   memcpy(o->roi, r, sizeof r); memcpy(o->in_roi, q, sizeof q);
-  o->n_ops = c->graph.n_file_ops; o->n_steps = (int)c->plan.steps.size(); o->device = c->device;
+  o->n_ops = c->graph.n_file_ops; o->n_steps = c->use_program ? 1 : (int)c->plan.steps.size(); o->device = c->device;
   o->norm_scale = c->norm_scale; o->norm_offset = c->norm_offset;
   o->nn_flops_per_frame = 2.0 * c->plan.macs_per_frame;
   o->act_bytes_per_stream = c->plan.arena_floats_per_stream * sizeof(float);
@@ -412,7 +442,8 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
                       bsx_launch_stat* out, int cap, void* stream) {
   if (!c || !d_frames || !d_bg || !d_out || !out || n <= 0 || n > c->n_streams || iters <= 0) return BSX_EINVAL;
   hipStream_t s = pick(c, stream);
-  const int L = 2 + (int)c->plan.steps.size() + 3;
+  const int n_net = c->use_program ? 1 : (int)c->plan.steps.size();
+  const int L = 2 + n_net + 3;
   if (cap < L) return BSX_EINVAL;
   std::vector<hipEvent_t> ev((size_t)2 * L);
   for (auto& e : ev) BSX_HIP(c, hipEventCreate(&e));
@@ -429,7 +460,11 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     } while (0)
     BSX_TIMED(launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
     BSX_TIMED(launch_prep_bilateral(c->d_canvas, c->tensor_ptr(c->plan.input), c->inW, c->inH, c->bilateral, n, s));
-    for (const Step& st : c->plan.steps) BSX_TIMED(launch_step(st, c->plan, c->d_arena, c->d_weights, n, c->n_streams, s));
+    if (c->use_program)
+      BSX_TIMED(launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena,
+                                     (long)c->plan.arena_floats_per_stream, c->d_net_in, c->d_net_out, c->d_weights, n, s));
+    else
+      for (const Step& st : c->plan.steps) BSX_TIMED(launch_step(st, c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s));
     BSX_TIMED(launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
     BSX_TIMED(launch_mask_upscale_blur(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, n, s));
     BSX_TIMED(launch_blend(d_bg, bg_stride, d_frames, c->d_masks, d_out, (size_t)c->width * c->height, n, s));
@@ -448,6 +483,11 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   // prep_resize: reads the touched part of the ROI (<= 3 B/px of the ROI), writes the 4 B/px canvas
   put(j++, "prep_resize", N * (3.0 * c->roi.w * c->roi.h + 4.0 * canvas), 0);
   put(j++, "prep_bilateral", N * (4.0 * canvas + 12.0 * canvas), 0);
+  if (c->use_program) {
+    // algorithmic bytes of the fused network = its input tensor + its output tensor + the weights once
+    double io = (double)c->inW * c->inH * c->inC + (double)c->outW * c->outH * c->outC;
+    put(j++, "frame_program", N * io * 4.0 + 4.0 * c->plan.weights.size(), N * 2.0 * c->plan.macs_per_frame);
+  } else
   for (const Step& st : c->plan.steps) {
     double in = (double)st.H * st.W * st.Cin, o = (double)st.OH * st.OW * st.Cout, b = 0;
     switch (st.kind) {

@@ -1,0 +1,49 @@
+// frame_program.hpp — the "one workgroup per camera frame" network program.
+//
+// MI355X-first execution of Interpreter::Invoke() (/root/reference/lib/libbackscrub.cc:307):
+// instead of one launch per operator over the whole batch, ONE launch runs the whole fused
+// step list; workgroup f (1024 lanes = 16 waves = one CU) walks the list for frame f with
+// every tensor that fits kept in that CU's 160 KB LDS ([pixel][C+pad] rows, pad chosen so
+// 16-byte row reads are bank-conflict free) and only the few large full-resolution tensors
+// spilled to that frame's slice of the HBM arena.  Streams are independent, so 256 frames
+// occupy the 256 CUs with no inter-workgroup communication at all; squeeze-excite and
+// decoder-gate global pools are plain workgroup reductions.
+//
+// This header is shared by the host planner (plan.cpp) and the device code
+// (kernels_frame.hip): plain PODs only.
+#pragma once
+#include <cstdint>
+
+namespace bsx {
+
+// kLocGlobal = the frame's PRIVATE slice of the HBM arena (frame-major: arena + frame*per_frame + off) — workgroups
+// run ahead of each other, so frames must never share arena bytes; kLocInput/kLocOutput = the batch-major network
+// input / output buffers shared with the image kernels.
+enum LocSpace : int { kLocNone = 0, kLocLds = 1, kLocGlobal = 2, kLocInput = 3, kLocOutput = 4 };
+
+struct Loc {
+  int space = kLocNone;
+  int off = 0;      // LDS: float offset into the dynamic LDS block; global: float offset inside the frame's arena slice (Plan::tensor_off)
+  int stride = 0;   // floats between consecutive pixels
+  int elems = 0;    // per-frame element count (global addressing)
+};
+
+struct MicroOp {
+  int kind = 0;     // StepKind
+  int H = 1, W = 1, Cin = 1, OH = 1, OW = 1, Cout = 1;
+  int kh = 1, kw = 1, sh = 1, sw = 1, dh = 1, dw = 1, pt = 0, pl = 0;
+  int act = 0, elt = 0, bcast1 = 0, align_corners = 0, half_pixel = 0;
+  int cout_pad = 0, cout_tile = 16;
+  int gemv = 0;     // 1: ≤4 output pixels → wave-per-output-channel dot products with [co][ci] weights
+  int n_cat = 0;
+  long long w_off = 0, b_off = 0, w2_off = 0;
+  Loc in0, in1, in2, res, scale, out;
+  Loc cat[4];
+  int cat_c[4] = {0, 0, 0, 0};
+};
+
+constexpr int kFrameThreads = 1024;          // 16 waves: 4 per SIMD
+constexpr int kLdsTotalFloats = 160 * 256;   // 160 KiB
+constexpr int kLdsScratchFloats = 4096;      // reduction scratch at the start of the LDS block (16 KiB)
+
+}  // namespace bsx

@@ -12,7 +12,14 @@ namespace bsx {
 // ---- network -------------------------------------------------------------------------
 // Executes one fused step for `n` streams.  `arena` holds every activation tensor at
 // arena + plan.tensor_off[t] * n_cap (frame i of tensor t at + i * elems(t)).
-hipError_t launch_step(const Step& st, const Plan& plan, float* arena, const float* weights, int n, int n_cap, hipStream_t s);
+// The network input / output tensors live in their own batch-major buffers (net_in / net_out).
+hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
+                       hipStream_t s);
+
+// Whole-network per-frame program (kernels_frame.hip): one 1024-lane workgroup per stream.
+hipError_t frame_program_prepare(int lds_floats);
+hipError_t launch_frame_program(const MicroOp* d_ops, int n_ops, int lds_floats, float* arena, long per_frame_floats, float* net_in, float* net_out,
+                                const float* weights, int n, hipStream_t s);
 
 // ---- image path ----------------------------------------------------------------------
 // Fixed-point bilinear tables of cv::resize(INTER_LINEAR, 8u) for one (src,dst) size pair

@@ -101,6 +101,28 @@ __global__ __launch_bounds__(kThreads) void pw_conv_k(const float* __restrict__ 
   }
 }
 
+// Few pixels (squeeze-excite / gate FCs: one "pixel" per stream): lane = one output value, so a
+// 256-stream batch still fills thousands of lanes instead of one workgroup.
+__global__ __launch_bounds__(kThreads) void pw_small_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ res, const float* __restrict__ scale, float* __restrict__ y, long total,
+                                                      int HW, int Cin, int Cout, int cout_pad, int act) {
+  long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  int co = (int)(i % Cout);
+  long p = i / Cout;
+  const float* xp = x + p * Cin;
+  const float* sp = scale ? scale + (p / HW) * (long)Cin : nullptr;
+  float acc = 0.f;
+  for (int ci = 0; ci < Cin; ci++) {
+    float xv = xp[ci];
+    if (sp) xv *= sp[ci];
+    acc = fmaf(xv, w[(long)ci * cout_pad + co], acc);
+  }
+  float v = act_fn(acc + bias[co], act);
+  if (res) v += res[i];
+  y[i] = v;
+}
+
 // -------------------------------------------------------------------------------------
 // general dense convolution (stem 3x3 s2, anything that is not 1x1 s1): lane = output pixel
 // -------------------------------------------------------------------------------------
@@ -184,7 +206,8 @@ __global__ __launch_bounds__(kThreads) void dw_conv_k(const float* __restrict__ 
 // -------------------------------------------------------------------------------------
 // global average pool: block = (frame, channel-quad chunk); rows of lanes stride the pixels
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void gap_k(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int CG) {
+__global__ __launch_bounds__(kThreads) void gap_k(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int CG, int out_c4_stride,
+                                                 int out_c4_off) {
   __shared__ float4 sm[kThreads];
   const int C4 = C >> 2;
   const int n = blockIdx.x;
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(kThreads) void gap_k(const float* __restrict__ x, f
     for (int r = 1; r < rows; r++) { float4 v = sm[r * CG + cg]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
     float inv = (float)HW;
     t.x /= inv; t.y /= inv; t.z /= inv; t.w /= inv;
-    reinterpret_cast<float4*>(y)[(long)n * C4 + cgi] = t;
+    reinterpret_cast<float4*>(y)[(long)n * out_c4_stride + out_c4_off + cgi] = t;
   }
 }
 
@@ -338,8 +361,14 @@ inline unsigned blocks_for(long total) { return (unsigned)((total + kThreads - 1
 
 }  // namespace
 
-hipError_t launch_step(const Step& st, const Plan& plan, float* arena, const float* weights, int n, int n_cap, hipStream_t s) {
-  auto P = [&](int t) -> float* { return t < 0 ? nullptr : arena + (size_t)plan.tensor_off[t] * (size_t)n_cap; };
+hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
+                       hipStream_t s) {
+  auto P = [&](int t) -> float* {
+    if (t < 0) return nullptr;
+    if (t == plan.input) return net_in;
+    if (t == plan.output) return net_out;
+    return arena + (size_t)plan.tensor_off[t] * (size_t)n_cap;
+  };
   const float* w = weights + st.w_off;
   const float* b = weights + st.b_off;
   switch (st.kind) {
@@ -347,6 +376,11 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, const flo
       long M = (long)n * st.OH * st.OW;
       dim3 grid(blocks_for(M), st.cout_pad / st.cout_tile);
       int HW = st.OH * st.OW;
+      if (M <= 4096) {
+        long total = M * st.Cout;
+        pw_small_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.out), total, HW, st.Cin, st.Cout, st.cout_pad, st.act);
+        break;
+      }
 #define BSX_PW(CT) pw_conv_k<CT><<<grid, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act)
       if (st.cout_tile == 8) BSX_PW(8); else if (st.cout_tile == 16) BSX_PW(16); else BSX_PW(32);
 #undef BSX_PW
@@ -367,11 +401,15 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, const flo
     }
     case StepKind::Gap: {
       if (st.Cin % 4) return hipErrorInvalidValue;
-      int C4 = st.Cin / 4;
-      int CG = 1;
-      while (CG * 2 <= C4 && CG * 2 <= 64) CG *= 2;  // power of two ≤ 64 so rows = 256/CG is exact
-      dim3 grid(n, (C4 + CG - 1) / CG);
-      gap_k<<<grid, kThreads, 0, s>>>(P(st.in0), P(st.out), st.H * st.W, st.Cin, CG);
+      auto one = [&](int tensor, int C, int c_off) {
+        int C4 = C / 4;
+        int CG = 1;
+        while (CG * 2 <= C4 && CG * 2 <= 64) CG *= 2;  // power of two ≤ 64 so rows = 256/CG is exact
+        dim3 grid(n, (C4 + CG - 1) / CG);
+        gap_k<<<grid, kThreads, 0, s>>>(P(tensor), P(st.out), st.H * st.W, C, CG, st.Cout / 4, c_off / 4);
+      };
+      if (st.concat_in.empty()) one(st.in0, st.Cin, 0);
+      else { int off = 0; for (size_t k = 0; k < st.concat_in.size(); k++) { one(st.concat_in[k], st.concat_c[k], off); off += st.concat_c[k]; } }
       break;
     }
     case StepKind::Eltwise: {

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 
 namespace bsx {
@@ -49,6 +50,87 @@ std::string Plan::describe() const {
     s += line;
   }
   return s;
+}
+
+// Lower the step list into the per-frame program: one MicroOp per step, every tensor that fits placed in
+// LDS (liveness-based first fit inside the 160 KiB block), the rest in the frame's slice of the HBM arena.
+static void build_frame_program(const Graph& g, Plan* plan) {
+  plan->program.clear();
+  const int NS = (int)plan->steps.size();
+  const int NT = (int)g.tensors.size();
+  std::vector<int> last(NT, -1);
+  for (int s = 0; s < NS; s++) {
+    const Step& st = plan->steps[s];
+    // steps without a micro-op form → no program (the per-launch path is used instead)
+    if ((st.kind == StepKind::PwConv || st.kind == StepKind::Eltwise || st.kind == StepKind::DwConv || st.kind == StepKind::Gap ||
+         st.kind == StepKind::TConv) && (st.Cin % 4)) return;
+    for (int t : {st.in0, st.in1, st.in2, st.residual, st.in_scale, st.out}) if (t >= 0) last[t] = s;
+    for (int t : st.concat_in) last[t] = s;
+  }
+  last[g.output] = NS + 1;
+  const bool no_lds = getenv("BSX_PROGRAM_NO_LDS") != nullptr;  // debugging: every tensor in the HBM arena
+  std::vector<Loc> loc(NT);
+  struct Blk { int off, len, until; };
+  std::vector<Blk> live;
+  const int cap = kLdsTotalFloats;
+  int high = kLdsScratchFloats;
+  auto place = [&](int t, int s) {
+    if (t < 0 || loc[t].space != kLocNone) return;
+    const TensorInfo& ti = g.tensors[t];
+    int C = ti.dims[3], P = ti.dims[1] * ti.dims[2];
+    Loc l;
+    l.elems = (int)ti.elems();
+    bool lds_ok = (C % 4 == 0) && t != g.input && t != g.output && !no_lds;
+    int pad = ((C / 4) % 2 == 0) ? 4 : 8;          // (C+pad)/4 odd → 16-byte row reads hit distinct bank quads
+    int stride = P > 1 ? C + pad : C;
+    int need = (P * stride + 3) / 4 * 4;
+    if (lds_ok) {
+      live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
+      std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+      int pos = kLdsScratchFloats;
+      for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
+      if (pos + need <= cap) {
+        l.space = kLocLds; l.off = pos; l.stride = stride;
+        live.push_back({pos, need, last[t]});
+        high = std::max(high, pos + need);
+        plan->program_lds_tensors++;
+        loc[t] = l;
+        return;
+      }
+    }
+    l.space = t == g.input ? kLocInput : (t == g.output ? kLocOutput : kLocGlobal);
+    l.off = (int)plan->tensor_off[t]; l.stride = C;
+    plan->program_global_tensors++;
+    loc[t] = l;
+  };
+  plan->program_lds_tensors = plan->program_global_tensors = 0;
+  place(g.input, -1);
+  std::vector<MicroOp> prog;
+  for (int s = 0; s < NS; s++) {
+    const Step& st = plan->steps[s];
+    place(st.out, s);
+    MicroOp m;
+    m.kind = (int)st.kind;
+    m.H = st.H; m.W = st.W; m.Cin = st.Cin; m.OH = st.OH; m.OW = st.OW; m.Cout = st.Cout;
+    m.kh = st.kh; m.kw = st.kw; m.sh = st.sh; m.sw = st.sw; m.dh = st.dh; m.dw = st.dw; m.pt = st.pad_t; m.pl = st.pad_l;
+    m.act = st.act; m.elt = st.elt; m.bcast1 = st.bcast1; m.align_corners = st.align_corners; m.half_pixel = st.half_pixel;
+    m.cout_pad = st.cout_pad; m.cout_tile = st.cout_tile;
+    m.w_off = (long long)st.w_off; m.b_off = (long long)st.b_off; m.w2_off = (long long)st.w2_off;
+    m.gemv = (st.kind == StepKind::PwConv && st.w2_off != 0) ? 1 : 0;
+    auto L = [&](int t) { return t >= 0 ? loc[t] : Loc(); };
+    m.in0 = L(st.in0); m.in1 = L(st.in1); m.in2 = L(st.in2); m.res = L(st.residual); m.scale = L(st.in_scale); m.out = L(st.out);
+    if (st.concat_in.size() > 4) return;
+    m.n_cat = (int)st.concat_in.size();
+    for (int k = 0; k < m.n_cat; k++) { m.cat[k] = L(st.concat_in[k]); m.cat_c[k] = st.concat_c[k]; }
+    if (st.kind == StepKind::PwConv && !m.gemv) {
+      // few pixels → narrower channel tiles so that all 16 waves of the workgroup get work
+      int P = st.OH * st.OW, chunks = (P + 63) / 64;
+      while (m.cout_tile > 8 && chunks * (st.cout_pad / m.cout_tile) < 16 && st.cout_pad % (m.cout_tile / 2) == 0) m.cout_tile /= 2;
+    }
+    prog.push_back(m);
+  }
+  plan->program = std::move(prog);
+  plan->program_lds_floats = high;
 }
 
 bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena) {
@@ -156,6 +238,13 @@ bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena) 
         st.b_off = W.size();
         W.resize(W.size() + st.cout_pad, 0.f);
         if (b) for (int o = 0; o < st.Cout; o++) W[st.b_off + o] = b->f32[o];
+        if (pw && st.OH * st.OW <= 4 && st.Cin % 4 == 0) {  // GEMV form: [co][ci]
+          align_w();
+          st.w2_off = W.size();
+          W.resize(W.size() + (size_t)st.Cout * st.Cin);
+          for (int o = 0; o < st.Cout; o++) for (int c = 0; c < st.Cin; c++)
+            W[st.w2_off + (size_t)o * st.Cin + c] = w.f32[fc ? ((size_t)o * st.Cin + c) : ((size_t)o * st.Cin + c)];
+        }
         st.macs = (double)st.OH * st.OW * st.Cout * st.kh * st.kw * st.Cin;
         st.out = chain_epilogue(n.output);
         st.label = (fc ? "fc#" : "conv#") + std::to_string(n.index);
@@ -233,6 +322,17 @@ bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena) 
         st.in0 = n.inputs[0]; st.out = n.output;
         st.H = x.dims[1]; st.W = x.dims[2]; st.Cin = st.Cout = x.dims[3];
         st.label = "gap#" + std::to_string(n.index);
+        if (st.Cin % 4) return fail("global average pool channels must be a multiple of 4");
+        // GAP(concat(a, b)) == concat(GAP(a), GAP(b)): pool the parts directly, never build the concat
+        if (single_user(st.in0) == i) {
+          for (size_t k = 0; k < steps.size(); k++)
+            if (steps[k].kind == StepKind::Concat && steps[k].out == st.in0) {
+              st.concat_in = steps[k].concat_in; st.concat_c = steps[k].concat_c; st.in0 = st.concat_in[0];
+              steps.erase(steps.begin() + k);
+              st.label = "gapcat#" + std::to_string(n.index);
+              break;
+            }
+        }
         break;
       }
       case OpType::Relu: case OpType::Relu6: case OpType::HardSwish: case OpType::Logistic: {
@@ -340,6 +440,7 @@ bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena) 
   plan->macs_per_frame = 0;
   for (const Step& st : steps) plan->macs_per_frame += st.macs;
   plan->steps = std::move(steps);
+  build_frame_program(g, plan);
   return true;
 }
 

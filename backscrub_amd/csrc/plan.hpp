@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "frame_program.hpp"
 #include "tflite_model.hpp"
 
 namespace bsx {
@@ -35,6 +36,7 @@ struct Step {
   int cout_pad = 0;                   // padded Cout of the packed weights
   int cout_tile = 16;                 // output channels per thread in the conv kernels
   size_t w_off = 0, b_off = 0;        // float offsets into the weight arena
+  size_t w2_off = 0;                  // [co][ci] copy of the weights for single-pixel (GEMV) steps, 0 if absent
   std::vector<int> concat_in;         // Concat: all inputs
   std::vector<int> concat_c;          // Concat: channels of each input
   double macs = 0;                    // per frame
@@ -48,6 +50,10 @@ struct Plan {
   size_t arena_floats_per_stream = 0; // arena size = this * n_streams
   int input = -1, output = -1;
   double macs_per_frame = 0;
+  // whole-network per-frame program (empty when some step has no micro-op form)
+  std::vector<MicroOp> program;
+  int program_lds_floats = 0;         // dynamic LDS the program needs (scratch included)
+  int program_lds_tensors = 0, program_global_tensors = 0;
   std::string describe() const;
 };
 

@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--dump-launches", default="", help="write the per-launch hipEvent table to this file")
     return ap.parse_args()
 
 
@@ -140,7 +141,7 @@ def main():
             "ms_per_step": round(1e3 * max_elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (network) / u8 (image kernels)", "data": "synthetic (%s)" % weights,
             "config": {"workload": "BASELINE configs[1]: batch=%d %dx%d frames, %s, 1 step = prep+network+decode+mask+blend" % (B, W, H, model_name),
-                       "streams_per_gpu": B, "frame": "%dx%d" % (W, H), "model": model_name, "sharding": "streams/%d GPUs, no data-path collective" % world,
+                       "streams_per_gpu": B, "frame": "%dx%d" % (W, H), "network": model_name, "sharding": "streams/%d GPUs, no data-path collective" % world,
                        "launches_per_step": mg.info["n_steps"] + 5},
             "checksum": checksum_all,
         }
@@ -151,6 +152,11 @@ def main():
         for s in stats:
             s["GBps"] = s["bytes"] / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
         tot_ms = sum(s["avg_ms"] for s in stats)
+        if args.dump_launches:
+            with open(args.dump_launches, "w") as f:
+                f.write(mg.plan())
+                for i, s in enumerate(stats):
+                    f.write("%3d %-22s %8.2f us %9.1f GB/s %8.2f GFLOP/s\n" % (i, s["name"], s["avg_ms"] * 1e3, s["GBps"], s["flops"] / max(s["avg_ms"], 1e-9) / 1e6))
         groups = {"prep": 0.0, "network": 0.0, "decode": 0.0, "mask": 0.0, "blend": 0.0}
         for s in stats:
             k = {"prep_resize": "prep", "prep_bilateral": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend"}.get(s["name"], "network")

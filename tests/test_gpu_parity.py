@@ -131,6 +131,36 @@ def test_stages_match_oracle(bs, oracle, key, res, real):
     mg.close()
 
 
+@pytest.mark.parametrize("key", ["lite", "mlkit", "deeplab"])
+def test_per_launch_path_agrees_with_frame_program(bs, oracle, key, monkeypatch):
+    """The network has two executions of the same fused plan: the per-frame LDS program (default) and one
+    launch per step (BSX_NO_FRAME_PROGRAM=1).  Both must meet the logit tolerance against the oracle."""
+    from backscrub_amd import synth
+    path = model_path(key)
+    W, H = VGA
+    f = synth.frame(W, H, 5)
+    oc = oracle.Ctx(path, W, H)
+    oc.prep(f)
+    want = oc.infer()
+    outs = []
+    for no_prog in ("", "1"):
+        if no_prog:
+            monkeypatch.setenv("BSX_NO_FRAME_PROGRAM", "1")
+        else:
+            monkeypatch.delenv("BSX_NO_FRAME_PROGRAM", raising=False)
+        mg = bs.MaskGen(path, W, H, n_streams=2)
+        assert ("frame program: ON" in mg.plan()) == (not no_prog)
+        mg.run_stage(0, _dev(np.stack([f, f])))
+        mg.run_stage(1, n=2)
+        got = mg.output_tensor().cpu().numpy()
+        assert np.array_equal(got[0], got[1])
+        err = float(np.abs(got[0] - want).max()) / max(1.0, float(np.abs(want).max()))
+        assert err < 1e-4, "%s path: rel err %g" % ("per-launch" if no_prog else "program", err)
+        outs.append(got[0])
+        mg.close()
+    oc.close()
+
+
 # --------------------------------------------------------------------------------------------
 # end to end: several frames per stream, temporal state carried on the GPU
 # --------------------------------------------------------------------------------------------
