@@ -60,6 +60,7 @@ SYMBOLS = [
     ("bsx_debug_run_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_plan_describe", C.c_char_p, [C.c_void_p]),
     ("bsx_debug_tensor", C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_long]),
+    ("bsx_debug_program_timeline", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p]),
     ("bsx_model_describe", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("bsx_profile_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.c_void_p]),
 ]
@@ -157,6 +158,16 @@ class MaskGen:
         if k < 0:
             _check(k, self.h, "bsx_profile_batch")
         return [dict(name=arr[i].name.decode(), avg_ms=arr[i].avg_ms, bytes=arr[i].bytes, flops=arr[i].flops) for i in range(k)]
+
+    def program_timeline(self, n=None):
+        """per-micro-op durations (microseconds, workgroup 0) of the per-frame network program"""
+        n = n or self.n_streams
+        cap = 512
+        arr = (C.c_ulonglong * cap)()
+        k = lib().bsx_debug_program_timeline(self.h, n, arr, cap, _stream_ptr())
+        if k < 0:
+            _check(k, self.h, "bsx_debug_program_timeline")
+        return [(arr[i + 1] - arr[i]) / 100.0 for i in range(k)]
 
     def masks(self):
         """torch u8 view [n_streams,H,W] of the lib-owned persistent masks (cf. `mask = ctx.mask`, libbackscrub.cc:374)."""

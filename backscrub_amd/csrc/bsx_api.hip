@@ -504,6 +504,22 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   return j;
 }
 
+int bsx_debug_program_timeline(bsx_ctx* c, int n, unsigned long long* ticks, int cap, void* stream) {
+  if (!c || !ticks || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  if (!c->use_program) return 0;
+  const int L = (int)c->plan.program.size();
+  if (cap < L + 1) return BSX_EINVAL;
+  unsigned long long* d = nullptr;
+  BSX_HIP(c, hipMalloc(&d, (L + 1) * sizeof(unsigned long long)));
+  hipStream_t s = pick(c, stream);
+  BSX_HIP(c, launch_frame_program(c->d_program, L, c->plan.program_lds_floats, c->d_arena, (long)c->plan.arena_floats_per_stream, c->d_net_in,
+                                  c->d_net_out, c->d_weights, n, s, d));
+  BSX_HIP(c, hipStreamSynchronize(s));
+  BSX_HIP(c, hipMemcpy(ticks, d, (L + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return L;
+}
+
 int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
   if (!model_path || !buf || !cap) return BSX_EINVAL;
   Graph g; Plan p; std::string err, out;

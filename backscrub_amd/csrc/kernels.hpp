@@ -19,7 +19,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
 // Whole-network per-frame program (kernels_frame.hip): one 1024-lane workgroup per stream.
 hipError_t frame_program_prepare(int lds_floats);
 hipError_t launch_frame_program(const MicroOp* d_ops, int n_ops, int lds_floats, float* arena, long per_frame_floats, float* net_in, float* net_out,
-                                const float* weights, int n, hipStream_t s);
+                                const float* weights, int n, hipStream_t s, unsigned long long* timeline = nullptr);
 
 // ---- image path ----------------------------------------------------------------------
 // Fixed-point bilinear tables of cv::resize(INTER_LINEAR, 8u) for one (src,dst) size pair

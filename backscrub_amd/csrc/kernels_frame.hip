@@ -1,13 +1,25 @@
 // kernels_frame.hip — the per-frame network program (see frame_program.hpp).
 //
 // One 1024-lane workgroup = one camera frame = one CU.  The workgroup interprets the fused step
-// list; tensors live in the CU's LDS ([pixel][C+pad] rows) unless the planner spilled them to
-// the frame's slice of the HBM arena.  Weights are read with wave-uniform addresses (scalar
-// loads + SGPR-operand FMAs): a wave always works on ONE output-channel tile, lanes are pixels.
+// list; tensors live in the CU's LDS ([pixel][C+pad] rows) unless the planner spilled them to the
+// frame's private slice of the HBM arena.
+//
+// gfx950 notes that shaped this file (all measured with tools/program_timeline.py):
+//  * generic ("flat") loads that land in LDS run at a small fraction of the ds_read rate, so every
+//    operand is accessed through an address-space-typed reference (`Ref`): ds_read/ds_write for
+//    LDS tensors, global_load/store for spilled ones, chosen by a wave-uniform branch;
+//  * a layer's weights are read by all 16 waves — they are staged ONCE per op into a 16 KiB LDS
+//    scratch with a coalesced cooperative copy and then read by broadcast (same address across the
+//    wave); only layers whose block does not fit use wave-uniform scalar loads (constant address
+//    space → s_load + SGPR-operand FMAs);
+//  * the micro-op table itself is read through the constant address space so that dims/offsets stay
+//    in SGPRs and every branch on them is scalar.
 //
 // Numerics are those of the per-launch kernels (kernels_nn.hip): ci-ascending FMA chains with the
 // bias added last, un-contracted bilinear taps; only the single-pixel GEMV steps and the global
 // average pools use tree reductions.
+#include <cstdlib>
+
 #include "frame_program.hpp"
 #include "kernels.hpp"
 
@@ -15,6 +27,23 @@ namespace bsx {
 namespace {
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
+
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(1))) float glb_f;
+// HIP's float4 is a class; address-space-qualified accesses use the builtin vector type underneath
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f4v lds_v4;
+typedef __attribute__((address_space(1))) f4v glb_v4;
+typedef __attribute__((address_space(4))) const float cfloat_t;
+typedef __attribute__((address_space(4))) const MicroOp cop_t;
+typedef __attribute__((address_space(4))) const Loc cloc_t;
+
+__device__ __forceinline__ cfloat_t* as_const(const float* p) { return (cfloat_t*)p; }
+__device__ __forceinline__ lds_f* lds_base() { return (lds_f*)smem; }
+__device__ __forceinline__ float4 ld_lds4(const lds_f* p) { f4v v = *(const lds_v4*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 ld_glb4(const glb_f* p) { f4v v = *(const glb_v4*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st_lds4(lds_f* p, float4 v) { f4v t = {v.x, v.y, v.z, v.w}; *(lds_v4*)p = t; }
+__device__ __forceinline__ void st_glb4(glb_f* p, float4 v) { f4v t = {v.x, v.y, v.z, v.w}; *(glb_v4*)p = t; }
 
 struct FrameCtx {
   float* arena;        // this frame's private slice
@@ -24,144 +53,227 @@ struct FrameCtx {
   int frame;
 };
 
+// Address-space-typed tensor reference.  `lds` is wave-uniform, so `ld4`/`st4` compile to one scalar
+// branch around a ds_* or a global_* instruction — never a flat access.
+struct Ref {
+  lds_f* l;
+  glb_f* g;
+  int stride;
+  bool lds, valid;
+};
+
+__device__ __forceinline__ Ref make_ref(cloc_t& loc, const FrameCtx& c) {
+  Ref r;
+  const int space = loc.space, off = loc.off;
+  r.stride = loc.stride;
+  r.valid = space != kLocNone;
+  r.lds = space == kLocLds;
+  r.l = lds_base() + off;
+  float* g = c.arena + off;
+  if (space == kLocInput) g = c.net_in + (size_t)c.frame * (size_t)loc.elems;
+  if (space == kLocOutput) g = c.net_out + (size_t)c.frame * (size_t)loc.elems;
+  r.g = (glb_f*)g;
+  return r;
+}
+__device__ __forceinline__ float4 ld4(const Ref& r, int off) {
+  if (r.lds) return ld_lds4(r.l + off);
+  return ld_glb4(r.g + off);
+}
+__device__ __forceinline__ void st4(const Ref& r, int off, float4 v) {
+  if (r.lds) st_lds4(r.l + off, v); else st_glb4(r.g + off, v);
+}
+// weight fetch: staged LDS copy or the global original (wave-uniform choice)
+__device__ __forceinline__ float4 ldw4(bool staged, const lds_f* l, const glb_f* g, int off) {
+  if (staged) return ld_lds4(l + off);
+  return ld_glb4(g + off);
+}
+__device__ __forceinline__ float ld1(const Ref& r, int off) { return r.lds ? r.l[off] : r.g[off]; }
+__device__ __forceinline__ void st1(const Ref& r, int off, float v) { if (r.lds) r.l[off] = v; else r.g[off] = v; }
+
+// Activations use the hardware exp2/rcp instructions (≈1 ulp) instead of the libm / IEEE-divide expansions: this
+// kernel runs every op exactly once per CU, so its speed floor is instruction-cache misses — code size matters more
+// than ALU work.  (The per-launch kernels in kernels_nn.hip keep the exact forms; both meet the 1e-4 logit bar.)
 __device__ __forceinline__ float fp_act(float v, int act) {
-  switch (act) {
-    case kActRelu: return fmaxf(v, 0.f);
-    case kActRelu6: return fminf(fmaxf(v, 0.f), 6.f);
-    case kActHswish: return v * fminf(6.f, fmaxf(0.f, v + 3.f)) / 6.f;
-    case kActSigmoid: return 1.f / (1.f + expf(-v));
-    default: return v;
-  }
+  if (act == kActNone) return v;
+  if (act == kActSigmoid) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+  const float hi = act == kActRelu ? 3.0e38f : 6.f;
+  if (act == kActHswish) return v * fminf(hi, fmaxf(0.f, v + 3.f)) * 0.16666667163372040f;
+  return fminf(fmaxf(v, 0.f), hi);
 }
-
-typedef __attribute__((address_space(4))) const Loc cloc_t;
-__device__ __forceinline__ float* loc_ptr(cloc_t& l, const FrameCtx& c) {
-  const int space = l.space, off = l.off, elems = l.elems;
-  if (space == kLocLds) return smem + off;
-  if (space == kLocGlobal) return c.arena + off;
-  if (space == kLocInput) return c.net_in + (size_t)c.frame * (size_t)elems;
-  if (space == kLocOutput) return c.net_out + (size_t)c.frame * (size_t)elems;
-  return nullptr;
+__device__ __forceinline__ float4 fp_act4(float4 v, int act) {
+  return make_float4(fp_act(v.x, act), fp_act(v.y, act), fp_act(v.z, act), fp_act(v.w, act));
 }
-
-// Weights never change while a kernel runs: reading them through the CONSTANT address space makes every
-// wave-uniform weight access a scalar load (s_load_dwordx8/16 into SGPRs) regardless of what alias analysis
-// can prove about the generic (LDS-or-HBM) activation pointers around it.
-typedef __attribute__((address_space(4))) const float cfloat_t;
-// The micro-op table is immutable too; reading it through the constant address space keeps every field
-// (dims, offsets, weight bases) wave-uniform in SGPRs — loads through generic pointers would be treated as divergent.
-typedef __attribute__((address_space(4))) const MicroOp cop_t;
-__device__ __forceinline__ cfloat_t* as_const(const float* p) { return (cfloat_t*)p; }
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// ---- 1x1 convolution: wave = (64-pixel chunk, CT-channel tile), lane = pixel ------------------------
-template <int CT>
-__device__ __forceinline__ void mo_pw(cop_t& op, const FrameCtx& c) {
-  const float* x = loc_ptr(op.in0, c);
-  float* y = loc_ptr(op.out, c);
-  const float* res = loc_ptr(op.res, c);
-  const float* sc = loc_ptr(op.scale, c);
+// cooperative global → LDS scratch copy of `nfloats` (multiple of 4) weights followed by `nbias` floats of bias
+__device__ __forceinline__ void stage_weights(const float* w, int nfloats, const float* bias, int nbias) {
+  const glb_v4* gw = (const glb_v4*)w;
+  const glb_v4* gb = (const glb_v4*)bias;
+  lds_v4* s = (lds_v4*)lds_base();
+  for (int i = threadIdx.x; i < (nfloats >> 2); i += kFrameThreads) s[i] = gw[i];
+  for (int i = threadIdx.x; i < ((nbias + 3) >> 2); i += kFrameThreads) s[(nfloats >> 2) + i] = gb[i];
+  __syncthreads();
+}
+
+// ---- 1x1 convolution: wave = (64-pixel chunk, CT-channel tile), lane = pixel ------------------------------
+template <int CT, bool STAGED>
+__device__ __forceinline__ void pw_quad(float (&acc)[CT], const float4 xv, const lds_f* wl, cfloat_t* wc, int cout_pad) {
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if constexpr (STAGED) {
+      float wr[CT];
+      if constexpr (CT >= 4) {
+#pragma unroll
+        for (int t = 0; t < CT; t += 4) {
+          float4 v = ld_lds4(wl + r * cout_pad + t);
+          wr[t] = v.x; wr[t + 1] = v.y; wr[t + 2] = v.z; wr[t + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < CT; t++) wr[t] = wl[r * cout_pad + t];
+      }
+#pragma unroll
+      for (int t = 0; t < CT; t++) acc[t] = fmaf(xs[r], wr[t], acc[t]);
+    } else {
+      cfloat_t* w0 = wc + (size_t)r * cout_pad;     // wave-uniform → s_load, SGPR-operand FMAs
+#pragma unroll
+      for (int t = 0; t < CT; t++) acc[t] = fmaf(xs[r], w0[t], acc[t]);
+    }
+  }
+}
+
+template <int CT, bool STAGED, bool XL>
+__device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
+  constexpr int kPF = 2;
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c), sc = make_ref(op.scale, c);
   const float* w = c.weights + op.w_off;
   const float* bias = c.weights + op.b_off;
-  const int xs = op.in0.stride, ys = op.out.stride, rs = op.res.stride;
   const int P = op.OH * op.OW, chunks = (P + 63) >> 6, tiles = op.cout_pad / CT;
   const int lane = threadIdx.x & 63, nw = kFrameThreads >> 6;
-  const int Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad, act = op.act;
+  const int Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad, act = op.act, nq = Cin >> 2;
+  const int wfloats = Cin * cout_pad;
+  if constexpr (STAGED) stage_weights(w, wfloats, bias, cout_pad);
+  const lds_f* wl = lds_base();
+  const lds_f* bl = lds_base() + wfloats;
+  const bool has_sc = sc.valid;          // SE scale vectors always live in LDS (planner)
   for (int wi = wave_id(); wi < chunks * tiles; wi += nw) {
     const int tile = wi / chunks, chunk = wi - tile * chunks;
     const int p = (chunk << 6) + lane;
     if (p >= P) continue;
     const int co0 = tile * CT;
-    const float* xp = x + (size_t)p * xs;
-    cfloat_t* wp = as_const(w + co0);
+    const int xo = p * x.stride;
     float acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; t++) acc[t] = 0.f;
-    for (int ci = 0; ci < Cin; ci += 4) {
-      float4 xv = *reinterpret_cast<const float4*>(xp + ci);
-      if (sc) {
-        float4 sv = *reinterpret_cast<const float4*>(sc + ci);
-        xv.x *= sv.x; xv.y *= sv.y; xv.z *= sv.z; xv.w *= sv.w;
+    float4 xb[kPF];
+#pragma unroll
+    for (int j = 0; j < kPF; j++) {
+      xb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < nq) {
+        if constexpr (XL) xb[j] = ld_lds4(x.l + xo + 4 * j); else xb[j] = ld_glb4(x.g + xo + 4 * j);
+        if (has_sc) { float4 sv = ld_lds4(sc.l + 4 * j); xb[j].x *= sv.x; xb[j].y *= sv.y; xb[j].z *= sv.z; xb[j].w *= sv.w; }
       }
-      cfloat_t* w0 = wp + (size_t)ci * cout_pad;
-#pragma unroll
-      for (int t = 0; t < CT; t++) acc[t] = fmaf(xv.x, w0[t], acc[t]);
-#pragma unroll
-      for (int t = 0; t < CT; t++) acc[t] = fmaf(xv.y, w0[cout_pad + t], acc[t]);
-#pragma unroll
-      for (int t = 0; t < CT; t++) acc[t] = fmaf(xv.z, w0[2 * cout_pad + t], acc[t]);
-#pragma unroll
-      for (int t = 0; t < CT; t++) acc[t] = fmaf(xv.w, w0[3 * cout_pad + t], acc[t]);
     }
-    float* yp = y + (size_t)p * ys + co0;
-    const float* rp = res ? res + (size_t)p * rs + co0 : nullptr;
-    cfloat_t* bp = as_const(bias + co0);
-    if ((Cout & 3) == 0) {
+    for (int q0 = 0; q0 < nq; q0 += kPF) {
 #pragma unroll
-      for (int t = 0; t < CT; t += 4) {
+      for (int j = 0; j < kPF; j++) {
+        const int q = q0 + j;
+        if (q < nq) {
+          const float4 xv = xb[j];
+          if (q + kPF < nq) {
+            if constexpr (XL) xb[j] = ld_lds4(x.l + xo + 4 * (q + kPF)); else xb[j] = ld_glb4(x.g + xo + 4 * (q + kPF));
+            if (has_sc) { float4 sv = ld_lds4(sc.l + 4 * (q + kPF)); xb[j].x *= sv.x; xb[j].y *= sv.y; xb[j].z *= sv.z; xb[j].w *= sv.w; }
+          }
+          pw_quad<CT, STAGED>(acc, xv, wl + (q * 4) * cout_pad + co0, as_const(w + (size_t)(q * 4) * cout_pad + co0), cout_pad);
+        }
+      }
+    }
+    float bv[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) { if constexpr (STAGED) bv[t] = bl[co0 + t]; else bv[t] = as_const(bias)[co0 + t]; }
+    const int yo = p * y.stride + co0, ro = p * res.stride + co0;
+    if (CT >= 4 && (Cout & 3) == 0) {
+#pragma unroll
+      for (int t = 0; t + 3 < CT; t += 4) {
         if (co0 + t < Cout) {
-          float4 v;
-          v.x = fp_act(acc[t] + bp[t], act); v.y = fp_act(acc[t + 1] + bp[t + 1], act);
-          v.z = fp_act(acc[t + 2] + bp[t + 2], act); v.w = fp_act(acc[t + 3] + bp[t + 3], act);
-          if (rp) { float4 r = *reinterpret_cast<const float4*>(rp + t); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-          *reinterpret_cast<float4*>(yp + t) = v;
+          float4 v = fp_act4(make_float4(acc[t] + bv[t], acc[t + 1] + bv[t + 1], acc[t + 2] + bv[t + 2], acc[t + 3] + bv[t + 3]), act);
+          if (res.valid) { float4 r = ld4(res, ro + t); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+          st4(y, yo + t, v);
         }
       }
     } else {
 #pragma unroll
       for (int t = 0; t < CT; t++) {
         if (co0 + t < Cout) {
-          float v = fp_act(acc[t] + bp[t], act);
-          if (rp) v += rp[t];
-          yp[t] = v;
+          float v = fp_act(acc[t] + bv[t], act);
+          if (res.valid) v += ld1(res, ro + t);
+          st1(y, yo + t, v);
         }
       }
     }
   }
 }
 
-// ---- 1x1 convolution on <= 4 pixels (SE / gate FCs): wave = one output value, lanes split K ----------
+__device__ __forceinline__ void mo_pw(cop_t& op, const FrameCtx& c) {
+  const bool xl = op.in0.space == kLocLds;
+  const bool staged = op.Cin * op.cout_pad + op.cout_pad <= kLdsScratchFloats;
+  if (!staged) { if (xl) pw_body<16, false, true>(op, c); else pw_body<16, false, false>(op, c); }   // planner: tile 16 when not staged
+  else if (op.cout_tile == 4) { if (xl) pw_body<4, true, true>(op, c); else pw_body<4, true, false>(op, c); }
+  else { if (xl) pw_body<16, true, true>(op, c); else pw_body<16, true, false>(op, c); }
+}
+
+// ---- 1x1 convolution on <= 4 pixels (SE / gate FCs): lane = (output channel, K-slice) ----------------------------
+// [ci][co] weight rows are read coalesced across lanes, all of a lane's loads in flight at once; the KS partial
+// sums per output meet in the LDS scratch.  Inputs/outputs of these steps are [1,1,C] vectors → always LDS.
 __device__ __forceinline__ void mo_gemv(cop_t& op, const FrameCtx& c) {
-  const float* x = loc_ptr(op.in0, c);
-  float* y = loc_ptr(op.out, c);
-  const float* res = loc_ptr(op.res, c);
-  const float* sc = loc_ptr(op.scale, c);
-  const float* w = c.weights + op.w2_off;
-  const float* bias = c.weights + op.b_off;
-  const int P = op.OH * op.OW, Cin = op.Cin, Cout = op.Cout;
-  const int lane = threadIdx.x & 63, nw = kFrameThreads >> 6;
-  for (int item = wave_id(); item < P * Cout; item += nw) {
-    const int p = item / Cout, co = item - p * Cout;
-    const float* xp = x + (size_t)p * op.in0.stride;
-    const float* wr = w + (size_t)co * Cin;
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c), sc = make_ref(op.scale, c);
+  const glb_f* w = (const glb_f*)(c.weights + op.w_off);       // [ci][cout_pad]
+  const glb_f* bias = (const glb_f*)(c.weights + op.b_off);
+  const int P = op.OH * op.OW, Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad;
+  int KS = 1;
+  while (KS * 2 * P * Cout <= kFrameThreads && KS * 2 <= 16 && (Cin % (KS * 2)) == 0) KS *= 2;
+  const int items = P * Cout * KS;            // planner guarantees P*Cout*16 <= kLdsScratchFloats
+  lds_f* scratch = lds_base();
+  const int klen = Cin / KS;
+  for (int i = threadIdx.x; i < items; i += kFrameThreads) {
+    const int co = i % Cout, r = i / Cout, p = r % P, ks = r / P;
+    const int xo = p * x.stride + ks * klen;
+    const glb_f* wr = w + (size_t)(ks * klen) * cout_pad + co;
     float acc = 0.f;
-    for (int ci = lane; ci < Cin; ci += 64) {
-      float xv = xp[ci];
-      if (sc) xv *= sc[ci];
-      acc = fmaf(xv, wr[ci], acc);
+#pragma unroll 8
+    for (int k = 0; k < klen; k++) {
+      float xv = ld1(x, xo + k);
+      if (sc.valid) xv *= ld1(sc, ks * klen + k);
+      acc = fmaf(xv, wr[(size_t)k * cout_pad], acc);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) {
-      float v = fp_act(acc + bias[co], op.act);
-      if (res) v += res[(size_t)p * op.res.stride + co];
-      y[(size_t)p * op.out.stride + co] = v;
-    }
+    scratch[i] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P * Cout; i += kFrameThreads) {
+    const int co = i % Cout, p = i / Cout;
+    float acc = 0.f;
+    for (int ks = 0; ks < KS; ks++) acc += scratch[(ks * P + p) * Cout + co];
+    float v = fp_act(acc + bias[co], op.act);
+    if (res.valid) v += ld1(res, p * res.stride + co);
+    st1(y, p * y.stride + co, v);
   }
 }
 
-// ---- dense k x k convolution (network stems): wave = (chunk, 16-channel tile), lane = output pixel ---------
+// ---- dense k x k convolution (network stems): wave = (chunk, 16-channel tile), lane = output pixel ---------------
 __device__ __forceinline__ void mo_conv(cop_t& op, const FrameCtx& c) {
   constexpr int CT = 16;
-  const float* x = loc_ptr(op.in0, c);
-  float* y = loc_ptr(op.out, c);
-  const float* res = loc_ptr(op.res, c);
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c);
   const float* w = c.weights + op.w_off;
   const float* bias = c.weights + op.b_off;
-  const int xs = op.in0.stride, ys = op.out.stride;
   const int P = op.OH * op.OW, chunks = (P + 63) >> 6, tiles = op.cout_pad / CT;
   const int lane = threadIdx.x & 63, nw = kFrameThreads >> 6;
+  const int wfloats = op.kh * op.kw * op.Cin * op.cout_pad;
+  const bool staged = wfloats + op.cout_pad <= kLdsScratchFloats;
+  if (staged) stage_weights(w, wfloats, bias, op.cout_pad);
+  const lds_f* wl = lds_base();
+  const lds_f* bl = lds_base() + wfloats;
   for (int wi = wave_id(); wi < chunks * tiles; wi += nw) {
     const int tile = wi / chunks, chunk = wi - tile * chunks;
     const int p = (chunk << 6) + lane;
@@ -172,68 +284,100 @@ __device__ __forceinline__ void mo_conv(cop_t& op, const FrameCtx& c) {
 #pragma unroll
     for (int t = 0; t < CT; t++) acc[t] = 0.f;
     for (int fy = 0; fy < op.kh; fy++) {
-      int iy = oy * op.sh - op.pt + fy * op.dh;
-      if (iy < 0 || iy >= op.H) continue;
+      const int iy = oy * op.sh - op.pt + fy * op.dh;
+      const bool vy = iy >= 0 && iy < op.H;
+      const int cy = min(max(iy, 0), op.H - 1);
       for (int fx = 0; fx < op.kw; fx++) {
-        int ix = ox * op.sw - op.pl + fx * op.dw;
-        if (ix < 0 || ix >= op.W) continue;
-        const float* xp = x + ((size_t)iy * op.W + ix) * xs;
-        cfloat_t* w0 = as_const(w + (size_t)(fy * op.kw + fx) * op.Cin * op.cout_pad + co0);
+        const int ix = ox * op.sw - op.pl + fx * op.dw;
+        const float m = (vy && ix >= 0 && ix < op.W) ? 1.f : 0.f;    // zero-padding as a multiplier: branch-free taps
+        const int cx = min(max(ix, 0), op.W - 1);
+        const int xo = (cy * op.W + cx) * x.stride;
+        const int wo = (fy * op.kw + fx) * op.Cin * op.cout_pad + co0;
         for (int ci = 0; ci < op.Cin; ci++) {
-          float xv = xp[ci];
+          const float xv = ld1(x, xo + ci) * m;
+          if (staged) {
 #pragma unroll
-          for (int t = 0; t < CT; t++) acc[t] = fmaf(xv, w0[(size_t)ci * op.cout_pad + t], acc[t]);
+            for (int t = 0; t < CT; t += 4) {
+              float4 wv = ld_lds4(wl + wo + ci * op.cout_pad + t);
+              acc[t] = fmaf(xv, wv.x, acc[t]); acc[t + 1] = fmaf(xv, wv.y, acc[t + 1]);
+              acc[t + 2] = fmaf(xv, wv.z, acc[t + 2]); acc[t + 3] = fmaf(xv, wv.w, acc[t + 3]);
+            }
+          } else {
+            cfloat_t* w0 = as_const(w + wo + (size_t)ci * op.cout_pad);
+#pragma unroll
+            for (int t = 0; t < CT; t++) acc[t] = fmaf(xv, w0[t], acc[t]);
+          }
         }
       }
     }
-    float* yp = y + (size_t)p * ys + co0;
+    const int yo = p * y.stride + co0;
 #pragma unroll
     for (int t = 0; t < CT; t++) {
       if (co0 + t < op.Cout) {
-        float v = fp_act(acc[t] + as_const(bias)[co0 + t], op.act);
-        if (res) v += res[(size_t)p * op.res.stride + co0 + t];
-        yp[t] = v;
+        float v = fp_act(acc[t] + (staged ? bl[co0 + t] : as_const(bias)[co0 + t]), op.act);
+        if (res.valid) v += ld1(res, p * res.stride + co0 + t);
+        st1(y, yo + t, v);
       }
     }
   }
 }
 
-// ---- depthwise: lane = (output pixel, channel quad) -----------------------------------------------------------------
-__device__ __forceinline__ void mo_dw(cop_t& op, const FrameCtx& c) {
-  const float* x = loc_ptr(op.in0, c);
-  float* y = loc_ptr(op.out, c);
-  const float* res = loc_ptr(op.res, c);
+// ---- depthwise: lane = (output pixel, channel quad) --------------------------------------------------------------------
+// Weights + bias staged in LDS when they fit; taps are branch-free (clamped address, zeroed weight outside the image:
+// 0 * finite == 0, summation order stays fy, fx ascending).
+template <int K, bool XL>
+__device__ __forceinline__ void dw_body(cop_t& op, const FrameCtx& c) {
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c);
   const float* w = c.weights + op.w_off;
   const float* bias = c.weights + op.b_off;
-  const int C = op.Cin, C4 = C >> 2, xs = op.in0.stride, ys = op.out.stride, rs = op.res.stride;
+  const int C = op.Cin, C4 = C >> 2;
+  const int kh = K ? K : op.kh, kw = K ? K : op.kw, kk = kh * kw;
+  const bool staged = (kk + 1) * C <= kLdsScratchFloats;
+  if (staged) stage_weights(w, kk * C, bias, C);
+  const lds_f* wl = lds_base();
+  const lds_f* bl = lds_base() + kk * C;
+  const glb_f* wg = (const glb_f*)w;
+  const glb_f* bg = (const glb_f*)bias;
   const int total = op.OH * op.OW * C4;
+  const int H = op.H, W = op.W, OW = op.OW, sh = op.sh, sw = op.sw, dh = op.dh, dw = op.dw, pt = op.pt, pl = op.pl, act = op.act;
   for (int i = threadIdx.x; i < total; i += kFrameThreads) {
     const int cq = i % C4, p = i / C4, ch = cq * 4;
-    const int oy = p / op.OW, ox = p - oy * op.OW;
+    const int oy = p / OW, ox = p - oy * OW;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int fy = 0; fy < op.kh; fy++) {
-      int iy = oy * op.sh - op.pt + fy * op.dh;
-      if (iy < 0 || iy >= op.H) continue;
-      for (int fx = 0; fx < op.kw; fx++) {
-        int ix = ox * op.sw - op.pl + fx * op.dw;
-        if (ix < 0 || ix >= op.W) continue;
-        float4 xv = *reinterpret_cast<const float4*>(x + ((size_t)iy * op.W + ix) * xs + ch);
-        float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(fy * op.kw + fx) * C + ch);
+#pragma unroll 1
+    for (int fy = 0; fy < kh; fy++) {
+      const int iy = oy * sh - pt + fy * dh;
+      const bool vy = iy >= 0 && iy < H;
+      const int cy = min(max(iy, 0), H - 1);
+#pragma unroll
+      for (int fx = 0; fx < kw; fx++) {
+        const int ix = ox * sw - pl + fx * dw;
+        const bool v = vy && ix >= 0 && ix < W;
+        const int cx = min(max(ix, 0), W - 1);
+        const int xo = (cy * W + cx) * x.stride + ch;
+        float4 xv;
+        if constexpr (XL) xv = ld_lds4(x.l + xo); else xv = ld_glb4(x.g + xo);
+        float4 wv = ldw4(staged, wl, wg, (fy * kw + fx) * C + ch);
+        if (!v) wv = make_float4(0.f, 0.f, 0.f, 0.f);
         acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
         acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
       }
     }
-    float4 b = *reinterpret_cast<const float4*>(bias + ch);
-    float4 v;
-    v.x = fp_act(acc.x + b.x, op.act); v.y = fp_act(acc.y + b.y, op.act); v.z = fp_act(acc.z + b.z, op.act); v.w = fp_act(acc.w + b.w, op.act);
-    if (res) { float4 r = *reinterpret_cast<const float4*>(res + (size_t)p * rs + ch); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-    *reinterpret_cast<float4*>(y + (size_t)p * ys + ch) = v;
+    const float4 b = ldw4(staged, bl, bg, ch);
+    float4 v = fp_act4(make_float4(acc.x + b.x, acc.y + b.y, acc.z + b.z, acc.w + b.w), act);
+    if (res.valid) { float4 r = ld4(res, p * res.stride + ch); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    st4(y, p * y.stride + ch, v);
   }
 }
+__device__ __forceinline__ void mo_dw(cop_t& op, const FrameCtx& c) {
+  const bool xl = op.in0.space == kLocLds;
+  if (op.kh == 3) { if (xl) dw_body<3, true>(op, c); else dw_body<3, false>(op, c); }     // planner admits 3x3 and 5x5 only
+  else { if (xl) dw_body<5, true>(op, c); else dw_body<5, false>(op, c); }
+}
 
-// ---- global average pool of one input into out[coff .. coff+C) (workgroup reduction through the scratch) ------
-__device__ void gap_one(const float* x, int xs, int HW, int C, float* out, int coff) {
-  float4* scratch = reinterpret_cast<float4*>(smem);  // kLdsScratchFloats = 1024 float4
+// ---- global average pool of one input into out[coff .. coff+C) (workgroup reduction through the scratch) --------
+__device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& out, int coff) {
+  lds_f* scratch = lds_base();  // kLdsScratchFloats = 1024 float4 slots
   const int C4 = C >> 2;
   int CG = 1;
   while (CG * 2 <= C4 && CG * 2 <= 64) CG *= 2;
@@ -244,39 +388,44 @@ __device__ void gap_one(const float* x, int xs, int HW, int C, float* out, int c
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cq < C4)
       for (int p = row; p < HW; p += rows) {
-        float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * xs + cq * 4);
+        float4 v = ld4(x, p * x.stride + cq * 4);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-    scratch[threadIdx.x] = acc;
+    st_lds4(scratch + 4 * threadIdx.x, acc);
     __syncthreads();
-    // tree over rows (rows is a power of two)
-    for (int half = rows >> 1; half > 0; half >>= 1) {
-      if (row < half) {
-        float4 a = scratch[row * CG + cg], b = scratch[(row + half) * CG + cg];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        scratch[row * CG + cg] = a;
+    // reduce the `rows` partial sums 8-to-1 per barrier pair
+    for (int span = rows; span > 1; span = (span + 7) >> 3) {
+      const int groups = (span + 7) >> 3;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < groups) {
+        for (int k = 0; k < 8; k++) {
+          const int r = row * 8 + k;
+          if (r < span) { float4 b = ld_lds4(scratch + 4 * (r * CG + cg)); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        }
       }
+      __syncthreads();
+      if (row < groups) st_lds4(scratch + 4 * (row * CG + cg), a);
       __syncthreads();
     }
     if (row == 0 && cq < C4) {
-      float4 t = scratch[cg];
+      float4 t = ld_lds4(scratch + 4 * cg);
       const float inv = (float)HW;
       t.x /= inv; t.y /= inv; t.z /= inv; t.w /= inv;
-      *reinterpret_cast<float4*>(out + coff + cq * 4) = t;
+      st4(out, coff + cq * 4, t);
     }
     __syncthreads();
   }
 }
 
 __device__ __forceinline__ void mo_gap(cop_t& op, const FrameCtx& c) {
-  float* out = loc_ptr(op.out, c);
+  const Ref out = make_ref(op.out, c);
   const int HW = op.H * op.W;
-  if (op.n_cat == 0) { gap_one(loc_ptr(op.in0, c), op.in0.stride, HW, op.Cin, out, 0); return; }
+  if (op.n_cat == 0) { gap_one(make_ref(op.in0, c), HW, op.Cin, out, 0); return; }
   int coff = 0;
-  for (int k = 0; k < op.n_cat; k++) { gap_one(loc_ptr(op.cat[k], c), op.cat[k].stride, HW, op.cat_c[k], out, coff); coff += op.cat_c[k]; }
+  for (int k = 0; k < op.n_cat; k++) { gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], out, coff); coff += op.cat_c[k]; }
 }
 
-// ---- elementwise ---------------------------------------------------------------------------------------------------------
+// ---- elementwise -----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float elt1(float a, float b, float cc, int e) {
   switch (e) {
     case kEltAdd: return a + b;
@@ -286,25 +435,20 @@ __device__ __forceinline__ float elt1(float a, float b, float cc, int e) {
   }
 }
 __device__ __forceinline__ void mo_elt(cop_t& op, const FrameCtx& c) {
-  const float* a = loc_ptr(op.in0, c);
-  const float* b = loc_ptr(op.in1, c);
-  const float* d = loc_ptr(op.in2, c);
-  float* y = loc_ptr(op.out, c);
-  const int C4 = op.Cin >> 2, total = op.H * op.W * C4;
+  const Ref a = make_ref(op.in0, c), b = make_ref(op.in1, c), d = make_ref(op.in2, c), y = make_ref(op.out, c);
+  const int C4 = op.Cin >> 2, total = op.H * op.W * C4, elt = op.elt, act = op.act, bc = op.bcast1;
   for (int i = threadIdx.x; i < total; i += kFrameThreads) {
     const int cq = i % C4, p = i / C4, ch = cq * 4;
-    float4 av = *reinterpret_cast<const float4*>(a + (size_t)p * op.in0.stride + ch);
+    const float4 av = ld4(a, p * a.stride + ch);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), dv = bv;
-    if (op.elt != kEltUnary) bv = *reinterpret_cast<const float4*>(op.bcast1 ? b + ch : b + (size_t)p * op.in1.stride + ch);
-    if (op.elt == kEltMulAdd) dv = *reinterpret_cast<const float4*>(d + (size_t)p * op.in2.stride + ch);
-    float4 v;
-    v.x = fp_act(elt1(av.x, bv.x, dv.x, op.elt), op.act); v.y = fp_act(elt1(av.y, bv.y, dv.y, op.elt), op.act);
-    v.z = fp_act(elt1(av.z, bv.z, dv.z, op.elt), op.act); v.w = fp_act(elt1(av.w, bv.w, dv.w, op.elt), op.act);
-    *reinterpret_cast<float4*>(y + (size_t)p * op.out.stride + ch) = v;
+    if (elt != kEltUnary) bv = ld4(b, bc ? ch : p * b.stride + ch);
+    if (elt == kEltMulAdd) dv = ld4(d, p * d.stride + ch);
+    float4 v = make_float4(elt1(av.x, bv.x, dv.x, elt), elt1(av.y, bv.y, dv.y, elt), elt1(av.z, bv.z, dv.z, elt), elt1(av.w, bv.w, dv.w, elt));
+    st4(y, p * y.stride + ch, fp_act4(v, act));
   }
 }
 
-// ---- bilinear resize (TFLite reference association) ---------------------------------------------------------------------------
+// ---- bilinear resize (TFLite reference association) -----------------------------------------------------------------------------
 __device__ __forceinline__ void fp_interp(int o, float scale, bool half_pixel, int in_size, float* frac, int* lo, int* hi) {
   float v = half_pixel ? __fadd_rn(__fmul_rn((float)o + 0.5f, scale), -0.5f) : __fmul_rn((float)o, scale);
   float fl = floorf(v);
@@ -320,87 +464,88 @@ __device__ __forceinline__ float fp_bilerp(float x00, float x10, float x01, floa
   return __fadd_rn(__fadd_rn(__fadd_rn(a, b), cc), d);
 }
 __device__ __forceinline__ void mo_resize(cop_t& op, const FrameCtx& c) {
-  const float* x = loc_ptr(op.in0, c);
-  float* y = loc_ptr(op.out, c);
-  const int xs = op.in0.stride, ys = op.out.stride;
-  float hs = (float)op.H / (float)op.OH, ws = (float)op.W / (float)op.OW;
-  if (op.align_corners && op.OH > 1) hs = (float)(op.H - 1) / (float)(op.OH - 1);
-  if (op.align_corners && op.OW > 1) ws = (float)(op.W - 1) / (float)(op.OW - 1);
-  const bool vec = (op.Cin & 3) == 0;
-  const int CV = vec ? op.Cin >> 2 : op.Cin, total = op.OH * op.OW * CV;
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c);
+  const int xs = x.stride, ys = y.stride, H = op.H, W = op.W, OW = op.OW;
+  float hs = (float)H / (float)op.OH, ws = (float)W / (float)OW;
+  if (op.align_corners && op.OH > 1) hs = (float)(H - 1) / (float)(op.OH - 1);
+  if (op.align_corners && OW > 1) ws = (float)(W - 1) / (float)(OW - 1);
+  const bool vec = (op.Cin & 3) == 0, hp = op.half_pixel;
+  const int CV = vec ? op.Cin >> 2 : op.Cin, total = op.OH * OW * CV;
   for (int i = threadIdx.x; i < total; i += kFrameThreads) {
     const int cv = i % CV, p = i / CV;
-    const int oy = p / op.OW, ox = p - oy * op.OW;
+    const int oy = p / OW, ox = p - oy * OW;
     float dy, dx; int y0, y1, x0, x1;
-    fp_interp(oy, hs, op.half_pixel, op.H, &dy, &y0, &y1);
-    fp_interp(ox, ws, op.half_pixel, op.W, &dx, &x0, &x1);
+    fp_interp(oy, hs, hp, H, &dy, &y0, &y1);
+    fp_interp(ox, ws, hp, W, &dx, &x0, &x1);
     if (vec) {
       const int ch = cv * 4;
-      float4 a = *reinterpret_cast<const float4*>(x + ((size_t)y0 * op.W + x0) * xs + ch);
-      float4 b = *reinterpret_cast<const float4*>(x + ((size_t)y1 * op.W + x0) * xs + ch);
-      float4 cc = *reinterpret_cast<const float4*>(x + ((size_t)y0 * op.W + x1) * xs + ch);
-      float4 d = *reinterpret_cast<const float4*>(x + ((size_t)y1 * op.W + x1) * xs + ch);
-      float4 v;
-      v.x = fp_bilerp(a.x, b.x, cc.x, d.x, dy, dx); v.y = fp_bilerp(a.y, b.y, cc.y, d.y, dy, dx);
-      v.z = fp_bilerp(a.z, b.z, cc.z, d.z, dy, dx); v.w = fp_bilerp(a.w, b.w, cc.w, d.w, dy, dx);
-      *reinterpret_cast<float4*>(y + (size_t)p * ys + ch) = v;
+      const float4 a = ld4(x, (y0 * W + x0) * xs + ch), b = ld4(x, (y1 * W + x0) * xs + ch);
+      const float4 cc = ld4(x, (y0 * W + x1) * xs + ch), d = ld4(x, (y1 * W + x1) * xs + ch);
+      st4(y, p * ys + ch, make_float4(fp_bilerp(a.x, b.x, cc.x, d.x, dy, dx), fp_bilerp(a.y, b.y, cc.y, d.y, dy, dx),
+                                      fp_bilerp(a.z, b.z, cc.z, d.z, dy, dx), fp_bilerp(a.w, b.w, cc.w, d.w, dy, dx)));
     } else {
-      y[(size_t)p * ys + cv] = fp_bilerp(x[((size_t)y0 * op.W + x0) * xs + cv], x[((size_t)y1 * op.W + x0) * xs + cv],
-                                          x[((size_t)y0 * op.W + x1) * xs + cv], x[((size_t)y1 * op.W + x1) * xs + cv], dy, dx);
+      st1(y, p * ys + cv, fp_bilerp(ld1(x, (y0 * W + x0) * xs + cv), ld1(x, (y1 * W + x0) * xs + cv), ld1(x, (y0 * W + x1) * xs + cv),
+                                    ld1(x, (y1 * W + x1) * xs + cv), dy, dx));
     }
   }
 }
 
 __device__ __forceinline__ void mo_concat(cop_t& op, const FrameCtx& c) {
-  float* y = loc_ptr(op.out, c);
+  const Ref y = make_ref(op.out, c);
   const int P = op.OH * op.OW;
   int coff = 0;
   for (int k = 0; k < op.n_cat; k++) {
-    const float* x = loc_ptr(op.cat[k], c);
+    const Ref x = make_ref(op.cat[k], c);
     const int C4 = op.cat_c[k] >> 2, total = P * C4;
     for (int i = threadIdx.x; i < total; i += kFrameThreads) {
       const int cq = i % C4, p = i / C4;
-      *reinterpret_cast<float4*>(y + (size_t)p * op.out.stride + coff + cq * 4) =
-          *reinterpret_cast<const float4*>(x + (size_t)p * op.cat[k].stride + cq * 4);
+      st4(y, p * y.stride + coff + cq * 4, ld4(x, p * x.stride + cq * 4));
     }
     coff += op.cat_c[k];
   }
 }
 
-// ---- Convolution2DTransposeBias, kernel == stride ---------------------------------------------------------------------------------
+// ---- Convolution2DTransposeBias, kernel == stride ------------------------------------------------------------------------------------
 __device__ __forceinline__ void mo_tconv(cop_t& op, const FrameCtx& c) {
-  const float* x = loc_ptr(op.in0, c);
-  float* y = loc_ptr(op.out, c);
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c);
   const float* w = c.weights + op.w_off;
   const float* bias = c.weights + op.b_off;
-  const int C4 = op.Cin >> 2, P = op.OH * op.OW;
+  const int C4 = op.Cin >> 2, P = op.OH * op.OW, Cout = op.Cout, Cin = op.Cin, kh = op.kh, kw = op.kw, OW = op.OW, W = op.W;
+  const int wfloats = kh * kw * Cout * Cin;
+  const bool staged = wfloats + Cout <= kLdsScratchFloats;
+  if (staged) stage_weights(w, wfloats, bias, Cout);
+  const lds_f* wl = lds_base();
+  const lds_f* bl = lds_base() + wfloats;
+  const glb_f* wg = (const glb_f*)w;
   for (int p = threadIdx.x; p < P; p += kFrameThreads) {
-    const int oy = p / op.OW, ox = p - oy * op.OW;
-    const int iy = oy / op.kh, fy = oy % op.kh, ix = ox / op.kw, fx = ox % op.kw;
-    const float* xp = x + ((size_t)iy * op.W + ix) * op.in0.stride;
-    for (int oc = 0; oc < op.Cout; oc++) {
-      const float* wp = w + ((size_t)(fy * op.kw + fx) * op.Cout + oc) * op.Cin;
-      float acc = bias[oc];
+    const int oy = p / OW, ox = p - oy * OW;
+    const int iy = oy / kh, fy = oy % kh, ix = ox / kw, fx = ox % kw;
+    const int xo = (iy * W + ix) * x.stride;
+    for (int oc = 0; oc < Cout; oc++) {
+      const int wo = ((fy * kw + fx) * Cout + oc) * Cin;
+      float acc = staged ? bl[oc] : as_const(bias)[oc];
       for (int q = 0; q < C4; q++) {
-        float4 xv = *reinterpret_cast<const float4*>(xp + q * 4), wv = *reinterpret_cast<const float4*>(wp + q * 4);
+        const float4 xv = ld4(x, xo + q * 4);
+        const float4 wv = ldw4(staged, wl, wg, wo + q * 4);
         acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
       }
-      y[(size_t)p * op.out.stride + oc] = fp_act(acc, op.act);
+      st1(y, p * y.stride + oc, fp_act(acc, op.act));
     }
   }
 }
 
 __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* __restrict__ ops, int n_ops, float* arena, long per_frame_floats,
-                                                                float* net_in, float* net_out, const float* __restrict__ weights) {
+                                                                float* net_in, float* net_out, const float* __restrict__ weights,
+                                                                unsigned long long* timeline, int repeat) {
   FrameCtx c{arena + (size_t)blockIdx.x * (size_t)per_frame_floats, net_in, net_out, weights, (int)blockIdx.x};
+  for (int rep = 0; rep < repeat; rep++)      // repeat > 1 only in timing experiments (warm caches on the later passes)
   for (int i = 0; i < n_ops; i++) {
+    if (timeline && blockIdx.x == 0 && threadIdx.x == 0) timeline[i] = wall_clock64();
     cop_t& op = ((cop_t*)ops)[i];
     switch ((StepKind)op.kind) {
       case StepKind::PwConv:
         if (op.gemv) mo_gemv(op, c);
-        else if (op.cout_tile == 8) mo_pw<8>(op, c);
-        else if (op.cout_tile == 16) mo_pw<16>(op, c);
-        else mo_pw<32>(op, c);
+        else mo_pw(op, c);
         break;
       case StepKind::Conv: mo_conv(op, c); break;
       case StepKind::DwConv: mo_dw(op, c); break;
@@ -409,9 +554,11 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
       case StepKind::Resize: mo_resize(op, c); break;
       case StepKind::Concat: mo_concat(op, c); break;
       case StepKind::TConv: mo_tconv(op, c); break;
+      default: break;
     }
     __syncthreads();
   }
+  if (timeline && blockIdx.x == 0 && threadIdx.x == 0) timeline[n_ops] = wall_clock64();
 }
 
 }  // namespace
@@ -421,8 +568,10 @@ hipError_t frame_program_prepare(int lds_floats) {
 }
 
 hipError_t launch_frame_program(const MicroOp* d_ops, int n_ops, int lds_floats, float* arena, long per_frame_floats, float* net_in, float* net_out,
-                                const float* weights, int n, hipStream_t s) {
-  frame_program_k<<<n, kFrameThreads, (size_t)lds_floats * sizeof(float), s>>>(d_ops, n_ops, arena, per_frame_floats, net_in, net_out, weights);
+                                const float* weights, int n, hipStream_t s, unsigned long long* timeline) {
+  static const int repeat = getenv("BSX_PROGRAM_REPEAT") ? atoi(getenv("BSX_PROGRAM_REPEAT")) : 1;
+  frame_program_k<<<n, kFrameThreads, (size_t)lds_floats * sizeof(float), s>>>(d_ops, n_ops, arena, per_frame_floats, net_in, net_out, weights, timeline,
+                                                                               repeat > 0 ? repeat : 1);
   return hipGetLastError();
 }
 

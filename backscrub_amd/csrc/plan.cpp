@@ -116,17 +116,22 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     m.act = st.act; m.elt = st.elt; m.bcast1 = st.bcast1; m.align_corners = st.align_corners; m.half_pixel = st.half_pixel;
     m.cout_pad = st.cout_pad; m.cout_tile = st.cout_tile;
     m.w_off = (long long)st.w_off; m.b_off = (long long)st.b_off; m.w2_off = (long long)st.w2_off;
-    m.gemv = (st.kind == StepKind::PwConv && st.w2_off != 0) ? 1 : 0;
+    m.gemv = (st.kind == StepKind::PwConv && st.OH * st.OW <= 4 && st.OH * st.OW * st.Cout * 16 <= kLdsScratchFloats) ? 1 : 0;
     auto L = [&](int t) { return t >= 0 ? loc[t] : Loc(); };
     m.in0 = L(st.in0); m.in1 = L(st.in1); m.in2 = L(st.in2); m.res = L(st.residual); m.scale = L(st.in_scale); m.out = L(st.out);
     if (st.concat_in.size() > 4) return;
     m.n_cat = (int)st.concat_in.size();
     for (int k = 0; k < m.n_cat; k++) { m.cat[k] = L(st.concat_in[k]); m.cat_c[k] = st.concat_c[k]; }
+    if (st.kind == StepKind::DwConv && !((st.kh == 3 && st.kw == 3) || (st.kh == 5 && st.kw == 5))) return;   // program has 3x3 / 5x5 bodies only
     if (st.kind == StepKind::PwConv && !m.gemv) {
-      // few pixels → narrower channel tiles so that all 16 waves of the workgroup get work
+      // program tiles: 16 channels per lane, or 4 when the step has so few pixels that 16 would leave waves idle
+      // (and the weight block fits the LDS scratch, which the 4-wide body requires)
       int P = st.OH * st.OW, chunks = (P + 63) / 64;
-      while (m.cout_tile > 8 && chunks * (st.cout_pad / m.cout_tile) < 16 && st.cout_pad % (m.cout_tile / 2) == 0) m.cout_tile /= 2;
+      bool fits = st.Cin * st.cout_pad + st.cout_pad <= kLdsScratchFloats;
+      m.cout_tile = (fits && chunks * (st.cout_pad / 16) < 16) ? 4 : 16;
     }
+    if (m.scale.space != kLocNone && m.scale.space != kLocLds) return;   // the pw micro-op reads SE scales with ds_read only
+    if (getenv("BSX_PROGRAM_NOP")) m.kind = 99;   // timing experiments: descriptor fetch + barrier only
     prog.push_back(m);
   }
   plan->program = std::move(prog);

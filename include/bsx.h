@@ -140,6 +140,11 @@ const char* bsx_plan_describe(bsx_ctx* ctx);
  * fusion are available); returns element count or negative error.  h_out may be NULL to query the size. */
 long bsx_debug_tensor(bsx_ctx* ctx, int tensor_idx, float* h_out, long cap);
 
+/* Per-frame-program timeline: runs the network once for n streams and returns, for workgroup 0, the wall-clock
+ * (100 MHz constant-rate counter) ticks at the start of every micro-op plus one final tick; ticks[i+1]-ticks[i] = op i.
+ * Returns the number of micro-ops (cap must be >= that + 1), 0 if the program path is off, negative on error. */
+int bsx_debug_program_timeline(bsx_ctx* ctx, int n, unsigned long long* ticks, int cap, void* stream);
+
 /* Parse a .tflite file and build the fused plan WITHOUT touching a GPU; writes a text description
  * ("ops=<n> nodes=<n> steps=<n> macs=<per frame> arena_floats=<per stream>" then one line per launch)
  * into buf (NUL-terminated, truncated to cap).  Returns 0, or BSX_EMODEL with the reason in buf. */

@@ -1,0 +1,28 @@
+"""Print the per-micro-op timeline of the per-frame network program (run on a GPU box).
+Usage: python tools/program_timeline.py [lite|full|mlkit|deeplab] [n_streams] [W H]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+import backscrub_amd  # noqa: E402
+from backscrub_amd import synth  # noqa: E402
+from conftest import MODEL_KEYS, model_path  # noqa: E402
+
+key = sys.argv[1] if len(sys.argv) > 1 else "lite"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (640, 480)
+mg = backscrub_amd.MaskGen(model_path(key) if key in MODEL_KEYS else key, W, H, n_streams=n)
+frames = torch.from_numpy(synth.frames(n, W, H, distinct=4)).cuda()
+mg.run_stage(0, frames)
+for _ in range(3):
+    tl = mg.program_timeline(n)
+steps = [l for l in mg.plan().splitlines() if l[:4].strip().isdigit()]
+tot = sum(tl)
+for i, us in enumerate(tl):
+    print("%6.2f us  %5.1f%%  %s" % (us, 100 * us / tot, steps[i] if i < len(steps) else "?"))
+print("total %.1f us for workgroup 0 (n=%d)" % (tot, n))
+print(mg.plan().splitlines()[-1])
