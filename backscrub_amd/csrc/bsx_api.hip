@@ -304,6 +304,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
              c->use_program ? "ON" : "off", c->plan.program.size(), c->plan.program_lds_floats, c->plan.program_lds_floats / 256.0,
              c->plan.program_lds_tensors, c->plan.program_global_tensors);
     c->plan_text += line;
+    for (size_t i = 0; i < c->plan.program_labels.size(); i++) { c->plan_text += "P" + std::to_string(i) + " " + c->plan.program_labels[i] + "\n"; }
   }
   return c.release();
 }
@@ -530,6 +531,10 @@ int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
     snprintf(head, sizeof head, "ops=%d nodes=%d steps=%d macs=%.0f arena_floats=%zu\n", g.n_file_ops, (int)g.nodes.size(), (int)p.steps.size(),
              p.macs_per_frame, p.arena_floats_per_stream);
     out = head + p.describe();
+    snprintf(head, sizeof head, "program micro-ops=%zu lds_floats=%d lds_tensors=%d hbm_tensors=%d\n", p.program.size(), p.program_lds_floats,
+             p.program_lds_tensors, p.program_global_tensors);
+    out += head;
+    for (size_t i = 0; i < p.program_labels.size(); i++) out += "P" + std::to_string(i) + " " + p.program_labels[i] + "\n";
   }
   snprintf(buf, cap, "%s", out.c_str());
   return rc;

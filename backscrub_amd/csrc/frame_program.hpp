@@ -34,16 +34,23 @@ struct MicroOp {
   int kh = 1, kw = 1, sh = 1, sw = 1, dh = 1, dw = 1, pt = 0, pl = 0;
   int act = 0, elt = 0, bcast1 = 0, align_corners = 0, half_pixel = 0;
   int cout_pad = 0, cout_tile = 16;
+  int stage_floats = 0;  // >0: the kernel copies weights[w_off .. w_off+stage_floats) (weights, then bias at b_off-w_off) into the LDS
+                         // scratch before the op; the copy is prefetched into registers while the PREVIOUS op runs
+  int mfma = 0;     // 1: pointwise conv runs on v_mfma_f32_16x16x4_f32 with the weight block staged in LDS
   int gemv = 0;     // 1: ≤4 output pixels → wave-per-output-channel dot products with [co][ci] weights
   int n_cat = 0;
   long long w_off = 0, b_off = 0, w2_off = 0;
+  // fused squeeze-excite / gate chain (kind == kMicroSe): GAP(in0 | cat[]) → FC1 (w2_off, b_off, act, Cout=C1) → FC2 (w3_off, b3_off, act2, C2)
+  long long w3_off = 0, b3_off = 0;
+  int C1 = 0, C2 = 0, act2 = 0, n_fc = 0;
   Loc in0, in1, in2, res, scale, out;
   Loc cat[4];
   int cat_c[4] = {0, 0, 0, 0};
 };
 
+constexpr int kMicroSe = 100;                // MicroOp::kind of the fused GAP→FC→FC chain
 constexpr int kFrameThreads = 1024;          // 16 waves: 4 per SIMD
 constexpr int kLdsTotalFloats = 160 * 256;   // 160 KiB
-constexpr int kLdsScratchFloats = 4096;      // reduction scratch at the start of the LDS block (16 KiB)
+constexpr int kLdsScratchFloats = 4160;      // weight-staging + reduction scratch at the start of the LDS block (16.25 KiB: 128x32 weights + bias)
 
 }  // namespace bsx

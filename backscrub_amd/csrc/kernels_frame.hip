@@ -106,16 +106,6 @@ __device__ __forceinline__ float4 fp_act4(float4 v, int act) {
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// cooperative global → LDS scratch copy of `nfloats` (multiple of 4) weights followed by `nbias` floats of bias
-__device__ __forceinline__ void stage_weights(const float* w, int nfloats, const float* bias, int nbias) {
-  const glb_v4* gw = (const glb_v4*)w;
-  const glb_v4* gb = (const glb_v4*)bias;
-  lds_v4* s = (lds_v4*)lds_base();
-  for (int i = threadIdx.x; i < (nfloats >> 2); i += kFrameThreads) s[i] = gw[i];
-  for (int i = threadIdx.x; i < ((nbias + 3) >> 2); i += kFrameThreads) s[(nfloats >> 2) + i] = gb[i];
-  __syncthreads();
-}
-
 // ---- 1x1 convolution: wave = (64-pixel chunk, CT-channel tile), lane = pixel ------------------------------
 template <int CT, bool STAGED>
 __device__ __forceinline__ void pw_quad(float (&acc)[CT], const float4 xv, const lds_f* wl, cfloat_t* wc, int cout_pad) {
@@ -147,14 +137,13 @@ __device__ __forceinline__ void pw_quad(float (&acc)[CT], const float4 xv, const
 template <int CT, bool STAGED, bool XL>
 __device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
   constexpr int kPF = 2;
-  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c), sc = make_ref(op.scale, c);
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c), sc = make_ref(op.scale, c), ad = make_ref(op.in2, c);
   const float* w = c.weights + op.w_off;
   const float* bias = c.weights + op.b_off;
   const int P = op.OH * op.OW, chunks = (P + 63) >> 6, tiles = op.cout_pad / CT;
   const int lane = threadIdx.x & 63, nw = kFrameThreads >> 6;
   const int Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad, act = op.act, nq = Cin >> 2;
   const int wfloats = Cin * cout_pad;
-  if constexpr (STAGED) stage_weights(w, wfloats, bias, cout_pad);
   const lds_f* wl = lds_base();
   const lds_f* bl = lds_base() + wfloats;
   const bool has_sc = sc.valid;          // SE scale vectors always live in LDS (planner)
@@ -173,7 +162,8 @@ __device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
       xb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < nq) {
         if constexpr (XL) xb[j] = ld_lds4(x.l + xo + 4 * j); else xb[j] = ld_glb4(x.g + xo + 4 * j);
-        if (has_sc) { float4 sv = ld_lds4(sc.l + 4 * j); xb[j].x *= sv.x; xb[j].y *= sv.y; xb[j].z *= sv.z; xb[j].w *= sv.w; }
+        if (has_sc) { float4 sv = ld_lds4(sc.l + 4 * j); xb[j].x = __fmul_rn(xb[j].x, sv.x); xb[j].y = __fmul_rn(xb[j].y, sv.y); xb[j].z = __fmul_rn(xb[j].z, sv.z); xb[j].w = __fmul_rn(xb[j].w, sv.w); }
+        if (ad.valid) { float4 av = ld4(ad, p * ad.stride + 4 * j); xb[j].x = __fadd_rn(xb[j].x, av.x); xb[j].y = __fadd_rn(xb[j].y, av.y); xb[j].z = __fadd_rn(xb[j].z, av.z); xb[j].w = __fadd_rn(xb[j].w, av.w); }
       }
     }
     for (int q0 = 0; q0 < nq; q0 += kPF) {
@@ -184,7 +174,8 @@ __device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
           const float4 xv = xb[j];
           if (q + kPF < nq) {
             if constexpr (XL) xb[j] = ld_lds4(x.l + xo + 4 * (q + kPF)); else xb[j] = ld_glb4(x.g + xo + 4 * (q + kPF));
-            if (has_sc) { float4 sv = ld_lds4(sc.l + 4 * (q + kPF)); xb[j].x *= sv.x; xb[j].y *= sv.y; xb[j].z *= sv.z; xb[j].w *= sv.w; }
+            if (has_sc) { float4 sv = ld_lds4(sc.l + 4 * (q + kPF)); xb[j].x = __fmul_rn(xb[j].x, sv.x); xb[j].y = __fmul_rn(xb[j].y, sv.y); xb[j].z = __fmul_rn(xb[j].z, sv.z); xb[j].w = __fmul_rn(xb[j].w, sv.w); }
+            if (ad.valid) { float4 av = ld4(ad, p * ad.stride + 4 * (q + kPF)); xb[j].x = __fadd_rn(xb[j].x, av.x); xb[j].y = __fadd_rn(xb[j].y, av.y); xb[j].z = __fadd_rn(xb[j].z, av.z); xb[j].w = __fadd_rn(xb[j].w, av.w); }
           }
           pw_quad<CT, STAGED>(acc, xv, wl + (q * 4) * cout_pad + co0, as_const(w + (size_t)(q * 4) * cout_pad + co0), cout_pad);
         }
@@ -216,19 +207,82 @@ __device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
   }
 }
 
+// ---- 1x1 convolution on the matrix cores -----------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32: exact f32 FMA chains at the f32 vector rate, but ONE instruction per 1024 MACs — the VALU
+// form of these skinny GEMMs (K, N = 16..128) was bound by instruction issue and LDS→FMA latency, not by math.
+// Wave = one 16-pixel x 16-channel tile.  Operand maps (cdna_hip_programming.md §3):
+//   A: lane l holds x[pixel m0 + (l&15)][k-group l>>4]   → each lane reads ONE float4 (4 consecutive channels of its
+//      group) per 16 input channels and feeds .x/.y/.z/.w to four successive MFMAs,
+//   B: lane l holds w[k-group l>>4][channel n0 + (l&15)] → one ds_read_b32 per MFMA from the staged weight block,
+//   D: lane l holds 4 pixels m0 + 4*(l>>4) + r of channel n0 + (l&15).
+// The k order inside the chain is (j, t, group) instead of ascending ci — a different but fixed f32 summation order.
+typedef float f4acc __attribute__((ext_vector_type(4)));
+
+template <bool XL>
+__device__ __forceinline__ void pw_mfma(cop_t& op, const FrameCtx& c) {
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c), sc = make_ref(op.scale, c), ad = make_ref(op.in2, c);
+  const glb_f* w = (const glb_f*)(c.weights + op.w_off);
+  const glb_f* bias = (const glb_f*)(c.weights + op.b_off);
+  const int P = op.OH * op.OW, Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad, act = op.act;
+  const int ws = cout_pad;                             // staged row stride (a 2-way bank conflict on the B reads is
+                                                       // invisible next to the 32-cycle MFMA; padding would cost LDS)
+  const lds_f* wl = lds_base();                       // staged by the main loop: weights, then bias
+  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
+  (void)w; (void)bias;
+  const int mt = (P + 15) >> 4, nt = cout_pad >> 4, nw = kFrameThreads >> 6;
+  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+  const bool has_sc = sc.valid, has_res = res.valid, has_add = ad.valid;
+  const int nj = (Cin + 15) >> 4;
+  for (int wi = wave_id(); wi < mt * nt; wi += nw) {
+    const int tn = wi / mt, tm = wi - tn * mt;          // consecutive waves share the weight tile, differ in pixels
+    const int m0 = tm << 4, n0 = tn << 4;
+    const int arow = min(m0 + li, P - 1);               // rows past the end read a valid pixel; their results are dropped
+    const int xo = arow * x.stride + 4 * g;
+    const lds_f* bp = wl + (4 * g) * ws + n0 + li;
+    f4acc acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nj; j++) {
+      const int k0 = 16 * j + 4 * g;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      if (k0 < Cin) {                                    // Cin % 4 == 0: a k-group is either fully valid or absent
+        if constexpr (XL) a = ld_lds4(x.l + xo + 16 * j); else a = ld_glb4(x.g + xo + 16 * j);
+        if (has_sc) { const float4 sv = ld_lds4(sc.l + k0); a.x = __fmul_rn(a.x, sv.x); a.y = __fmul_rn(a.y, sv.y); a.z = __fmul_rn(a.z, sv.z); a.w = __fmul_rn(a.w, sv.w); }
+        if (has_add) { const float4 av = ld4(ad, arow * ad.stride + k0); a.x = __fadd_rn(a.x, av.x); a.y = __fadd_rn(a.y, av.y); a.z = __fadd_rn(a.z, av.z); a.w = __fadd_rn(a.w, av.w); }
+        const lds_f* br = bp + (16 * j) * ws;
+        b0 = br[0]; b1 = br[ws]; b2 = br[2 * ws]; b3 = br[3 * ws];
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc, 0, 0, 0);
+    }
+    const int co = n0 + li;
+    if (co < Cout) {
+      const float bv = bl[co];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int pix = m0 + 4 * g + r;
+        if (pix < P) {
+          float v = fp_act(acc[r] + bv, act);
+          if (has_res) v += ld1(res, pix * res.stride + co);
+          st1(y, pix * y.stride + co, v);
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void mo_pw(cop_t& op, const FrameCtx& c) {
   const bool xl = op.in0.space == kLocLds;
-  const bool staged = op.Cin * op.cout_pad + op.cout_pad <= kLdsScratchFloats;
-  if (!staged) { if (xl) pw_body<16, false, true>(op, c); else pw_body<16, false, false>(op, c); }   // planner: tile 16 when not staged
-  else if (op.cout_tile == 4) { if (xl) pw_body<4, true, true>(op, c); else pw_body<4, true, false>(op, c); }
-  else { if (xl) pw_body<16, true, true>(op, c); else pw_body<16, true, false>(op, c); }
+  if (op.mfma) { if (xl) pw_mfma<true>(op, c); else pw_mfma<false>(op, c); return; }
+  if (xl) pw_body<16, false, true>(op, c); else pw_body<16, false, false>(op, c);   // weight block too large to stage: SGPR-fed VALU form
 }
 
 // ---- 1x1 convolution on <= 4 pixels (SE / gate FCs): lane = (output channel, K-slice) ----------------------------
 // [ci][co] weight rows are read coalesced across lanes, all of a lane's loads in flight at once; the KS partial
 // sums per output meet in the LDS scratch.  Inputs/outputs of these steps are [1,1,C] vectors → always LDS.
 __device__ __forceinline__ void mo_gemv(cop_t& op, const FrameCtx& c) {
-  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c), sc = make_ref(op.scale, c);
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c), sc = make_ref(op.scale, c), ad = make_ref(op.in2, c);
   const glb_f* w = (const glb_f*)(c.weights + op.w_off);       // [ci][cout_pad]
   const glb_f* bias = (const glb_f*)(c.weights + op.b_off);
   const int P = op.OH * op.OW, Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad;
@@ -269,11 +323,9 @@ __device__ __forceinline__ void mo_conv(cop_t& op, const FrameCtx& c) {
   const float* bias = c.weights + op.b_off;
   const int P = op.OH * op.OW, chunks = (P + 63) >> 6, tiles = op.cout_pad / CT;
   const int lane = threadIdx.x & 63, nw = kFrameThreads >> 6;
-  const int wfloats = op.kh * op.kw * op.Cin * op.cout_pad;
-  const bool staged = wfloats + op.cout_pad <= kLdsScratchFloats;
-  if (staged) stage_weights(w, wfloats, bias, op.cout_pad);
+  const bool staged = op.stage_floats > 0;
   const lds_f* wl = lds_base();
-  const lds_f* bl = lds_base() + wfloats;
+  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
   for (int wi = wave_id(); wi < chunks * tiles; wi += nw) {
     const int tile = wi / chunks, chunk = wi - tile * chunks;
     const int p = (chunk << 6) + lane;
@@ -332,33 +384,43 @@ __device__ __forceinline__ void dw_body(cop_t& op, const FrameCtx& c) {
   const float* bias = c.weights + op.b_off;
   const int C = op.Cin, C4 = C >> 2;
   const int kh = K ? K : op.kh, kw = K ? K : op.kw, kk = kh * kw;
-  const bool staged = (kk + 1) * C <= kLdsScratchFloats;
-  if (staged) stage_weights(w, kk * C, bias, C);
+  const bool staged = op.stage_floats > 0;
   const lds_f* wl = lds_base();
-  const lds_f* bl = lds_base() + kk * C;
+  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
+  (void)kk;
   const glb_f* wg = (const glb_f*)w;
   const glb_f* bg = (const glb_f*)bias;
   const int total = op.OH * op.OW * C4;
   const int H = op.H, W = op.W, OW = op.OW, sh = op.sh, sw = op.sw, dh = op.dh, dw = op.dw, pt = op.pt, pl = op.pl, act = op.act;
-  for (int i = threadIdx.x; i < total; i += kFrameThreads) {
-    const int cq = i % C4, p = i / C4, ch = cq * 4;
-    const int oy = p / OW, ox = p - oy * OW;
+  // lane = (channel quad, pixel row): the quad is fixed per lane and (oy, ox) advance incrementally — no per-item division
+  const int rows = kFrameThreads / C4, cq = threadIdx.x % C4, r0 = threadIdx.x / C4, ch = cq * 4;
+  const int step_y = rows / OW, step_x = rows - step_y * OW, P = total / C4;
+  int oy = r0 / OW, ox = r0 - oy * OW;
+  if (r0 < rows)
+  for (int p = r0; p < P; p += rows, ox += step_x, oy += step_y) {
+    if (ox >= OW) { ox -= OW; oy++; }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // column addresses / validity are shared by all rows of the window
+    int cxo[K ? K : 8];
+    bool vx[K ? K : 8];
+#pragma unroll
+    for (int fx = 0; fx < kw; fx++) {
+      const int ix = ox * sw - pl + fx * dw;
+      vx[fx] = ix >= 0 && ix < W;
+      cxo[fx] = min(max(ix, 0), W - 1) * x.stride + ch;
+    }
 #pragma unroll 1
     for (int fy = 0; fy < kh; fy++) {
       const int iy = oy * sh - pt + fy * dh;
       const bool vy = iy >= 0 && iy < H;
-      const int cy = min(max(iy, 0), H - 1);
+      const int rowo = min(max(iy, 0), H - 1) * W * x.stride;
+      const int wrow = fy * kw * C + ch;
 #pragma unroll
       for (int fx = 0; fx < kw; fx++) {
-        const int ix = ox * sw - pl + fx * dw;
-        const bool v = vy && ix >= 0 && ix < W;
-        const int cx = min(max(ix, 0), W - 1);
-        const int xo = (cy * W + cx) * x.stride + ch;
         float4 xv;
-        if constexpr (XL) xv = ld_lds4(x.l + xo); else xv = ld_glb4(x.g + xo);
-        float4 wv = ldw4(staged, wl, wg, (fy * kw + fx) * C + ch);
-        if (!v) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (XL) xv = ld_lds4(x.l + rowo + cxo[fx]); else xv = ld_glb4(x.g + rowo + cxo[fx]);
+        float4 wv = ldw4(staged, wl, wg, wrow + fx * C);
+        if (!(vy && vx[fx])) wv = make_float4(0.f, 0.f, 0.f, 0.f);
         acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
         acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
       }
@@ -425,6 +487,68 @@ __device__ __forceinline__ void mo_gap(cop_t& op, const FrameCtx& c) {
   for (int k = 0; k < op.n_cat; k++) { gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], out, coff); coff += op.cat_c[k]; }
 }
 
+// ---- fused squeeze-excite / decoder-gate chain: GAP → FC(+act) [→ FC(+act)] ---------------------------------------------
+// One micro-op instead of three: the means stay in LDS, each FC output is a dot product split over L consecutive lanes
+// (float4 reads of the [co][ci] weight rows, shuffle reduction) — no scratch round trip, two barriers in total.
+// FC layer over L-lane groups.  `fc_preload` fetches a lane's slice of its (first) output row into registers so that
+// the global latency overlaps whatever runs before the matching `fc_lanes` call (the pooling phase / the previous FC).
+constexpr int kFcPre = 4;   // float4s per lane held in registers (covers Cin <= 128 with 8 lanes per output)
+struct FcPre { float4 w[kFcPre]; float b; };
+__device__ __forceinline__ int fc_group(int Cin) { int L = 8; while (L > 1 && (Cin % (4 * L)) != 0) L >>= 1; return L; }
+__device__ __forceinline__ FcPre fc_preload(int Cin, const glb_f* w2, const glb_f* bias, int Cout) {
+  FcPre p;
+  const int L = fc_group(Cin), klen = Cin / L, sub = threadIdx.x % L, co = threadIdx.x / L;
+#pragma unroll
+  for (int q = 0; q < kFcPre; q++) p.w[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  p.b = 0.f;
+  if (co < Cout) {
+    const glb_f* wr = w2 + (size_t)co * Cin + sub * klen;
+#pragma unroll
+    for (int q = 0; q < kFcPre; q++) if (4 * q < klen) p.w[q] = ld_glb4(wr + 4 * q);
+    p.b = bias[co];
+  }
+  return p;
+}
+__device__ __forceinline__ void fc_lanes(const Ref& x, int Cin, const glb_f* w2, const glb_f* bias, int Cout, int act, const Ref& y, const FcPre& pre) {
+  const int L = fc_group(Cin), klen = Cin / L, sub = threadIdx.x % L, per = kFrameThreads / L;
+  const bool pre_ok = klen <= 4 * kFcPre;
+  for (int co = threadIdx.x / L, it = 0; co < Cout; co += per, it++) {
+    const glb_f* wr = w2 + (size_t)co * Cin + sub * klen;
+    float acc = 0.f;
+    if (it == 0 && pre_ok) {
+#pragma unroll
+      for (int q = 0; q < kFcPre; q++) {
+        if (4 * q < klen) {
+          const float4 xv = ld4(x, sub * klen + 4 * q), wv = pre.w[q];
+          acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+        }
+      }
+    } else {
+      for (int k = 0; k < klen; k += 4) {
+        const float4 xv = ld4(x, sub * klen + k), wv = ld_glb4(wr + k);
+        acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+      }
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (sub == 0) st1(y, co, fp_act(acc + ((it == 0 && pre_ok) ? pre.b : bias[co]), act));
+  }
+}
+__device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
+  const Ref mean = make_ref(op.in1, c), hid = make_ref(op.in2, c), out = make_ref(op.out, c);
+  const int HW = op.H * op.W;
+  const glb_f* wts = (const glb_f*)c.weights;
+  // both FCs' weight slices are requested up front: their HBM/L2 latency hides behind the pooling reductions
+  const FcPre p1 = fc_preload(op.Cin, wts + op.w2_off, wts + op.b_off, op.C1);
+  FcPre p2 = p1;
+  if (op.n_fc == 2) p2 = fc_preload(op.C1, wts + op.w3_off, wts + op.b3_off, op.C2);
+  if (op.n_cat == 0) gap_one(make_ref(op.in0, c), HW, op.Cin, mean, 0);
+  else { int coff = 0; for (int k = 0; k < op.n_cat; k++) { gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], mean, coff); coff += op.cat_c[k]; } }
+  if (op.n_fc == 1) { fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, out, p1); return; }
+  fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, hid, p1);
+  __syncthreads();
+  fc_lanes(hid, op.C1, wts + op.w3_off, wts + op.b3_off, op.C2, op.act2, out, p2);
+}
+
 // ---- elementwise -----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float elt1(float a, float b, float cc, int e) {
   switch (e) {
@@ -437,8 +561,9 @@ __device__ __forceinline__ float elt1(float a, float b, float cc, int e) {
 __device__ __forceinline__ void mo_elt(cop_t& op, const FrameCtx& c) {
   const Ref a = make_ref(op.in0, c), b = make_ref(op.in1, c), d = make_ref(op.in2, c), y = make_ref(op.out, c);
   const int C4 = op.Cin >> 2, total = op.H * op.W * C4, elt = op.elt, act = op.act, bc = op.bcast1;
-  for (int i = threadIdx.x; i < total; i += kFrameThreads) {
-    const int cq = i % C4, p = i / C4, ch = cq * 4;
+  const int rows = kFrameThreads / C4, ch = (threadIdx.x % C4) * 4, r0 = threadIdx.x / C4, P = total / C4;
+  if (r0 < rows)
+  for (int p = r0; p < P; p += rows) {
     const float4 av = ld4(a, p * a.stride + ch);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), dv = bv;
     if (elt != kEltUnary) bv = ld4(b, bc ? ch : p * b.stride + ch);
@@ -471,9 +596,12 @@ __device__ __forceinline__ void mo_resize(cop_t& op, const FrameCtx& c) {
   if (op.align_corners && OW > 1) ws = (float)(W - 1) / (float)(OW - 1);
   const bool vec = (op.Cin & 3) == 0, hp = op.half_pixel;
   const int CV = vec ? op.Cin >> 2 : op.Cin, total = op.OH * OW * CV;
-  for (int i = threadIdx.x; i < total; i += kFrameThreads) {
-    const int cv = i % CV, p = i / CV;
-    const int oy = p / OW, ox = p - oy * OW;
+  const int rows = kFrameThreads / CV, cv = threadIdx.x % CV, r0 = threadIdx.x / CV, P = total / CV;
+  const int step_y = rows / OW, step_x = rows - step_y * OW;
+  int oy = r0 / OW, ox = r0 - oy * OW;
+  if (r0 < rows)
+  for (int p = r0; p < P; p += rows, ox += step_x, oy += step_y) {
+    if (ox >= OW) { ox -= OW; oy++; }
     float dy, dx; int y0, y1, x0, x1;
     fp_interp(oy, hs, hp, H, &dy, &y0, &y1);
     fp_interp(ox, ws, hp, W, &dx, &x0, &x1);
@@ -497,10 +625,10 @@ __device__ __forceinline__ void mo_concat(cop_t& op, const FrameCtx& c) {
   for (int k = 0; k < op.n_cat; k++) {
     const Ref x = make_ref(op.cat[k], c);
     const int C4 = op.cat_c[k] >> 2, total = P * C4;
-    for (int i = threadIdx.x; i < total; i += kFrameThreads) {
-      const int cq = i % C4, p = i / C4;
-      st4(y, p * y.stride + coff + cq * 4, ld4(x, p * x.stride + cq * 4));
-    }
+    const int rows = kFrameThreads / C4, cq = threadIdx.x % C4, r0 = threadIdx.x / C4;
+    (void)total;
+    if (r0 < rows)
+      for (int p = r0; p < P; p += rows) st4(y, p * y.stride + coff + cq * 4, ld4(x, p * x.stride + cq * 4));
     coff += op.cat_c[k];
   }
 }
@@ -511,11 +639,9 @@ __device__ __forceinline__ void mo_tconv(cop_t& op, const FrameCtx& c) {
   const float* w = c.weights + op.w_off;
   const float* bias = c.weights + op.b_off;
   const int C4 = op.Cin >> 2, P = op.OH * op.OW, Cout = op.Cout, Cin = op.Cin, kh = op.kh, kw = op.kw, OW = op.OW, W = op.W;
-  const int wfloats = kh * kw * Cout * Cin;
-  const bool staged = wfloats + Cout <= kLdsScratchFloats;
-  if (staged) stage_weights(w, wfloats, bias, Cout);
+  const bool staged = op.stage_floats > 0;
   const lds_f* wl = lds_base();
-  const lds_f* bl = lds_base() + wfloats;
+  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
   const glb_f* wg = (const glb_f*)w;
   for (int p = threadIdx.x; p < P; p += kFrameThreads) {
     const int oy = p / OW, ox = p - oy * OW;
@@ -538,10 +664,37 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
                                                                 float* net_in, float* net_out, const float* __restrict__ weights,
                                                                 unsigned long long* timeline, int repeat) {
   FrameCtx c{arena + (size_t)blockIdx.x * (size_t)per_frame_floats, net_in, net_out, weights, (int)blockIdx.x};
+  // Weight staging is software-pipelined across ops: while op i computes, every lane already holds its float4 of op
+  // i+1's weight block in registers; at the top of op i+1 it only has to drop it into the LDS scratch.
+  const glb_f* gw = (const glb_f*)weights;
+  // (a block of up to 2 float4 per lane: kLdsScratchFloats <= 8 * kFrameThreads)
+  f4v pf = {0.f, 0.f, 0.f, 0.f}, pf2 = pf;
+  const int t4 = (int)threadIdx.x * 4, t4b = t4 + 4 * kFrameThreads;
+  {
+    cop_t& op0 = ((cop_t*)ops)[0];
+    const int sf0 = op0.stage_floats;
+    if (t4 < sf0) pf = *(const glb_v4*)(gw + op0.w_off + t4);
+    if (t4b < sf0) pf2 = *(const glb_v4*)(gw + op0.w_off + t4b);
+  }
   for (int rep = 0; rep < repeat; rep++)      // repeat > 1 only in timing experiments (warm caches on the later passes)
   for (int i = 0; i < n_ops; i++) {
     if (timeline && blockIdx.x == 0 && threadIdx.x == 0) timeline[i] = wall_clock64();
     cop_t& op = ((cop_t*)ops)[i];
+    {
+      const int sf = op.stage_floats;
+      if (sf) {
+        if (t4 < sf) *(lds_v4*)(lds_base() + t4) = pf;
+        if (t4b < sf) *(lds_v4*)(lds_base() + t4b) = pf2;
+        __syncthreads();
+      }
+      const int nxt = i + 1 < n_ops ? i + 1 : 0;
+      if (i + 1 < n_ops || rep + 1 < repeat) {
+        cop_t& opn = ((cop_t*)ops)[nxt];
+        const int sfn = opn.stage_floats;
+        if (t4 < sfn) pf = *(const glb_v4*)(gw + opn.w_off + t4);
+        if (t4b < sfn) pf2 = *(const glb_v4*)(gw + opn.w_off + t4b);
+      }
+    }
     switch ((StepKind)op.kind) {
       case StepKind::PwConv:
         if (op.gemv) mo_gemv(op, c);
@@ -554,7 +707,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
       case StepKind::Resize: mo_resize(op, c); break;
       case StepKind::Concat: mo_concat(op, c); break;
       case StepKind::TConv: mo_tconv(op, c); break;
-      default: break;
+      default: if (op.kind == kMicroSe) mo_se(op, c); break;
     }
     __syncthreads();
   }

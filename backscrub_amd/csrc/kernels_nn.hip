@@ -38,12 +38,13 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 template <int CT>
 __global__ __launch_bounds__(kThreads) void pw_conv_k(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ res,
-                                                     const float* __restrict__ scale, float* __restrict__ y, long M, int HW,
-                                                     int Cin, int Cout, int cout_pad, int act) {
+                                                     const float* __restrict__ scale, const float* __restrict__ addx,
+                                                     float* __restrict__ y, long M, int HW, int Cin, int Cout, int cout_pad, int act) {
   long p = (long)blockIdx.x * kThreads + threadIdx.x;
   if (p >= M) return;
   const int co0 = blockIdx.y * CT;
   const float* xp = x + p * Cin;
+  const float* ap = addx ? addx + p * Cin : nullptr;   // x' = x*s + a (a fused MUL+ADD feeding this conv): two roundings, like the graph
   const float* sp = scale ? scale + (p / HW) * (long)Cin : nullptr;
   const float* wp = w + co0;
   float acc[CT];
@@ -54,7 +55,11 @@ __global__ __launch_bounds__(kThreads) void pw_conv_k(const float* __restrict__ 
       float4 xv = *reinterpret_cast<const float4*>(xp + ci);
       if (sp) {
         float4 sv = *reinterpret_cast<const float4*>(sp + ci);
-        xv.x *= sv.x; xv.y *= sv.y; xv.z *= sv.z; xv.w *= sv.w;
+        xv.x = __fmul_rn(xv.x, sv.x); xv.y = __fmul_rn(xv.y, sv.y); xv.z = __fmul_rn(xv.z, sv.z); xv.w = __fmul_rn(xv.w, sv.w);
+      }
+      if (ap) {
+        float4 av = *reinterpret_cast<const float4*>(ap + ci);
+        xv.x = __fadd_rn(xv.x, av.x); xv.y = __fadd_rn(xv.y, av.y); xv.z = __fadd_rn(xv.z, av.z); xv.w = __fadd_rn(xv.w, av.w);
       }
       const float* w0 = wp + (long)ci * cout_pad;
 #pragma unroll
@@ -69,7 +74,8 @@ __global__ __launch_bounds__(kThreads) void pw_conv_k(const float* __restrict__ 
   } else {
     for (int ci = 0; ci < Cin; ci++) {
       float xv = xp[ci];
-      if (sp) xv *= sp[ci];
+      if (sp) xv = __fmul_rn(xv, sp[ci]);
+      if (ap) xv = __fadd_rn(xv, ap[ci]);
       const float* w0 = wp + (long)ci * cout_pad;
 #pragma unroll
       for (int t = 0; t < CT; t++) acc[t] = fmaf(xv, w0[t], acc[t]);
@@ -104,8 +110,8 @@ __global__ __launch_bounds__(kThreads) void pw_conv_k(const float* __restrict__ 
 // Few pixels (squeeze-excite / gate FCs: one "pixel" per stream): lane = one output value, so a
 // 256-stream batch still fills thousands of lanes instead of one workgroup.
 __global__ __launch_bounds__(kThreads) void pw_small_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                      const float* __restrict__ res, const float* __restrict__ scale, float* __restrict__ y, long total,
-                                                      int HW, int Cin, int Cout, int cout_pad, int act) {
+                                                      const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
+                                                      float* __restrict__ y, long total, int HW, int Cin, int Cout, int cout_pad, int act) {
   long i = (long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= total) return;
   int co = (int)(i % Cout);
@@ -115,7 +121,8 @@ __global__ __launch_bounds__(kThreads) void pw_small_k(const float* __restrict__
   float acc = 0.f;
   for (int ci = 0; ci < Cin; ci++) {
     float xv = xp[ci];
-    if (sp) xv *= sp[ci];
+    if (sp) xv = __fmul_rn(xv, sp[ci]);
+    if (addx) xv = __fadd_rn(xv, addx[p * Cin + ci]);
     acc = fmaf(xv, w[(long)ci * cout_pad + co], acc);
   }
   float v = act_fn(acc + bias[co], act);
@@ -378,11 +385,11 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       int HW = st.OH * st.OW;
       if (M <= 4096) {
         long total = M * st.Cout;
-        pw_small_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.out), total, HW, st.Cin, st.Cout, st.cout_pad, st.act);
+        pw_small_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), total, HW, st.Cin, st.Cout, st.cout_pad, st.act);
         break;
       }
-#define BSX_PW(CT) pw_conv_k<CT><<<grid, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act)
-      if (st.cout_tile == 8) BSX_PW(8); else if (st.cout_tile == 16) BSX_PW(16); else BSX_PW(32);
+#define BSX_PW(CT) pw_conv_k<CT><<<grid, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act)
+      if (st.cout_tile == 16) BSX_PW(16); else BSX_PW(32);
 #undef BSX_PW
       break;
     }

@@ -56,6 +56,7 @@ std::string Plan::describe() const {
 // LDS (liveness-based first fit inside the 160 KiB block), the rest in the frame's slice of the HBM arena.
 static void build_frame_program(const Graph& g, Plan* plan) {
   plan->program.clear();
+  plan->program_labels.clear();
   const int NS = (int)plan->steps.size();
   const int NT = (int)g.tensors.size();
   std::vector<int> last(NT, -1);
@@ -106,6 +107,7 @@ static void build_frame_program(const Graph& g, Plan* plan) {
   plan->program_lds_tensors = plan->program_global_tensors = 0;
   place(g.input, -1);
   std::vector<MicroOp> prog;
+  std::vector<std::string> labels;
   for (int s = 0; s < NS; s++) {
     const Step& st = plan->steps[s];
     place(st.out, s);
@@ -123,24 +125,75 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     m.n_cat = (int)st.concat_in.size();
     for (int k = 0; k < m.n_cat; k++) { m.cat[k] = L(st.concat_in[k]); m.cat_c[k] = st.concat_c[k]; }
     if (st.kind == StepKind::DwConv && !((st.kh == 3 && st.kw == 3) || (st.kh == 5 && st.kw == 5))) return;   // program has 3x3 / 5x5 bodies only
+    // weights + bias are contiguous in the arena ([w][pad to 4][b]); stage the whole range when it fits the scratch
+    {
+      long nb = st.kind == StepKind::DwConv ? st.Cout : (st.kind == StepKind::TConv ? st.Cout : st.cout_pad);
+      long range = ((long)st.b_off - (long)st.w_off) + ((nb + 3) / 4) * 4;
+      bool uses = (st.kind == StepKind::PwConv && !m.gemv) || st.kind == StepKind::Conv || st.kind == StepKind::DwConv || st.kind == StepKind::TConv;
+      m.stage_floats = (uses && st.b_off > st.w_off && range <= kLdsScratchFloats) ? (int)range : 0;
+    }
     if (st.kind == StepKind::PwConv && !m.gemv) {
-      // program tiles: 16 channels per lane, or 4 when the step has so few pixels that 16 would leave waves idle
-      // (and the weight block fits the LDS scratch, which the 4-wide body requires)
-      int P = st.OH * st.OW, chunks = (P + 63) / 64;
-      bool fits = st.Cin * st.cout_pad + st.cout_pad <= kLdsScratchFloats;
-      m.cout_tile = (fits && chunks * (st.cout_pad / 16) < 16) ? 4 : 16;
+      // MFMA form whenever the weight block + bias fits the 16 KiB LDS scratch and Cout tiles by 16
+      m.cout_tile = 16;
+      m.mfma = (st.cout_pad % 16 == 0 && m.stage_floats > 0) ? 1 : 0;
+      if (!m.mfma) m.stage_floats = 0;   // the SGPR-fed VALU body reads its weights from memory
     }
     if (m.scale.space != kLocNone && m.scale.space != kLocLds) return;   // the pw micro-op reads SE scales with ds_read only
-    if (getenv("BSX_PROGRAM_NOP")) m.kind = 99;   // timing experiments: descriptor fetch + barrier only
+    if (getenv("BSX_PROGRAM_NOP")) m.kind = 99;
+    if (const char* only = getenv("BSX_PROGRAM_ONLY")) { if (atoi(only) != s) m.kind = 99; }   // timing experiments: one live op
     prog.push_back(m);
+    {
+      char buf[200];
+      snprintf(buf, sizeof buf, "%-12s %dx%dx%d->%dx%dx%d%s%s in:%s out:%s", st.label.c_str(), st.H, st.W, st.Cin, st.OH, st.OW, st.Cout,
+               m.mfma ? " mfma" : "", m.gemv ? " gemv" : "", m.in0.space == kLocLds ? "lds" : "hbm", m.out.space == kLocLds ? "lds" : "hbm");
+      labels.push_back(buf);
+    }
+  }
+  // peephole: GAP → FC(act) [→ FC(act)] on single-pixel vectors → one fused micro-op (means/hidden stay in their LDS slots)
+  if (!getenv("BSX_PROGRAM_NO_SE")) {
+    std::vector<MicroOp> fusedp;
+    std::vector<std::string> flabels;
+    for (size_t i = 0; i < prog.size(); i++) {
+      const MicroOp& g0 = prog[i];
+      auto is_fc = [&](size_t k, const Loc& in) {
+        if (k >= prog.size()) return false;
+        const MicroOp& f = prog[k];
+        const Step& st = plan->steps[k];
+        return f.kind == (int)StepKind::PwConv && f.OH * f.OW == 1 && st.w2_off != 0 && f.res.space == kLocNone && f.scale.space == kLocNone &&
+               f.in0.space == kLocLds && f.in0.off == in.off && f.out.space == kLocLds && f.Cin % 4 == 0;
+      };
+      auto single_use = [&](size_t k) { const Step& st = plan->steps[k]; return last[st.out] == (int)k + 1; };
+      if (g0.kind == (int)StepKind::Gap && g0.out.space == kLocLds && is_fc(i + 1, g0.out) && single_use(i)) {
+        MicroOp m = g0;
+        const MicroOp& f1 = prog[i + 1];
+        m.kind = kMicroSe; m.in1 = g0.out; m.in2 = f1.out; m.n_fc = 1;
+        m.w2_off = (long long)plan->steps[i + 1].w2_off; m.b_off = f1.b_off; m.act = f1.act; m.C1 = f1.Cout; m.out = f1.out;
+        size_t used = 2;
+        if (is_fc(i + 2, f1.out) && single_use(i + 1)) {
+          const MicroOp& f2 = prog[i + 2];
+          m.n_fc = 2; m.w3_off = (long long)plan->steps[i + 2].w2_off; m.b3_off = f2.b_off; m.act2 = f2.act; m.C2 = f2.Cout; m.out = f2.out;
+          used = 3;
+        }
+        fusedp.push_back(m);
+        flabels.push_back("se[" + std::to_string(m.n_fc) + "fc] " + labels[i]);
+        i += used - 1;
+      } else {
+        fusedp.push_back(g0);
+        flabels.push_back(labels[i]);
+      }
+    }
+    prog.swap(fusedp);
+    labels.swap(flabels);
   }
   plan->program = std::move(prog);
+  plan->program_labels = std::move(labels);
   plan->program_lds_floats = high;
 }
 
-bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena) {
+bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_arena) {
   auto fail = [&](const std::string& m) { if (err) *err = m; return false; };
-  const int NT = (int)g.tensors.size();
+  Graph g = g_in;                       // local copy: the rewrite passes below may append synthetic tensors
+  int NT = (int)g.tensors.size();
   const int NN = (int)g.nodes.size();
 
   // consumers of each tensor
@@ -228,7 +281,7 @@ bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena) 
           }
         }
         // pack weights [kh][kw][ci][co_pad]
-        int ct = st.Cout <= 8 ? 8 : (st.Cout <= 16 ? 16 : 32);
+        int ct = st.Cout <= 16 ? 16 : 32;
         if (!pw) ct = 16;
         st.cout_tile = ct;
         st.cout_pad = round_up(st.Cout, ct);
@@ -406,6 +459,55 @@ bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena) 
   }
   // a fused group executes where its LAST op stood, so every external input already exists
   std::stable_sort(steps.begin(), steps.end(), [](const Step& a, const Step& b) { return a.last_node < b.last_node; });
+
+  // ---- linear-algebra rewrites on the step list ------------------------------------------------------------------
+  auto uses_of = [&](int t) { int n = 0; for (const Step& q : steps) { for (int u : {q.in0, q.in1, q.in2, q.residual, q.in_scale}) n += (u == t); for (int u : q.concat_in) n += (u == t); } return n + (t == g.output); };
+  const bool no_rewrites = getenv("BSX_NO_REWRITES") != nullptr;
+  // (a) pw(resize(x)) → resize(pw(x)): a 1x1 convolution without activation commutes with bilinear interpolation (both
+  //     are linear and the interpolation weights sum to 1, so the bias passes through); done at the LOW resolution the
+  //     convolution costs 1/4 of the MACs and the up-sampled many-channel tensor is never materialised.  The result differs
+  //     from the reference order only by f32 rounding (covered by the 1e-4 logit tolerance).
+  for (size_t i = 0; i < steps.size() && !no_rewrites; i++) {
+    if (steps[i].kind != StepKind::Resize || uses_of(steps[i].out) != 1) continue;
+    size_t j = i + 1;
+    for (; j < steps.size(); j++) if (steps[j].in0 == steps[i].out) break;
+    if (j >= steps.size()) continue;
+    Step& R = steps[i];
+    Step& Pw = steps[j];
+    if (Pw.kind != StepKind::PwConv || Pw.act != kActNone || Pw.residual >= 0 || Pw.in_scale >= 0 || Pw.in2 >= 0) continue;
+    if (R.OH * R.OW <= R.H * R.W) continue;   // only worth it when up-sampling
+    TensorInfo nt;
+    nt.dims[0] = 1; nt.dims[1] = R.H; nt.dims[2] = R.W; nt.dims[3] = Pw.Cout;
+    nt.shape = {1, R.H, R.W, Pw.Cout};
+    nt.name = "lowres_pw";
+    g.tensors.push_back(nt);
+    const int tnew = (int)g.tensors.size() - 1;
+    Step pw2 = Pw, r2 = R;
+    pw2.in0 = R.in0; pw2.H = pw2.OH = R.H; pw2.W = pw2.OW = R.W; pw2.out = tnew;
+    pw2.macs = (double)R.H * R.W * Pw.Cout * Pw.Cin;
+    pw2.label = Pw.label + "@lo";
+    r2.in0 = tnew; r2.Cin = r2.Cout = Pw.Cout; r2.out = Pw.out;
+    r2.label = R.label + "'";
+    steps.erase(steps.begin() + j);
+    steps[i] = pw2;
+    steps.insert(steps.begin() + i + 1, r2);
+  }
+  NT = (int)g.tensors.size();
+  // (b) y = a*s + b feeding only a 1x1 convolution: formed on the fly while the convolution loads its input
+  //     (same two roundings as the separate MUL and ADD ops, so bit-identical to the unfused form)
+  for (size_t i = 0; i < steps.size() && !no_rewrites; i++) {
+    if (steps[i].kind != StepKind::Eltwise || steps[i].elt != kEltMulAdd || !steps[i].bcast1 || steps[i].act != kActNone) continue;
+    if (uses_of(steps[i].out) != 1) continue;
+    size_t j = i + 1;
+    for (; j < steps.size(); j++) if (steps[j].in0 == steps[i].out) break;
+    if (j >= steps.size()) continue;
+    Step& Pw = steps[j];
+    if (Pw.kind != StepKind::PwConv || Pw.in_scale >= 0 || Pw.in2 >= 0 || Pw.Cin % 4) continue;
+    Pw.in0 = steps[i].in0; Pw.in_scale = steps[i].in1; Pw.in2 = steps[i].in2;   // in2 of a conv step = tensor added to the scaled input
+    Pw.label += "+muladd";
+    steps.erase(steps.begin() + i);
+    i--;
+  }
 
   // ---- activation arena: first-fit over [first def, last use] intervals, in per-stream float units
   plan->tensor_off.assign(NT, -1);

@@ -52,6 +52,7 @@ struct Plan {
   double macs_per_frame = 0;
   // whole-network per-frame program (empty when some step has no micro-op form)
   std::vector<MicroOp> program;
+  std::vector<std::string> program_labels;
   int program_lds_floats = 0;         // dynamic LDS the program needs (scratch included)
   int program_lds_tensors = 0, program_global_tensors = 0;
   std::string describe() const;

@@ -28,8 +28,9 @@ def test_loader_and_planner_agree_with_python_reader(bs, key, real):
     head = dict(kv.split("=") for kv in txt.splitlines()[0].split())
     assert int(head["ops"]) == len(m.ops)
     assert int(head["nodes"]) == sum(1 for o in m.ops if o.name != "DEQUANTIZE")
-    assert abs(float(head["macs"]) - MACS[key]) / MACS[key] < 0.01
-    steps = txt.splitlines()[1:]
+    # the planner may only REMOVE work (pw∘resize → resize∘pw runs the 1x1 conv at the low resolution)
+    assert 0.85 * MACS[key] <= float(head["macs"]) <= 1.01 * MACS[key]
+    steps = [l for l in txt.splitlines()[1:] if l[:4].strip().isdigit()]
     assert int(head["steps"]) == len(steps) < int(head["nodes"])       # fusion happened
     # every activation op was folded into its producer in the Meet/MLKit graphs
     if key != "deeplab":

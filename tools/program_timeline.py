@@ -20,9 +20,9 @@ frames = torch.from_numpy(synth.frames(n, W, H, distinct=4)).cuda()
 mg.run_stage(0, frames)
 for _ in range(3):
     tl = mg.program_timeline(n)
-steps = [l for l in mg.plan().splitlines() if l[:4].strip().isdigit()]
+steps = [l for l in mg.plan().splitlines() if l.startswith("P") and l[1:2].isdigit()]
 tot = sum(tl)
 for i, us in enumerate(tl):
     print("%6.2f us  %5.1f%%  %s" % (us, 100 * us / tot, steps[i] if i < len(steps) else "?"))
 print("total %.1f us for workgroup 0 (n=%d)" % (tot, n))
-print(mg.plan().splitlines()[-1])
+print([l for l in mg.plan().splitlines() if l.startswith("frame program")][0])
