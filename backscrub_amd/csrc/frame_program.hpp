@@ -36,6 +36,7 @@ struct MicroOp {
   int cout_pad = 0, cout_tile = 16;
   int stage_floats = 0;  // >0: the kernel copies weights[w_off .. w_off+stage_floats) (weights, then bias at b_off-w_off) into the LDS
                          // scratch before the op; the copy is prefetched into registers while the PREVIOUS op runs
+  int ws_off = 0, band_rows = 0;   // dense conv on the matrix cores: LDS workspace (float offset) holding a band of input rows; output rows per band
   int mfma = 0;     // 1: pointwise conv runs on v_mfma_f32_16x16x4_f32 with the weight block staged in LDS
   int gemv = 0;     // 1: ≤4 output pixels → wave-per-output-channel dot products with [co][ci] weights
   int n_cat = 0;

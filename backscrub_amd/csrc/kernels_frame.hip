@@ -374,6 +374,127 @@ __device__ __forceinline__ void mo_conv(cop_t& op, const FrameCtx& c) {
   }
 }
 
+// ---- dense k x k convolution on the matrix cores (network stems) ---------------------------------------------------------
+// The input (HBM, dense rows) is streamed through an LDS band of (band_rows-1)*stride + k input rows with one coalesced
+// cooperative copy per band; a wave then owns a tile of 16 consecutive output pixels of one row x 16 output channels and
+// runs ceil(K/4) MFMA steps over the im2col axis K = kh*kw*Cin (27 for the RGB stems): operand A is gathered from the
+// band through a per-k offset table, operand B comes from the staged [K][cout_pad] weight block.  Out-of-image taps
+// (SAME padding) and the K tail contribute an exact 0.
+__device__ __forceinline__ void mo_conv_mfma(cop_t& op, const FrameCtx& c) {
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c);
+  const int H = op.H, W = op.W, Cin = op.Cin, OH = op.OH, OW = op.OW, Cout = op.Cout, cout_pad = op.cout_pad, act = op.act;
+  const int kh = op.kh, kw = op.kw, sh = op.sh, sw = op.sw, pt = op.pt, pl = op.pl;
+  const int K = kh * kw * Cin, nsteps = (K + 3) >> 2;
+  const int rowf = W * Cin;                                      // floats per input row
+  const int band_in = (op.band_rows - 1) * sh + kh;              // input rows per band
+  lds_f* band = lds_base() + op.ws_off;
+  lds_f* ktab = band + band_in * rowf;                           // per-k table: offset inside the band, fy, fx  (3 ints per k)
+  const lds_f* wl = lds_base();
+  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
+  for (int k = threadIdx.x; k < nsteps * 4; k += kFrameThreads) {
+    int fy = 0, fx = 0, ci = 0, valid = k < K;
+    if (valid) { fy = k / (kw * Cin); const int r = k - fy * kw * Cin; fx = r / Cin; ci = r - fx * Cin; }
+    ((__attribute__((address_space(3))) int*)ktab)[3 * k] = valid ? (fy * W + fx) * Cin + ci : 0;
+    ((__attribute__((address_space(3))) int*)ktab)[3 * k + 1] = valid ? fy : -100000;     // invalid k → never inside the image
+    ((__attribute__((address_space(3))) int*)ktab)[3 * k + 2] = fx;
+  }
+  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, nw = kFrameThreads >> 6;
+  const int mtx = (OW + 15) >> 4, nt = cout_pad >> 4;
+  // band rows are double-buffered through registers: the next band's HBM loads are in flight while this band's tiles run
+  constexpr int kBandRegs = 4;                                   // planner keeps a band <= 16384 floats = 4 float4 per lane
+  f4v breg[kBandRegs];
+  auto band_load = [&](int oy0) {
+    const int iy0 = oy0 * sh - pt;
+#pragma unroll
+    for (int q = 0; q < kBandRegs; q++) {
+      const int i = (q * kFrameThreads + (int)threadIdx.x) * 4;
+      f4v v = {0.f, 0.f, 0.f, 0.f};
+      if (i < band_in * rowf) {
+        if ((rowf & 3) == 0) {
+          const int iy = iy0 + i / rowf;
+          if (iy >= 0 && iy < H) v = *(const glb_v4*)(x.g + (long)iy0 * rowf + i);
+        } else {
+          for (int e = 0; e < 4; e++) {
+            const int ii = i + e, yy = iy0 + ii / rowf;
+            if (ii < band_in * rowf && yy >= 0 && yy < H) v[e] = x.g[(long)iy0 * rowf + ii];
+          }
+        }
+      }
+      breg[q] = v;
+    }
+  };
+  band_load(0);
+  // the (<= 8) im2col entries this lane feeds — k = 4*step + g — live in registers for the whole op
+  constexpr int kKReg = 8;
+  int koff[kKReg], kfy[kKReg], kfx[kKReg], kw_row[kKReg];
+  __syncthreads();
+#pragma unroll
+  for (int s4 = 0; s4 < kKReg; s4++) {
+    const int k = min(4 * s4 + g, nsteps * 4 - 1);
+    koff[s4] = ((const __attribute__((address_space(3))) int*)ktab)[3 * k];
+    kfy[s4] = ((const __attribute__((address_space(3))) int*)ktab)[3 * k + 1];
+    kfx[s4] = ((const __attribute__((address_space(3))) int*)ktab)[3 * k + 2];
+    kw_row[s4] = min(k, K - 1) * cout_pad;
+  }
+  for (int oy0 = 0; oy0 < OH; oy0 += op.band_rows) {
+    const int rows_out = min(op.band_rows, OH - oy0);
+    __syncthreads();                                             // previous band fully consumed (and ktab written)
+#pragma unroll
+    for (int q = 0; q < kBandRegs; q++) {
+      const int i = (q * kFrameThreads + (int)threadIdx.x) * 4;
+      if (i < band_in * rowf) *(lds_v4*)(band + i) = breg[q];
+    }
+    __syncthreads();
+    if (oy0 + op.band_rows < OH) band_load(oy0 + op.band_rows);
+    const int tiles = rows_out * mtx * nt;
+    for (int wi = wave_id(); wi < tiles; wi += nw) {
+      const int tn = wi / (rows_out * mtx), rem = wi - tn * rows_out * mtx;
+      const int ry = rem / mtx, tm = rem - ry * mtx;
+      const int oy = oy0 + ry, ox = min(tm * 16 + li, OW - 1), n0 = tn << 4;
+      const int base = (ry * sh * W + (ox * sw - pl)) * Cin;      // band offset of tap (0,0); may point left of the row start
+      const int iyb = oy * sh - pt, ixb = ox * sw - pl;
+      f4acc acc = {0.f, 0.f, 0.f, 0.f};
+      if (nsteps <= kKReg) {
+        // all operand loads of the tile are independent: issue them together, then run the MFMA chain
+        float av[kKReg], bv4[kKReg];
+#pragma unroll
+        for (int s4 = 0; s4 < kKReg; s4++) {
+          av[s4] = 0.f; bv4[s4] = 0.f;
+          if (s4 < nsteps) {
+            const int iy = iyb + kfy[s4], ix = ixb + kfx[s4];
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            av[s4] = ok ? band[base + koff[s4]] : 0.f;
+            bv4[s4] = wl[kw_row[s4] + n0 + li];
+          }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < kKReg; s4++)
+          if (s4 < nsteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv4[s4], acc, 0, 0, 0);
+      } else
+      for (int s4 = 0; s4 < nsteps; s4++) {
+        const int k = 4 * s4 + g;
+        const int koff = ((const __attribute__((address_space(3))) int*)ktab)[3 * k];
+        const int fy = ((const __attribute__((address_space(3))) int*)ktab)[3 * k + 1];
+        const int fx = ((const __attribute__((address_space(3))) int*)ktab)[3 * k + 2];
+        const int iy = iyb + fy, ix = ixb + fx;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float a = ok ? band[base + koff] : 0.f;
+        const float b = wl[min(k, K - 1) * cout_pad + n0 + li];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+      const int co = n0 + li;
+      if (co < Cout) {
+        const float bv = bl[co];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int oxr = tm * 16 + 4 * g + r;
+          if (oxr < OW) st1(y, (oy * OW + oxr) * y.stride + co, fp_act(acc[r] + bv, act));
+        }
+      }
+    }
+  }
+}
+
 // ---- depthwise: lane = (output pixel, channel quad) --------------------------------------------------------------------
 // Weights + bias staged in LDS when they fit; taps are branch-free (clamped address, zeroed weight outside the image:
 // 0 * finite == 0, summation order stays fy, fx ascending).
@@ -700,7 +821,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
         if (op.gemv) mo_gemv(op, c);
         else mo_pw(op, c);
         break;
-      case StepKind::Conv: mo_conv(op, c); break;
+      case StepKind::Conv: if (op.mfma) mo_conv_mfma(op, c); else mo_conv(op, c); break;
       case StepKind::DwConv: mo_dw(op, c); break;
       case StepKind::Gap: mo_gap(op, c); break;
       case StepKind::Eltwise: mo_elt(op, c); break;

@@ -137,50 +137,120 @@ __global__ __launch_bounds__(kThreads) void decode_k(int type, const float* __re
   out[i] = (uint8_t)((val & 0xE0) | (out[i] >> 3));
 }
 
-// ---- mask: upscale + 5x5 box blur, LDS tiled ---------------------------------------------------
-// Tile = 64x16 output pixels per 256-lane workgroup.  Phase 1 computes the (64+4)x(16+4)
-// up-scaled neighbourhood (REFLECT_101 of the ROI-sized image) into LDS, phase 2 forms the
-// horizontal 5-sums, phase 3 the vertical 5-sums and (s+12)/25, 4 pixels per lane packed
-// into one 32-bit store.
-constexpr int kTW = 64, kTH = 16;
+// ---- mask: upscale + 5x5 box blur, LDS tiled, separable -------------------------------------------------------------
+// Tile = 128x32 output pixels per 256-lane workgroup.  All table lookups happen once per tile column / tile row:
+//   1. per column of the (128+4)-wide halo tile: reflected ROI x → (sx, sx1, a0, a1);  per row of the (32+4)-tall
+//      halo tile: reflected ROI y → (sy0, sy1, b0, b1)                               [LDS]
+//   2. horizontal pass of cv::resize for the <= kMaxSrcRows source rows the tile touches:  hq[sy][x] = (S0*a0 + S1*a1) >> 4
+//   3. vertical pass: up[y][x] = (((b0*hq[sy0][x]) >> 16) + ((b1*hq[sy1][x]) >> 16) + 2) >> 2   (exactly OpenCV's 8u formula)
+//   4. horizontal 5-sums (u16), 5. vertical 5-sums, (s+12)/25, 4 pixels per 32-bit store.
+// Steps 2-3 are the separable form of the per-pixel bilinear sample: identical integers, ~4x fewer operations.
+constexpr int kTW = 128, kTH = 32, kHW = kTW + 4, kHH = kTH + 4, kMaxSrcRows = 40;
 __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                                uint8_t* __restrict__ mask, int W, int H, Rect4 roi) {
-  __shared__ uint8_t up[(kTH + 4) * (kTW + 4)];
-  __shared__ uint16_t hs[(kTH + 4) * kTW];
+  __shared__ int col_sx[kHW], col_sx1[kHW], col_a0[kHW], col_a1[kHW];
+  __shared__ int row_s0[kHH], row_s1[kHH], row_b0[kHH], row_b1[kHH];
+  __shared__ __attribute__((aligned(16))) uint16_t hq[kMaxSrcRows * kHW];
+  __shared__ __attribute__((aligned(16))) uint8_t up[kHH * kHW + 8];
+  __shared__ __attribute__((aligned(16))) uint16_t hs[kHH * kTW];
+  __shared__ int s_min, s_max;
   const int n = blockIdx.z;
   const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
   const uint8_t* src = ofinal + (long)n * outW * outH + (long)q.y * outW + q.x;
-  for (int k = threadIdx.x; k < (kTH + 4) * (kTW + 4); k += kThreads) {
-    int ly = k / (kTW + 4), lx = k % (kTW + 4);
-    int gx = reflect101(min(tx0 + lx - 2, roi.w + 1), roi.w), gy = reflect101(min(ty0 + ly - 2, roi.h + 1), roi.h);
-    int v;
-    sample_linear<1>(src, outW, tab, gx, gy, &v);
-    up[k] = (uint8_t)v;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_min = 1 << 30; s_max = -1; }
+  __syncthreads();
+  // 1. column / row tables
+  if (tid < kHW) {
+    const int gx = reflect101(min(tx0 + tid - 2, roi.w + 1), roi.w);
+    int sx, sx1, a0, a1;
+    if (tab.mode == 1) { sx = sx1 = gx; a0 = 2048; a1 = 0; }
+    else if (tab.mode == 2) { sx = 2 * gx; sx1 = 2 * gx + 1; a0 = a1 = 0; }
+    else { sx = tab.xofs[gx]; sx1 = min(sx + 1, tab.sw - 1); a0 = tab.xa[2 * gx]; a1 = tab.xa[2 * gx + 1]; }
+    col_sx[tid] = sx; col_sx1[tid] = sx1; col_a0[tid] = a0; col_a1[tid] = a1;
+  } else if (tid >= 192 && tid < 192 + kHH) {
+    const int r = tid - 192;
+    const int gy = reflect101(min(ty0 + r - 2, roi.h + 1), roi.h);
+    int s0, s1, b0, b1;
+    if (tab.mode == 1) { s0 = s1 = gy; b0 = 2048; b1 = 0; }
+    else if (tab.mode == 2) { s0 = 2 * gy; s1 = 2 * gy + 1; b0 = b1 = 0; }
+    else { const int sy = tab.yofs[gy]; s0 = min(max(sy, 0), tab.sh - 1); s1 = min(max(sy + 1, 0), tab.sh - 1); b0 = tab.ya[2 * gy]; b1 = tab.ya[2 * gy + 1]; }
+    row_s0[r] = s0; row_s1[r] = s1; row_b0[r] = b0; row_b1[r] = b1;
+    atomicMin(&s_min, s0);
+    atomicMax(&s_max, s1);
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < (kTH + 4) * kTW; k += kThreads) {
-    int ly = k / kTW, lx = k % kTW;
-    const uint8_t* p = up + ly * (kTW + 4) + lx;
-    hs[k] = (uint16_t)(p[0] + p[1] + p[2] + p[3] + p[4]);
-  }
-  __syncthreads();
-  // 256 lanes → 16 rows x 16 groups of 4 pixels
-  int ly = threadIdx.x / 16, lx = (threadIdx.x % 16) * 4;
-  int gy = ty0 + ly, gx = tx0 + lx;
-  if (gy >= roi.h || gx >= roi.w) return;
-  uint32_t packed = 0;
-  uint8_t vals[4];
+  const int smin = s_min, nsr = s_max - smin + 1;
+  if (tab.mode == 0 && nsr <= kMaxSrcRows) {
+    // 2. horizontal pass on the touched source rows
+    for (int k = tid; k < nsr * kHW; k += kThreads) {
+      const int r = k / kHW, x = k - r * kHW;
+      const uint8_t* sr = src + (long)(smin + r) * outW;
+      hq[k] = (uint16_t)((sr[col_sx[x]] * col_a0[x] + sr[col_sx1[x]] * col_a1[x]) >> 4);
+    }
+    __syncthreads();
+    // 3. vertical pass, 4 pixels per lane (64-bit LDS reads of the two source rows, one 32-bit write)
+    for (int k = tid; k < kHH * (kHW / 4); k += kThreads) {
+      const int y = k / (kHW / 4), x = (k - y * (kHW / 4)) * 4;
+      const int b0 = row_b0[y], b1 = row_b1[y];
+      const uint2 r0 = *reinterpret_cast<const uint2*>(&hq[(row_s0[y] - smin) * kHW + x]);
+      const uint2 r1 = *reinterpret_cast<const uint2*>(&hq[(row_s1[y] - smin) * kHW + x]);
+      const int h0[4] = {(int)(r0.x & 0xffff), (int)(r0.x >> 16), (int)(r0.y & 0xffff), (int)(r0.y >> 16)};
+      const int h1[4] = {(int)(r1.x & 0xffff), (int)(r1.x >> 16), (int)(r1.y & 0xffff), (int)(r1.y >> 16)};
+      uint32_t packed = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    int s = hs[ly * kTW + lx + j] + hs[(ly + 1) * kTW + lx + j] + hs[(ly + 2) * kTW + lx + j] + hs[(ly + 3) * kTW + lx + j] + hs[(ly + 4) * kTW + lx + j];
-    vals[j] = (uint8_t)((s + 12) / 25);
-    packed |= (uint32_t)vals[j] << (8 * j);
-  }
-  uint8_t* dst = mask + (long)n * W * H + (long)(roi.y + gy) * W + roi.x + gx;
-  if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) {
-    *reinterpret_cast<uint32_t*>(dst) = packed;
+      for (int j = 0; j < 4; j++) packed |= (uint32_t)((((b0 * h0[j]) >> 16) + ((b1 * h1[j]) >> 16) + 2) >> 2) << (8 * j);
+      *reinterpret_cast<uint32_t*>(&up[y * kHW + x]) = packed;
+    }
   } else {
-    for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = vals[j];
+    // copy / exact-2x area / very strong down-scale: direct per-pixel sample
+    for (int k = tid; k < kHH * kHW; k += kThreads) {
+      const int y = k / kHW, x = k - y * kHW;
+      int v;
+      if (tab.mode == 1) v = src[(long)row_s0[y] * outW + col_sx[x]];
+      else if (tab.mode == 2) v = (src[(long)row_s0[y] * outW + col_sx[x]] + src[(long)row_s0[y] * outW + col_sx1[x]] + src[(long)row_s1[y] * outW + col_sx[x]] +
+                                   src[(long)row_s1[y] * outW + col_sx1[x]] + 2) >> 2;
+      else {
+        const int h0 = src[(long)row_s0[y] * outW + col_sx[x]] * col_a0[x] + src[(long)row_s0[y] * outW + col_sx1[x]] * col_a1[x];
+        const int h1 = src[(long)row_s1[y] * outW + col_sx[x]] * col_a0[x] + src[(long)row_s1[y] * outW + col_sx1[x]] * col_a1[x];
+        v = (((row_b0[y] * (h0 >> 4)) >> 16) + ((row_b1[y] * (h1 >> 4)) >> 16) + 2) >> 2;
+      }
+      up[k] = (uint8_t)v;
+    }
+  }
+  __syncthreads();
+  // 4. horizontal 5-sums, 4 per lane: 8 consecutive bytes in, 4 u16 out
+  for (int k = tid; k < kHH * (kTW / 4); k += kThreads) {
+    const int ly = k / (kTW / 4), lx = (k - ly * (kTW / 4)) * 4;
+    const uint2 v = *reinterpret_cast<const uint2*>(&up[ly * kHW + lx]);
+    const int b[8] = {(int)(v.x & 255), (int)((v.x >> 8) & 255), (int)((v.x >> 16) & 255), (int)(v.x >> 24),
+                      (int)(v.y & 255), (int)((v.y >> 8) & 255), (int)((v.y >> 16) & 255), (int)(v.y >> 24)};
+    const int s0 = b[0] + b[1] + b[2] + b[3] + b[4];
+    const int s1 = s0 - b[0] + b[5], s2 = s1 - b[1] + b[6], s3 = s2 - b[2] + b[7];
+    *reinterpret_cast<uint2*>(&hs[ly * kTW + lx]) = make_uint2((uint32_t)s0 | ((uint32_t)s1 << 16), (uint32_t)s2 | ((uint32_t)s3 << 16));
+  }
+  __syncthreads();
+  // 5. vertical 5-sums: 32 rows x 32 groups of 4 pixels = 1024 items, 4 per lane
+  for (int k = tid; k < kTH * (kTW / 4); k += kThreads) {
+    const int ly = k / (kTW / 4), lx = (k - ly * (kTW / 4)) * 4;
+    const int gy = ty0 + ly, gx = tx0 + lx;
+    if (gy >= roi.h || gx >= roi.w) continue;
+    int sum[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      const uint2 v = *reinterpret_cast<const uint2*>(&hs[(ly + r) * kTW + lx]);
+      sum[0] += (int)(v.x & 0xffff); sum[1] += (int)(v.x >> 16); sum[2] += (int)(v.y & 0xffff); sum[3] += (int)(v.y >> 16);
+    }
+    uint32_t packed = 0;
+    uint8_t vals[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      vals[j] = (uint8_t)((sum[j] + 12) / 25);
+      packed |= (uint32_t)vals[j] << (8 * j);
+    }
+    uint8_t* dst = mask + (long)n * W * H + (long)(roi.y + gy) * W + roi.x + gx;
+    if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
+    else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = vals[j];
   }
 }
 

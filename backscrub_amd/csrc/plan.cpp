@@ -138,6 +138,24 @@ static void build_frame_program(const Graph& g, Plan* plan) {
       m.mfma = (st.cout_pad % 16 == 0 && m.stage_floats > 0) ? 1 : 0;
       if (!m.mfma) m.stage_floats = 0;   // the SGPR-fed VALU body reads its weights from memory
     }
+    if (st.kind == StepKind::Conv && m.stage_floats > 0 && st.cout_pad % 16 == 0 && m.in0.space != kLocLds && st.residual < 0 &&
+        st.dh == 1 && st.dw == 1 && st.kh * st.kw * st.Cin <= 256) {
+      // matrix-core stem: find an LDS workspace for a band of input rows (+ the per-k table) among the free blocks at this step
+      const int rowf = st.W * st.Cin;
+      int band = 16;
+      auto need_for = [&](int b) { return ((b - 1) * st.sh + st.kh) * rowf + 3 * (((st.kh * st.kw * st.Cin + 3) / 4) * 4) + 8; };
+      while (band > 1 && need_for(band) > 16384) band /= 2;
+      const int need = (need_for(band) + 3) / 4 * 4;
+      live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
+      std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+      int pos = kLdsScratchFloats;
+      for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
+      if (pos + need <= cap) {
+        m.mfma = 1; m.ws_off = pos; m.band_rows = band;
+        live.push_back({pos, need, s});          // occupied for this step only
+        high = std::max(high, pos + need);
+      }
+    }
     if (m.scale.space != kLocNone && m.scale.space != kLocLds) return;   // the pw micro-op reads SE scales with ds_read only
     if (getenv("BSX_PROGRAM_NOP")) m.kind = 99;
     if (const char* only = getenv("BSX_PROGRAM_ONLY")) { if (atoi(only) != s) m.kind = 99; }   // timing experiments: one live op
