@@ -172,7 +172,10 @@ int init_device_state(bsx_ctx* c) {
   BSX_HIP(c, hipMalloc(&c->d_net_out, N * c->outW * c->outH * c->outC * sizeof(float)));
   BSX_HIP(c, hipMalloc(&c->d_weights, std::max<size_t>(c->plan.weights.size(), 4) * sizeof(float)));
   BSX_HIP(c, hipMemcpy(c->d_weights, c->plan.weights.data(), c->plan.weights.size() * sizeof(float), hipMemcpyHostToDevice));
-  c->use_program = !c->plan.program.empty() && getenv("BSX_NO_FRAME_PROGRAM") == nullptr;
+  // The per-frame program pays off when most tensors stay in LDS (Meet / MLKit families); graphs whose tensors mostly
+  // spill (DeepLab: 33x33x480) run faster as one batch-wide launch per step.  BSX_FORCE_FRAME_PROGRAM / BSX_NO_FRAME_PROGRAM override.
+  c->use_program = !c->plan.program.empty() && getenv("BSX_NO_FRAME_PROGRAM") == nullptr &&
+                   (c->plan.program_lds_tensors >= c->plan.program_global_tensors || getenv("BSX_FORCE_FRAME_PROGRAM") != nullptr);
   if (c->use_program) {
     BSX_HIP(c, hipMalloc(&c->d_program, c->plan.program.size() * sizeof(MicroOp)));
     BSX_HIP(c, hipMemcpy(c->d_program, c->plan.program.data(), c->plan.program.size() * sizeof(MicroOp), hipMemcpyHostToDevice));

@@ -69,8 +69,9 @@ def cpu_baseline(model_path, width, height, target_s):
     cores = os.cpu_count() or 1
     frames = synth.frames(cores, width, height, distinct=min(cores, 4))
     bg = synth.background(width, height)
-    sec, _, _ = oracle_py.baseline_run(model_path, frames, bg, 1, cores)     # calibration pass (also warms caches)
-    per_iter = max(sec, 1e-3)
+    oracle_py.baseline_run(model_path, frames, bg, 1, cores)                 # warm-up (page faults, thread pool)
+    sec, _, _ = oracle_py.baseline_run(model_path, frames, bg, 3, cores)     # calibration
+    per_iter = max(sec / 3, 1e-3)
     iters = int(max(2, min(200, target_s / per_iter)))
     sec, stages, _ = oracle_py.baseline_run(model_path, frames, bg, iters, cores)
     fps = cores * iters / sec
@@ -172,7 +173,7 @@ def main():
                 pmc = pj["kernels"]
         except Exception:
             pass
-        pmc_names = {"blend": "blend16_k", "mask_upscale_blur": "mask_upscale_blur_k", "prep_resize": "prep_resize_k",
+        pmc_names = {"frame_program": "frame_program_k", "blend": "blend16_k", "mask_upscale_blur": "mask_upscale_blur_k", "prep_resize": "prep_resize_k",
                      "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k"}
 
         def traffic(s):
@@ -187,7 +188,8 @@ def main():
             if s["flops"] > 0 and s["flops"] / max(s["bytes"], 1) > FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
                 a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
                 return {"kernel": s["name"], "bound": "mfma", "achieved": round(a, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(a / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_ms": round(s["avg_ms"], 4)}
+                        "frac": round(a / FP32_PEAK_TFLOPS, 4), "traffic": traffic(s), "avg_ms": round(s["avg_ms"], 4),
+                        "note": "f32 MFMA/VALU peak; the fused network launch is issue/latency bound, see DESIGN.md"}
             return {"kernel": s["name"], "bound": "hbm", "achieved": round(s["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic(s), "avg_ms": round(s["avg_ms"], 4),
                     "algorithmic_bytes_per_launch": int(s["bytes"])}

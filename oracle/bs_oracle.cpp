@@ -575,10 +575,20 @@ static void bilateral_c3(const uint8_t* src, int w, int h, uint8_t* dst, int d, 
 // cv::blur(src,dst,Size(5,5)) on CV_8UC1: normalised box, REFLECT_101, int sums scaled by 1/25
 // and rounded → (s+12)/25 (no ties possible).  Call site: lib/libbackscrub.cc:371.
 static void blur5_u8(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride) {
-  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
-    int s = 0;
-    for (int j = -2; j <= 2; j++) { const uint8_t* row = src + (size_t)reflect101(y + j, h) * sstride; for (int i = -2; i <= 2; i++) s += row[reflect101(x + i, w)]; }
-    dst[y * dstride + x] = (uint8_t)cv_round(s * (1. / 25));
+  // separable form of the 25-tap sum (row sums, then column sums — OpenCV's RowSum/ColumnSum structure); same integers
+  std::vector<int> rows((size_t)h * w);
+  std::vector<int> xi(w + 4);
+  for (int x = -2; x < w + 2; x++) xi[x + 2] = reflect101(x, w);
+  for (int y = 0; y < h; y++) {
+    const uint8_t* r = src + (size_t)y * sstride;
+    int* o = &rows[(size_t)y * w];
+    for (int x = 0; x < w; x++) o[x] = r[xi[x]] + r[xi[x + 1]] + r[xi[x + 2]] + r[xi[x + 3]] + r[xi[x + 4]];
+  }
+  for (int y = 0; y < h; y++) {
+    const int* r0 = &rows[(size_t)reflect101(y - 2, h) * w]; const int* r1 = &rows[(size_t)reflect101(y - 1, h) * w];
+    const int* r2 = &rows[(size_t)y * w]; const int* r3 = &rows[(size_t)reflect101(y + 1, h) * w]; const int* r4 = &rows[(size_t)reflect101(y + 2, h) * w];
+    uint8_t* d = dst + (size_t)y * dstride;
+    for (int x = 0; x < w; x++) d[x] = (uint8_t)cv_round((r0[x] + r1[x] + r2[x] + r3[x] + r4[x]) * (1. / 25));
   }
 }
 

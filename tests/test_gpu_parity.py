@@ -143,6 +143,7 @@ def test_per_launch_path_agrees_with_frame_program(bs, oracle, key, monkeypatch)
     oc.prep(f)
     want = oc.infer()
     outs = []
+    monkeypatch.setenv("BSX_FORCE_FRAME_PROGRAM", "1")   # DeepLab defaults to the per-launch path; exercise both here
     for no_prog in ("", "1"):
         if no_prog:
             monkeypatch.setenv("BSX_NO_FRAME_PROGRAM", "1")
