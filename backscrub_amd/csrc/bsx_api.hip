@@ -392,9 +392,25 @@ int bsx_composite_batch(bsx_ctx* c, const uint8_t* d_bg, size_t bg_frame_stride,
 }
 
 int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream) {
-  int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
-  if (rc) return rc;
-  return bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, d_out, n, stream);
+  if (!c || !d_frames || !d_bg || !d_out || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  const bool fuse = !c->onmask && getenv("BSX_NO_MASK_BLEND_FUSION") == nullptr &&
+                    mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, d_out);
+  if (!fuse) {
+    int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
+    if (rc) return rc;
+    return bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, d_out, n, stream);
+  }
+  // process (prep → network → decode), then mask-upscale+blur and alpha blend of each tile in ONE launch
+  hipStream_t s = pick(c, stream);
+  int rc;
+  if ((rc = run_prep(c, d_frames, n, s))) return rc;
+  if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }
+  if ((rc = run_infer(c, n, s))) return rc;
+  if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); }
+  if ((rc = run_decode(c, n, s))) return rc;
+  BSX_HIP(c, launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg,
+                               bg_frame_stride, d_frames, d_out, n, s));
+  return BSX_OK;
 }
 
 int bsx_resize_bgr(bsx_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream) {
@@ -447,7 +463,9 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   if (!c || !d_frames || !d_bg || !d_out || !out || n <= 0 || n > c->n_streams || iters <= 0) return BSX_EINVAL;
   hipStream_t s = pick(c, stream);
   const int n_net = c->use_program ? 1 : (int)c->plan.steps.size();
-  const int L = 2 + n_net + 3;
+  const bool fuse_tail = !c->onmask && getenv("BSX_NO_MASK_BLEND_FUSION") == nullptr &&
+                         mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
+  const int L = 2 + n_net + (fuse_tail ? 2 : 3);
   if (cap < L) return BSX_EINVAL;
   std::vector<hipEvent_t> ev((size_t)2 * L);
   for (auto& e : ev) BSX_HIP(c, hipEventCreate(&e));
@@ -470,8 +488,13 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     else
       for (const Step& st : c->plan.steps) BSX_TIMED(launch_step(st, c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s));
     BSX_TIMED(launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
-    BSX_TIMED(launch_mask_upscale_blur(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, n, s));
-    BSX_TIMED(launch_blend(d_bg, bg_stride, d_frames, c->d_masks, d_out, (size_t)c->width * c->height, n, s));
+    if (fuse_tail) {
+      BSX_TIMED(launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg, bg_stride,
+                                  d_frames, d_out, n, s));
+    } else {
+      BSX_TIMED(launch_mask_upscale_blur(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, n, s));
+      BSX_TIMED(launch_blend(d_bg, bg_stride, d_frames, c->d_masks, d_out, (size_t)c->width * c->height, n, s));
+    }
 #undef BSX_TIMED
     BSX_HIP(c, hipStreamSynchronize(s));
     for (int j = 0; j < L; j++) { float ms = 0; BSX_HIP(c, hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1])); sum[j] += ms; }
@@ -503,8 +526,13 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     put(j++, st.label, N * b * 4.0, N * 2.0 * st.macs);
   }
   put(j++, "decode_iir", N * ((double)c->outW * c->outH * c->outC * 4.0 + 2.0 * c->outW * c->outH), 0);
-  put(j++, "mask_upscale_blur", N * ((double)c->in_roi.w * c->in_roi.h + (double)c->roi.w * c->roi.h), 0);
-  put(j++, "blend", N * 10.0 * px, 0);
+  if (fuse_tail) {
+    // fused: model-res mask in, full-res mask out (1 B/px), bg + frame in (6 B/px), composite out (3 B/px)
+    put(j++, "mask_blend", N * ((double)c->in_roi.w * c->in_roi.h + 10.0 * px), 0);
+  } else {
+    put(j++, "mask_upscale_blur", N * ((double)c->in_roi.w * c->in_roi.h + (double)c->roi.w * c->roi.h), 0);
+    put(j++, "blend", N * 10.0 * px, 0);
+  }
   return j;
 }
 

@@ -145,9 +145,16 @@ __global__ __launch_bounds__(kThreads) void decode_k(int type, const float* __re
 //   3. vertical pass: up[y][x] = (((b0*hq[sy0][x]) >> 16) + ((b1*hq[sy1][x]) >> 16) + 2) >> 2   (exactly OpenCV's 8u formula)
 //   4. horizontal 5-sums (u16), 5. vertical 5-sums, (s+12)/25, 4 pixels per 32-bit store.
 // Steps 2-3 are the separable form of the per-pixel bilinear sample: identical integers, ~4x fewer operations.
+// With BLEND the same workgroup also composites its tile (deepseg.cc:108-134) while the mask bytes are still in
+// registers: the mask is written once and never re-read, and the HBM-bound blend traffic of some workgroups overlaps
+// the LDS/ALU-bound mask phases of others.  (Used when the ROI is the whole frame.)
 constexpr int kTW = 128, kTH = 32, kHW = kTW + 4, kHH = kTH + 4, kMaxSrcRows = 40;
+__device__ __forceinline__ uint32_t blend4w(uint32_t a, uint32_t b, int m0, int m1, int m2, int m3);
+template <bool BLEND>
 __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
-                                                               uint8_t* __restrict__ mask, int W, int H, Rect4 roi) {
+                                                               uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
+                                                               const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
+                                                               uint8_t* __restrict__ outp) {
   __shared__ int col_sx[kHW], col_sx1[kHW], col_a0[kHW], col_a1[kHW];
   __shared__ int row_s0[kHH], row_s1[kHH], row_b0[kHH], row_b1[kHH];
   __shared__ __attribute__((aligned(16))) uint16_t hq[kMaxSrcRows * kHW];
@@ -251,10 +258,24 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
     uint8_t* dst = mask + (long)n * W * H + (long)(roi.y + gy) * W + roi.x + gx;
     if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
     else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = vals[j];
+    if constexpr (BLEND) {
+      // roi == whole frame and W % 4 == 0 (checked by the launcher): 4 pixels = 12 bytes = 3 aligned words per image
+      const long pix = (long)gy * W + gx;
+      const uint32_t* ap = reinterpret_cast<const uint32_t*>(bg + (bg_stride ? n * bg_stride : 0) + pix * 3);
+      const uint32_t* bp = reinterpret_cast<const uint32_t*>(frames + ((long)n * W * H + pix) * 3);
+      uint32_t* op = reinterpret_cast<uint32_t*>(outp + ((long)n * W * H + pix) * 3);
+      const uint32_t a0 = ap[0], a1 = ap[1], a2 = ap[2], b0 = bp[0], b1 = bp[1], b2 = bp[2];
+      const int m0 = vals[0], m1 = vals[1], m2 = vals[2], m3 = vals[3];
+      op[0] = blend4w(a0, b0, m0, m0, m0, m1);
+      op[1] = blend4w(a1, b1, m1, m1, m2, m2);
+      op[2] = blend4w(a2, b2, m2, m3, m3, m3);
+    }
   }
 }
 
 // ---- alpha blend: 16 pixels (16 mask bytes, 48+48 source bytes, 48 output bytes) per lane -----
+__device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, int m0, int m1, int m2, int m3);
+__device__ __forceinline__ uint32_t blend4w(uint32_t a, uint32_t b, int m0, int m1, int m2, int m3) { return blend4(a, b, m0, m1, m2, m3); }
 __device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, int m0, int m1, int m2, int m3) {
   // four consecutive bytes of the packed BGR stream; mX = mask of the pixel byte X belongs to
   uint32_t r;
@@ -376,7 +397,19 @@ hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, i
 hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                                     int n, hipStream_t s) {
   dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
-  mask_upscale_blur_k<<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi);
+  mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr);
+  return hipGetLastError();
+}
+
+bool mask_blend_fusable(int W, int H, Rect4 roi, const uint8_t* bg, size_t bg_stride, const uint8_t* frames, const uint8_t* out) {
+  return roi.x == 0 && roi.y == 0 && roi.w == W && roi.h == H && (W % 4) == 0 && (bg_stride % 4) == 0 &&
+         ((((uintptr_t)bg) | ((uintptr_t)frames) | ((uintptr_t)out)) & 3) == 0;
+}
+
+hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
+                             const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s) {
+  dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
+  mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
   return hipGetLastError();
 }
 

@@ -160,10 +160,11 @@ def main():
                     f.write("%3d %-22s %8.2f us %9.1f GB/s %8.2f GFLOP/s\n" % (i, s["name"], s["avg_ms"] * 1e3, s["GBps"], s["flops"] / max(s["avg_ms"], 1e-9) / 1e6))
         groups = {"prep": 0.0, "network": 0.0, "decode": 0.0, "mask": 0.0, "blend": 0.0}
         for s in stats:
-            k = {"prep_resize": "prep", "prep_bilateral": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend"}.get(s["name"], "network")
+            k = {"prep_resize": "prep", "prep_bilateral": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend",
+                 "mask_blend": "blend"}.get(s["name"], "network")
             groups[k] += s["avg_ms"]
         dom = max(stats, key=lambda s: s["avg_ms"])
-        blend = [s for s in stats if s["name"] == "blend"][0]
+        blend = [s for s in stats if s["name"] in ("blend", "mask_blend")][0]
 
         pmc = {}
         try:
@@ -173,7 +174,7 @@ def main():
                 pmc = pj["kernels"]
         except Exception:
             pass
-        pmc_names = {"frame_program": "frame_program_k", "blend": "blend16_k", "mask_upscale_blur": "mask_upscale_blur_k", "prep_resize": "prep_resize_k",
+        pmc_names = {"frame_program": "frame_program_k", "blend": "blend16_k", "mask_blend": "mask_upscale_blur_k<true>", "mask_upscale_blur": "mask_upscale_blur_k", "prep_resize": "prep_resize_k",
                      "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k"}
 
         def traffic(s):
