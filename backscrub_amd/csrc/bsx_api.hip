@@ -540,14 +540,15 @@ int bsx_debug_program_timeline(bsx_ctx* c, int n, unsigned long long* ticks, int
   if (!c || !ticks || n <= 0 || n > c->n_streams) return BSX_EINVAL;
   if (!c->use_program) return 0;
   const int L = (int)c->plan.program.size();
-  if (cap < L + 1) return BSX_EINVAL;
+  if (cap < L + 1 || L + 1 > 256) return BSX_EINVAL;
   unsigned long long* d = nullptr;
-  BSX_HIP(c, hipMalloc(&d, (L + 1) * sizeof(unsigned long long)));
+  BSX_HIP(c, hipMalloc(&d, 512 * sizeof(unsigned long long)));
+  BSX_HIP(c, hipMemset(d, 0, 512 * sizeof(unsigned long long)));
   hipStream_t s = pick(c, stream);
   BSX_HIP(c, launch_frame_program(c->d_program, L, c->plan.program_lds_floats, c->d_arena, (long)c->plan.arena_floats_per_stream, c->d_net_in,
                                   c->d_net_out, c->d_weights, n, s, d));
   BSX_HIP(c, hipStreamSynchronize(s));
-  BSX_HIP(c, hipMemcpy(ticks, d, (L + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  BSX_HIP(c, hipMemcpy(ticks, d, (size_t)std::min(cap, 512) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   (void)hipFree(d);
   return L;
 }

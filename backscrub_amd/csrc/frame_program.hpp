@@ -44,11 +44,17 @@ struct MicroOp {
   // fused squeeze-excite / gate chain (kind == kMicroSe): GAP(in0 | cat[]) → FC1 (w2_off, b_off, act, Cout=C1) → FC2 (w3_off, b3_off, act2, C2)
   long long w3_off = 0, b3_off = 0;
   int C1 = 0, C2 = 0, act2 = 0, n_fc = 0;
+  // fused decoder tail (kind == kMicroTail): z = act(pw(x*s + a)) → t = z + act2(dw3x3(z)) → out = act3(tconv2x2(t)); z lives in an LDS row band
+  //   pw: w_off/b_off (Cin → cout_pad), dw: w3_off/b3_off, tconv: w4_off/b4_off (Cout = C2); H,W = tail resolution; ws_off/band_rows = z band
+  long long w4_off = 0, b4_off = 0;
+  int act3 = 0;
+  unsigned magic_w = 0;   // ceil(2^32 / W): floor(n / W) == __umulhi(n, magic_w) for n < 65536 (integer division is ~40 instructions)
   Loc in0, in1, in2, res, scale, out;
   Loc cat[4];
   int cat_c[4] = {0, 0, 0, 0};
 };
 
+constexpr int kMicroTail = 101;              // MicroOp::kind of the fused pw → dw(+residual) → transpose-conv tail
 constexpr int kMicroSe = 100;                // MicroOp::kind of the fused GAP→FC→FC chain
 constexpr int kFrameThreads = 1024;          // 16 waves: 4 per SIMD
 constexpr int kLdsTotalFloats = 160 * 256;   // 160 KiB

@@ -51,6 +51,7 @@ struct FrameCtx {
   float* net_out;      // batch-major network output [n][outH][outW][outC]
   const float* weights;
   int frame;
+  unsigned long long* tl;   // debug timeline (nullptr normally); slots 256.. are free for sub-phase accumulators
 };
 
 // Address-space-typed tensor reference.  `lds` is wave-uniform, so `ld4`/`st4` compile to one scalar
@@ -272,6 +273,154 @@ __device__ __forceinline__ void pw_mfma(cop_t& op, const FrameCtx& c) {
   }
 }
 
+// ---- fused decoder tail: z = act(pw(x*s + a)) → t = z + act2(dw3x3(z)) → out = act3(tconv2x2(t)) ------------------------------
+// The three full-resolution ops of the decoder's last level used to round-trip z and t through HBM (the tensors are too
+// big for LDS).  Here the frame is processed in bands of R rows: phase A computes the z rows of the band (+1 halo row on
+// each side, zero outside the image) on the matrix cores straight into an LDS band; phase B has one lane per pixel form
+// t = z + act2(dw(z)) in registers and emit its 2x2 block of transpose-conv outputs.  Arithmetic (order of every FMA
+// chain) is exactly that of pw_mfma / dw_body / mo_tconv, so the result is bit-identical to the unfused program.
+template <int C>
+__device__ __forceinline__ void tail_body(cop_t& op, const FrameCtx& c) {
+  constexpr int ZS = C + 4;                                // LDS row stride of a z pixel
+  const Ref x = make_ref(op.in0, c), sc = make_ref(op.scale, c), ad = make_ref(op.in2, c), out = make_ref(op.out, c);
+  const int H = op.H, W = op.W, R = op.band_rows, act = op.act, act2 = op.act2, act3 = op.act3, Co = op.C2, OW = op.OW;
+  const unsigned mw = op.magic_w;                          // n / W == __umulhi(n, mw)
+  const glb_f* gw = (const glb_f*)c.weights;
+  // stage the three weight blocks: [pw C x C | pw bias C | dw 9 x C | dw bias C | tconv 4 x Co x C | tconv bias Co]
+  lds_f* wpw = lds_base();
+  lds_f* bpw = wpw + C * C;
+  lds_f* wdw = bpw + C;
+  lds_f* bdw = wdw + 9 * C;
+  lds_f* wtc = bdw + C;
+  lds_f* btc = wtc + 4 * Co * C;
+  for (int i = threadIdx.x; i < C * C; i += kFrameThreads) wpw[i] = gw[op.w_off + i];
+  for (int i = threadIdx.x; i < C; i += kFrameThreads) { bpw[i] = gw[op.b_off + i]; bdw[i] = gw[op.b3_off + i]; }
+  for (int i = threadIdx.x; i < 9 * C; i += kFrameThreads) wdw[i] = gw[op.w3_off + i];
+  for (int i = threadIdx.x; i < 4 * Co * C; i += kFrameThreads) wtc[i] = gw[op.w4_off + i];
+  for (int i = threadIdx.x; i < Co; i += kFrameThreads) btc[i] = gw[op.b4_off + i];
+  lds_f* zb = lds_base() + op.ws_off;                     // z band: (R+2) rows, stride ZS
+  lds_f* yb = zb + (R + 2) * W * ZS;                       // y = x*s + a band: (R+2) rows, dense C floats per pixel
+  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, nw = kFrameThreads >> 6;
+  const bool has_sc = sc.valid, has_add = ad.valid;
+  constexpr int NT = C / 16, NJ = C / 16;
+  // The band's input rows are contiguous in HBM: every lane fetches its float4s of x (and a), forms y = x*s + a with the
+  // graph's two roundings, and keeps them in registers while the PREVIOUS band is being consumed (HBM latency hidden).
+  constexpr int kYRegs = 4;                                // planner: (R+2)*W*C <= 16384 floats
+  float4 yreg[kYRegs];
+  const int C4 = C / 4;
+  auto y_load = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < kYRegs; q++) {
+      const int i4 = q * kFrameThreads + (int)threadIdx.x;          // float4 index inside the band
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i4 < (R + 2) * W * C4) {
+        const int bp = i4 / C4, k0 = (i4 - bp * C4) * 4, brow = (int)__umulhi((unsigned)bp, mw), iy = r0 - 1 + brow;
+        if (iy >= 0 && iy < H) {
+          const int pix = iy * W + (bp - brow * W);
+          v = ld4(x, pix * x.stride + k0);
+          if (has_sc) { const float4 sv = ld_lds4(sc.l + k0); v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w); }
+          if (has_add) { const float4 av = ld4(ad, pix * ad.stride + k0); v.x = __fadd_rn(v.x, av.x); v.y = __fadd_rn(v.y, av.y); v.z = __fadd_rn(v.z, av.z); v.w = __fadd_rn(v.w, av.w); }
+        }
+      }
+      yreg[q] = v;
+    }
+  };
+  y_load(0);
+  const bool dbg = c.tl && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long tA = 0, tB = 0, tS = 0, t0 = 0;
+  for (int r0 = 0; r0 < H; r0 += R) {
+    const int zrows = R + 2, npix = zrows * W, mt = (npix + 15) >> 4;
+    if (dbg) t0 = wall_clock64();
+    __syncthreads();                                       // previous band consumed (and weights staged)
+#pragma unroll
+    for (int q = 0; q < kYRegs; q++) {
+      const int i4 = q * kFrameThreads + (int)threadIdx.x;
+      if (i4 < npix * C4) st_lds4(yb + 4 * i4, yreg[q]);
+    }
+    __syncthreads();
+    if (r0 + R < H) y_load(r0 + R);
+    if (dbg) { const unsigned long long t1 = wall_clock64(); tS += t1 - t0; t0 = t1; }
+    // ---- phase A: z band rows r0-1 .. r0+R from the y band, on the matrix cores
+    for (int wi = wave_id(); wi < mt * NT; wi += nw) {
+      const int tn = wi / mt, tm = wi - tn * mt, m0 = tm << 4, n0 = tn << 4;
+      const int bp = min(m0 + li, npix - 1);
+      f4acc acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const float4 a = ld_lds4(yb + bp * C + 16 * j + 4 * g);
+        const lds_f* br = wpw + (16 * j + 4 * g) * C + n0 + li;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, br[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, br[C], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, br[2 * C], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, br[3 * C], acc, 0, 0, 0);
+      }
+      const int co = n0 + li;
+      const float bv = bpw[co];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int p2 = m0 + 4 * g + r;
+        if (p2 < npix) {
+          const int row2 = (int)__umulhi((unsigned)p2, mw), iy2 = r0 - 1 + row2;
+          zb[p2 * ZS + co] = (iy2 >= 0 && iy2 < H) ? fp_act(acc[r] + bv, act) : 0.f;   // rows outside the image are zero padding
+        }
+      }
+    }
+    __syncthreads();
+    if (dbg) { const unsigned long long t1 = wall_clock64(); tA += t1 - t0; t0 = t1; }
+    // ---- phase B: one lane per pixel of the R band rows
+    const int rows_here = min(R, H - r0);
+    for (int p = threadIdx.x; p < rows_here * W; p += kFrameThreads) {
+      const int ry = (int)__umulhi((unsigned)p, mw), ix = p - ry * W, iy = r0 + ry;
+      float t[C];
+#pragma unroll
+      for (int q = 0; q < C / 4; q++) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int fy = 0; fy < 3; fy++) {
+#pragma unroll 1
+          for (int fx = 0; fx < 3; fx++) {
+            const int xx = ix - 1 + fx;
+            const bool v = xx >= 0 && xx < W;                                 // rows are handled by the zero band rows
+            const float4 zv = ld_lds4(zb + ((ry + fy) * W + min(max(xx, 0), W - 1)) * ZS + 4 * q);
+            float4 wv = ld_lds4(wdw + (fy * 3 + fx) * C + 4 * q);
+            if (!v) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.x = fmaf(zv.x, wv.x, acc.x); acc.y = fmaf(zv.y, wv.y, acc.y); acc.z = fmaf(zv.z, wv.z, acc.z); acc.w = fmaf(zv.w, wv.w, acc.w);
+          }
+        }
+        const float4 b = ld_lds4(bdw + 4 * q), zc = ld_lds4(zb + ((ry + 1) * W + ix) * ZS + 4 * q);
+        const float4 d = fp_act4(make_float4(acc.x + b.x, acc.y + b.y, acc.z + b.z, acc.w + b.w), act2);
+        t[4 * q] = d.x + zc.x; t[4 * q + 1] = d.y + zc.y; t[4 * q + 2] = d.z + zc.z; t[4 * q + 3] = d.w + zc.w;   // dw epilogue: act, then + residual
+      }
+      // the 2x2xCo outputs of this input pixel form two contiguous runs of 2*Co floats (one per output row): with Co == 2
+      // each run is ONE 16-byte store, and consecutive lanes write consecutive 16-byte chunks
+#pragma unroll 1
+      for (int fy = 0; fy < 2; fy++) {
+        float o4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int fx = 0; fx < 2; fx++) {
+          for (int oc = 0; oc < Co; oc++) {
+            const lds_f* wr = wtc + ((fy * 2 + fx) * Co + oc) * C;
+            float acc = btc[oc];
+#pragma unroll
+            for (int k = 0; k < C; k += 4) {
+              const float4 wv = ld_lds4(wr + k);
+              acc = fmaf(t[k], wv.x, acc); acc = fmaf(t[k + 1], wv.y, acc); acc = fmaf(t[k + 2], wv.z, acc); acc = fmaf(t[k + 3], wv.w, acc);
+            }
+            const float v = fp_act(acc, act3);
+            if (Co == 2) { if (fx == 0) { if (oc == 0) o4[0] = v; else o4[1] = v; } else { if (oc == 0) o4[2] = v; else o4[3] = v; } }
+            else st1(out, ((2 * iy + fy) * OW + 2 * ix + fx) * out.stride + oc, v);
+          }
+        }
+        if (Co == 2) st4(out, ((2 * iy + fy) * OW + 2 * ix) * out.stride, make_float4(o4[0], o4[1], o4[2], o4[3]));
+      }
+    }
+    if (dbg) { const unsigned long long t1 = wall_clock64(); tB += t1 - t0; t0 = t1; }
+  }
+  if (dbg) { c.tl[256] = tS; c.tl[257] = tA; c.tl[258] = tB; }
+}
+__device__ __forceinline__ void mo_tail(cop_t& op, const FrameCtx& c) {
+  tail_body<16>(op, c);   // the planner only forms this micro-op for 16-channel tails
+}
+
 __device__ __forceinline__ void mo_pw(cop_t& op, const FrameCtx& c) {
   const bool xl = op.in0.space == kLocLds;
   if (op.mfma) { if (xl) pw_mfma<true>(op, c); else pw_mfma<false>(op, c); return; }
@@ -401,7 +550,7 @@ __device__ __forceinline__ void mo_conv_mfma(cop_t& op, const FrameCtx& c) {
   const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, nw = kFrameThreads >> 6;
   const int mtx = (OW + 15) >> 4, nt = cout_pad >> 4;
   // band rows are double-buffered through registers: the next band's HBM loads are in flight while this band's tiles run
-  constexpr int kBandRegs = 4;                                   // planner keeps a band <= 16384 floats = 4 float4 per lane
+  constexpr int kBandRegs = 2;                                   // planner keeps a band <= 8192 floats = 2 float4 per lane
   f4v breg[kBandRegs];
   auto band_load = [&](int oy0) {
     const int iy0 = oy0 * sh - pt;
@@ -426,15 +575,13 @@ __device__ __forceinline__ void mo_conv_mfma(cop_t& op, const FrameCtx& c) {
   band_load(0);
   // the (<= 8) im2col entries this lane feeds — k = 4*step + g — live in registers for the whole op
   constexpr int kKReg = 8;
-  int koff[kKReg], kfy[kKReg], kfx[kKReg], kw_row[kKReg];
+  int koff[kKReg], kfyx[kKReg];                                  // fy and fx packed as (fy << 8) | fx; invalid k has fy = -100000
   __syncthreads();
 #pragma unroll
   for (int s4 = 0; s4 < kKReg; s4++) {
     const int k = min(4 * s4 + g, nsteps * 4 - 1);
     koff[s4] = ((const __attribute__((address_space(3))) int*)ktab)[3 * k];
-    kfy[s4] = ((const __attribute__((address_space(3))) int*)ktab)[3 * k + 1];
-    kfx[s4] = ((const __attribute__((address_space(3))) int*)ktab)[3 * k + 2];
-    kw_row[s4] = min(k, K - 1) * cout_pad;
+    kfyx[s4] = ((const __attribute__((address_space(3))) int*)ktab)[3 * k + 1] * 256 + ((const __attribute__((address_space(3))) int*)ktab)[3 * k + 2];
   }
   for (int oy0 = 0; oy0 < OH; oy0 += op.band_rows) {
     const int rows_out = min(op.band_rows, OH - oy0);
@@ -461,10 +608,10 @@ __device__ __forceinline__ void mo_conv_mfma(cop_t& op, const FrameCtx& c) {
         for (int s4 = 0; s4 < kKReg; s4++) {
           av[s4] = 0.f; bv4[s4] = 0.f;
           if (s4 < nsteps) {
-            const int iy = iyb + kfy[s4], ix = ixb + kfx[s4];
+            const int iy = iyb + (kfyx[s4] >> 8), ix = ixb + (kfyx[s4] & 255);
             const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
             av[s4] = ok ? band[base + koff[s4]] : 0.f;
-            bv4[s4] = wl[kw_row[s4] + n0 + li];
+            bv4[s4] = wl[min(4 * s4 + g, K - 1) * cout_pad + n0 + li];
           }
         }
 #pragma unroll
@@ -784,7 +931,7 @@ __device__ __forceinline__ void mo_tconv(cop_t& op, const FrameCtx& c) {
 __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* __restrict__ ops, int n_ops, float* arena, long per_frame_floats,
                                                                 float* net_in, float* net_out, const float* __restrict__ weights,
                                                                 unsigned long long* timeline, int repeat) {
-  FrameCtx c{arena + (size_t)blockIdx.x * (size_t)per_frame_floats, net_in, net_out, weights, (int)blockIdx.x};
+  FrameCtx c{arena + (size_t)blockIdx.x * (size_t)per_frame_floats, net_in, net_out, weights, (int)blockIdx.x, timeline};
   // Weight staging is software-pipelined across ops: while op i computes, every lane already holds its float4 of op
   // i+1's weight block in registers; at the top of op i+1 it only has to drop it into the LDS scratch.
   const glb_f* gw = (const glb_f*)weights;
@@ -828,7 +975,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
       case StepKind::Resize: mo_resize(op, c); break;
       case StepKind::Concat: mo_concat(op, c); break;
       case StepKind::TConv: mo_tconv(op, c); break;
-      default: if (op.kind == kMicroSe) mo_se(op, c); break;
+      default: if (op.kind == kMicroSe) mo_se(op, c); else if (op.kind == kMicroTail) mo_tail(op, c); break;
     }
     __syncthreads();
   }

@@ -108,8 +108,32 @@ static void build_frame_program(const Graph& g, Plan* plan) {
   place(g.input, -1);
   std::vector<MicroOp> prog;
   std::vector<std::string> labels;
+  std::vector<int> tail_ws(NS, -1), tail_rows(NS, 0);
+  auto tail_pattern = [&](int s) {
+    if (s + 2 >= NS || getenv("BSX_PROGRAM_NO_TAIL")) return false;
+    const Step& a = plan->steps[s];
+    const Step& b = plan->steps[s + 1];
+    const Step& c2 = plan->steps[s + 2];
+    return a.kind == StepKind::PwConv && a.residual < 0 && a.Cin == 16 && a.cout_pad == 16 && a.Cout == 16 &&
+           a.OH * a.OW > 1024 && last[a.out] == s + 1 &&
+           b.kind == StepKind::DwConv && b.in0 == a.out && b.residual == a.out && b.kh == 3 && b.kw == 3 && b.sh == 1 && b.sw == 1 && b.dh == 1 &&
+           b.dw == 1 && b.pad_t == 1 && b.pad_l == 1 && last[b.out] == s + 2 &&
+           c2.kind == StepKind::TConv && c2.in0 == b.out && c2.kh == 2 && c2.kw == 2 && c2.Cout <= 4;
+  };
   for (int s = 0; s < NS; s++) {
     const Step& st = plan->steps[s];
+    if (tail_pattern(s)) {
+      // z row band: (R+2) rows x W pixels x (C+4) floats, alive for the three fused steps
+      int R = 8;
+      auto need_for = [&](int r) { return (r + 2) * st.W * (st.Cout + 4) + (r + 2) * st.W * st.Cin; };   // z band + y band
+      while (R > 1 && ((R + 2) * st.W * st.Cin > 16384 || need_for(R) > 30000)) R /= 2;
+      const int need = need_for(R);
+      live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
+      std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+      int pos = kLdsScratchFloats;
+      for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
+      if (pos + need <= cap) { tail_ws[s] = pos; tail_rows[s] = R; live.push_back({pos, need, s + 2}); high = std::max(high, pos + need); }
+    }
     place(st.out, s);
     MicroOp m;
     m.kind = (int)st.kind;
@@ -144,13 +168,14 @@ static void build_frame_program(const Graph& g, Plan* plan) {
       const int rowf = st.W * st.Cin;
       int band = 16;
       auto need_for = [&](int b) { return ((b - 1) * st.sh + st.kh) * rowf + 3 * (((st.kh * st.kw * st.Cin + 3) / 4) * 4) + 8; };
-      while (band > 1 && need_for(band) > 16384) band /= 2;
+      auto band_floats = [&](int b) { return ((b - 1) * st.sh + st.kh) * rowf; };
+      while (band > 1 && band_floats(band) > 8192) band /= 2;   // the band is double-buffered through 2 float4 registers per lane
       const int need = (need_for(band) + 3) / 4 * 4;
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
       int pos = kLdsScratchFloats;
       for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
-      if (pos + need <= cap) {
+      if (pos + need <= cap && band_floats(band) <= 8192) {
         m.mfma = 1; m.ws_off = pos; m.band_rows = band;
         live.push_back({pos, need, s});          // occupied for this step only
         high = std::max(high, pos + need);
@@ -181,6 +206,22 @@ static void build_frame_program(const Graph& g, Plan* plan) {
                f.in0.space == kLocLds && f.in0.off == in.off && f.out.space == kLocLds && f.Cin % 4 == 0;
       };
       auto single_use = [&](size_t k) { const Step& st = plan->steps[k]; return last[st.out] == (int)k + 1; };
+      if (tail_ws[i] >= 0 && prog[i].mfma && prog[i].out.space == kLocGlobal && prog[i].scale.space != kLocGlobal) {
+        // pw(+muladd) → dw 3x3 (+act, + z) → tconv 2x2: z never leaves LDS, t never leaves registers
+        MicroOp m = prog[i];
+        const MicroOp& d = prog[i + 1];
+        const MicroOp& t = prog[i + 2];
+        m.kind = kMicroTail; m.mfma = 0; m.stage_floats = 0;
+        m.w3_off = d.w_off; m.b3_off = d.b_off; m.act2 = d.act;
+        m.w4_off = t.w_off; m.b4_off = t.b_off; m.act3 = t.act; m.C2 = t.Cout;
+        m.OH = t.OH; m.OW = t.OW; m.out = t.out;
+        m.ws_off = tail_ws[i]; m.band_rows = tail_rows[i];
+        m.magic_w = (unsigned)((0x100000000ull + (unsigned long long)m.W - 1) / (unsigned long long)m.W);
+        fusedp.push_back(m);
+        flabels.push_back("tail[pw+dw+tconv] " + labels[i]);
+        i += 2;
+        continue;
+      }
       if (g0.kind == (int)StepKind::Gap && g0.out.space == kLocLds && is_fc(i + 1, g0.out) && single_use(i)) {
         MicroOp m = g0;
         const MicroOp& f1 = prog[i + 1];

@@ -24,5 +24,6 @@ steps = [l for l in mg.plan().splitlines() if l.startswith("P") and l[1:2].isdig
 tot = sum(tl)
 for i, us in enumerate(tl):
     print("%6.2f us  %5.1f%%  %s" % (us, 100 * us / tot, steps[i] if i < len(steps) else "?"))
+print("sub-phase accumulators (us):", [round(v, 1) for v in mg.last_subphase_us])
 print("total %.1f us for workgroup 0 (n=%d)" % (tot, n))
 print([l for l in mg.plan().splitlines() if l.startswith("frame program")][0])
