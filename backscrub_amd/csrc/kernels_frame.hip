@@ -299,55 +299,33 @@ __device__ __forceinline__ void tail_body(cop_t& op, const FrameCtx& c) {
   for (int i = threadIdx.x; i < 4 * Co * C; i += kFrameThreads) wtc[i] = gw[op.w4_off + i];
   for (int i = threadIdx.x; i < Co; i += kFrameThreads) btc[i] = gw[op.b4_off + i];
   lds_f* zb = lds_base() + op.ws_off;                     // z band: (R+2) rows, stride ZS
-  lds_f* yb = zb + (R + 2) * W * ZS;                       // y = x*s + a band: (R+2) rows, dense C floats per pixel
   const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, nw = kFrameThreads >> 6;
   const bool has_sc = sc.valid, has_add = ad.valid;
   constexpr int NT = C / 16, NJ = C / 16;
-  // The band's input rows are contiguous in HBM: every lane fetches its float4s of x (and a), forms y = x*s + a with the
-  // graph's two roundings, and keeps them in registers while the PREVIOUS band is being consumed (HBM latency hidden).
-  constexpr int kYRegs = 4;                                // planner: (R+2)*W*C <= 16384 floats
-  float4 yreg[kYRegs];
-  const int C4 = C / 4;
-  auto y_load = [&](int r0) {
-#pragma unroll
-    for (int q = 0; q < kYRegs; q++) {
-      const int i4 = q * kFrameThreads + (int)threadIdx.x;          // float4 index inside the band
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i4 < (R + 2) * W * C4) {
-        const int bp = i4 / C4, k0 = (i4 - bp * C4) * 4, brow = (int)__umulhi((unsigned)bp, mw), iy = r0 - 1 + brow;
-        if (iy >= 0 && iy < H) {
-          const int pix = iy * W + (bp - brow * W);
-          v = ld4(x, pix * x.stride + k0);
-          if (has_sc) { const float4 sv = ld_lds4(sc.l + k0); v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w); }
-          if (has_add) { const float4 av = ld4(ad, pix * ad.stride + k0); v.x = __fadd_rn(v.x, av.x); v.y = __fadd_rn(v.y, av.y); v.z = __fadd_rn(v.z, av.z); v.w = __fadd_rn(v.w, av.w); }
-        }
-      }
-      yreg[q] = v;
-    }
-  };
-  y_load(0);
   const bool dbg = c.tl && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long tA = 0, tB = 0, tS = 0, t0 = 0;
   for (int r0 = 0; r0 < H; r0 += R) {
     const int zrows = R + 2, npix = zrows * W, mt = (npix + 15) >> 4;
     if (dbg) t0 = wall_clock64();
     __syncthreads();                                       // previous band consumed (and weights staged)
-#pragma unroll
-    for (int q = 0; q < kYRegs; q++) {
-      const int i4 = q * kFrameThreads + (int)threadIdx.x;
-      if (i4 < npix * C4) st_lds4(yb + 4 * i4, yreg[q]);
-    }
-    __syncthreads();
-    if (r0 + R < H) y_load(r0 + R);
     if (dbg) { const unsigned long long t1 = wall_clock64(); tS += t1 - t0; t0 = t1; }
-    // ---- phase A: z band rows r0-1 .. r0+R from the y band, on the matrix cores
+    // ---- phase A: z band rows r0-1 .. r0+R on the matrix cores (A operand = x*s + a straight from HBM / LDS)
     for (int wi = wave_id(); wi < mt * NT; wi += nw) {
       const int tn = wi / mt, tm = wi - tn * mt, m0 = tm << 4, n0 = tn << 4;
       const int bp = min(m0 + li, npix - 1);
+      const int brow = (int)__umulhi((unsigned)bp, mw), bx = bp - brow * W, iy = r0 - 1 + brow;
+      const bool rv = iy >= 0 && iy < H;
+      const int pix = (rv ? iy : 0) * W + bx;
       f4acc acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        const float4 a = ld_lds4(yb + bp * C + 16 * j + 4 * g);
+        const int k0 = 16 * j + 4 * g;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rv) {
+          a = ld4(x, pix * x.stride + k0);
+          if (has_sc) { const float4 sv = ld_lds4(sc.l + k0); a.x = __fmul_rn(a.x, sv.x); a.y = __fmul_rn(a.y, sv.y); a.z = __fmul_rn(a.z, sv.z); a.w = __fmul_rn(a.w, sv.w); }
+          if (has_add) { const float4 av = ld4(ad, pix * ad.stride + k0); a.x = __fadd_rn(a.x, av.x); a.y = __fadd_rn(a.y, av.y); a.z = __fadd_rn(a.z, av.z); a.w = __fadd_rn(a.w, av.w); }
+        }
         const lds_f* br = wpw + (16 * j + 4 * g) * C + n0 + li;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, br[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, br[C], acc, 0, 0, 0);

@@ -125,8 +125,8 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     if (tail_pattern(s)) {
       // z row band: (R+2) rows x W pixels x (C+4) floats, alive for the three fused steps
       int R = 8;
-      auto need_for = [&](int r) { return (r + 2) * st.W * (st.Cout + 4) + (r + 2) * st.W * st.Cin; };   // z band + y band
-      while (R > 1 && ((R + 2) * st.W * st.Cin > 16384 || need_for(R) > 30000)) R /= 2;
+      auto need_for = [&](int r) { return (r + 2) * st.W * (st.Cout + 4); };
+      while (R > 1 && need_for(R) > 20000) R /= 2;
       const int need = need_for(R);
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
