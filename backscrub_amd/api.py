@@ -56,6 +56,7 @@ SYMBOLS = [
     ("bsx_step_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_resize_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_bgr_to_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("bsx_yuyv_to_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_debug_buffer", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("bsx_debug_run_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_plan_describe", C.c_char_p, [C.c_void_p]),
@@ -191,6 +192,14 @@ class MaskGen:
         out = torch.empty((n, h, w, 2), dtype=torch.uint8, device=bgr.device)
         _check(lib().bsx_bgr_to_yuyv(self.h, C.c_void_p(bgr.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, _stream_ptr()),
                self.h, "bsx_bgr_to_yuyv")
+        return out
+
+    def yuyv_to_bgr(self, yuyv):
+        torch = _torch()
+        n, h, w, _ = yuyv.shape
+        out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=yuyv.device)
+        _check(lib().bsx_yuyv_to_bgr(self.h, C.c_void_p(yuyv.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, _stream_ptr()),
+               self.h, "bsx_yuyv_to_bgr")
         return out
 
     # ---- drop-in single frame path (host buffers) -----------------------------------------------

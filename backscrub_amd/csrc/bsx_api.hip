@@ -433,6 +433,12 @@ int bsx_bgr_to_yuyv(bsx_ctx* c, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, in
   return BSX_OK;
 }
 
+int bsx_yuyv_to_bgr(bsx_ctx* c, const uint8_t* d_yuyv, uint8_t* d_bgr, int w, int h, int n, void* stream) {
+  if (!c || !d_yuyv || !d_bgr || w <= 0 || h <= 0 || n <= 0 || (((long)w * h) & 1)) return BSX_EINVAL;
+  BSX_HIP(c, launch_yuyv_to_bgr(d_yuyv, d_bgr, w, h, n, pick(c, stream)));
+  return BSX_OK;
+}
+
 int bsx_debug_buffer(bsx_ctx* c, int which, void** d_ptr, size_t* bytes) {
   if (!c || !d_ptr || !bytes) return BSX_EINVAL;
   const size_t N = (size_t)c->n_streams;
@@ -465,7 +471,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   const int n_net = c->use_program ? 1 : (int)c->plan.steps.size();
   const bool fuse_tail = !c->onmask && getenv("BSX_NO_MASK_BLEND_FUSION") == nullptr &&
                          mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
-  const int L = 2 + n_net + (fuse_tail ? 2 : 3);
+  const int L = 2 + n_net + (fuse_tail ? 2 : 3) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
   if (cap < L) return BSX_EINVAL;
   std::vector<hipEvent_t> ev((size_t)2 * L);
   for (auto& e : ev) BSX_HIP(c, hipEventCreate(&e));
@@ -491,6 +497,8 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     if (fuse_tail) {
       BSX_TIMED(launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg, bg_stride,
                                   d_frames, d_out, n, s));
+      // not part of the step: the plain alpha-blend kernel (bsx_composite_batch) on the same buffers, for its own roofline line
+      BSX_TIMED(launch_blend(d_bg, bg_stride, d_frames, c->d_masks, d_out, (size_t)c->width * c->height, n, s));
     } else {
       BSX_TIMED(launch_mask_upscale_blur(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, n, s));
       BSX_TIMED(launch_blend(d_bg, bg_stride, d_frames, c->d_masks, d_out, (size_t)c->width * c->height, n, s));
@@ -529,6 +537,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   if (fuse_tail) {
     // fused: model-res mask in, full-res mask out (1 B/px), bg + frame in (6 B/px), composite out (3 B/px)
     put(j++, "mask_blend", N * ((double)c->in_roi.w * c->in_roi.h + 10.0 * px), 0);
+    put(j++, "blend(standalone)", N * 10.0 * px, 0);
   } else {
     put(j++, "mask_upscale_blur", N * ((double)c->in_roi.w * c->in_roi.h + (double)c->roi.w * c->roi.h), 0);
     put(j++, "blend", N * 10.0 * px, 0);

@@ -63,6 +63,8 @@ hipError_t launch_blend(const uint8_t* bg, size_t bg_stride, const uint8_t* fram
 hipError_t launch_resize_bgr(const uint8_t* src, uint8_t* dst, ResizeTab tab, int n, hipStream_t s);
 // BGR → YUYV.  deepseg.cc:87-106
 hipError_t launch_bgr_to_yuyv(const uint8_t* bgr, uint8_t* yuyv, int w, int h, int n, hipStream_t s);
+// YUYV → BGR ingest.  deepseg.cc:553 (CAP_PROP_CONVERT_RGB), :725
+hipError_t launch_yuyv_to_bgr(const uint8_t* yuyv, uint8_t* bgr, int w, int h, int n, hipStream_t s);
 // fill
 hipError_t launch_fill_u8(uint8_t* p, uint8_t v, size_t bytes, hipStream_t s);
 

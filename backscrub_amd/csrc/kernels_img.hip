@@ -367,6 +367,20 @@ __global__ __launch_bounds__(kThreads) void yuyv_k(const uint8_t* __restrict__ i
   out[i] = (uint32_t)y0 | (v << 8) | ((uint32_t)y1 << 16) | (u << 24);
 }
 
+// ---- YUYV → BGR ingest (cv::COLOR_YUV2BGR_YUYV, BT.601 limited range, 20-bit fixed point) --------------------------------
+__global__ __launch_bounds__(kThreads) void yuyv_to_bgr_k(const uint32_t* __restrict__ in, uint8_t* __restrict__ out, long pairs) {
+  long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= pairs) return;
+  const int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
+  const uint32_t p = in[i];                       // Y0 | U<<8 | Y1<<16 | V<<24
+  const int y0 = p & 255, u = (int)((p >> 8) & 255) - 128, y1 = (p >> 16) & 255, v = (int)(p >> 24) - 128;
+  const int ruv = (1 << (SH - 1)) + CVR * v, guv = (1 << (SH - 1)) + CVG * v + CUG * u, buv = (1 << (SH - 1)) + CUB * u;
+  const int ya = max(0, y0 - 16) * CY, yb = max(0, y1 - 16) * CY;
+  uint8_t* o = out + 6 * i;
+  o[0] = (uint8_t)min(max((ya + buv) >> SH, 0), 255); o[1] = (uint8_t)min(max((ya + guv) >> SH, 0), 255); o[2] = (uint8_t)min(max((ya + ruv) >> SH, 0), 255);
+  o[3] = (uint8_t)min(max((yb + buv) >> SH, 0), 255); o[4] = (uint8_t)min(max((yb + guv) >> SH, 0), 255); o[5] = (uint8_t)min(max((yb + ruv) >> SH, 0), 255);
+}
+
 __global__ __launch_bounds__(kThreads) void fill_k(uint4* p, uint4 v, long n16) {
   long i = (long)blockIdx.x * kThreads + threadIdx.x;
   if (i < n16) p[i] = v;
@@ -436,6 +450,12 @@ hipError_t launch_resize_bgr(const uint8_t* src, uint8_t* dst, ResizeTab tab, in
 hipError_t launch_bgr_to_yuyv(const uint8_t* bgr, uint8_t* yuyv, int w, int h, int n, hipStream_t s) {
   long pairs = (long)n * w * h / 2;
   yuyv_k<<<blocks_for(pairs), kThreads, 0, s>>>(bgr, reinterpret_cast<uint32_t*>(yuyv), pairs);
+  return hipGetLastError();
+}
+
+hipError_t launch_yuyv_to_bgr(const uint8_t* yuyv, uint8_t* bgr, int w, int h, int n, hipStream_t s) {
+  long pairs = (long)n * w * h / 2;
+  yuyv_to_bgr_k<<<blocks_for(pairs), kThreads, 0, s>>>(reinterpret_cast<const uint32_t*>(yuyv), bgr, pairs);
   return hipGetLastError();
 }
 

@@ -152,6 +152,8 @@ def main():
         stats = mg.profile(d_frames, d_bg, d_out, iters=args.profile_iters)
         for s in stats:
             s["GBps"] = s["bytes"] / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
+        extra = [s for s in stats if s["name"].endswith("(standalone)")]   # measured for its roofline line, not part of the step
+        stats = [s for s in stats if not s["name"].endswith("(standalone)")]
         tot_ms = sum(s["avg_ms"] for s in stats)
         if args.dump_launches:
             with open(args.dump_launches, "w") as f:
@@ -164,7 +166,8 @@ def main():
                  "mask_blend": "blend"}.get(s["name"], "network")
             groups[k] += s["avg_ms"]
         dom = max(stats, key=lambda s: s["avg_ms"])
-        blend = [s for s in stats if s["name"] in ("blend", "mask_blend")][0]
+        blend = (extra or [s for s in stats if s["name"] in ("blend", "mask_blend")])[0]
+        blend = dict(blend, name="blend")
 
         pmc = {}
         try:
@@ -197,6 +200,8 @@ def main():
 
         result["roofline"] = roof(dom)
         result["roofline_blend"] = roof(blend)
+        if extra:
+            result["roofline_blend"]["note"] = "bsx_composite_batch kernel timed stand-alone; inside the step the blend is fused with mask upscale+blur (mask_blend)"
         result["stage_ms"] = {k: round(v, 4) for k, v in groups.items()}
         result["stage_ms"]["sum_of_launches"] = round(tot_ms, 4)
         result["top_launches"] = [{"name": s["name"], "ms": round(s["avg_ms"], 4), "GBps": round(s["GBps"], 1)}

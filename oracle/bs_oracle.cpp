@@ -623,6 +623,24 @@ static void bgr_to_yuyv(const uint8_t* in, int w, int h, uint8_t* out) {
   }
 }
 
+// YUYV (YUY2, bytes Y0 U Y1 V) → BGR — the ingest conversion OpenCV's VideoCapture performs for app/deepseg.cc:553
+// (CAP_PROP_CONVERT_RGB) and the explicit cv::cvtColor(COLOR_YUV2BGR_YUYV) of the debug view (:725).  OpenCV 8u path
+// (color_yuv, ITU-R BT.601 limited range, 20-bit fixed point): CY 1220542, CUB 2116026, CUG -409993, CVG -852492,
+// CVR 1673527;  y = max(0, Y-16)*CY;  c = sat((y + (1<<19) + coeffs·(U-128, V-128)) >> 20).
+static void yuyv_to_bgr(const uint8_t* in, int w, int h, uint8_t* out) {
+  const int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
+  auto sat = [](int v) { return (uint8_t)std::min(std::max(v, 0), 255); };
+  size_t pairs = (size_t)w * h / 2;
+  for (size_t i = 0; i < pairs; i++) {
+    int y0 = in[4 * i], u = in[4 * i + 1] - 128, y1 = in[4 * i + 2], v = in[4 * i + 3] - 128;
+    int ruv = (1 << (SH - 1)) + CVR * v, guv = (1 << (SH - 1)) + CVG * v + CUG * u, buv = (1 << (SH - 1)) + CUB * u;
+    int ya = std::max(0, y0 - 16) * CY, yb = std::max(0, y1 - 16) * CY;
+    uint8_t* o = out + 6 * i;
+    o[0] = sat((ya + buv) >> SH); o[1] = sat((ya + guv) >> SH); o[2] = sat((ya + ruv) >> SH);
+    o[3] = sat((yb + buv) >> SH); o[4] = sat((yb + guv) >> SH); o[5] = sat((yb + ruv) >> SH);
+  }
+}
+
 // decode + temporal IIR — follows lib/libbackscrub.cc:317-357.
 //   type 1 DeepLab: 21-way argmax (first max wins, init -10000), person==15 → 0 else 255
 //   type 2 MLKit/BodyPix: p > 0.65 (double compare) → 0 else 255
@@ -783,6 +801,7 @@ void bso_bilateral_c3(const uint8_t* src, int w, int h, uint8_t* dst, int d, dou
 void bso_blur5_u8(const uint8_t* src, int w, int h, long sstride, uint8_t* dst, long dstride) { blur5_u8(src, w, h, (size_t)sstride, dst, (size_t)dstride); }
 void bso_alpha_blend(const uint8_t* bg, const uint8_t* fr, const uint8_t* m, uint8_t* out, long npix) { alpha_blend(bg, fr, m, out, (size_t)npix); }
 void bso_bgr_to_yuyv(const uint8_t* in, int w, int h, uint8_t* out) { bgr_to_yuyv(in, w, h, out); }
+void bso_yuyv_to_bgr(const uint8_t* in, int w, int h, uint8_t* out) { yuyv_to_bgr(in, w, h, out); }
 void bso_decode_iir(int type, const float* t, long npix, int nch, uint8_t* out) { decode_iir(type, t, (size_t)npix, nch, out); }
 void bso_convert_f32(const uint8_t* in, long n, float scale, float off, float* out) { for (long i = 0; i < n; i++) out[i] = (float)in[i] * scale + off; }
 

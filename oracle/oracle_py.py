@@ -42,6 +42,7 @@ def _load(name):
     lib.bso_blur5_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_long, _u8p, C.c_long]
     lib.bso_alpha_blend.argtypes = [_u8p, _u8p, _u8p, _u8p, C.c_long]
     lib.bso_bgr_to_yuyv.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
+    lib.bso_yuyv_to_bgr.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
     lib.bso_decode_iir.argtypes = [C.c_int, _f32p, C.c_long, C.c_int, _u8p]
     lib.bso_convert_f32.argtypes = [_u8p, C.c_long, C.c_float, C.c_float, _f32p]
     lib.bso_ctx_new.restype = C.c_void_p
@@ -119,6 +120,13 @@ def bgr_to_yuyv(img) -> np.ndarray:
     img = np.ascontiguousarray(img)
     out = np.zeros((img.shape[0], img.shape[1], 2), np.uint8)
     lib().bso_bgr_to_yuyv(_u8(img), img.shape[1], img.shape[0], _u8(out))
+    return out
+
+
+def yuyv_to_bgr(img) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    out = np.zeros((img.shape[0], img.shape[1], 3), np.uint8)
+    lib().bso_yuyv_to_bgr(_u8(img), img.shape[1], img.shape[0], _u8(out))
     return out
 
 

@@ -291,6 +291,16 @@ def test_yuyv_matches_oracle(bs, oracle):
     mg.close()
 
 
+def test_yuyv_to_bgr_matches_oracle(bs, oracle):
+    from backscrub_amd import synth
+    img = synth.random_u8((2, 480, 640, 2), 13)
+    mg = bs.MaskGen(synthetic_model_path("lite"), 640, 480, n_streams=1)
+    got = mg.yuyv_to_bgr(_dev(img)).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.yuyv_to_bgr(img[i]))
+    mg.close()
+
+
 # --------------------------------------------------------------------------------------------
 # size-independent properties at the BASELINE batch size (256 VGA streams, segm_lite)
 # --------------------------------------------------------------------------------------------
@@ -331,4 +341,50 @@ def test_full_batch_properties(bs, oracle):
             want = oc.process(frames[i])
         assert _iou_fg(m[i], want) >= 0.999
         oc.close()
+    mg.close()
+
+
+# --------------------------------------------------------------------------------------------
+# ragged / odd inputs and argument errors
+# --------------------------------------------------------------------------------------------
+def test_partial_batches_and_odd_frame_sizes(bs, oracle):
+    """n < n_streams batches touch only their streams; odd frame sizes (unaligned rows, partial tiles) stay exact."""
+    from backscrub_amd import synth
+    path = model_path("lite")
+    for (W, H) in ((322, 242), (641, 479), (160, 96)):
+        cap = 5
+        mg = bs.MaskGen(path, W, H, n_streams=cap)
+        oc = [oracle.Ctx(path, W, H) for _ in range(cap)]
+        bg = synth.background(W, H)
+        out = torch.empty((cap, H, W, 3), dtype=torch.uint8, device="cuda")
+        for t, n in enumerate((5, 2, 3)):                       # ragged: later batches use only the first n streams
+            frames = np.stack([synth.frame(W, H, s, t) for s in range(n)])
+            mg.step(_dev(frames), _dev(bg), out[:n])
+            got_m = mg.masks().cpu().numpy()
+            got_o = out.cpu().numpy()
+            for i in range(n):
+                want = oc[i].process(frames[i])
+                assert _iou_fg(got_m[i], want) >= 0.999, (W, H, t, i)
+                if np.array_equal(got_m[i], want):
+                    assert np.array_equal(got_o[i], oracle.alpha_blend(bg, frames[i], want))
+            for i in range(n, cap):                             # untouched streams keep their previous state exactly
+                assert np.array_equal(got_m[i], oc[i].mask())
+        for c in oc:
+            c.close()
+        mg.close()
+
+
+def test_argument_errors(bs):
+    from backscrub_amd import synth
+    W, H = VGA
+    mg = bs.MaskGen(synthetic_model_path("lite"), W, H, n_streams=2)
+    f3 = _dev(synth.frames(3, W, H, distinct=1))
+    with pytest.raises(bs.BsxError):
+        mg.process_batch(f3)                                    # batch larger than n_streams
+    with pytest.raises(bs.BsxError):
+        mg.process_batch(_dev(synth.frames(1, W // 2, H, distinct=1)))   # wrong geometry
+    with pytest.raises(bs.BsxError):
+        mg.process_host(np.zeros((H, W // 2, 3), np.uint8))
+    assert bs.lib().bsx_process_batch(None, None, 1, None, None) == -1      # BSX_EINVAL on a NULL context (libbackscrub.cc:280)
+    assert bs.lib().bsx_process_batch(mg.h, None, 1, None, None) == -1
     mg.close()

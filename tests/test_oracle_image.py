@@ -189,3 +189,22 @@ def test_context_is_deterministic_and_border_persists(oracle):
     assert (ma[:, :x] == 255).all() and (ma[:, x + w:] == 255).all()
     a.close()
     b.close()
+
+
+def test_yuyv_to_bgr_formula_and_roundtrip_bound(oracle):
+    rng = np.random.default_rng(4)
+    yuyv = rng.integers(0, 256, (6, 10, 2), dtype=np.uint8)
+    got = oracle.yuyv_to_bgr(yuyv).reshape(-1, 2, 3).astype(np.int64)
+    p = yuyv.reshape(-1, 4).astype(np.int64)
+    u, v = p[:, 1] - 128, p[:, 3] - 128
+    for k, yy in enumerate((p[:, 0], p[:, 2])):
+        y = np.maximum(0, yy - 16) * 1220542
+        b = np.clip((y + (1 << 19) + 2116026 * u) >> 20, 0, 255)
+        g = np.clip((y + (1 << 19) - 852492 * v - 409993 * u) >> 20, 0, 255)
+        r = np.clip((y + (1 << 19) + 1673527 * v) >> 20, 0, 255)
+        assert np.array_equal(got[:, k, 0], b) and np.array_equal(got[:, k, 1], g) and np.array_equal(got[:, k, 2], r)
+    # grey ramp: U = V = 128 → B = G = R = clamp(1.164 * (Y - 16))
+    grey = np.stack([np.arange(256, dtype=np.uint8), np.full(256, 128, np.uint8)], -1).reshape(1, 256, 2)
+    out = oracle.yuyv_to_bgr(grey)[0]
+    assert (out[:, 0] == out[:, 1]).all() and (out[:, 1] == out[:, 2]).all()
+    assert out[16, 0] == 0 and out[235, 0] == 255
