@@ -168,7 +168,7 @@ class MaskGen:
         k = lib().bsx_debug_program_timeline(self.h, n, arr, cap, _stream_ptr())
         if k < 0:
             _check(k, self.h, "bsx_debug_program_timeline")
-        self.last_subphase_us = [arr[256 + i] / 100.0 for i in range(8)]   # debug accumulators of instrumented micro-ops
+        self.last_subphase_us = [arr[256 + i] / 100.0 for i in range(12)]   # debug accumulators of instrumented micro-ops
         return [(arr[i + 1] - arr[i]) / 100.0 for i in range(k)]
 
     def masks(self):

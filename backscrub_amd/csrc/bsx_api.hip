@@ -143,6 +143,7 @@ void report(bsx_ctx* c, bsx_debug_fn fn, void* user, const char* fmt, ...) {
 int upload_tab(bsx_ctx* c, const HostResizeTab& h, DevResizeTab* d) {
   d->tab.sw = h.sw; d->tab.sh = h.sh; d->tab.dw = h.dw; d->tab.dh = h.dh; d->tab.mode = h.mode;
   if (h.mode != 0) return BSX_OK;
+  d->tab.tile_ok = mask_tile_fits(h.xofs.data(), h.yofs.data(), h.sw, h.sh, h.dw, h.dh) ? 1 : 0;
   size_t b_xofs = h.xofs.size() * 4, b_yofs = h.yofs.size() * 4, b_xa = h.xa.size() * 2, b_ya = h.ya.size() * 2;
   auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
   size_t total = up16(b_xofs) + up16(b_yofs) + up16(b_xa) + up16(b_ya);
@@ -181,7 +182,7 @@ int init_device_state(bsx_ctx* c) {
     BSX_HIP(c, hipMemcpy(c->d_program, c->plan.program.data(), c->plan.program.size() * sizeof(MicroOp), hipMemcpyHostToDevice));
     BSX_HIP(c, frame_program_prepare(c->plan.program_lds_floats));
   }
-  BSX_HIP(c, hipMalloc(&c->d_canvas, N * c->inW * c->inH * sizeof(uint32_t)));
+  BSX_HIP(c, hipMalloc(&c->d_canvas, N * canvas_elems(c->inW, c->inH) * sizeof(uint32_t)));
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
   BSX_HIP(c, hipMalloc(&c->d_masks, N * c->width * c->height));
   BSX_HIP(c, hipMemset(c->d_ofinal, 0, N * c->outW * c->outH));            // :257 leaves it uninitialised; defined as 0
@@ -205,6 +206,7 @@ int init_device_state(bsx_ctx* c) {
     }
     c->bilateral.color_lut = c->d_color_lut;
     c->bilateral.scale = c->norm_scale; c->bilateral.offset = c->norm_offset;
+    if (k != 13 || !bilateral_taps_match(c->bilateral)) { c->last_error = "bilateral tap table does not match the kernel"; return BSX_EDEVICE; }
   }
   int rc = upload_tab(c, make_resize_tab(c->roi.w, c->roi.h, c->in_roi.w, c->in_roi.h), &c->tab_down);
   if (rc) return rc;
@@ -258,7 +260,8 @@ const char* bsx_last_error(const bsx_ctx* ctx) { return ctx ? ctx->last_error.c_
 
 bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t height, int n_streams, int device, bsx_debug_fn ondebug,
                  bsx_stage_fn onprep, bsx_stage_fn oninfer, bsx_stage_fn onmask, void* caller_ctx) {
-  if (!model_path || !width || !height || n_streams <= 0) { report(nullptr, ondebug, caller_ctx, "error: bad arguments to bsx_new\n"); return nullptr; }
+  if (!model_path || !width || !height || n_streams <= 0 || n_streams > 65535) {   // grid.z of the mask kernel carries the stream index
+    report(nullptr, ondebug, caller_ctx, "error: bad arguments to bsx_new\n"); return nullptr; }
   std::unique_ptr<bsx_ctx> c(new bsx_ctx);
   c->ondebug = ondebug; c->onprep = onprep; c->oninfer = oninfer; c->onmask = onmask; c->caller_ctx = caller_ctx;
   c->threads = threads; c->width = (int)width; c->height = (int)height; c->n_streams = n_streams; c->device = device;

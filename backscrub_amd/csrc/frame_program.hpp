@@ -58,6 +58,6 @@ constexpr int kMicroTail = 101;              // MicroOp::kind of the fused pw â†
 constexpr int kMicroSe = 100;                // MicroOp::kind of the fused GAPâ†’FCâ†’FC chain
 constexpr int kFrameThreads = 1024;          // 16 waves: 4 per SIMD
 constexpr int kLdsTotalFloats = 160 * 256;   // 160 KiB
-constexpr int kLdsScratchFloats = 4160;      // weight-staging + reduction scratch at the start of the LDS block (16.25 KiB: 128x32 weights + bias)
+constexpr int kLdsScratchFloats = 4224;      // weight-staging + reduction scratch at the start of the LDS block (16.5 KiB: 128x32 weights + 128 bias)
 
 }  // namespace bsx

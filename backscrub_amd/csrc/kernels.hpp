@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 #include "plan.hpp"
@@ -31,7 +32,9 @@ struct ResizeTab {
   const short* ya = nullptr;     // [2*dh] vertical coefficients (b0,b1)
   int sw = 0, sh = 0, dw = 0, dh = 0;
   int mode = 0;                  // 0 linear, 1 copy (same size), 2 INTER_AREA 2x2 (both scales exactly 2)
+  int tile_ok = 0;               // mask_tile_fits(): every mask tile's source block fits the LDS staging area
 };
+bool mask_tile_fits(const int* xofs, const int* yofs, int sw, int sh, int dw, int dh);
 
 struct Rect4 { int x, y, w, h; };
 
@@ -42,7 +45,11 @@ struct BilateralParams {
   float scale, offset;
 };
 
-// frame ROI ↓ → model canvas (packed RGBX u32, bars = 0).  libbackscrub.cc:285-290
+// The model canvas carries a 2-pixel BORDER_REFLECT_101 apron: (inW + 4) x (inH + 4) packed RGBX u32 per frame.
+constexpr int kCanvasPad = 2;
+inline size_t canvas_elems(int inW, int inH) { return (size_t)(inW + 2 * kCanvasPad) * (size_t)(inH + 2 * kCanvasPad); }
+bool bilateral_taps_match(const BilateralParams& bp);   // host table order == the kernel's hard-wired 13 taps
+// frame ROI ↓ → model canvas (packed RGBX u32, bars = 0, apron filled).  libbackscrub.cc:285-290
 hipError_t launch_prep_resize(const uint8_t* frames, int W, int H, Rect4 roi, uint32_t* canvas, int inW, int inH, Rect4 in_roi,
                               ResizeTab tab, int n, hipStream_t s);
 // bilateral(5,100,100) + convertTo f32 → network input [n][inH][inW][3].  libbackscrub.cc:295-302

@@ -683,40 +683,40 @@ __device__ __forceinline__ void mo_dw(cop_t& op, const FrameCtx& c) {
   else { if (xl) dw_body<5, true>(op, c); else dw_body<5, false>(op, c); }
 }
 
-// ---- global average pool of one input into out[coff .. coff+C) (workgroup reduction through the scratch) --------
+// ---- global average pool of one input into out[coff .. coff+C) -------------------------------------------------------------
+// Lane layout: CG channel-quads x (64/CG) pixel rows inside a wave, so the row reduction is wave shuffles; the 16 per-wave
+// partials meet in the scratch once.  Two barriers per channel block instead of a multi-level LDS tree.
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& out, int coff) {
-  lds_f* scratch = lds_base();  // kLdsScratchFloats = 1024 float4 slots
+  lds_f* scratch = lds_base();
   const int C4 = C >> 2;
   int CG = 1;
   while (CG * 2 <= C4 && CG * 2 <= 64) CG *= 2;
   const int rows = kFrameThreads / CG;
   const int cg = threadIdx.x % CG, row = threadIdx.x / CG;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int base = 0; base < C4; base += CG) {
     const int cq = base + cg;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cq < C4)
-      for (int p = row; p < HW; p += rows) {
-        float4 v = ld4(x, p * x.stride + cq * 4);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (cq < C4) {
+      int p = row;
+      for (; p + 3 * rows < HW; p += 4 * rows) {       // four independent loads in flight
+        const float4 v0 = ld4(x, p * x.stride + cq * 4), v1 = ld4(x, (p + rows) * x.stride + cq * 4);
+        const float4 v2 = ld4(x, (p + 2 * rows) * x.stride + cq * 4), v3 = ld4(x, (p + 3 * rows) * x.stride + cq * 4);
+        a0 = add4(a0, v0); a1 = add4(a1, v1); a2 = add4(a2, v2); a3 = add4(a3, v3);
       }
-    st_lds4(scratch + 4 * threadIdx.x, acc);
-    __syncthreads();
-    // reduce the `rows` partial sums 8-to-1 per barrier pair
-    for (int span = rows; span > 1; span = (span + 7) >> 3) {
-      const int groups = (span + 7) >> 3;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < groups) {
-        for (int k = 0; k < 8; k++) {
-          const int r = row * 8 + k;
-          if (r < span) { float4 b = ld_lds4(scratch + 4 * (r * CG + cg)); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-        }
-      }
-      __syncthreads();
-      if (row < groups) st_lds4(scratch + 4 * (row * CG + cg), a);
-      __syncthreads();
+      for (; p < HW; p += rows) a0 = add4(a0, ld4(x, p * x.stride + cq * 4));
     }
-    if (row == 0 && cq < C4) {
-      float4 t = ld_lds4(scratch + 4 * cg);
+    float4 acc = add4(add4(a0, a1), add4(a2, a3));
+    for (int o = CG; o < 64; o <<= 1) {
+      acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+    }
+    if (lane < CG) st_lds4(scratch + 4 * (wave * CG + lane), acc);
+    __syncthreads();
+    if (threadIdx.x < CG && cq < C4) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < kFrameThreads / 64; w++) t = add4(t, ld_lds4(scratch + 4 * (w * CG + threadIdx.x)));
       const float inv = (float)HW;
       t.x /= inv; t.y /= inv; t.z /= inv; t.w /= inv;
       st4(out, coff + cq * 4, t);
@@ -783,16 +783,21 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
   const Ref mean = make_ref(op.in1, c), hid = make_ref(op.in2, c), out = make_ref(op.out, c);
   const int HW = op.H * op.W;
   const glb_f* wts = (const glb_f*)c.weights;
+  const bool dbg = c.tl != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long t0 = dbg ? wall_clock64() : 0ull, t1 = 0ull, t2 = 0ull, t3 = 0ull;
   // both FCs' weight slices are requested up front: their HBM/L2 latency hides behind the pooling reductions
   const FcPre p1 = fc_preload(op.Cin, wts + op.w2_off, wts + op.b_off, op.C1);
   FcPre p2 = p1;
   if (op.n_fc == 2) p2 = fc_preload(op.C1, wts + op.w3_off, wts + op.b3_off, op.C2);
   if (op.n_cat == 0) gap_one(make_ref(op.in0, c), HW, op.Cin, mean, 0);
   else { int coff = 0; for (int k = 0; k < op.n_cat; k++) { gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], mean, coff); coff += op.cat_c[k]; } }
+  if (dbg) t1 = wall_clock64();
   if (op.n_fc == 1) { fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, out, p1); return; }
   fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, hid, p1);
   __syncthreads();
+  if (dbg) t2 = wall_clock64();
   fc_lanes(hid, op.C1, wts + op.w3_off, wts + op.b3_off, op.C2, op.act2, out, p2);
+  if (dbg) { t3 = wall_clock64(); c.tl[260] += t1 - t0; c.tl[261] += t2 - t1; c.tl[262] += t3 - t2; }
 }
 
 // ---- elementwise -----------------------------------------------------------------------------------------------------------
@@ -941,6 +946,9 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
         if (t4b < sfn) pf2 = *(const glb_v4*)(gw + opn.w_off + t4b);
       }
     }
+    const bool dbg = timeline && blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long tq0 = 0ull, tq1 = 0ull;
+    if (dbg) { tq0 = wall_clock64(); timeline[264] += tq0 - timeline[i]; }
     switch ((StepKind)op.kind) {
       case StepKind::PwConv:
         if (op.gemv) mo_gemv(op, c);
@@ -955,7 +963,9 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
       case StepKind::TConv: mo_tconv(op, c); break;
       default: if (op.kind == kMicroSe) mo_se(op, c); else if (op.kind == kMicroTail) mo_tail(op, c); break;
     }
+    if (dbg) { tq1 = wall_clock64(); timeline[265] += tq1 - tq0; }
     __syncthreads();
+    if (dbg) timeline[266] += wall_clock64() - tq1;
   }
   if (timeline && blockIdx.x == 0 && threadIdx.x == 0) timeline[n_ops] = wall_clock64();
 }

@@ -11,12 +11,15 @@
 //   blend16_k            deepseg.cc:108-134       alpha_blend
 //   resize_bgr_k         background.cc:186,190    cv::resize of the background
 //   yuyv_k               deepseg.cc:87-106        convert_rgb_to_yuyv
+#include <algorithm>
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace bsx {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kMaxGridY = 65535;
 inline unsigned blocks_for(long total) { return (unsigned)((total + kThreads - 1) / kThreads); }
 
 __device__ __forceinline__ int reflect101(int p, int len) {  // cv::borderInterpolate(BORDER_REFLECT_101)
@@ -58,14 +61,18 @@ __device__ __forceinline__ void sample_linear(const uint8_t* __restrict__ src, l
 }
 
 // ---- prep 1: frame ROI → model canvas, packed R | G<<8 | B<<16 (bars stay 0) -----------------
+// Index math is 32-bit inside a frame (grid.y = frame): a 64-bit div/mod pair per lane costs more than the sample itself.
+// The canvas is stored WITH its BORDER_REFLECT_101 apron (kCanvasPad pixels on every side, (inW+4) x (inH+4)): the
+// bilateral taps of the next kernel are then unconditional loads at fixed offsets (border arithmetic per tap was most of
+// its instruction count).  An apron pixel is the sample of the interior pixel it mirrors.
 __global__ __launch_bounds__(kThreads) void prep_resize_k(const uint8_t* __restrict__ frames, int W, int H, Rect4 roi,
-                                                         uint32_t* __restrict__ canvas, int inW, int inH, Rect4 q, ResizeTab tab, long total) {
-  long i = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= total) return;
-  int x = (int)(i % inW);
-  long r = i / inW;
-  int y = (int)(r % inH);
-  long n = r / inH;
+                                                         uint32_t* __restrict__ canvas, int inW, int inH, Rect4 q, ResizeTab tab) {
+  const int PW = inW + 2 * kCanvasPad, PH = inH + 2 * kCanvasPad;
+  const unsigned p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= (unsigned)(PW * PH)) return;
+  const long n = blockIdx.y;
+  const int py = (int)(p / (unsigned)PW), px = (int)(p - (unsigned)py * (unsigned)PW);
+  const int x = reflect101(px - kCanvasPad, inW), y = reflect101(py - kCanvasPad, inH);
   uint32_t v = 0;
   int dx = x - q.x, dy = y - q.y;
   if (dx >= 0 && dx < q.w && dy >= 0 && dy < q.h) {
@@ -74,45 +81,54 @@ __global__ __launch_bounds__(kThreads) void prep_resize_k(const uint8_t* __restr
     sample_linear<3>(src, (long)W * 3, tab, dx, dy, bgr);
     v = (uint32_t)bgr[2] | ((uint32_t)bgr[1] << 8) | ((uint32_t)bgr[0] << 16);  // BGR2RGB
   }
-  canvas[i] = v;
+  canvas[n * (long)PW * PH + p] = v;
 }
 
 // ---- prep 2: bilateral d=5 on the RGB canvas + u8→f32 normalise -----------------------------
 // f32 accumulation in tap order with separate multiply and add (no FMA contraction), then
 // cvRound(sum * (1/wsum)) — the association the oracle defines.
+constexpr int kBilPix = 4;   // pixels per lane: amortises the 768-entry LUT fill + barrier of every workgroup
+// the 13 taps of a radius-2 disc in OpenCV's (dy, dx) row-major order; bsx_api.hip builds bp.space_w in the same order
+// and refuses to start if its table ever disagrees (bilateral_taps_match)
+__device__ constexpr int kTapY[13] = {-2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2};
+__device__ constexpr int kTapX[13] = {0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0};
 __global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __restrict__ canvas, float* __restrict__ input, int inW, int inH,
-                                                            BilateralParams bp, long total) {
+                                                            BilateralParams bp) {
   __shared__ float lut[768];
   for (int k = threadIdx.x; k < 768; k += kThreads) lut[k] = bp.color_lut[k];
   __syncthreads();
-  long i = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= total) return;
-  int x = (int)(i % inW);
-  long r = i / inW;
-  int y = (int)(r % inH);
-  long n = r / inH;
-  const uint32_t* img = canvas + n * (long)inW * inH;
-  uint32_t c0 = img[(long)y * inW + x];
-  int r0 = c0 & 255, g0 = (c0 >> 8) & 255, b0 = (c0 >> 16) & 255;
-  float sr = 0.f, sg = 0.f, sb = 0.f, ws = 0.f;
+  const int PW = inW + 2 * kCanvasPad, PH = inH + 2 * kCanvasPad;
+  const long n = blockIdx.y;
+  const uint32_t* img = canvas + n * (long)PW * PH;
+#pragma unroll 2
+  for (int it = 0; it < kBilPix; it++) {
+    const unsigned p = (blockIdx.x * kBilPix + it) * kThreads + threadIdx.x;
+    if (p >= (unsigned)(inW * inH)) return;
+    const int y = (int)(p / (unsigned)inW), x = (int)(p - (unsigned)y * (unsigned)inW);
+    const uint32_t* row[5];
 #pragma unroll
-  for (int k = 0; k < 13; k++) {
-    int yy = reflect101(y + bp.off_y[k], inH), xx = reflect101(x + bp.off_x[k], inW);
-    uint32_t c = img[(long)yy * inW + xx];
-    int rr = c & 255, gg = (c >> 8) & 255, bb = (c >> 16) & 255;
-    float w = __fmul_rn(bp.space_w[k], lut[abs(rr - r0) + abs(gg - g0) + abs(bb - b0)]);
-    sr = __fadd_rn(sr, __fmul_rn((float)rr, w));
-    sg = __fadd_rn(sg, __fmul_rn((float)gg, w));
-    sb = __fadd_rn(sb, __fmul_rn((float)bb, w));
-    ws = __fadd_rn(ws, w);
+    for (int d = 0; d < 5; d++) row[d] = img + (y + d) * PW + (x + kCanvasPad);     // canvas rows y-2 .. y+2 at column x
+    const uint32_t c0 = row[2][0];                // R | G<<8 | B<<16, top byte 0
+    float sr = 0.f, sg = 0.f, sb = 0.f, ws = 0.f;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+      const uint32_t c = row[kTapY[k] + 2][kTapX[k]];
+      // |dR| + |dG| + |dB| in one instruction (v_sad_u8 over the four bytes; the top bytes are both 0)
+      const float w = __fmul_rn(bp.space_w[k], lut[__builtin_amdgcn_sad_u8(c, c0, 0u)]);
+      const float rr = (float)(c & 255), gg = (float)((c >> 8) & 255), bb = (float)((c >> 16) & 255);
+      sr = __fadd_rn(sr, __fmul_rn(rr, w));
+      sg = __fadd_rn(sg, __fmul_rn(gg, w));
+      sb = __fadd_rn(sb, __fmul_rn(bb, w));
+      ws = __fadd_rn(ws, w);
+    }
+    ws = __fdiv_rn(1.f, ws);
+    int qr = __float2int_rn(__fmul_rn(sr, ws)), qg = __float2int_rn(__fmul_rn(sg, ws)), qb = __float2int_rn(__fmul_rn(sb, ws));
+    qr = min(max(qr, 0), 255); qg = min(max(qg, 0), 255); qb = min(max(qb, 0), 255);
+    float* o = input + (n * (long)inW * inH + p) * 3;
+    o[0] = __fadd_rn(__fmul_rn((float)qr, bp.scale), bp.offset);
+    o[1] = __fadd_rn(__fmul_rn((float)qg, bp.scale), bp.offset);
+    o[2] = __fadd_rn(__fmul_rn((float)qb, bp.scale), bp.offset);
   }
-  ws = __fdiv_rn(1.f, ws);
-  int qr = __float2int_rn(__fmul_rn(sr, ws)), qg = __float2int_rn(__fmul_rn(sg, ws)), qb = __float2int_rn(__fmul_rn(sb, ws));
-  qr = min(max(qr, 0), 255); qg = min(max(qg, 0), 255); qb = min(max(qb, 0), 255);
-  float* o = input + i * 3;
-  o[0] = __fadd_rn(__fmul_rn((float)qr, bp.scale), bp.offset);
-  o[1] = __fadd_rn(__fmul_rn((float)qg, bp.scale), bp.offset);
-  o[2] = __fadd_rn(__fmul_rn((float)qb, bp.scale), bp.offset);
 }
 
 // ---- decode + temporal IIR -------------------------------------------------------------------
@@ -148,23 +164,51 @@ __global__ __launch_bounds__(kThreads) void decode_k(int type, const float* __re
 // With BLEND the same workgroup also composites its tile (deepseg.cc:108-134) while the mask bytes are still in
 // registers: the mask is written once and never re-read, and the HBM-bound blend traffic of some workgroups overlaps
 // the LDS/ALU-bound mask phases of others.  (Used when the ROI is the whole frame.)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));   // v_pk_*_u16 operand
 constexpr int kTW = 128, kTH = 32, kHW = kTW + 4, kHH = kTH + 4, kMaxSrcRows = 40;
-__device__ __forceinline__ uint32_t blend4w(uint32_t a, uint32_t b, int m0, int m1, int m2, int m3);
+__device__ __forceinline__ void blend_quad_fwd(const uint32_t a[3], const uint32_t b[3], uint32_t mw, uint32_t o[3]);
 template <bool BLEND>
 __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                                uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                                const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
                                                                uint8_t* __restrict__ outp) {
-  __shared__ int col_sx[kHW], col_sx1[kHW], col_a0[kHW], col_a1[kHW];
-  __shared__ int row_s0[kHH], row_s1[kHH], row_b0[kHH], row_b1[kHH];
-  __shared__ __attribute__((aligned(16))) uint16_t hq[kMaxSrcRows * kHW];
+  // coefficients are 0..2048: kept as 16-bit so that every product below is a full-rate 24-bit multiply
+  __shared__ int col_sx[kHW], col_sx1[kHW], row_s0[kHH], row_s1[kHH];
+  __shared__ short col_a0[kHW], col_a1[kHW], row_b0[kHH], row_b1[kHH];
+  // hq (steps 2-3) and hs (steps 4-5) are never live together: one buffer, more workgroups per CU
+  __shared__ __attribute__((aligned(16))) uint16_t hq_hs[kMaxSrcRows * kHW > kHH * kTW ? kMaxSrcRows * kHW : kHH * kTW];
   __shared__ __attribute__((aligned(16))) uint8_t up[kHH * kHW + 8];
-  __shared__ __attribute__((aligned(16))) uint16_t hs[kHH * kTW];
+  uint16_t* const hq = hq_hs;
+  uint16_t* const hs = hq_hs;
   __shared__ int s_min, s_max;
   const int n = blockIdx.z;
   const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
   const uint8_t* src = ofinal + (long)n * outW * outH + (long)q.y * outW + q.x;
   const int tid = threadIdx.x;
+  // BLEND: request this lane's background / frame words early — the HBM latency of the composite then hides behind the
+  // LDS/ALU phases of the mask instead of being exposed after them (the kernel is otherwise latency-bound per workgroup).
+  constexpr int kItems = kTH * (kTW / 4) / kThreads;     // step-5 items per lane
+  static_assert(kItems * kThreads == kTH * (kTW / 4), "tile must divide evenly");
+  uint32_t pa[kItems][3], pb[kItems][3];
+  auto prefetch_blend_operands = [&]() {
+    if constexpr (BLEND) {
+      const int ly0 = tid / (kTW / 4), gx = tx0 + (tid % (kTW / 4)) * 4;
+      const long pix0 = (long)(ty0 + ly0) * W + gx;
+      const uint8_t* const a0 = bg + (bg_stride ? n * bg_stride : 0) + pix0 * 3;
+      const uint8_t* const b0 = frames + ((long)n * W * H + pix0) * 3;
+#pragma unroll
+      for (int i = 0; i < kItems; i++) {           // item i sits 8 rows below item i-1
+        pa[i][0] = pa[i][1] = pa[i][2] = pb[i][0] = pb[i][1] = pb[i][2] = 0;
+        if (ty0 + ly0 + 8 * i < roi.h && gx < roi.w) {
+          const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0 + (long)(8 * i) * W * 3);
+          const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * 3);
+          pa[i][0] = ap[0]; pa[i][1] = ap[1]; pa[i][2] = ap[2];
+          pb[i][0] = bp[0]; pb[i][1] = bp[1]; pb[i][2] = bp[2];
+        }
+      }
+    }
+  };
+  prefetch_blend_operands();
   if (tid == 0) { s_min = 1 << 30; s_max = -1; }
   __syncthreads();
   // 1. column / row tables
@@ -174,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
     if (tab.mode == 1) { sx = sx1 = gx; a0 = 2048; a1 = 0; }
     else if (tab.mode == 2) { sx = 2 * gx; sx1 = 2 * gx + 1; a0 = a1 = 0; }
     else { sx = tab.xofs[gx]; sx1 = min(sx + 1, tab.sw - 1); a0 = tab.xa[2 * gx]; a1 = tab.xa[2 * gx + 1]; }
-    col_sx[tid] = sx; col_sx1[tid] = sx1; col_a0[tid] = a0; col_a1[tid] = a1;
+    col_sx[tid] = sx; col_sx1[tid] = sx1; col_a0[tid] = (short)a0; col_a1[tid] = (short)a1;
   } else if (tid >= 192 && tid < 192 + kHH) {
     const int r = tid - 192;
     const int gy = reflect101(min(ty0 + r - 2, roi.h + 1), roi.h);
@@ -182,23 +226,34 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
     if (tab.mode == 1) { s0 = s1 = gy; b0 = 2048; b1 = 0; }
     else if (tab.mode == 2) { s0 = 2 * gy; s1 = 2 * gy + 1; b0 = b1 = 0; }
     else { const int sy = tab.yofs[gy]; s0 = min(max(sy, 0), tab.sh - 1); s1 = min(max(sy + 1, 0), tab.sh - 1); b0 = tab.ya[2 * gy]; b1 = tab.ya[2 * gy + 1]; }
-    row_s0[r] = s0; row_s1[r] = s1; row_b0[r] = b0; row_b1[r] = b1;
+    row_s0[r] = s0; row_s1[r] = s1; row_b0[r] = (short)b0; row_b1[r] = (short)b1;
     atomicMin(&s_min, s0);
     atomicMax(&s_max, s1);
   }
   __syncthreads();
   const int smin = s_min, nsr = s_max - smin + 1;
   if (tab.mode == 0 && nsr <= kMaxSrcRows) {
-    // 2. horizontal pass on the touched source rows
-    for (int k = tid; k < nsr * kHW; k += kThreads) {
-      const int r = k / kHW, x = k - r * kHW;
-      const uint8_t* sr = src + (long)(smin + r) * outW;
-      hq[k] = (uint16_t)((sr[col_sx[x]] * col_a0[x] + sr[col_sx1[x]] * col_a1[x]) >> 4);
+    // 2. horizontal pass on the touched source rows.  A lane keeps ONE column (its table entries stay in registers) and
+    //    walks the source rows — columns 0..127 two rows per pass, the four halo columns 128..131 by the first 4*nsr
+    //    lanes.  No index division, 32-bit offsets from a uniform base, 24-bit multiplies.
+    static_assert(kThreads == 2 * kTW && 4 * kMaxSrcRows <= kThreads, "lane mapping of step 2");
+    {
+      const uint8_t* const base = src + (long)smin * outW;
+      const int x = tid & (kTW - 1), half = tid >> 7;
+      const int a0 = col_a0[x], a1 = col_a1[x];
+      unsigned o0 = (unsigned)(half * outW + col_sx[x]), o1 = (unsigned)(half * outW + col_sx1[x]);
+      for (int r = half; r < nsr; r += 2, o0 += 2u * outW, o1 += 2u * outW)
+        hq[r * kHW + x] = (uint16_t)((base[o0] * a0 + base[o1] * a1) >> 4);
+      if (tid < 4 * nsr) {
+        const int xr = kTW + (tid & 3), r = tid >> 2;
+        hq[r * kHW + xr] = (uint16_t)((base[(unsigned)(r * outW + col_sx[xr])] * col_a0[xr] + base[(unsigned)(r * outW + col_sx1[xr])] * col_a1[xr]) >> 4);
+      }
     }
     __syncthreads();
     // 3. vertical pass, 4 pixels per lane (64-bit LDS reads of the two source rows, one 32-bit write)
-    for (int k = tid; k < kHH * (kHW / 4); k += kThreads) {
-      const int y = k / (kHW / 4), x = (k - y * (kHW / 4)) * 4;
+    constexpr int kG = kHW / 4;                          // 4-pixel groups per halo row; (y, xg) advance without a division
+    for (int y = tid / kG, xg = tid % kG; y < kHH;) {
+      const int x = xg * 4;
       const int b0 = row_b0[y], b1 = row_b1[y];
       const uint2 r0 = *reinterpret_cast<const uint2*>(&hq[(row_s0[y] - smin) * kHW + x]);
       const uint2 r1 = *reinterpret_cast<const uint2*>(&hq[(row_s1[y] - smin) * kHW + x]);
@@ -208,6 +263,8 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
 #pragma unroll
       for (int j = 0; j < 4; j++) packed |= (uint32_t)((((b0 * h0[j]) >> 16) + ((b1 * h1[j]) >> 16) + 2) >> 2) << (8 * j);
       *reinterpret_cast<uint32_t*>(&up[y * kHW + x]) = packed;
+      xg += kThreads % kG; y += kThreads / kG;
+      if (xg >= kG) { xg -= kG; y++; }
     }
   } else {
     // copy / exact-2x area / very strong down-scale: direct per-pixel sample
@@ -226,77 +283,235 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
     }
   }
   __syncthreads();
-  // 4. horizontal 5-sums, 4 per lane: 8 consecutive bytes in, 4 u16 out
+  // 4. horizontal 5-sums, 4 per lane: 8 consecutive bytes in, 4 u16 out.  v_sad_u8 against 0 adds the four bytes of a
+  //    word (+ an accumulator) in one instruction; the sliding windows come from v_alignbyte.
   for (int k = tid; k < kHH * (kTW / 4); k += kThreads) {
     const int ly = k / (kTW / 4), lx = (k - ly * (kTW / 4)) * 4;
-    const uint2 v = *reinterpret_cast<const uint2*>(&up[ly * kHW + lx]);
-    const int b[8] = {(int)(v.x & 255), (int)((v.x >> 8) & 255), (int)((v.x >> 16) & 255), (int)(v.x >> 24),
-                      (int)(v.y & 255), (int)((v.y >> 8) & 255), (int)((v.y >> 16) & 255), (int)(v.y >> 24)};
-    const int s0 = b[0] + b[1] + b[2] + b[3] + b[4];
-    const int s1 = s0 - b[0] + b[5], s2 = s1 - b[1] + b[6], s3 = s2 - b[2] + b[7];
-    *reinterpret_cast<uint2*>(&hs[ly * kTW + lx]) = make_uint2((uint32_t)s0 | ((uint32_t)s1 << 16), (uint32_t)s2 | ((uint32_t)s3 << 16));
+    const uint2 v = *reinterpret_cast<const uint2*>(&up[ly * kHW + lx]);            // bytes b0..b3 | b4..b7
+    const uint32_t s0 = __builtin_amdgcn_sad_u8(v.x, 0u, v.y & 255u);                                                  // b0..b4
+    const uint32_t s1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 1), 0u, (v.y >> 8) & 255u);      // b1..b5
+    const uint32_t s2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 2), 0u, (v.y >> 16) & 255u);     // b2..b6
+    const uint32_t s3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 3), 0u, v.y >> 24);              // b3..b7
+    *reinterpret_cast<uint2*>(&hs[ly * kTW + lx]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
   }
   __syncthreads();
-  // 5. vertical 5-sums: 32 rows x 32 groups of 4 pixels = 1024 items, 4 per lane
-  for (int k = tid; k < kTH * (kTW / 4); k += kThreads) {
-    const int ly = k / (kTW / 4), lx = (k - ly * (kTW / 4)) * 4;
-    const int gy = ty0 + ly, gx = tx0 + lx;
+  // 5. vertical 5-sums: 32 rows x 32 groups of 4 pixels = 1024 items, 4 per lane.  Item i of a lane is 8 rows below item
+  //    i-1 (kThreads / 32 = 8), so every address below is "item 0 + i * uniform step".
+  static_assert(kThreads == 8 * (kTW / 4), "row step of a lane's items");
+  const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
+  const int gx = tx0 + lx;
+  uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx;
+  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(ty0 + ly0) * W + gx) * 3 : nullptr;
+#pragma unroll
+  for (int i = 0; i < kItems; i++) {
+    const int ly = ly0 + 8 * i, gy = ty0 + ly;
     if (gy >= roi.h || gx >= roi.w) continue;
-    int sum[4] = {0, 0, 0, 0};
+    // sums of five u16 (<= 25 * 255) stay inside a u16 lane: packed adds on the words as loaded
+    uint2 acc = *reinterpret_cast<const uint2*>(&hs[ly * kTW + lx]);
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
+    for (int r = 1; r < 5; r++) {
       const uint2 v = *reinterpret_cast<const uint2*>(&hs[(ly + r) * kTW + lx]);
-      sum[0] += (int)(v.x & 0xffff); sum[1] += (int)(v.x >> 16); sum[2] += (int)(v.y & 0xffff); sum[3] += (int)(v.y >> 16);
+      acc.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.x) + __builtin_bit_cast(us2, v.x));
+      acc.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.y) + __builtin_bit_cast(us2, v.y));
     }
-    uint32_t packed = 0;
-    uint8_t vals[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      vals[j] = (uint8_t)((sum[j] + 12) / 25);
-      packed |= (uint32_t)vals[j] << (8 * j);
-    }
-    uint8_t* dst = mask + (long)n * W * H + (long)(roi.y + gy) * W + roi.x + gx;
+    // (s + 12) / 25 == ((s + 12) * 5243) >> 17 for s <= 25 * 255 (exhaustively checked); one v_mad_u32_u24 each
+    const uint32_t m0 = (__umul24(acc.x & 0xffffu, 5243u) + 12u * 5243u) >> 17, m1 = (__umul24(acc.x >> 16, 5243u) + 12u * 5243u) >> 17;
+    const uint32_t m2 = (__umul24(acc.y & 0xffffu, 5243u) + 12u * 5243u) >> 17, m3 = (__umul24(acc.y >> 16, 5243u) + 12u * 5243u) >> 17;
+    const uint32_t packed = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+    uint8_t* dst = dst0 + (long)(8 * i) * W;
     if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
-    else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = vals[j];
+    else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
     if constexpr (BLEND) {
       // roi == whole frame and W % 4 == 0 (checked by the launcher): 4 pixels = 12 bytes = 3 aligned words per image
-      const long pix = (long)gy * W + gx;
-      const uint32_t* ap = reinterpret_cast<const uint32_t*>(bg + (bg_stride ? n * bg_stride : 0) + pix * 3);
-      const uint32_t* bp = reinterpret_cast<const uint32_t*>(frames + ((long)n * W * H + pix) * 3);
-      uint32_t* op = reinterpret_cast<uint32_t*>(outp + ((long)n * W * H + pix) * 3);
-      const uint32_t a0 = ap[0], a1 = ap[1], a2 = ap[2], b0 = bp[0], b1 = bp[1], b2 = bp[2];
-      const int m0 = vals[0], m1 = vals[1], m2 = vals[2], m3 = vals[3];
-      op[0] = blend4w(a0, b0, m0, m0, m0, m1);
-      op[1] = blend4w(a1, b1, m1, m1, m2, m2);
-      op[2] = blend4w(a2, b2, m2, m3, m3, m3);
+      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * 3);
+      uint32_t o3[3];
+      blend_quad_fwd(pa[i], pb[i], packed, o3);
+      op[0] = o3[0]; op[1] = o3[1]; op[2] = o3[2];
+    }
+  }
+}
+
+// ---- mask tile, single-round-trip form ---------------------------------------------------------------------------------
+// Same integers as mask_upscale_blur_k, restructured around what actually bounds it: with the composite fused in, a
+// workgroup's life is a chain of dependent memory round trips taken while HBM is saturated by the blend traffic
+// (loaded latency of several microseconds each).  Here every global load of the tile is issued in the first few
+// instructions: the source-block extents come from four uniform (scalar) table reads, then the raw ofinal block, this
+// lane's table entries and its composite operands are all requested back to back.  Steps 2-5 then run from LDS only.
+// Used when the host verified that every tile's source block fits (ResizeTab::tile_ok); other cases take the kernel above.
+constexpr int kSrcBlockBytes = kHH * kHW;        // the raw block lives in `up` until step 3 overwrites it
+template <bool BLEND>
+__global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
+                                                       uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
+                                                       const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
+                                                       uint8_t* __restrict__ outp) {
+  __shared__ short col_c0[kHW], col_c1[kHW], col_a0[kHW], col_a1[kHW];     // block-relative tap columns, coefficients
+  __shared__ short row_r0[kHH], row_r1[kHH], row_b0[kHH], row_b1[kHH];     // block-relative tap rows, coefficients
+  __shared__ __attribute__((aligned(16))) uint16_t hq_hs[kMaxSrcRows * kHW > kHH * kTW ? kMaxSrcRows * kHW : kHH * kTW];
+  __shared__ __attribute__((aligned(16))) uint8_t up[kHH * kHW + 8];
+  uint16_t* const hq = hq_hs;
+  uint16_t* const hs = hq_hs;
+  uint8_t* const blk = up;
+  const int n = blockIdx.z, tid = threadIdx.x;
+  const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
+  // extents of the source block: xofs / yofs are monotonic, so the extreme destination rows / columns give them
+  const int gy_lo = max(ty0 - 2, 0), gy_hi = min(ty0 + kTH + 1, roi.h - 1);
+  const int gx_lo = max(tx0 - 2, 0), gx_hi = min(tx0 + kTW + 1, roi.w - 1);
+  const int smin = min(max(tab.yofs[gy_lo], 0), tab.sh - 1), smax = min(max(tab.yofs[gy_hi] + 1, 0), tab.sh - 1);
+  const int cmin = tab.xofs[gx_lo], cmax = min(tab.xofs[gx_hi] + 1, tab.sw - 1);
+  const int nsr = smax - smin + 1, ncol = cmax - cmin + 1;
+  const uint8_t* const base = ofinal + (long)n * outW * outH + (long)(q.y + smin) * outW + q.x + cmin;
+  // (a) raw block: 12 rows x 64 columns in three loads per lane cover the usual 5x up-scale; anything larger loops below
+  uint32_t raw[3];
+  const int br = tid >> 6, bc = tid & 63;
+#pragma unroll
+  for (int j = 0; j < 3; j++) { raw[j] = 0; if (br + 4 * j < nsr && bc < ncol) raw[j] = base[(unsigned)((br + 4 * j) * outW + bc)]; }
+  // (b) this lane's table entries
+  int t_s = 0, t_a0 = 0, t_a1 = 0;
+  if (tid < kHW) {
+    const int gx = reflect101(min(tx0 + tid - 2, roi.w + 1), roi.w);
+    t_s = tab.xofs[gx]; t_a0 = tab.xa[2 * gx]; t_a1 = tab.xa[2 * gx + 1];
+  } else if (tid >= 192 && tid < 192 + kHH) {
+    const int gy = reflect101(min(ty0 + (tid - 192) - 2, roi.h + 1), roi.h);
+    t_s = tab.yofs[gy]; t_a0 = tab.ya[2 * gy]; t_a1 = tab.ya[2 * gy + 1];
+  }
+  // (c) composite operands
+  constexpr int kItems = kTH * (kTW / 4) / kThreads;
+  static_assert(kItems * kThreads == kTH * (kTW / 4) && kThreads == 8 * (kTW / 4), "tile / lane mapping");
+  const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4, gx4 = tx0 + lx;
+  uint32_t pa[kItems][3], pb[kItems][3];
+  if constexpr (BLEND) {
+    const long pix0 = (long)(ty0 + ly0) * W + gx4;
+    const uint8_t* const a0p = bg + (bg_stride ? n * bg_stride : 0) + pix0 * 3;
+    const uint8_t* const b0p = frames + ((long)n * W * H + pix0) * 3;
+#pragma unroll
+    for (int i = 0; i < kItems; i++) {
+      pa[i][0] = pa[i][1] = pa[i][2] = pb[i][0] = pb[i][1] = pb[i][2] = 0;
+      if (ty0 + ly0 + 8 * i < roi.h && gx4 < roi.w) {
+        const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0p + (long)(8 * i) * W * 3);
+        const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0p + (long)(8 * i) * W * 3);
+        pa[i][0] = ap[0]; pa[i][1] = ap[1]; pa[i][2] = ap[2];
+        pb[i][0] = bp[0]; pb[i][1] = bp[1]; pb[i][2] = bp[2];
+      }
+    }
+  }
+  // 1. block and tables into LDS
+#pragma unroll
+  for (int j = 0; j < 3; j++) if (br + 4 * j < nsr && bc < ncol) blk[(br + 4 * j) * ncol + bc] = (uint8_t)raw[j];
+  if (nsr > 12 || ncol > 64)
+    for (int r = br; r < nsr; r += 4)
+      for (int cc = bc; cc < ncol; cc += 64)
+        if (r >= 12 || cc >= 64) blk[r * ncol + cc] = base[(unsigned)(r * outW + cc)];
+  if (tid < kHW) {
+    col_c0[tid] = (short)(t_s - cmin); col_c1[tid] = (short)(min(t_s + 1, tab.sw - 1) - cmin);
+    col_a0[tid] = (short)t_a0; col_a1[tid] = (short)t_a1;
+  } else if (tid >= 192 && tid < 192 + kHH) {
+    const int r = tid - 192;
+    row_r0[r] = (short)(min(max(t_s, 0), tab.sh - 1) - smin); row_r1[r] = (short)(min(max(t_s + 1, 0), tab.sh - 1) - smin);
+    row_b0[r] = (short)t_a0; row_b1[r] = (short)t_a1;
+  }
+  __syncthreads();
+  // 2. horizontal pass of the block rows: hq[r][x] = (S0*a0 + S1*a1) >> 4, all 132 columns, k = r * 132 + x walks without a division
+  for (int r = tid / kHW, x = tid % kHW; r < nsr;) {
+    hq[r * kHW + x] = (uint16_t)((blk[r * ncol + col_c0[x]] * col_a0[x] + blk[r * ncol + col_c1[x]] * col_a1[x]) >> 4);
+    x += kThreads % kHW; r += kThreads / kHW;
+    if (x >= kHW) { x -= kHW; r++; }
+  }
+  __syncthreads();
+  // 3. vertical pass, 4 pixels per lane
+  constexpr int kG = kHW / 4;
+  for (int y = tid / kG, xg = tid % kG; y < kHH;) {
+    const int x = xg * 4;
+    const int b0 = row_b0[y], b1 = row_b1[y];
+    const uint2 r0 = *reinterpret_cast<const uint2*>(&hq[row_r0[y] * kHW + x]);
+    const uint2 r1 = *reinterpret_cast<const uint2*>(&hq[row_r1[y] * kHW + x]);
+    const int h0[4] = {(int)(r0.x & 0xffff), (int)(r0.x >> 16), (int)(r0.y & 0xffff), (int)(r0.y >> 16)};
+    const int h1[4] = {(int)(r1.x & 0xffff), (int)(r1.x >> 16), (int)(r1.y & 0xffff), (int)(r1.y >> 16)};
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) packed |= (uint32_t)((((b0 * h0[j]) >> 16) + ((b1 * h1[j]) >> 16) + 2) >> 2) << (8 * j);
+    *reinterpret_cast<uint32_t*>(&up[y * kHW + x]) = packed;
+    xg += kThreads % kG; y += kThreads / kG;
+    if (xg >= kG) { xg -= kG; y++; }
+  }
+  __syncthreads();
+  // 4. horizontal 5-sums (see mask_upscale_blur_k)
+  for (int k = tid; k < kHH * (kTW / 4); k += kThreads) {
+    const int ly = k / (kTW / 4), x4 = (k - ly * (kTW / 4)) * 4;
+    const uint2 v = *reinterpret_cast<const uint2*>(&up[ly * kHW + x4]);
+    const uint32_t s0 = __builtin_amdgcn_sad_u8(v.x, 0u, v.y & 255u);
+    const uint32_t s1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 1), 0u, (v.y >> 8) & 255u);
+    const uint32_t s2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 2), 0u, (v.y >> 16) & 255u);
+    const uint32_t s3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 3), 0u, v.y >> 24);
+    *reinterpret_cast<uint2*>(&hs[ly * kTW + x4]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+  }
+  __syncthreads();
+  // 5. vertical 5-sums, (s + 12) / 25, mask store and composite
+  uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx4;
+  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(ty0 + ly0) * W + gx4) * 3 : nullptr;
+#pragma unroll
+  for (int i = 0; i < kItems; i++) {
+    const int ly = ly0 + 8 * i, gy = ty0 + ly;
+    if (gy >= roi.h || gx4 >= roi.w) continue;
+    uint2 acc = *reinterpret_cast<const uint2*>(&hs[ly * kTW + lx]);
+#pragma unroll
+    for (int r = 1; r < 5; r++) {
+      const uint2 v = *reinterpret_cast<const uint2*>(&hs[(ly + r) * kTW + lx]);
+      acc.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.x) + __builtin_bit_cast(us2, v.x));
+      acc.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.y) + __builtin_bit_cast(us2, v.y));
+    }
+    const uint32_t m0 = (__umul24(acc.x & 0xffffu, 5243u) + 12u * 5243u) >> 17, m1 = (__umul24(acc.x >> 16, 5243u) + 12u * 5243u) >> 17;
+    const uint32_t m2 = (__umul24(acc.y & 0xffffu, 5243u) + 12u * 5243u) >> 17, m3 = (__umul24(acc.y >> 16, 5243u) + 12u * 5243u) >> 17;
+    const uint32_t packed = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+    uint8_t* dst = dst0 + (long)(8 * i) * W;
+    if (gx4 + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
+    else for (int j = 0; j < 4 && gx4 + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
+    if constexpr (BLEND) {
+      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * 3);
+      uint32_t o3[3];
+      blend_quad_fwd(pa[i], pb[i], packed, o3);
+      op[0] = o3[0]; op[1] = o3[1]; op[2] = o3[2];
     }
   }
 }
 
 // ---- alpha blend: 16 pixels (16 mask bytes, 48+48 source bytes, 48 output bytes) per lane -----
-__device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, int m0, int m1, int m2, int m3);
-__device__ __forceinline__ uint32_t blend4w(uint32_t a, uint32_t b, int m0, int m1, int m2, int m3) { return blend4(a, b, m0, m1, m2, m3); }
-__device__ __forceinline__ uint32_t blend4(uint32_t a, uint32_t b, int m0, int m1, int m2, int m3) {
-  // four consecutive bytes of the packed BGR stream; mX = mask of the pixel byte X belongs to
-  uint32_t r;
-  int a0 = a & 255, a1 = (a >> 8) & 255, a2 = (a >> 16) & 255, a3 = a >> 24;
-  int b0 = b & 255, b1 = (b >> 8) & 255, b2 = (b >> 16) & 255, b3 = b >> 24;
-  r = (uint32_t)((a0 * m0 + b0 * (255 - m0)) / 255);
-  r |= (uint32_t)((a1 * m1 + b1 * (255 - m1)) / 255) << 8;
-  r |= (uint32_t)((a2 * m2 + b2 * (255 - m2)) / 255) << 16;
-  r |= (uint32_t)((a3 * m3 + b3 * (255 - m3)) / 255) << 24;
-  return r;
+// Packed form of the same integers (v_pk_*_u16, two bytes per instruction):  a*m + b*(255-m) <= 255*255 fits a u16 lane,
+// and floor(t/255) == (t + 1 + (t >> 8)) >> 8 for every t in [0, 65025] (exhaustively checked; the sum stays < 65536).
+__device__ __forceinline__ us2 pk_blend(uint32_t a, uint32_t b, uint32_t m) {   // operands: two u8 values in the u16 halves
+  const us2 av = __builtin_bit_cast(us2, a), bv = __builtin_bit_cast(us2, b), mv = __builtin_bit_cast(us2, m);
+  const us2 iv = __builtin_bit_cast(us2, 0x00ff00ffu - m);
+  us2 t = av * mv + bv * iv;
+  const us2 one = {1, 1};
+  t = (t + one + (t >> 8)) >> 8;
+  return t;
+}
+__device__ __forceinline__ uint32_t blend_word(uint32_t a, uint32_t b, uint32_t m02, uint32_t m13) {
+  const uint32_t K = 0x00ff00ffu;
+  const uint32_t r02 = __builtin_bit_cast(uint32_t, pk_blend(a & K, b & K, m02));
+  const uint32_t r13 = __builtin_bit_cast(uint32_t, pk_blend((a >> 8) & K, (b >> 8) & K, m13));
+  return r02 | (r13 << 8);
+}
+// 4 pixels = 12 bytes = 3 words; mw holds their 4 mask bytes.  Byte→pixel map of the words: (0,0,0,1) (1,1,2,2) (2,3,3,3).
+__device__ __forceinline__ void blend_quad(const uint32_t a[3], const uint32_t b[3], uint32_t mw, uint32_t o[3]) {
+  const uint32_t m00 = __builtin_amdgcn_perm(mw, mw, 0x0c000c00u), m01 = __builtin_amdgcn_perm(mw, mw, 0x0c010c00u);
+  const uint32_t m12 = __builtin_amdgcn_perm(mw, mw, 0x0c020c01u);
+  const uint32_t m23 = __builtin_amdgcn_perm(mw, mw, 0x0c030c02u), m33 = __builtin_amdgcn_perm(mw, mw, 0x0c030c03u);
+  o[0] = blend_word(a[0], b[0], m00, m01);
+  o[1] = blend_word(a[1], b[1], m12, m12);
+  o[2] = blend_word(a[2], b[2], m23, m33);
 }
 
+__device__ __forceinline__ void blend_quad_fwd(const uint32_t a[3], const uint32_t b[3], uint32_t mw, uint32_t o[3]) { blend_quad(a, b, mw, o); }
+
 __global__ __launch_bounds__(kThreads) void blend16_k(const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ fr,
-                                                     const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, long groups_per_frame,
-                                                     long npix, long total_groups) {
-  long gi = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (gi >= total_groups) return;
-  long n = gi / groups_per_frame, g = gi % groups_per_frame;
-  long pix = n * npix + g * 16;
+                                                     const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, unsigned groups_per_frame,
+                                                     long npix) {
+  const unsigned g = blockIdx.x * kThreads + threadIdx.x;      // 16-pixel group inside frame blockIdx.y
+  if (g >= groups_per_frame) return;
+  const long n = blockIdx.y;
+  const long pix = n * npix + (long)g * 16;
   const uint4 mv = *reinterpret_cast<const uint4*>(mask + pix);
-  const uint4* ap = reinterpret_cast<const uint4*>(bg + (bg_stride ? n * bg_stride : 0) + g * 48);
+  const uint4* ap = reinterpret_cast<const uint4*>(bg + (bg_stride ? n * bg_stride : 0) + (long)g * 48);
   const uint4* bp = reinterpret_cast<const uint4*>(fr + pix * 3);
   uint4* op = reinterpret_cast<uint4*>(out + pix * 3);
   uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
@@ -309,23 +524,17 @@ __global__ __launch_bounds__(kThreads) void blend16_k(const uint8_t* __restrict_
   }
   // word j of the 12 covers bytes 4j..4j+3 → pixels (4j)/3 .. (4j+3)/3 ; every 3 words = 4 pixels = 1 mask word
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    int m0 = mw[q] & 255, m1 = (mw[q] >> 8) & 255, m2 = (mw[q] >> 16) & 255, m3 = mw[q] >> 24;
-    ow[3 * q + 0] = blend4(aw[3 * q + 0], bw[3 * q + 0], m0, m0, m0, m1);
-    ow[3 * q + 1] = blend4(aw[3 * q + 1], bw[3 * q + 1], m1, m1, m2, m2);
-    ow[3 * q + 2] = blend4(aw[3 * q + 2], bw[3 * q + 2], m2, m3, m3, m3);
-  }
+  for (int q = 0; q < 4; q++) blend_quad(&aw[3 * q], &bw[3 * q], mw[q], &ow[3 * q]);
 #pragma unroll
   for (int k = 0; k < 3; k++) op[k] = make_uint4(ow[4 * k], ow[4 * k + 1], ow[4 * k + 2], ow[4 * k + 3]);
 }
 
 // scalar tail / unaligned fallback: one pixel per lane
 __global__ __launch_bounds__(kThreads) void blend1_k(const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ fr,
-                                                    const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, long npix, long first, long total) {
-  long i = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= total) return;
-  long per = npix - first;
-  long n = i / per, p = first + i % per;
+                                                    const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, long npix) {
+  const long p = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (p >= npix) return;
+  const long n = blockIdx.y;
   int m = mask[n * npix + p];
   const uint8_t* a = bg + (bg_stride ? n * bg_stride : 0) + p * 3;
   const uint8_t* b = fr + (n * npix + p) * 3;
@@ -335,16 +544,14 @@ __global__ __launch_bounds__(kThreads) void blend1_k(const uint8_t* __restrict__
 }
 
 // ---- generic BGR resize -------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void resize_bgr_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ResizeTab tab, long total) {
-  long i = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= total) return;
-  int x = (int)(i % tab.dw);
-  long r = i / tab.dw;
-  int y = (int)(r % tab.dh);
-  long n = r / tab.dh;
+__global__ __launch_bounds__(kThreads) void resize_bgr_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ResizeTab tab) {
+  const unsigned p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= (unsigned)(tab.dw * tab.dh)) return;
+  const int y = (int)(p / (unsigned)tab.dw), x = (int)(p - (unsigned)y * (unsigned)tab.dw);
+  const long n = blockIdx.y;
   int v[3];
   sample_linear<3>(src + n * (long)tab.sw * tab.sh * 3, (long)tab.sw * 3, tab, x, y, v);
-  uint8_t* o = dst + i * 3;
+  uint8_t* o = dst + (n * (long)tab.dw * tab.dh + p) * 3;
   o[0] = (uint8_t)v[0]; o[1] = (uint8_t)v[1]; o[2] = (uint8_t)v[2];
 }
 
@@ -390,14 +597,27 @@ __global__ __launch_bounds__(kThreads) void fill_k(uint4* p, uint4 v, long n16) 
 
 hipError_t launch_prep_resize(const uint8_t* frames, int W, int H, Rect4 roi, uint32_t* canvas, int inW, int inH, Rect4 in_roi, ResizeTab tab,
                               int n, hipStream_t s) {
-  long total = (long)n * inW * inH;
-  prep_resize_k<<<blocks_for(total), kThreads, 0, s>>>(frames, W, H, roi, canvas, inW, inH, in_roi, tab, total);
+  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {     // grid.y carries the frame index
+    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
+    prep_resize_k<<<dim3(blocks_for((long)canvas_elems(inW, inH)), nn), kThreads, 0, s>>>(frames + (size_t)n0 * W * H * 3, W, H, roi,
+                                                                                          canvas + (size_t)n0 * canvas_elems(inW, inH), inW, inH, in_roi, tab);
+  }
   return hipGetLastError();
 }
 
+bool bilateral_taps_match(const BilateralParams& bp) {
+  static const int ty[13] = {-2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2}, tx[13] = {0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0};
+  for (int k = 0; k < 13; k++) if (bp.off_y[k] != ty[k] || bp.off_x[k] != tx[k]) return false;
+  return true;
+}
+
 hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, int inW, int inH, BilateralParams bp, int n, hipStream_t s) {
-  long total = (long)n * inW * inH;
-  prep_bilateral_k<<<blocks_for(total), kThreads, 0, s>>>(canvas, input, inW, inH, bp, total);
+  const long per_frame = (long)inW * inH;
+  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
+    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
+    prep_bilateral_k<<<dim3(blocks_for((per_frame + kBilPix - 1) / kBilPix), nn), kThreads, 0, s>>>(canvas + (size_t)n0 * canvas_elems(inW, inH),
+                                                                                                    input + (size_t)n0 * per_frame * 3, inW, inH, bp);
+  }
   return hipGetLastError();
 }
 
@@ -408,10 +628,29 @@ hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, i
   return hipGetLastError();
 }
 
+// Every tile's source block must fit the LDS staging area of mask_tile_k (host tables, checked once per ResizeTab).
+bool mask_tile_fits(const int* xofs, const int* yofs, int sw, int sh, int dw, int dh) {
+  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+  int max_rows = 0, max_cols = 0;
+  for (int ty0 = 0; ty0 < dh; ty0 += kTH) {
+    const int lo = std::max(ty0 - 2, 0), hi = std::min(ty0 + kTH + 1, dh - 1);
+    max_rows = std::max(max_rows, clampi(yofs[hi] + 1, 0, sh - 1) - clampi(yofs[lo], 0, sh - 1) + 1);
+  }
+  for (int tx0 = 0; tx0 < dw; tx0 += kTW) {
+    const int lo = std::max(tx0 - 2, 0), hi = std::min(tx0 + kTW + 1, dw - 1);
+    max_cols = std::max(max_cols, std::min(xofs[hi] + 1, sw - 1) - xofs[lo] + 1);
+  }
+  return max_rows <= kMaxSrcRows && max_rows * max_cols <= kSrcBlockBytes;
+}
+
+// BSX_NO_MASK_TILE=1 (read at every launch) forces the generic kernel: the parity tests use it to cover both.
+static bool mask_tile_usable(const ResizeTab& tab) { return tab.mode == 0 && tab.tile_ok && !getenv("BSX_NO_MASK_TILE"); }
+
 hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                                     int n, hipStream_t s) {
   dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
-  mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr);
+  if (mask_tile_usable(tab)) mask_tile_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr);
+  else mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr);
   return hipGetLastError();
 }
 
@@ -423,27 +662,32 @@ bool mask_blend_fusable(int W, int H, Rect4 roi, const uint8_t* bg, size_t bg_st
 hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                              const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s) {
   dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
-  mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
+  if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
+  else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
   return hipGetLastError();
 }
 
 hipError_t launch_blend(const uint8_t* bg, size_t bg_stride, const uint8_t* frames, const uint8_t* masks, uint8_t* out, size_t npix, int n,
                         hipStream_t s) {
   bool aligned = (((uintptr_t)bg | (uintptr_t)frames | (uintptr_t)masks | (uintptr_t)out) & 15) == 0 && (npix % 16 == 0) && (bg_stride % 16 == 0);
-  long groups = aligned ? (long)(npix / 16) : 0;
-  if (groups) {
-    long total = groups * n;
-    blend16_k<<<blocks_for(total), kThreads, 0, s>>>(bg, (long)bg_stride, frames, masks, out, groups, (long)npix, total);
-  } else {
-    long total = (long)npix * n;
-    blend1_k<<<blocks_for(total), kThreads, 0, s>>>(bg, (long)bg_stride, frames, masks, out, (long)npix, 0, total);
+  const long groups = aligned ? (long)(npix / 16) : 0;
+  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
+    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
+    const uint8_t* bgp = bg + (size_t)n0 * bg_stride;
+    const uint8_t* fp = frames + (size_t)n0 * npix * 3;
+    const uint8_t* mp = masks + (size_t)n0 * npix;
+    uint8_t* op = out + (size_t)n0 * npix * 3;
+    if (groups) blend16_k<<<dim3(blocks_for(groups), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (unsigned)groups, (long)npix);
+    else blend1_k<<<dim3(blocks_for((long)npix), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (long)npix);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_resize_bgr(const uint8_t* src, uint8_t* dst, ResizeTab tab, int n, hipStream_t s) {
-  long total = (long)n * tab.dw * tab.dh;
-  resize_bgr_k<<<blocks_for(total), kThreads, 0, s>>>(src, dst, tab, total);
+  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
+    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
+    resize_bgr_k<<<dim3(blocks_for((long)tab.dw * tab.dh), nn), kThreads, 0, s>>>(src + (size_t)n0 * tab.sw * tab.sh * 3, dst + (size_t)n0 * tab.dw * tab.dh * 3, tab);
+  }
   return hipGetLastError();
 }
 

@@ -131,6 +131,59 @@ def test_stages_match_oracle(bs, oracle, key, res, real):
     mg.close()
 
 
+@pytest.mark.parametrize("res", [VGA, (322, 242)])
+def test_generic_mask_kernel_matches_tile_kernel(bs, oracle, res, monkeypatch):
+    """The single-round-trip tile kernel (default) and the generic mask kernel (BSX_NO_MASK_TILE=1; also the fallback when
+    a tile's source block does not fit LDS) must both be bit-exact against the oracle, stand-alone and fused with the blend."""
+    from backscrub_amd import synth
+    W, H = res
+    path = model_path("lite")
+    n = 3
+    frames = np.stack([synth.frame(W, H, s) for s in range(n)])
+    bg = synth.background(W, H)
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("BSX_NO_MASK_TILE", "1")
+        else:
+            monkeypatch.delenv("BSX_NO_MASK_TILE", raising=False)
+        # stand-alone: decode + upscale + blur from the oracle's logits over a noisy previous state (every weight exercised)
+        mg = bs.MaskGen(path, W, H, n_streams=n)
+        oc = [oracle.Ctx(path, W, H) for _ in range(n)]
+        info = mg.info
+        prev = synth.random_u8((n, info["out_h"], info["out_w"]), 5)
+        for i in range(n):
+            oc[i].prep(frames[i])
+            oc[i].infer()
+            oc[i].set_ofinal(prev[i])
+        mg.output_tensor().copy_(_dev(np.stack([c.output() for c in oc])))
+        mg.ofinal().copy_(_dev(prev))
+        mg.run_stage(2, n=n)
+        mg.run_stage(3, n=n)
+        got = mg.masks().cpu().numpy()
+        for i in range(n):
+            oc[i].post()
+            assert np.array_equal(got[i], oc[i].mask()), "generic=%s stream %d: %d px differ" % (generic, i, (got[i] != oc[i].mask()).sum())
+        for c in oc:
+            c.close()
+        mg.close()
+        # fused with the composite (bsx_step_batch)
+        mg = bs.MaskGen(path, W, H, n_streams=n)
+        oc = [oracle.Ctx(path, W, H) for _ in range(n)]
+        out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+        mg.step(_dev(frames), _dev(bg), out)
+        got_m, got_o, got_of = mg.masks().cpu().numpy(), out.cpu().numpy(), mg.ofinal().cpu().numpy()
+        for i in range(n):
+            want = oc[i].process(frames[i])
+            assert _iou_fg(got_m[i], want) >= 0.999
+            if np.array_equal(got_of[i], oc[i].ofinal()):    # same model-resolution mask → everything after it is integer work
+                assert np.array_equal(got_m[i], want), "fused, generic=%s stream %d" % (generic, i)
+                assert np.array_equal(got_o[i], oracle.alpha_blend(bg, frames[i], want))
+        for c in oc:
+            c.close()
+        mg.close()
+    monkeypatch.delenv("BSX_NO_MASK_TILE", raising=False)
+
+
 @pytest.mark.parametrize("key", ["lite", "mlkit", "deeplab"])
 def test_per_launch_path_agrees_with_frame_program(bs, oracle, key, monkeypatch):
     """The network has two executions of the same fused plan: the per-frame LDS program (default) and one
