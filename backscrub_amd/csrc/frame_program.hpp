@@ -34,8 +34,9 @@ struct MicroOp {
   int kh = 1, kw = 1, sh = 1, sw = 1, dh = 1, dw = 1, pt = 0, pl = 0;
   int act = 0, elt = 0, bcast1 = 0, align_corners = 0, half_pixel = 0;
   int cout_pad = 0, cout_tile = 16;
-  int stage_floats = 0;  // >0: the kernel copies weights[w_off .. w_off+stage_floats) (weights, then bias at b_off-w_off) into the LDS
-                         // scratch before the op; the copy is prefetched into registers while the PREVIOUS op runs
+  int stage_floats = 0;  // >0: weights[w_off .. w_off+stage_floats) (weights, then bias at b_off-w_off) are copied to LDS at float offset
+  int w_lds = 0;         //     w_lds by an asynchronous globalâ†’LDS DMA issued while the PREVIOUS op runs (the planner gives the slot a
+                         //     lifetime of [previous op, this op] in the same first-fit allocation as the tensors)
   int ws_off = 0, band_rows = 0;   // dense conv on the matrix cores: LDS workspace (float offset) holding a band of input rows; output rows per band
   int mfma = 0;     // 1: pointwise conv runs on v_mfma_f32_16x16x4_f32 with the weight block staged in LDS
   int gemv = 0;     // 1: â‰¤4 output pixels â†’ wave-per-output-channel dot products with [co][ci] weights
@@ -58,6 +59,7 @@ constexpr int kMicroTail = 101;              // MicroOp::kind of the fused pw â†
 constexpr int kMicroSe = 100;                // MicroOp::kind of the fused GAPâ†’FCâ†’FC chain
 constexpr int kFrameThreads = 1024;          // 16 waves: 4 per SIMD
 constexpr int kLdsTotalFloats = 160 * 256;   // 160 KiB
-constexpr int kLdsScratchFloats = 4224;      // weight-staging + reduction scratch at the start of the LDS block (16.5 KiB: 128x32 weights + 128 bias)
+constexpr int kLdsScratchFloats = 2048;      // reduction scratch at the start of the LDS block (pooling partials, gemv partials, the tail's small weight set)
+constexpr int kLdsMaxStageFloats = 4224;     // largest weight block staged in LDS (128x32 weights + 128 bias)
 
 }  // namespace bsx

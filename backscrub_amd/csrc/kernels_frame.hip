@@ -145,8 +145,8 @@ __device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
   const int lane = threadIdx.x & 63, nw = kFrameThreads >> 6;
   const int Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad, act = op.act, nq = Cin >> 2;
   const int wfloats = Cin * cout_pad;
-  const lds_f* wl = lds_base();
-  const lds_f* bl = lds_base() + wfloats;
+  const lds_f* wl = lds_base() + op.w_lds;
+  const lds_f* bl = wl + wfloats;
   const bool has_sc = sc.valid;          // SE scale vectors always live in LDS (planner)
   for (int wi = wave_id(); wi < chunks * tiles; wi += nw) {
     const int tile = wi / chunks, chunk = wi - tile * chunks;
@@ -227,8 +227,8 @@ __device__ __forceinline__ void pw_mfma(cop_t& op, const FrameCtx& c) {
   const int P = op.OH * op.OW, Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad, act = op.act;
   const int ws = cout_pad;                             // staged row stride (a 2-way bank conflict on the B reads is
                                                        // invisible next to the 32-cycle MFMA; padding would cost LDS)
-  const lds_f* wl = lds_base();                       // staged by the main loop: weights, then bias
-  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
+  const lds_f* wl = lds_base() + op.w_lds;             // staged by the main loop: weights, then bias
+  const lds_f* bl = wl + (int)(op.b_off - op.w_off);
   (void)w; (void)bias;
   const int mt = (P + 15) >> 4, nt = cout_pad >> 4, nw = kFrameThreads >> 6;
   const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
@@ -267,6 +267,91 @@ __device__ __forceinline__ void pw_mfma(cop_t& op, const FrameCtx& c) {
           float v = fp_act(acc[r] + bv, act);
           if (has_res) v += ld1(res, pix * res.stride + co);
           st1(y, pix * y.stride + co, v);
+        }
+      }
+    }
+  }
+}
+
+// Global-memory input: the op is bound by load round trips, not math (one 16-pixel tile = 4..32 MFMAs against a ~2 us HBM/L2
+// latency with only 4 waves per SIMD to hide it).  So a wave (1) reads each A tile ONCE and runs all of its channel tiles from
+// registers, and (2) requests the A operands of B consecutive pixel tiles before touching any of them.  FMA order per
+// output is unchanged (j ascending), i.e. bit-identical to pw_mfma<false>.
+template <int NJ, int B>
+__device__ __forceinline__ void pw_mfma_glb(cop_t& op, const FrameCtx& c) {
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c), sc = make_ref(op.scale, c), ad = make_ref(op.in2, c);
+  const int P = op.OH * op.OW, Cin = op.Cin, Cout = op.Cout, cout_pad = op.cout_pad, act = op.act;
+  const int ws = cout_pad;
+  const lds_f* wl = lds_base() + op.w_lds;
+  const lds_f* bl = wl + (int)(op.b_off - op.w_off);
+  const int mt = (P + 15) >> 4, nt = cout_pad >> 4, nw = kFrameThreads >> 6;
+  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+  const bool has_sc = sc.valid, has_res = res.valid, has_add = ad.valid;
+  for (int t0 = wave_id() * B; t0 < mt; t0 += nw * B) {
+    float4 a[B][NJ];
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+      const int arow = min(((t0 + i) << 4) + li, P - 1);      // tiles / rows past the end read a valid pixel; results are dropped
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int k0 = 16 * j + 4 * g;
+        a[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 < Cin) a[i][j] = ld_glb4(x.g + arow * x.stride + k0);
+      }
+    }
+    if (has_sc || has_add) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int k0 = 16 * j + 4 * g;
+        if (k0 < Cin) {
+          float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (has_sc) sv = ld_lds4(sc.l + k0);
+#pragma unroll
+          for (int i = 0; i < B; i++) {
+            float4 v = a[i][j];
+            if (has_sc) { v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w); }
+            if (has_add) {
+              const int arow = min(((t0 + i) << 4) + li, P - 1);
+              const float4 av = ld4(ad, arow * ad.stride + k0);
+              v.x = __fadd_rn(v.x, av.x); v.y = __fadd_rn(v.y, av.y); v.z = __fadd_rn(v.z, av.z); v.w = __fadd_rn(v.w, av.w);
+            }
+            a[i][j] = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+      const int m0 = (t0 + i) << 4;
+      if (m0 >= P) break;
+      for (int tn = 0; tn < nt; tn++) {
+        const int n0 = tn << 4;
+        const lds_f* bp = wl + (4 * g) * ws + n0 + li;
+        f4acc acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const int k0 = 16 * j + 4 * g;
+          float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+          if (k0 < Cin) { const lds_f* br = bp + (16 * j) * ws; b0 = br[0]; b1 = br[ws]; b2 = br[2 * ws]; b3 = br[3 * ws]; }
+          if (16 * j < Cin) {                                 // wave-uniform: skip k-steps beyond Cin entirely
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j].x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j].y, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j].z, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j].w, b3, acc, 0, 0, 0);
+          }
+        }
+        const int co = n0 + li;
+        if (co < Cout) {
+          const float bv = bl[co];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int pix = m0 + 4 * g + r;
+            if (pix < P) {
+              float v = fp_act(acc[r] + bv, act);
+              if (has_res) v += ld1(res, pix * res.stride + co);
+              st1(y, pix * y.stride + co, v);
+            }
+          }
         }
       }
     }
@@ -401,7 +486,14 @@ __device__ __forceinline__ void mo_tail(cop_t& op, const FrameCtx& c) {
 
 __device__ __forceinline__ void mo_pw(cop_t& op, const FrameCtx& c) {
   const bool xl = op.in0.space == kLocLds;
-  if (op.mfma) { if (xl) pw_mfma<true>(op, c); else pw_mfma<false>(op, c); return; }
+  if (op.mfma) {
+    if (xl) { pw_mfma<true>(op, c); return; }
+    const int nj = (op.Cin + 15) >> 4;
+    if (nj == 1) pw_mfma_glb<1, 4>(op, c);
+    else if (nj <= 2) pw_mfma_glb<2, 2>(op, c);
+    else pw_mfma<false>(op, c);
+    return;
+  }
   if (xl) pw_body<16, false, true>(op, c); else pw_body<16, false, false>(op, c);   // weight block too large to stage: SGPR-fed VALU form
 }
 
@@ -451,8 +543,8 @@ __device__ __forceinline__ void mo_conv(cop_t& op, const FrameCtx& c) {
   const int P = op.OH * op.OW, chunks = (P + 63) >> 6, tiles = op.cout_pad / CT;
   const int lane = threadIdx.x & 63, nw = kFrameThreads >> 6;
   const bool staged = op.stage_floats > 0;
-  const lds_f* wl = lds_base();
-  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
+  const lds_f* wl = lds_base() + op.w_lds;
+  const lds_f* bl = wl + (int)(op.b_off - op.w_off);
   for (int wi = wave_id(); wi < chunks * tiles; wi += nw) {
     const int tile = wi / chunks, chunk = wi - tile * chunks;
     const int p = (chunk << 6) + lane;
@@ -516,8 +608,8 @@ __device__ __forceinline__ void mo_conv_mfma(cop_t& op, const FrameCtx& c) {
   const int band_in = (op.band_rows - 1) * sh + kh;              // input rows per band
   lds_f* band = lds_base() + op.ws_off;
   lds_f* ktab = band + band_in * rowf;                           // per-k table: offset inside the band, fy, fx  (3 ints per k)
-  const lds_f* wl = lds_base();
-  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
+  const lds_f* wl = lds_base() + op.w_lds;
+  const lds_f* bl = wl + (int)(op.b_off - op.w_off);
   for (int k = threadIdx.x; k < nsteps * 4; k += kFrameThreads) {
     int fy = 0, fx = 0, ci = 0, valid = k < K;
     if (valid) { fy = k / (kw * Cin); const int r = k - fy * kw * Cin; fx = r / Cin; ci = r - fx * Cin; }
@@ -631,8 +723,8 @@ __device__ __forceinline__ void dw_body(cop_t& op, const FrameCtx& c) {
   const int C = op.Cin, C4 = C >> 2;
   const int kh = K ? K : op.kh, kw = K ? K : op.kw, kk = kh * kw;
   const bool staged = op.stage_floats > 0;
-  const lds_f* wl = lds_base();
-  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
+  const lds_f* wl = lds_base() + op.w_lds;
+  const lds_f* bl = wl + (int)(op.b_off - op.w_off);
   (void)kk;
   const glb_f* wg = (const glb_f*)w;
   const glb_f* bg = (const glb_f*)bias;
@@ -687,11 +779,12 @@ __device__ __forceinline__ void mo_dw(cop_t& op, const FrameCtx& c) {
 // Lane layout: CG channel-quads x (64/CG) pixel rows inside a wave, so the row reduction is wave shuffles; the 16 per-wave
 // partials meet in the scratch once.  Two barriers per channel block instead of a multi-level LDS tree.
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& out, int coff) {
+template <bool XL>
+__device__ __forceinline__ void gap_body(const Ref& x, int HW, int C, const Ref& out, int coff) {
   lds_f* scratch = lds_base();
   const int C4 = C >> 2;
   int CG = 1;
-  while (CG * 2 <= C4 && CG * 2 <= 64) CG *= 2;
+  while (CG * 2 <= C4 && CG * 2 <= 32) CG *= 2;      // 16 waves x CG float4 partials fit kLdsScratchFloats
   const int rows = kFrameThreads / CG;
   const int cg = threadIdx.x % CG, row = threadIdx.x / CG;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -700,12 +793,13 @@ __device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& 
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     if (cq < C4) {
       int p = row;
-      for (; p + 3 * rows < HW; p += 4 * rows) {       // four independent loads in flight
-        const float4 v0 = ld4(x, p * x.stride + cq * 4), v1 = ld4(x, (p + rows) * x.stride + cq * 4);
-        const float4 v2 = ld4(x, (p + 2 * rows) * x.stride + cq * 4), v3 = ld4(x, (p + 3 * rows) * x.stride + cq * 4);
+      auto ldx = [&](int pp) { if constexpr (XL) return ld_lds4(x.l + pp * x.stride + cq * 4); else return ld_glb4(x.g + pp * x.stride + cq * 4); };
+      for (; p + 3 * rows < HW; p += 4 * rows) {       // four independent loads in flight (address space fixed at compile time:
+        const float4 v0 = ldx(p), v1 = ldx(p + rows);  //  a run-time space test per load would serialise them)
+        const float4 v2 = ldx(p + 2 * rows), v3 = ldx(p + 3 * rows);
         a0 = add4(a0, v0); a1 = add4(a1, v1); a2 = add4(a2, v2); a3 = add4(a3, v3);
       }
-      for (; p < HW; p += rows) a0 = add4(a0, ld4(x, p * x.stride + cq * 4));
+      for (; p < HW; p += rows) a0 = add4(a0, ldx(p));
     }
     float4 acc = add4(add4(a0, a1), add4(a2, a3));
     for (int o = CG; o < 64; o <<= 1) {
@@ -723,6 +817,10 @@ __device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& 
     }
     __syncthreads();
   }
+}
+
+__device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& out, int coff) {
+  if (x.lds) gap_body<true>(x, HW, C, out, coff); else gap_body<false>(x, HW, C, out, coff);
 }
 
 __device__ __forceinline__ void mo_gap(cop_t& op, const FrameCtx& c) {
@@ -891,8 +989,8 @@ __device__ __forceinline__ void mo_tconv(cop_t& op, const FrameCtx& c) {
   const float* bias = c.weights + op.b_off;
   const int C4 = op.Cin >> 2, P = op.OH * op.OW, Cout = op.Cout, Cin = op.Cin, kh = op.kh, kw = op.kw, OW = op.OW, W = op.W;
   const bool staged = op.stage_floats > 0;
-  const lds_f* wl = lds_base();
-  const lds_f* bl = lds_base() + (int)(op.b_off - op.w_off);
+  const lds_f* wl = lds_base() + op.w_lds;
+  const lds_f* bl = wl + (int)(op.b_off - op.w_off);
   const glb_f* wg = (const glb_f*)w;
   for (int p = threadIdx.x; p < P; p += kFrameThreads) {
     const int oy = p / OW, ox = p - oy * OW;
@@ -911,44 +1009,35 @@ __device__ __forceinline__ void mo_tconv(cop_t& op, const FrameCtx& c) {
   }
 }
 
+// One wave instruction moves 64 lanes x 16 B = 256 floats: LDS address = M0 (wave-uniform base) + lane * 16.
+__device__ __forceinline__ void stage_weights_async(cop_t& op, const glb_f* gw) {
+  const int sf = op.stage_floats;            // multiple of 4; source and slot are 16-byte aligned
+  if (sf == 0) return;
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef const __attribute__((address_space(1))) void* glb_vp;
+  const int lane4 = (int)(threadIdx.x & 63) * 4;
+  const glb_f* src = gw + op.w_off;
+  lds_f* dst = lds_base() + op.w_lds;
+  for (int c0 = wave_id() * 256; c0 < sf; c0 += (kFrameThreads >> 6) * 256)
+    if (c0 + lane4 < sf) __builtin_amdgcn_global_load_lds((glb_vp)(src + c0 + lane4), (lds_vp)(dst + c0), 16, 0, 0);
+}
+
 __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* __restrict__ ops, int n_ops, float* arena, long per_frame_floats,
                                                                 float* net_in, float* net_out, const float* __restrict__ weights,
                                                                 unsigned long long* timeline, int repeat) {
   FrameCtx c{arena + (size_t)blockIdx.x * (size_t)per_frame_floats, net_in, net_out, weights, (int)blockIdx.x, timeline};
-  // Weight staging is software-pipelined across ops: while op i computes, every lane already holds its float4 of op
-  // i+1's weight block in registers; at the top of op i+1 it only has to drop it into the LDS scratch.
+  // Weight staging: an asynchronous global→LDS DMA (global_load_lds_dwordx4: no VGPRs, tracked by vmcnt) of op i+1's
+  // block is issued at the top of op i into the slot the planner reserved for it; the barrier that ends op i (vmcnt(0)
+  // first) publishes it.  One barrier per op, nothing carried in registers across ops.
   const glb_f* gw = (const glb_f*)weights;
-  // (a block of up to 2 float4 per lane: kLdsScratchFloats <= 8 * kFrameThreads)
-  f4v pf = {0.f, 0.f, 0.f, 0.f}, pf2 = pf;
-  const int t4 = (int)threadIdx.x * 4, t4b = t4 + 4 * kFrameThreads;
-  {
-    cop_t& op0 = ((cop_t*)ops)[0];
-    const int sf0 = op0.stage_floats;
-    if (t4 < sf0) pf = *(const glb_v4*)(gw + op0.w_off + t4);
-    if (t4b < sf0) pf2 = *(const glb_v4*)(gw + op0.w_off + t4b);
-  }
+  stage_weights_async(((cop_t*)ops)[0], gw);
   for (int rep = 0; rep < repeat; rep++)      // repeat > 1 only in timing experiments (warm caches on the later passes)
   for (int i = 0; i < n_ops; i++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                           // previous op complete, this op's weights in LDS
     if (timeline && blockIdx.x == 0 && threadIdx.x == 0) timeline[i] = wall_clock64();
     cop_t& op = ((cop_t*)ops)[i];
-    {
-      const int sf = op.stage_floats;
-      if (sf) {
-        if (t4 < sf) *(lds_v4*)(lds_base() + t4) = pf;
-        if (t4b < sf) *(lds_v4*)(lds_base() + t4b) = pf2;
-        __syncthreads();
-      }
-      const int nxt = i + 1 < n_ops ? i + 1 : 0;
-      if (i + 1 < n_ops || rep + 1 < repeat) {
-        cop_t& opn = ((cop_t*)ops)[nxt];
-        const int sfn = opn.stage_floats;
-        if (t4 < sfn) pf = *(const glb_v4*)(gw + opn.w_off + t4);
-        if (t4b < sfn) pf2 = *(const glb_v4*)(gw + opn.w_off + t4b);
-      }
-    }
-    const bool dbg = timeline && blockIdx.x == 0 && threadIdx.x == 0;
-    unsigned long long tq0 = 0ull, tq1 = 0ull;
-    if (dbg) { tq0 = wall_clock64(); timeline[264] += tq0 - timeline[i]; }
+    if (i + 1 < n_ops || rep + 1 < repeat) stage_weights_async(((cop_t*)ops)[i + 1 < n_ops ? i + 1 : 0], gw);
     switch ((StepKind)op.kind) {
       case StepKind::PwConv:
         if (op.gemv) mo_gemv(op, c);
@@ -963,10 +1052,9 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
       case StepKind::TConv: mo_tconv(op, c); break;
       default: if (op.kind == kMicroSe) mo_se(op, c); else if (op.kind == kMicroTail) mo_tail(op, c); break;
     }
-    if (dbg) { tq1 = wall_clock64(); timeline[265] += tq1 - tq0; }
-    __syncthreads();
-    if (dbg) timeline[266] += wall_clock64() - tq1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (timeline && blockIdx.x == 0 && threadIdx.x == 0) timeline[n_ops] = wall_clock64();
 }
 

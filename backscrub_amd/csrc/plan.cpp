@@ -106,6 +106,28 @@ static void build_frame_program(const Graph& g, Plan* plan) {
   };
   plan->program_lds_tensors = plan->program_global_tensors = 0;
   place(g.input, -1);
+  // Weight staging slots.  stage[s] floats of step s are DMA'd to LDS while the PREVIOUS micro-op runs, so the slot must be
+  // free from the first step of that previous micro-op (q) to s.  q is conservative: a GAP → FC.. chain may fuse into one op.
+  auto gemv_form = [&](const Step& st) { return st.kind == StepKind::PwConv && st.OH * st.OW <= 4 && st.OH * st.OW * st.Cout * 16 <= kLdsScratchFloats; };
+  std::vector<int> stage(NS, 0), slot(NS, 0);
+  std::vector<std::vector<int>> slots_from(NS);
+  for (int s = 0; s < NS; s++) {
+    const Step& st = plan->steps[s];
+    long nb = st.kind == StepKind::DwConv ? st.Cout : (st.kind == StepKind::TConv ? st.Cout : st.cout_pad);
+    long range = ((long)st.b_off - (long)st.w_off) + ((nb + 3) / 4) * 4;
+    bool uses = (st.kind == StepKind::PwConv && !gemv_form(st)) || st.kind == StepKind::Conv || st.kind == StepKind::DwConv || st.kind == StepKind::TConv;
+    if (st.kind == StepKind::PwConv && st.cout_pad % 16 != 0) uses = false;     // only the matrix-core form stages
+    if (!(uses && st.b_off > st.w_off && range <= kLdsMaxStageFloats)) continue;
+    stage[s] = (int)range;
+    int q = s > 0 ? s - 1 : 0;
+    auto fc_like = [&](int k) { const Step& f = plan->steps[k]; return f.kind == StepKind::PwConv && f.OH * f.OW == 1; };
+    if (s > 0 && fc_like(q)) {
+      while (q > 0 && fc_like(q - 1)) q--;
+      if (q > 0 && plan->steps[q - 1].kind == StepKind::Gap) q--;
+    }
+    if (s > 2 && plan->steps[s - 1].kind == StepKind::TConv && plan->steps[s - 2].kind == StepKind::DwConv) q = std::min(q, s - 3);
+    slots_from[q].push_back(s);
+  }
   std::vector<MicroOp> prog;
   std::vector<std::string> labels;
   std::vector<int> tail_ws(NS, -1), tail_rows(NS, 0);
@@ -122,6 +144,15 @@ static void build_frame_program(const Graph& g, Plan* plan) {
   };
   for (int s = 0; s < NS; s++) {
     const Step& st = plan->steps[s];
+    for (int s2 : slots_from[s]) {
+      const int need = (stage[s2] + 3) / 4 * 4;
+      live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
+      std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+      int pos = kLdsScratchFloats;
+      for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
+      if (pos + need <= cap) { slot[s2] = pos; live.push_back({pos, need, s2}); high = std::max(high, pos + need); }
+      else stage[s2] = 0;                       // no room: the op falls back to its unstaged form
+    }
     if (tail_pattern(s)) {
       // z row band: (R+2) rows x W pixels x (C+4) floats, alive for the three fused steps
       int R = 8;
@@ -142,22 +173,17 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     m.act = st.act; m.elt = st.elt; m.bcast1 = st.bcast1; m.align_corners = st.align_corners; m.half_pixel = st.half_pixel;
     m.cout_pad = st.cout_pad; m.cout_tile = st.cout_tile;
     m.w_off = (long long)st.w_off; m.b_off = (long long)st.b_off; m.w2_off = (long long)st.w2_off;
-    m.gemv = (st.kind == StepKind::PwConv && st.OH * st.OW <= 4 && st.OH * st.OW * st.Cout * 16 <= kLdsScratchFloats) ? 1 : 0;
+    m.gemv = gemv_form(st) ? 1 : 0;
     auto L = [&](int t) { return t >= 0 ? loc[t] : Loc(); };
     m.in0 = L(st.in0); m.in1 = L(st.in1); m.in2 = L(st.in2); m.res = L(st.residual); m.scale = L(st.in_scale); m.out = L(st.out);
     if (st.concat_in.size() > 4) return;
     m.n_cat = (int)st.concat_in.size();
     for (int k = 0; k < m.n_cat; k++) { m.cat[k] = L(st.concat_in[k]); m.cat_c[k] = st.concat_c[k]; }
     if (st.kind == StepKind::DwConv && !((st.kh == 3 && st.kw == 3) || (st.kh == 5 && st.kw == 5))) return;   // program has 3x3 / 5x5 bodies only
-    // weights + bias are contiguous in the arena ([w][pad to 4][b]); stage the whole range when it fits the scratch
-    {
-      long nb = st.kind == StepKind::DwConv ? st.Cout : (st.kind == StepKind::TConv ? st.Cout : st.cout_pad);
-      long range = ((long)st.b_off - (long)st.w_off) + ((nb + 3) / 4) * 4;
-      bool uses = (st.kind == StepKind::PwConv && !m.gemv) || st.kind == StepKind::Conv || st.kind == StepKind::DwConv || st.kind == StepKind::TConv;
-      m.stage_floats = (uses && st.b_off > st.w_off && range <= kLdsScratchFloats) ? (int)range : 0;
-    }
+    // weights + bias are contiguous in the arena ([w][pad to 4][b]); the whole range is staged in the slot planned above
+    m.stage_floats = stage[s]; m.w_lds = slot[s];
     if (st.kind == StepKind::PwConv && !m.gemv) {
-      // MFMA form whenever the weight block + bias fits the 16 KiB LDS scratch and Cout tiles by 16
+      // MFMA form whenever the weight block + bias got an LDS slot and Cout tiles by 16
       m.cout_tile = 16;
       m.mfma = (st.cout_pad % 16 == 0 && m.stage_floats > 0) ? 1 : 0;
       if (!m.mfma) m.stage_floats = 0;   // the SGPR-fed VALU body reads its weights from memory
