@@ -208,6 +208,37 @@ __device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
   }
 }
 
+typedef float f4acc __attribute__((ext_vector_type(4)));
+
+// ---- MFMA tile epilogue ----------------------------------------------------------------------------------------------------------
+// The 16x16 accumulator has lane (g, li) holding pixels 4g..4g+3 of ONE channel li: four 4-byte stores per lane, each wave
+// store touching 64-byte fragments.  A 4x4 transpose inside every quad of lanes (two DPP exchanges) turns that into
+// pixel 4g + (li&3), channels 4*(li>>2) .. +3 per lane — one 16-byte store, and the residual / bias as one 16-byte load.
+__device__ __forceinline__ float dpp_quad(float v, const int ctrl_xor) {   // ctrl_xor: 1 → lane^1, 2 → lane^2 (inside a quad)
+  const int i = __builtin_bit_cast(int, v);
+  const int r = ctrl_xor == 1 ? __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xf, 0xf, true);
+  return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float4 quad_transpose(const f4acc acc, int q) {
+  const bool odd = q & 1, hi = q & 2;
+  const float rx = dpp_quad(odd ? acc[0] : acc[1], 1), ry = dpp_quad(odd ? acc[2] : acc[3], 1);
+  const float t0 = odd ? rx : acc[0], t1 = odd ? acc[1] : rx, t2 = odd ? ry : acc[2], t3 = odd ? acc[3] : ry;
+  const float r0 = dpp_quad(hi ? t0 : t2, 2), r1 = dpp_quad(hi ? t1 : t3, 2);
+  return hi ? make_float4(r0, r1, t2, t3) : make_float4(t0, t1, r0, r1);
+}
+// out[pix][n0 + 4k .. +3] = act(acc + bias) (+ residual); pix = m0 + 4g + q
+__device__ __forceinline__ void mfma_store_tile(const f4acc acc, int m0, int n0, int P, int Cout, const lds_f* bl, int act, bool has_res,
+                                                const Ref& res, const Ref& y, int li, int g) {
+  const int q = li & 3, c0 = n0 + (li & ~3), pix = m0 + 4 * g + q;
+  float4 v = quad_transpose(acc, q);
+  if (c0 < Cout && pix < P) {
+    const float4 bv = ld_lds4(bl + c0);
+    v = fp_act4(make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w), act);
+    if (has_res) { const float4 rv = ld4(res, pix * res.stride + c0); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+    st4(y, pix * y.stride + c0, v);
+  }
+}
+
 // ---- 1x1 convolution on the matrix cores -----------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32: exact f32 FMA chains at the f32 vector rate, but ONE instruction per 1024 MACs — the VALU
 // form of these skinny GEMMs (K, N = 16..128) was bound by instruction issue and LDS→FMA latency, not by math.
@@ -217,7 +248,6 @@ __device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
 //   B: lane l holds w[k-group l>>4][channel n0 + (l&15)] → one ds_read_b32 per MFMA from the staged weight block,
 //   D: lane l holds 4 pixels m0 + 4*(l>>4) + r of channel n0 + (l&15).
 // The k order inside the chain is (j, t, group) instead of ascending ci — a different but fixed f32 summation order.
-typedef float f4acc __attribute__((ext_vector_type(4)));
 
 template <bool XL>
 __device__ __forceinline__ void pw_mfma(cop_t& op, const FrameCtx& c) {
@@ -257,19 +287,7 @@ __device__ __forceinline__ void pw_mfma(cop_t& op, const FrameCtx& c) {
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc, 0, 0, 0);
     }
-    const int co = n0 + li;
-    if (co < Cout) {
-      const float bv = bl[co];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int pix = m0 + 4 * g + r;
-        if (pix < P) {
-          float v = fp_act(acc[r] + bv, act);
-          if (has_res) v += ld1(res, pix * res.stride + co);
-          st1(y, pix * y.stride + co, v);
-        }
-      }
-    }
+    mfma_store_tile(acc, m0, n0, P, Cout, bl, act, has_res, res, y, li, g);
   }
 }
 
@@ -340,19 +358,7 @@ __device__ __forceinline__ void pw_mfma_glb(cop_t& op, const FrameCtx& c) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j].w, b3, acc, 0, 0, 0);
           }
         }
-        const int co = n0 + li;
-        if (co < Cout) {
-          const float bv = bl[co];
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int pix = m0 + 4 * g + r;
-            if (pix < P) {
-              float v = fp_act(acc[r] + bv, act);
-              if (has_res) v += ld1(res, pix * res.stride + co);
-              st1(y, pix * y.stride + co, v);
-            }
-          }
-        }
+        mfma_store_tile(acc, m0, n0, P, Cout, bl, act, has_res, res, y, li, g);
       }
     }
   }
