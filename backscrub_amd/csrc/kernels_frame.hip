@@ -370,14 +370,15 @@ __device__ __forceinline__ void pw_mfma_glb(cop_t& op, const FrameCtx& c) {
 // each side, zero outside the image) on the matrix cores straight into an LDS band; phase B has one lane per pixel form
 // t = z + act2(dw(z)) in registers and emit its 2x2 block of transpose-conv outputs.  Arithmetic (order of every FMA
 // chain) is exactly that of pw_mfma / dw_body / mo_tconv, so the result is bit-identical to the unfused program.
-template <int C>
-__device__ __forceinline__ void tail_body(cop_t& op, const FrameCtx& c) {
+template <int C, bool XL, bool AL>       // XL / AL: x / the add operand live in LDS (else HBM) — fixed at compile time so that
+__device__ __forceinline__ void tail_body(cop_t& op, const FrameCtx& c) {   // the batched loads below really are issued back to back
   constexpr int ZS = C + 4;                                // LDS row stride of a z pixel
   const Ref x = make_ref(op.in0, c), sc = make_ref(op.scale, c), ad = make_ref(op.in2, c), out = make_ref(op.out, c);
   const int H = op.H, W = op.W, R = op.band_rows, act = op.act, act2 = op.act2, act3 = op.act3, Co = op.C2, OW = op.OW;
   const unsigned mw = op.magic_w;                          // n / W == __umulhi(n, mw)
   const glb_f* gw = (const glb_f*)c.weights;
   // stage the three weight blocks: [pw C x C | pw bias C | dw 9 x C | dw bias C | tconv 4 x Co x C | tconv bias Co]
+  // (scalar-load weights in phase B were measured slower than these uniform LDS reads)
   lds_f* wpw = lds_base();
   lds_f* bpw = wpw + C * C;
   lds_f* wdw = bpw + C;
@@ -400,37 +401,55 @@ __device__ __forceinline__ void tail_body(cop_t& op, const FrameCtx& c) {
     if (dbg) t0 = wall_clock64();
     __syncthreads();                                       // previous band consumed (and weights staged)
     if (dbg) { const unsigned long long t1 = wall_clock64(); tS += t1 - t0; t0 = t1; }
-    // ---- phase A: z band rows r0-1 .. r0+R on the matrix cores (A operand = x*s + a straight from HBM / LDS)
-    for (int wi = wave_id(); wi < mt * NT; wi += nw) {
-      const int tn = wi / mt, tm = wi - tn * mt, m0 = tm << 4, n0 = tn << 4;
-      const int bp = min(m0 + li, npix - 1);
-      const int brow = (int)__umulhi((unsigned)bp, mw), bx = bp - brow * W, iy = r0 - 1 + brow;
-      const bool rv = iy >= 0 && iy < H;
-      const int pix = (rv ? iy : 0) * W + bx;
-      f4acc acc = {0.f, 0.f, 0.f, 0.f};
+    // ---- phase A: z band rows r0-1 .. r0+R on the matrix cores (A operand = x*s + a straight from HBM / LDS).
+    // A wave requests the operands of ALL its tiles of the band (<= TB) before the first MFMA: one memory round trip per band.
+    constexpr int TB = 4;
+    for (int w0 = wave_id(); w0 < mt * NT; w0 += nw * TB) {
+      float4 a[TB][NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        const int k0 = 16 * j + 4 * g;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rv) {
-          a = ld4(x, pix * x.stride + k0);
-          if (has_sc) { const float4 sv = ld_lds4(sc.l + k0); a.x = __fmul_rn(a.x, sv.x); a.y = __fmul_rn(a.y, sv.y); a.z = __fmul_rn(a.z, sv.z); a.w = __fmul_rn(a.w, sv.w); }
-          if (has_add) { const float4 av = ld4(ad, pix * ad.stride + k0); a.x = __fadd_rn(a.x, av.x); a.y = __fadd_rn(a.y, av.y); a.z = __fadd_rn(a.z, av.z); a.w = __fadd_rn(a.w, av.w); }
+      for (int t = 0; t < TB; t++) {
+        const int wi = w0 + t * nw;
+        const int tm = wi % mt, bp = min((tm << 4) + li, npix - 1);
+        const int brow = (int)__umulhi((unsigned)bp, mw), bx = bp - brow * W, iy = r0 - 1 + brow;
+        const bool rv = wi < mt * NT && iy >= 0 && iy < H;
+        const int pix = (rv ? iy : 0) * W + bx;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const int k0 = 16 * j + 4 * g;
+          a[t][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rv) {
+            float4 v, av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (XL) v = ld_lds4(x.l + pix * x.stride + k0); else v = ld_glb4(x.g + pix * x.stride + k0);
+            if (has_add) { if constexpr (AL) av = ld_lds4(ad.l + pix * ad.stride + k0); else av = ld_glb4(ad.g + pix * ad.stride + k0); }
+            if (has_sc) { const float4 sv = ld_lds4(sc.l + k0); v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w); }
+            if (has_add) { v.x = __fadd_rn(v.x, av.x); v.y = __fadd_rn(v.y, av.y); v.z = __fadd_rn(v.z, av.z); v.w = __fadd_rn(v.w, av.w); }
+            a[t][j] = v;
+          }
         }
-        const lds_f* br = wpw + (16 * j + 4 * g) * C + n0 + li;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, br[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, br[C], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, br[2 * C], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, br[3 * C], acc, 0, 0, 0);
       }
-      const int co = n0 + li;
-      const float bv = bpw[co];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int p2 = m0 + 4 * g + r;
+      for (int t = 0; t < TB; t++) {
+        const int wi = w0 + t * nw;
+        if (wi >= mt * NT) break;
+        const int tn = wi / mt, tm = wi - tn * mt, m0 = tm << 4, n0 = tn << 4;
+        f4acc acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const lds_f* br = wpw + (16 * j + 4 * g) * C + n0 + li;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].x, br[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].y, br[C], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].z, br[2 * C], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j].w, br[3 * C], acc, 0, 0, 0);
+        }
+        // quad-transposed epilogue: this lane owns pixel m0 + 4g + (li&3), channels 4*(li>>2) .. +3 → one 16-byte LDS store
+        const int q = li & 3, c0 = n0 + (li & ~3), p2 = m0 + 4 * g + q;
+        float4 v = quad_transpose(acc, q);
         if (p2 < npix) {
           const int row2 = (int)__umulhi((unsigned)p2, mw), iy2 = r0 - 1 + row2;
-          zb[p2 * ZS + co] = (iy2 >= 0 && iy2 < H) ? fp_act(acc[r] + bv, act) : 0.f;   // rows outside the image are zero padding
+          const float4 bv = ld_lds4(bpw + c0);
+          v = fp_act4(make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w), act);
+          if (!(iy2 >= 0 && iy2 < H)) v = make_float4(0.f, 0.f, 0.f, 0.f);          // rows outside the image are zero padding
+          st_lds4(zb + p2 * ZS + c0, v);
         }
       }
     }
@@ -487,7 +506,9 @@ __device__ __forceinline__ void tail_body(cop_t& op, const FrameCtx& c) {
   if (dbg) { c.tl[256] = tS; c.tl[257] = tA; c.tl[258] = tB; }
 }
 __device__ __forceinline__ void mo_tail(cop_t& op, const FrameCtx& c) {
-  tail_body<16>(op, c);   // the planner only forms this micro-op for 16-channel tails
+  const bool xl = op.in0.space == kLocLds, al = op.in2.space == kLocLds;   // the planner only forms this micro-op for 16-channel tails
+  if (xl) { if (al) tail_body<16, true, true>(op, c); else tail_body<16, true, false>(op, c); }
+  else { if (al) tail_body<16, false, true>(op, c); else tail_body<16, false, false>(op, c); }
 }
 
 __device__ __forceinline__ void mo_pw(cop_t& op, const FrameCtx& c) {
@@ -887,21 +908,16 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
   const Ref mean = make_ref(op.in1, c), hid = make_ref(op.in2, c), out = make_ref(op.out, c);
   const int HW = op.H * op.W;
   const glb_f* wts = (const glb_f*)c.weights;
-  const bool dbg = c.tl != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-  unsigned long long t0 = dbg ? wall_clock64() : 0ull, t1 = 0ull, t2 = 0ull, t3 = 0ull;
   // both FCs' weight slices are requested up front: their HBM/L2 latency hides behind the pooling reductions
   const FcPre p1 = fc_preload(op.Cin, wts + op.w2_off, wts + op.b_off, op.C1);
   FcPre p2 = p1;
   if (op.n_fc == 2) p2 = fc_preload(op.C1, wts + op.w3_off, wts + op.b3_off, op.C2);
   if (op.n_cat == 0) gap_one(make_ref(op.in0, c), HW, op.Cin, mean, 0);
   else { int coff = 0; for (int k = 0; k < op.n_cat; k++) { gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], mean, coff); coff += op.cat_c[k]; } }
-  if (dbg) t1 = wall_clock64();
   if (op.n_fc == 1) { fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, out, p1); return; }
   fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, hid, p1);
   __syncthreads();
-  if (dbg) t2 = wall_clock64();
   fc_lanes(hid, op.C1, wts + op.w3_off, wts + op.b3_off, op.C2, op.act2, out, p2);
-  if (dbg) { t3 = wall_clock64(); c.tl[260] += t1 - t0; c.tl[261] += t2 - t1; c.tl[262] += t3 - t2; }
 }
 
 // ---- elementwise -----------------------------------------------------------------------------------------------------------
