@@ -177,8 +177,8 @@ def main():
                 pmc = pj["kernels"]
         except Exception:
             pass
-        pmc_names = {"frame_program": "frame_program_k", "blend": "blend16_k", "mask_blend": "mask_upscale_blur_k<true>", "mask_upscale_blur": "mask_upscale_blur_k", "prep_resize": "prep_resize_k",
-                     "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k"}
+        pmc_names = {"frame_program": "frame_program_k", "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
+                     "mask_upscale_blur": "mask_tile_k<false>", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k"}
 
         def traffic(s):
             """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json):

@@ -38,8 +38,26 @@ def pmc(paths):
             print("| %s | %s | %d | %.1f | %.1f |" % (short(n), cn, c, v, mx))
 
 
+def pmc_json(tag, paths):
+    """FETCH_SIZE / WRITE_SIZE (KiB, average per dispatch) per kernel → the JSON bench.py reads for roofline.traffic."""
+    import json
+    kernels = {}
+    for path in paths:
+        db = sqlite3.connect(path)
+        q = ("select kernel_name, counter_name, avg(v) from (select kernel_name, counter_name, dispatch_id, sum(value) v "
+             "from counters_collection group by kernel_name, counter_name, dispatch_id) group by kernel_name, counter_name")
+        for n, cn, v in db.execute(q).fetchall():
+            if cn in ("FETCH_SIZE", "WRITE_SIZE") and "bsx::" in n:
+                kernels.setdefault(short(n), {})[cn + "_KiB"] = round(v, 1)
+    print(json.dumps({"round": tag, "workload": {"batch": 256, "width": 640, "height": 480, "model": "segm_lite_v681.tflite"},
+                      "note": "avg per dispatch; traffic bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section",
+                      "kernels": kernels}, indent=1))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--pmc":
+    if sys.argv[1] == "--pmc-json":
+        pmc_json(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "--pmc":
         pmc(sys.argv[2:])
     else:
         kernel_stats(sys.argv[1])
