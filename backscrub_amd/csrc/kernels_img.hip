@@ -144,11 +144,20 @@ __global__ __launch_bounds__(kThreads) void decode_k(int type, const float* __re
   } else if (type == 2) {  // MLKit / BodyPix: float promoted to double against the double literal 0.65
     val = ((double)t[i] > 0.65) ? 0 : 255;
   } else {  // Meet: expf on both logits, normalise, compare (NaN from inf/inf compares false → 255)
-    float2 l = reinterpret_cast<const float2*>(t)[i];
-    float e0 = (float)exp((double)l.x), e1 = (float)exp((double)l.y);  // correctly-rounded stand-in for libm expf
-    float s = __fadd_rn(e0, e1);
-    float p0 = __fdiv_rn(e0, s), p1 = __fdiv_rn(e1, s);
-    val = p0 < p1 ? 0 : 255;
+    const float2 l = reinterpret_cast<const float2*>(t)[i];
+    // Decided-by-margin fast path.  For logits in [-80, 80] (no overflow of exp or of the sum) that differ by >= 1e-4 the
+    // outcome of the reference arithmetic is forced: exp is monotone with relative error < 2^-23, so e1/e0 > 1 + 9.9e-5;
+    // the two correctly-rounded divisions by the same s perturb that ratio by < 2^-23 more, hence p0 < p1 strictly (and
+    // symmetrically p0 > p1).  Only near-ties and out-of-range / NaN logits take the exact path below.
+    const float d = l.y - l.x;
+    if (fabsf(l.x) <= 80.f && fabsf(l.y) <= 80.f && fabsf(d) >= 1e-4f) {
+      val = d > 0.f ? 0 : 255;
+    } else {
+      float e0 = (float)exp((double)l.x), e1 = (float)exp((double)l.y);  // correctly-rounded stand-in for libm expf
+      float s = __fadd_rn(e0, e1);
+      float p0 = __fdiv_rn(e0, s), p1 = __fdiv_rn(e1, s);
+      val = p0 < p1 ? 0 : 255;
+    }
   }
   out[i] = (uint8_t)((val & 0xE0) | (out[i] >> 3));
 }
@@ -166,7 +175,130 @@ __global__ __launch_bounds__(kThreads) void decode_k(int type, const float* __re
 // the LDS/ALU-bound mask phases of others.  (Used when the ROI is the whole frame.)
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));   // v_pk_*_u16 operand
 constexpr int kTW = 128, kTH = 32, kHW = kTW + 4, kHH = kTH + 4, kMaxSrcRows = 40;
-__device__ __forceinline__ void blend_quad_fwd(const uint32_t a[3], const uint32_t b[3], uint32_t mw, uint32_t o[3]);
+constexpr int kTileItems = kTH * (kTW / 4) / kThreads;     // 4-pixel groups per lane in the last step
+static_assert(kTileItems * kThreads == kTH * (kTW / 4) && kThreads == 8 * (kTW / 4), "tile / lane mapping: item i of a lane sits 8 rows below item i-1");
+
+// ---- packed alpha-blend arithmetic (deepseg.cc:108-134), shared by the mask tile kernels and blend16_k --------------------
+// Packed form of the same integers (v_pk_*_u16, two bytes per instruction):  a*m + b*(255-m) <= 255*255 fits a u16 lane,
+// and floor(t/255) == (t + 1 + (t >> 8)) >> 8 for every t in [0, 65025] (exhaustively checked; the sum stays < 65536).
+__device__ __forceinline__ us2 pk_blend(uint32_t a, uint32_t b, uint32_t m) {   // operands: two u8 values in the u16 halves
+  const us2 av = __builtin_bit_cast(us2, a), bv = __builtin_bit_cast(us2, b), mv = __builtin_bit_cast(us2, m);
+  const us2 iv = __builtin_bit_cast(us2, 0x00ff00ffu - m);
+  us2 t = av * mv + bv * iv;
+  const us2 one = {1, 1};
+  t = (t + one + (t >> 8)) >> 8;
+  return t;
+}
+__device__ __forceinline__ uint32_t blend_word(uint32_t a, uint32_t b, uint32_t m02, uint32_t m13) {
+  const uint32_t K = 0x00ff00ffu;
+  const uint32_t r02 = __builtin_bit_cast(uint32_t, pk_blend(a & K, b & K, m02));
+  const uint32_t r13 = __builtin_bit_cast(uint32_t, pk_blend((a >> 8) & K, (b >> 8) & K, m13));
+  return r02 | (r13 << 8);
+}
+// 4 pixels = 12 bytes = 3 words; mw holds their 4 mask bytes.  Byte→pixel map of the words: (0,0,0,1) (1,1,2,2) (2,3,3,3).
+__device__ __forceinline__ void blend_quad(const uint32_t a[3], const uint32_t b[3], uint32_t mw, uint32_t o[3]) {
+  const uint32_t m00 = __builtin_amdgcn_perm(mw, mw, 0x0c000c00u), m01 = __builtin_amdgcn_perm(mw, mw, 0x0c010c00u);
+  const uint32_t m12 = __builtin_amdgcn_perm(mw, mw, 0x0c020c01u);
+  const uint32_t m23 = __builtin_amdgcn_perm(mw, mw, 0x0c030c02u), m33 = __builtin_amdgcn_perm(mw, mw, 0x0c030c03u);
+  o[0] = blend_word(a[0], b[0], m00, m01);
+  o[1] = blend_word(a[1], b[1], m12, m12);
+  o[2] = blend_word(a[2], b[2], m23, m33);
+}
+
+// ---- pieces shared by the two mask tile kernels ------------------------------------------------------------------------------
+// Composite operands of a lane's kTileItems 4-pixel groups (12 B of background + 12 B of frame each), requested at the very
+// top of the kernel so that their HBM latency hides behind the LDS phases.
+struct TileBlendOperands { uint32_t a[kTileItems][3], b[kTileItems][3]; };
+template <bool BLEND>
+__device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
+                                                         int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid) {
+  if constexpr (BLEND) {
+    const int ly0 = tid / (kTW / 4), gx = tx0 + (tid % (kTW / 4)) * 4;
+    const long pix0 = (long)(ty0 + ly0) * W + gx;
+    const uint8_t* const a0 = bg + (bg_stride ? n * bg_stride : 0) + pix0 * 3;
+    const uint8_t* const b0 = frames + ((long)n * W * H + pix0) * 3;
+#pragma unroll
+    for (int i = 0; i < kTileItems; i++) {
+      o.a[i][0] = o.a[i][1] = o.a[i][2] = o.b[i][0] = o.b[i][1] = o.b[i][2] = 0;
+      if (ty0 + ly0 + 8 * i < roi.h && gx < roi.w) {
+        const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0 + (long)(8 * i) * W * 3);
+        const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * 3);
+        o.a[i][0] = ap[0]; o.a[i][1] = ap[1]; o.a[i][2] = ap[2];
+        o.b[i][0] = bp[0]; o.b[i][1] = bp[1]; o.b[i][2] = bp[2];
+      }
+    }
+  }
+}
+// Step 3: vertical pass of cv::resize, 4 pixels per lane (64-bit LDS reads of the two source rows, one 32-bit write).
+// row0 / row1: LDS tables of the two hq rows of every halo row; (y, xg) advance without a division.
+template <typename RowT>
+__device__ __forceinline__ void tile_vertical_pass(const uint16_t* hq, uint8_t* up, const RowT* row0, const RowT* row1, int row_bias, const short* row_b0,
+                                                   const short* row_b1, int tid) {
+  constexpr int kG = kHW / 4;
+  for (int y = tid / kG, xg = tid % kG; y < kHH;) {
+    const int x = xg * 4;
+    const int b0 = row_b0[y], b1 = row_b1[y];                  // 16-bit coefficients: the products below are 24-bit multiplies
+    const uint2 r0 = *reinterpret_cast<const uint2*>(&hq[((int)row0[y] - row_bias) * kHW + x]);
+    const uint2 r1 = *reinterpret_cast<const uint2*>(&hq[((int)row1[y] - row_bias) * kHW + x]);
+    const int h0[4] = {(int)(r0.x & 0xffff), (int)(r0.x >> 16), (int)(r0.y & 0xffff), (int)(r0.y >> 16)};
+    const int h1[4] = {(int)(r1.x & 0xffff), (int)(r1.x >> 16), (int)(r1.y & 0xffff), (int)(r1.y >> 16)};
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) packed |= (uint32_t)((((b0 * h0[j]) >> 16) + ((b1 * h1[j]) >> 16) + 2) >> 2) << (8 * j);
+    *reinterpret_cast<uint32_t*>(&up[y * kHW + x]) = packed;
+    xg += kThreads % kG; y += kThreads / kG;
+    if (xg >= kG) { xg -= kG; y++; }
+  }
+}
+// Step 4: horizontal 5-sums, 4 per lane: 8 consecutive bytes in, 4 u16 out.  v_sad_u8 against 0 adds the four bytes of a
+// word (+ an accumulator) in one instruction; the sliding windows come from v_alignbyte.
+__device__ __forceinline__ void tile_hsum5(const uint8_t* up, uint16_t* hs, int tid) {
+  for (int k = tid; k < kHH * (kTW / 4); k += kThreads) {
+    const int ly = k / (kTW / 4), lx = (k - ly * (kTW / 4)) * 4;
+    const uint2 v = *reinterpret_cast<const uint2*>(&up[ly * kHW + lx]);            // bytes b0..b3 | b4..b7
+    const uint32_t s0 = __builtin_amdgcn_sad_u8(v.x, 0u, v.y & 255u);                                                  // b0..b4
+    const uint32_t s1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 1), 0u, (v.y >> 8) & 255u);      // b1..b5
+    const uint32_t s2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 2), 0u, (v.y >> 16) & 255u);     // b2..b6
+    const uint32_t s3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 3), 0u, v.y >> 24);              // b3..b7
+    *reinterpret_cast<uint2*>(&hs[ly * kTW + lx]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+  }
+}
+// Step 5: vertical 5-sums (packed u16 adds: five sums <= 25*255 stay inside a u16 lane), (s + 12) / 25 as
+// ((s + 12) * 5243) >> 17 (exhaustively checked for s <= 25*255), mask store, and with BLEND the composite of the same
+// 4 pixels (ROI == whole frame and W % 4 == 0, checked by the launcher: 12 bytes = 3 aligned words per image).
+template <bool BLEND>
+__device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __restrict__ mask, uint8_t* __restrict__ outp, const TileBlendOperands& o,
+                                                 int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid) {
+  const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
+  const int gx = tx0 + lx;
+  uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx;
+  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(ty0 + ly0) * W + gx) * 3 : nullptr;
+#pragma unroll
+  for (int i = 0; i < kTileItems; i++) {
+    const int ly = ly0 + 8 * i, gy = ty0 + ly;
+    if (gy >= roi.h || gx >= roi.w) continue;
+    uint2 acc = *reinterpret_cast<const uint2*>(&hs[ly * kTW + lx]);
+#pragma unroll
+    for (int r = 1; r < 5; r++) {
+      const uint2 v = *reinterpret_cast<const uint2*>(&hs[(ly + r) * kTW + lx]);
+      acc.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.x) + __builtin_bit_cast(us2, v.x));
+      acc.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.y) + __builtin_bit_cast(us2, v.y));
+    }
+    const uint32_t m0 = (__umul24(acc.x & 0xffffu, 5243u) + 12u * 5243u) >> 17, m1 = (__umul24(acc.x >> 16, 5243u) + 12u * 5243u) >> 17;
+    const uint32_t m2 = (__umul24(acc.y & 0xffffu, 5243u) + 12u * 5243u) >> 17, m3 = (__umul24(acc.y >> 16, 5243u) + 12u * 5243u) >> 17;
+    const uint32_t packed = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+    uint8_t* dst = dst0 + (long)(8 * i) * W;
+    if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
+    else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
+    if constexpr (BLEND) {
+      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * 3);
+      uint32_t o3[3];
+      blend_quad(o.a[i], o.b[i], packed, o3);
+      op[0] = o3[0]; op[1] = o3[1]; op[2] = o3[2];
+    }
+  }
+}
+
 template <bool BLEND>
 __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                                uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
@@ -185,30 +317,8 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
   const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
   const uint8_t* src = ofinal + (long)n * outW * outH + (long)q.y * outW + q.x;
   const int tid = threadIdx.x;
-  // BLEND: request this lane's background / frame words early — the HBM latency of the composite then hides behind the
-  // LDS/ALU phases of the mask instead of being exposed after them (the kernel is otherwise latency-bound per workgroup).
-  constexpr int kItems = kTH * (kTW / 4) / kThreads;     // step-5 items per lane
-  static_assert(kItems * kThreads == kTH * (kTW / 4), "tile must divide evenly");
-  uint32_t pa[kItems][3], pb[kItems][3];
-  auto prefetch_blend_operands = [&]() {
-    if constexpr (BLEND) {
-      const int ly0 = tid / (kTW / 4), gx = tx0 + (tid % (kTW / 4)) * 4;
-      const long pix0 = (long)(ty0 + ly0) * W + gx;
-      const uint8_t* const a0 = bg + (bg_stride ? n * bg_stride : 0) + pix0 * 3;
-      const uint8_t* const b0 = frames + ((long)n * W * H + pix0) * 3;
-#pragma unroll
-      for (int i = 0; i < kItems; i++) {           // item i sits 8 rows below item i-1
-        pa[i][0] = pa[i][1] = pa[i][2] = pb[i][0] = pb[i][1] = pb[i][2] = 0;
-        if (ty0 + ly0 + 8 * i < roi.h && gx < roi.w) {
-          const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0 + (long)(8 * i) * W * 3);
-          const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * 3);
-          pa[i][0] = ap[0]; pa[i][1] = ap[1]; pa[i][2] = ap[2];
-          pb[i][0] = bp[0]; pb[i][1] = bp[1]; pb[i][2] = bp[2];
-        }
-      }
-    }
-  };
-  prefetch_blend_operands();
+  TileBlendOperands ops;
+  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid);
   if (tid == 0) { s_min = 1 << 30; s_max = -1; }
   __syncthreads();
   // 1. column / row tables
@@ -250,22 +360,7 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
       }
     }
     __syncthreads();
-    // 3. vertical pass, 4 pixels per lane (64-bit LDS reads of the two source rows, one 32-bit write)
-    constexpr int kG = kHW / 4;                          // 4-pixel groups per halo row; (y, xg) advance without a division
-    for (int y = tid / kG, xg = tid % kG; y < kHH;) {
-      const int x = xg * 4;
-      const int b0 = row_b0[y], b1 = row_b1[y];
-      const uint2 r0 = *reinterpret_cast<const uint2*>(&hq[(row_s0[y] - smin) * kHW + x]);
-      const uint2 r1 = *reinterpret_cast<const uint2*>(&hq[(row_s1[y] - smin) * kHW + x]);
-      const int h0[4] = {(int)(r0.x & 0xffff), (int)(r0.x >> 16), (int)(r0.y & 0xffff), (int)(r0.y >> 16)};
-      const int h1[4] = {(int)(r1.x & 0xffff), (int)(r1.x >> 16), (int)(r1.y & 0xffff), (int)(r1.y >> 16)};
-      uint32_t packed = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) packed |= (uint32_t)((((b0 * h0[j]) >> 16) + ((b1 * h1[j]) >> 16) + 2) >> 2) << (8 * j);
-      *reinterpret_cast<uint32_t*>(&up[y * kHW + x]) = packed;
-      xg += kThreads % kG; y += kThreads / kG;
-      if (xg >= kG) { xg -= kG; y++; }
-    }
+    tile_vertical_pass(hq, up, row_s0, row_s1, smin, row_b0, row_b1, tid);   // 3.
   } else {
     // copy / exact-2x area / very strong down-scale: direct per-pixel sample
     for (int k = tid; k < kHH * kHW; k += kThreads) {
@@ -283,52 +378,9 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
     }
   }
   __syncthreads();
-  // 4. horizontal 5-sums, 4 per lane: 8 consecutive bytes in, 4 u16 out.  v_sad_u8 against 0 adds the four bytes of a
-  //    word (+ an accumulator) in one instruction; the sliding windows come from v_alignbyte.
-  for (int k = tid; k < kHH * (kTW / 4); k += kThreads) {
-    const int ly = k / (kTW / 4), lx = (k - ly * (kTW / 4)) * 4;
-    const uint2 v = *reinterpret_cast<const uint2*>(&up[ly * kHW + lx]);            // bytes b0..b3 | b4..b7
-    const uint32_t s0 = __builtin_amdgcn_sad_u8(v.x, 0u, v.y & 255u);                                                  // b0..b4
-    const uint32_t s1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 1), 0u, (v.y >> 8) & 255u);      // b1..b5
-    const uint32_t s2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 2), 0u, (v.y >> 16) & 255u);     // b2..b6
-    const uint32_t s3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 3), 0u, v.y >> 24);              // b3..b7
-    *reinterpret_cast<uint2*>(&hs[ly * kTW + lx]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
-  }
+  tile_hsum5(up, hs, tid);                                                                       // 4.
   __syncthreads();
-  // 5. vertical 5-sums: 32 rows x 32 groups of 4 pixels = 1024 items, 4 per lane.  Item i of a lane is 8 rows below item
-  //    i-1 (kThreads / 32 = 8), so every address below is "item 0 + i * uniform step".
-  static_assert(kThreads == 8 * (kTW / 4), "row step of a lane's items");
-  const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
-  const int gx = tx0 + lx;
-  uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx;
-  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(ty0 + ly0) * W + gx) * 3 : nullptr;
-#pragma unroll
-  for (int i = 0; i < kItems; i++) {
-    const int ly = ly0 + 8 * i, gy = ty0 + ly;
-    if (gy >= roi.h || gx >= roi.w) continue;
-    // sums of five u16 (<= 25 * 255) stay inside a u16 lane: packed adds on the words as loaded
-    uint2 acc = *reinterpret_cast<const uint2*>(&hs[ly * kTW + lx]);
-#pragma unroll
-    for (int r = 1; r < 5; r++) {
-      const uint2 v = *reinterpret_cast<const uint2*>(&hs[(ly + r) * kTW + lx]);
-      acc.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.x) + __builtin_bit_cast(us2, v.x));
-      acc.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.y) + __builtin_bit_cast(us2, v.y));
-    }
-    // (s + 12) / 25 == ((s + 12) * 5243) >> 17 for s <= 25 * 255 (exhaustively checked); one v_mad_u32_u24 each
-    const uint32_t m0 = (__umul24(acc.x & 0xffffu, 5243u) + 12u * 5243u) >> 17, m1 = (__umul24(acc.x >> 16, 5243u) + 12u * 5243u) >> 17;
-    const uint32_t m2 = (__umul24(acc.y & 0xffffu, 5243u) + 12u * 5243u) >> 17, m3 = (__umul24(acc.y >> 16, 5243u) + 12u * 5243u) >> 17;
-    const uint32_t packed = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
-    uint8_t* dst = dst0 + (long)(8 * i) * W;
-    if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
-    else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
-    if constexpr (BLEND) {
-      // roi == whole frame and W % 4 == 0 (checked by the launcher): 4 pixels = 12 bytes = 3 aligned words per image
-      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * 3);
-      uint32_t o3[3];
-      blend_quad_fwd(pa[i], pb[i], packed, o3);
-      op[0] = o3[0]; op[1] = o3[1]; op[2] = o3[2];
-    }
-  }
+  tile_vsum5_store<BLEND>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid);                     // 5.
 }
 
 // ---- mask tile, single-round-trip form ---------------------------------------------------------------------------------
@@ -375,25 +427,8 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
     t_s = tab.yofs[gy]; t_a0 = tab.ya[2 * gy]; t_a1 = tab.ya[2 * gy + 1];
   }
   // (c) composite operands
-  constexpr int kItems = kTH * (kTW / 4) / kThreads;
-  static_assert(kItems * kThreads == kTH * (kTW / 4) && kThreads == 8 * (kTW / 4), "tile / lane mapping");
-  const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4, gx4 = tx0 + lx;
-  uint32_t pa[kItems][3], pb[kItems][3];
-  if constexpr (BLEND) {
-    const long pix0 = (long)(ty0 + ly0) * W + gx4;
-    const uint8_t* const a0p = bg + (bg_stride ? n * bg_stride : 0) + pix0 * 3;
-    const uint8_t* const b0p = frames + ((long)n * W * H + pix0) * 3;
-#pragma unroll
-    for (int i = 0; i < kItems; i++) {
-      pa[i][0] = pa[i][1] = pa[i][2] = pb[i][0] = pb[i][1] = pb[i][2] = 0;
-      if (ty0 + ly0 + 8 * i < roi.h && gx4 < roi.w) {
-        const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0p + (long)(8 * i) * W * 3);
-        const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0p + (long)(8 * i) * W * 3);
-        pa[i][0] = ap[0]; pa[i][1] = ap[1]; pa[i][2] = ap[2];
-        pb[i][0] = bp[0]; pb[i][1] = bp[1]; pb[i][2] = bp[2];
-      }
-    }
-  }
+  TileBlendOperands ops;
+  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid);
   // 1. block and tables into LDS
 #pragma unroll
   for (int j = 0; j < 3; j++) if (br + 4 * j < nsr && bc < ncol) blk[(br + 4 * j) * ncol + bc] = (uint8_t)raw[j];
@@ -417,92 +452,14 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
     if (x >= kHW) { x -= kHW; r++; }
   }
   __syncthreads();
-  // 3. vertical pass, 4 pixels per lane
-  constexpr int kG = kHW / 4;
-  for (int y = tid / kG, xg = tid % kG; y < kHH;) {
-    const int x = xg * 4;
-    const int b0 = row_b0[y], b1 = row_b1[y];
-    const uint2 r0 = *reinterpret_cast<const uint2*>(&hq[row_r0[y] * kHW + x]);
-    const uint2 r1 = *reinterpret_cast<const uint2*>(&hq[row_r1[y] * kHW + x]);
-    const int h0[4] = {(int)(r0.x & 0xffff), (int)(r0.x >> 16), (int)(r0.y & 0xffff), (int)(r0.y >> 16)};
-    const int h1[4] = {(int)(r1.x & 0xffff), (int)(r1.x >> 16), (int)(r1.y & 0xffff), (int)(r1.y >> 16)};
-    uint32_t packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) packed |= (uint32_t)((((b0 * h0[j]) >> 16) + ((b1 * h1[j]) >> 16) + 2) >> 2) << (8 * j);
-    *reinterpret_cast<uint32_t*>(&up[y * kHW + x]) = packed;
-    xg += kThreads % kG; y += kThreads / kG;
-    if (xg >= kG) { xg -= kG; y++; }
-  }
+  tile_vertical_pass(hq, up, row_r0, row_r1, 0, row_b0, row_b1, tid);                             // 3.
   __syncthreads();
-  // 4. horizontal 5-sums (see mask_upscale_blur_k)
-  for (int k = tid; k < kHH * (kTW / 4); k += kThreads) {
-    const int ly = k / (kTW / 4), x4 = (k - ly * (kTW / 4)) * 4;
-    const uint2 v = *reinterpret_cast<const uint2*>(&up[ly * kHW + x4]);
-    const uint32_t s0 = __builtin_amdgcn_sad_u8(v.x, 0u, v.y & 255u);
-    const uint32_t s1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 1), 0u, (v.y >> 8) & 255u);
-    const uint32_t s2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 2), 0u, (v.y >> 16) & 255u);
-    const uint32_t s3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(v.y, v.x, 3), 0u, v.y >> 24);
-    *reinterpret_cast<uint2*>(&hs[ly * kTW + x4]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
-  }
+  tile_hsum5(up, hs, tid);                                                                       // 4.
   __syncthreads();
-  // 5. vertical 5-sums, (s + 12) / 25, mask store and composite
-  uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx4;
-  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(ty0 + ly0) * W + gx4) * 3 : nullptr;
-#pragma unroll
-  for (int i = 0; i < kItems; i++) {
-    const int ly = ly0 + 8 * i, gy = ty0 + ly;
-    if (gy >= roi.h || gx4 >= roi.w) continue;
-    uint2 acc = *reinterpret_cast<const uint2*>(&hs[ly * kTW + lx]);
-#pragma unroll
-    for (int r = 1; r < 5; r++) {
-      const uint2 v = *reinterpret_cast<const uint2*>(&hs[(ly + r) * kTW + lx]);
-      acc.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.x) + __builtin_bit_cast(us2, v.x));
-      acc.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.y) + __builtin_bit_cast(us2, v.y));
-    }
-    const uint32_t m0 = (__umul24(acc.x & 0xffffu, 5243u) + 12u * 5243u) >> 17, m1 = (__umul24(acc.x >> 16, 5243u) + 12u * 5243u) >> 17;
-    const uint32_t m2 = (__umul24(acc.y & 0xffffu, 5243u) + 12u * 5243u) >> 17, m3 = (__umul24(acc.y >> 16, 5243u) + 12u * 5243u) >> 17;
-    const uint32_t packed = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
-    uint8_t* dst = dst0 + (long)(8 * i) * W;
-    if (gx4 + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
-    else for (int j = 0; j < 4 && gx4 + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
-    if constexpr (BLEND) {
-      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * 3);
-      uint32_t o3[3];
-      blend_quad_fwd(pa[i], pb[i], packed, o3);
-      op[0] = o3[0]; op[1] = o3[1]; op[2] = o3[2];
-    }
-  }
+  tile_vsum5_store<BLEND>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid);                     // 5.
 }
 
-// ---- alpha blend: 16 pixels (16 mask bytes, 48+48 source bytes, 48 output bytes) per lane -----
-// Packed form of the same integers (v_pk_*_u16, two bytes per instruction):  a*m + b*(255-m) <= 255*255 fits a u16 lane,
-// and floor(t/255) == (t + 1 + (t >> 8)) >> 8 for every t in [0, 65025] (exhaustively checked; the sum stays < 65536).
-__device__ __forceinline__ us2 pk_blend(uint32_t a, uint32_t b, uint32_t m) {   // operands: two u8 values in the u16 halves
-  const us2 av = __builtin_bit_cast(us2, a), bv = __builtin_bit_cast(us2, b), mv = __builtin_bit_cast(us2, m);
-  const us2 iv = __builtin_bit_cast(us2, 0x00ff00ffu - m);
-  us2 t = av * mv + bv * iv;
-  const us2 one = {1, 1};
-  t = (t + one + (t >> 8)) >> 8;
-  return t;
-}
-__device__ __forceinline__ uint32_t blend_word(uint32_t a, uint32_t b, uint32_t m02, uint32_t m13) {
-  const uint32_t K = 0x00ff00ffu;
-  const uint32_t r02 = __builtin_bit_cast(uint32_t, pk_blend(a & K, b & K, m02));
-  const uint32_t r13 = __builtin_bit_cast(uint32_t, pk_blend((a >> 8) & K, (b >> 8) & K, m13));
-  return r02 | (r13 << 8);
-}
-// 4 pixels = 12 bytes = 3 words; mw holds their 4 mask bytes.  Byte→pixel map of the words: (0,0,0,1) (1,1,2,2) (2,3,3,3).
-__device__ __forceinline__ void blend_quad(const uint32_t a[3], const uint32_t b[3], uint32_t mw, uint32_t o[3]) {
-  const uint32_t m00 = __builtin_amdgcn_perm(mw, mw, 0x0c000c00u), m01 = __builtin_amdgcn_perm(mw, mw, 0x0c010c00u);
-  const uint32_t m12 = __builtin_amdgcn_perm(mw, mw, 0x0c020c01u);
-  const uint32_t m23 = __builtin_amdgcn_perm(mw, mw, 0x0c030c02u), m33 = __builtin_amdgcn_perm(mw, mw, 0x0c030c03u);
-  o[0] = blend_word(a[0], b[0], m00, m01);
-  o[1] = blend_word(a[1], b[1], m12, m12);
-  o[2] = blend_word(a[2], b[2], m23, m33);
-}
-
-__device__ __forceinline__ void blend_quad_fwd(const uint32_t a[3], const uint32_t b[3], uint32_t mw, uint32_t o[3]) { blend_quad(a, b, mw, o); }
-
+// ---- alpha blend: 16 pixels (16 mask bytes, 48+48 source bytes, 48 output bytes) per lane (helpers: see blend_quad above) -----
 __global__ __launch_bounds__(kThreads) void blend16_k(const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ fr,
                                                      const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, unsigned groups_per_frame,
                                                      long npix) {

@@ -131,6 +131,38 @@ def test_stages_match_oracle(bs, oracle, key, res, real):
     mg.close()
 
 
+def test_meet_decode_edge_logits(bs, oracle):
+    """Softmax-2 decode on adversarial logits: exact ties, 1-ulp and 1e-4-scale gaps (the fast path's margin), huge / infinite /
+    NaN values (exp overflow → inf/inf = NaN → 255).  Must equal the oracle's expf-divide-compare byte for byte."""
+    from backscrub_amd import synth
+    W, H = VGA
+    mg = bs.MaskGen(model_path("lite"), W, H, n_streams=2)
+    info = mg.info
+    oh, ow = info["out_h"], info["out_w"]
+    rng = np.random.default_rng(3)
+    npix = oh * ow
+    base = rng.uniform(-12, 12, size=(2, npix)).astype(np.float32)
+    gaps = np.concatenate([np.zeros(200), np.array([1e-7, 1e-6, 9e-5, 9.99e-5, 1e-4, 1.01e-4, 2e-4, 1e-3]).repeat(100),
+                           rng.uniform(-3e-4, 3e-4, size=4000)]).astype(np.float32)
+    logits = np.stack([base, base + rng.normal(0, 2, size=base.shape).astype(np.float32)], axis=-1)
+    k = gaps.size
+    logits[0, :k, 1] = logits[0, :k, 0] + gaps                       # near ties around the margin
+    logits[0, k:k + 300, 1] = np.nextafter(logits[0, k:k + 300, 0], np.float32(np.inf))   # 1 ulp apart
+    special = np.array([[90, 91], [91, 90], [1e30, 1e30], [-1e30, -1e30], [np.inf, 0], [0, np.inf], [-np.inf, -np.inf], [np.nan, 0], [0, np.nan],
+                        [88.7, 88.8], [-104, -103], [-200, -100], [80, 80.0001], [-80.00001, -80], [79.9999, 80.0001]], np.float32)
+    logits[1, :special.shape[0]] = special
+    logits = logits.reshape(2, oh, ow, 2)
+    prev = synth.random_u8((2, oh, ow), 9)
+    mg.output_tensor().copy_(_dev(logits))
+    mg.ofinal().copy_(_dev(prev))
+    mg.run_stage(2, n=2)
+    got = mg.ofinal().cpu().numpy()
+    for i in range(2):
+        want = oracle.decode_iir(info["model_type"], logits[i], prev[i])
+        assert np.array_equal(got[i], want), "stream %d: %d px differ" % (i, (got[i] != want).sum())
+    mg.close()
+
+
 @pytest.mark.parametrize("res", [VGA, (322, 242)])
 def test_generic_mask_kernel_matches_tile_kernel(bs, oracle, res, monkeypatch):
     """The single-round-trip tile kernel (default) and the generic mask kernel (BSX_NO_MASK_TILE=1; also the fallback when
