@@ -22,6 +22,7 @@
 
 #include "frame_program.hpp"
 #include "kernels.hpp"
+#include "mfma_tile.hpp"
 
 namespace bsx {
 namespace {
@@ -208,24 +209,7 @@ __device__ __forceinline__ void pw_body(cop_t& op, const FrameCtx& c) {
   }
 }
 
-typedef float f4acc __attribute__((ext_vector_type(4)));
-
-// ---- MFMA tile epilogue ----------------------------------------------------------------------------------------------------------
-// The 16x16 accumulator has lane (g, li) holding pixels 4g..4g+3 of ONE channel li: four 4-byte stores per lane, each wave
-// store touching 64-byte fragments.  A 4x4 transpose inside every quad of lanes (two DPP exchanges) turns that into
-// pixel 4g + (li&3), channels 4*(li>>2) .. +3 per lane — one 16-byte store, and the residual / bias as one 16-byte load.
-__device__ __forceinline__ float dpp_quad(float v, const int ctrl_xor) {   // ctrl_xor: 1 → lane^1, 2 → lane^2 (inside a quad)
-  const int i = __builtin_bit_cast(int, v);
-  const int r = ctrl_xor == 1 ? __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xf, 0xf, true);
-  return __builtin_bit_cast(float, r);
-}
-__device__ __forceinline__ float4 quad_transpose(const f4acc acc, int q) {
-  const bool odd = q & 1, hi = q & 2;
-  const float rx = dpp_quad(odd ? acc[0] : acc[1], 1), ry = dpp_quad(odd ? acc[2] : acc[3], 1);
-  const float t0 = odd ? rx : acc[0], t1 = odd ? acc[1] : rx, t2 = odd ? ry : acc[2], t3 = odd ? acc[3] : ry;
-  const float r0 = dpp_quad(hi ? t0 : t2, 2), r1 = dpp_quad(hi ? t1 : t3, 2);
-  return hi ? make_float4(r0, r1, t2, t3) : make_float4(t0, t1, r0, r1);
-}
+// ---- MFMA tile epilogue (quad_transpose: mfma_tile.hpp) -------------------------------------------------------------------------
 // out[pix][n0 + 4k .. +3] = act(acc + bias) (+ residual); pix = m0 + 4g + q
 __device__ __forceinline__ void mfma_store_tile(const f4acc acc, int m0, int n0, int P, int Cout, const lds_f* bl, int act, bool has_res,
                                                 const Ref& res, const Ref& y, int li, int g) {

@@ -10,12 +10,17 @@
 //    channels.  The weight address depends only on (ci, blockIdx.y), i.e. it is
 //    wave-uniform, so hipcc emits scalar loads (s_load_dwordx8/16) and the FMAs take the
 //    weight from an SGPR — no LDS staging, no per-lane weight traffic.  K and N of these
-//    GEMMs are 8..128, far too skinny to feed MFMA tiles; the layers are HBM/L2-bound.
+//    GEMMs are 8..128 in the Meet / MLKit graphs; this SGPR form serves the small layers.
+//  * Pointwise convolutions with enough work (DeepLab: M = streams x 33x33 .. 129x129 pixels, K up to 960, N up to 256)
+//    are real GEMMs: pw_gemm_mfma_k tiles them 128 x 64 x 32 through LDS onto v_mfma_f32_16x16x4_f32 (exact f32).
 //  * Depthwise: lanes run along channel-quads then x, so every tap is a coalesced float4
 //    row segment; neighbouring lanes re-use taps through L1.
 //  * Accumulation is ci-ascending FMA with the bias added last, the same association as
 //    the TFLite reference kernels the CPU oracle restates (differences are FMA rounding).
+#include <cstdlib>
+
 #include "kernels.hpp"
+#include "mfma_tile.hpp"
 
 namespace bsx {
 namespace {
@@ -102,6 +107,117 @@ __global__ __launch_bounds__(kThreads) void pw_conv_k(const float* __restrict__ 
         float v = act_fn(acc[t] + bp[t], act);
         if (rp) v += rp[t];
         yp[t] = v;
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------
+// 1x1 convolution as an LDS-tiled MFMA GEMM:  y[M][Cout] = act(x'[M][Cin] * w[Cin][cout_pad] + b) (+ res),  x' = x*s + a
+// -------------------------------------------------------------------------------------
+// Workgroup (4 waves) = 128 x 64 output tile, K in steps of 32.  Wave w owns rows 32w..32w+31 (2 m-tiles) x 4 n-tiles =
+// 8 accumulators.  Per K step a lane reads ONE float4 of A per m-tile and 16-row chunk (k = 4g..4g+3 feed four successive
+// MFMAs as .x/.y/.z/.w) and one scalar of B per MFMA (row 4g+j, column li) — the k assignment is a bijection shared by
+// both operands, so the sum is the exact f32 FMA chain in a fixed order.  The next K tile is fetched into registers while
+// the current one is multiplied; SE scale / fused a-add are applied while the A tile is written to LDS.
+constexpr int kGemmBM = 128, kGemmBN = 64, kGemmBK = 32;
+constexpr int kGemmSA = kGemmBK + 4;      // (SA / 4) odd: the 16-byte A reads of 16 consecutive rows hit distinct bank quads
+constexpr int kGemmSB = kGemmBN + 4;      // 4 * SB = 16 (mod 32): the four k-rows a wave reads per MFMA split over both bank halves
+__global__ __launch_bounds__(kThreads) void pw_gemm_mfma_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
+                                                          float* __restrict__ y, long M, int HW, int Cin, int Cout, int cout_pad, int act) {
+  __shared__ __attribute__((aligned(16))) float As[kGemmBM * kGemmSA];
+  __shared__ __attribute__((aligned(16))) float Bs[kGemmBK * kGemmSB];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const long m_base = (long)blockIdx.x * kGemmBM;
+  const int n_base = blockIdx.y * kGemmBN;
+  const int nt = min(4, (cout_pad - n_base) >> 4);          // valid 16-wide n-tiles of this workgroup (wave-uniform)
+  // loader mapping: A = 128 rows x 8 float4 (4 per lane), B = 32 rows x 16 float4 (2 per lane)
+  float4 ra[4], rb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int f = tid + i * kThreads, row = f >> 3, kq = (f & 7) * 4;
+      const long m = m_base + row;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M && k0 + kq < Cin) {
+        float4 v = *reinterpret_cast<const float4*>(x + m * Cin + k0 + kq);
+        if (scale) {
+          const float4 sv = *reinterpret_cast<const float4*>(scale + (m / HW) * (long)Cin + k0 + kq);
+          v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w);
+        }
+        if (addx) {
+          const float4 av = *reinterpret_cast<const float4*>(addx + m * Cin + k0 + kq);
+          v.x = __fadd_rn(v.x, av.x); v.y = __fadd_rn(v.y, av.y); v.z = __fadd_rn(v.z, av.z); v.w = __fadd_rn(v.w, av.w);
+        }
+        ra[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int f = tid + i * kThreads, kr = f >> 4, nq = (f & 15) * 4;
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + kr < Cin && n_base + nq < cout_pad) rb[i] = *reinterpret_cast<const float4*>(w + (long)(k0 + kr) * cout_pad + n_base + nq);
+    }
+  };
+  f4acc acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = f4acc{0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  for (int k0 = 0; k0 < Cin; k0 += kGemmBK) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int f = tid + i * kThreads; *reinterpret_cast<float4*>(&As[(f >> 3) * kGemmSA + (f & 7) * 4]) = ra[i]; }
+#pragma unroll
+    for (int i = 0; i < 2; i++) { const int f = tid + i * kThreads; *reinterpret_cast<float4*>(&Bs[(f >> 4) * kGemmSB + (f & 15) * 4]) = rb[i]; }
+    __syncthreads();
+    if (k0 + kGemmBK < Cin) fetch(k0 + kGemmBK);            // in flight while this tile is multiplied
+#pragma unroll
+    for (int jj = 0; jj < kGemmBK / 16; jj++) {
+      float4 a[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; mi++) a[mi] = *reinterpret_cast<const float4*>(&As[(32 * wave + 16 * mi + li) * kGemmSA + 16 * jj + 4 * g]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++) {
+        if (ni < nt) {
+          const float* br = &Bs[(16 * jj + 4 * g) * kGemmSB + 16 * ni + li];
+          const float b0 = br[0], b1 = br[kGemmSB], b2 = br[2 * kGemmSB], b3 = br[3 * kGemmSB];
+#pragma unroll
+          for (int mi = 0; mi < 2; mi++) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].x, b0, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].y, b1, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].z, b2, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi].w, b3, acc[mi][ni], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // epilogue: quad transpose → this lane owns pixel (4g + q) of the m-tile, channels c0 .. c0+3 of the n-tile
+  const int q = li & 3;
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++) {
+    const long m = m_base + 32 * wave + 16 * mi + 4 * g + q;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      if (ni >= nt) continue;
+      const int c0 = n_base + 16 * ni + (li & ~3);
+      const float4 v = quad_transpose(acc[mi][ni], q);
+      if (m >= M || c0 >= Cout) continue;
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      if ((Cout & 3) == 0) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+        float4 o = make_float4(act_fn(vv[0] + bv.x, act), act_fn(vv[1] + bv.y, act), act_fn(vv[2] + bv.z, act), act_fn(vv[3] + bv.w, act));
+        if (res) { const float4 r = *reinterpret_cast<const float4*>(res + m * Cout + c0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        *reinterpret_cast<float4*>(y + m * Cout + c0) = o;
+      } else {
+        for (int e = 0; e < 4 && c0 + e < Cout; e++) {
+          float o = act_fn(vv[e] + bias[c0 + e], act);
+          if (res) o += res[m * Cout + c0 + e];
+          y[m * Cout + c0 + e] = o;
+        }
       }
     }
   }
@@ -386,6 +502,13 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       if (M <= 4096) {
         long total = M * st.Cout;
         pw_small_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), total, HW, st.Cin, st.Cout, st.cout_pad, st.act);
+        break;
+      }
+      // enough rows and channels to fill 128 x 64 MFMA tiles → the GEMM form (BSX_NO_PW_GEMM=1 keeps the lane-per-pixel form)
+      static const bool no_gemm = getenv("BSX_NO_PW_GEMM") != nullptr;
+      if (!no_gemm && M >= 8192 && (st.Cin & 3) == 0 && st.Cin >= 16 && st.cout_pad % 16 == 0 && st.cout_pad >= 32) {
+        dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);
+        pw_gemm_mfma_k<<<gg, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act);
         break;
       }
 #define BSX_PW(CT) pw_conv_k<CT><<<grid, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act)
