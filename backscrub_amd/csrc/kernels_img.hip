@@ -162,6 +162,25 @@ __global__ __launch_bounds__(kThreads) void decode_k(int type, const float* __re
   out[i] = (uint8_t)((val & 0xE0) | (out[i] >> 3));
 }
 
+// DeepLab argmax over nch interleaved classes: the 256 pixels of a workgroup are one contiguous block of 256*nch floats —
+// read it with coalesced 4-byte loads into LDS, then every lane scans its own nch values (stride nch, conflict-free for odd
+// nch).  A lane reading its classes straight from HBM touches 64 cache lines per load instruction.
+constexpr int kArgmaxMaxCh = 32;
+__global__ __launch_bounds__(kThreads) void decode_argmax_k(const float* __restrict__ t, uint8_t* __restrict__ out, long total, int nch) {
+  __shared__ float tile[kThreads * kArgmaxMaxCh];
+  const long p0 = (long)blockIdx.x * kThreads;
+  const int valid = (int)min((long)kThreads, total - p0);
+  const float* src = t + p0 * nch;
+  for (int i = threadIdx.x; i < valid * nch; i += kThreads) tile[i] = src[i];
+  __syncthreads();
+  if ((int)threadIdx.x >= valid) return;
+  const float* p = tile + threadIdx.x * nch;
+  float maxval = -10000.f; int maxpos = 0;                       // libbackscrub.cc:318-332: first maximum wins
+  for (int c = 0; c < nch; c++) { const float v = p[c]; if (v > maxval) { maxval = v; maxpos = c; } }
+  const uint8_t val = maxpos == 15 ? 0 : 255;                    // class 15 = person
+  out[p0 + threadIdx.x] = (uint8_t)((val & 0xE0) | (out[p0 + threadIdx.x] >> 3));
+}
+
 // ---- mask: upscale + 5x5 box blur, LDS tiled, separable -------------------------------------------------------------
 // Tile = 128x32 output pixels per 256-lane workgroup.  All table lookups happen once per tile column / tile row:
 //   1. per column of the (128+4)-wide halo tile: reflected ROI x → (sx, sx1, a0, a1);  per row of the (32+4)-tall
@@ -581,7 +600,8 @@ hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, int inW, 
 hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, int npix, int nch, int n, hipStream_t s) {
   long total = (long)n * npix;
   int type = model_type == 1 ? 1 : (model_type == 3 ? 3 : 2);
-  decode_k<<<blocks_for(total), kThreads, 0, s>>>(type, logits, ofinal, total, nch);
+  if (type == 1 && nch <= kArgmaxMaxCh) decode_argmax_k<<<blocks_for(total), kThreads, 0, s>>>(logits, ofinal, total, nch);
+  else decode_k<<<blocks_for(total), kThreads, 0, s>>>(type, logits, ofinal, total, nch);
   return hipGetLastError();
 }
 

@@ -437,6 +437,32 @@ __global__ __launch_bounds__(kThreads) void resize_k(const float* __restrict__ x
   }
 }
 
+// Channel counts that are not a multiple of 4 (DeepLab's 21 classes): lane = output PIXEL.  The interpolation coefficients
+// are computed once per pixel instead of once per element, the C results of 256 consecutive pixels are staged in LDS
+// (stride C: odd or small → conflict-free) and leave as fully coalesced 4-byte stores of one contiguous block.
+constexpr int kResizePxMaxC = 32;
+__global__ __launch_bounds__(kThreads) void resize_px_k(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int OH, int OW, float hs,
+                                                       float ws, int half_pixel) {
+  __shared__ float tile[kThreads * kResizePxMaxC];
+  const long n = blockIdx.y;
+  const unsigned p0 = blockIdx.x * kThreads, P = (unsigned)(OH * OW);
+  const unsigned p = p0 + threadIdx.x;
+  if (p < P) {
+    const int oy = (int)(p / (unsigned)OW), ox = (int)(p - (unsigned)oy * (unsigned)OW);
+    float dy, dx; int y0, y1, x0, x1;
+    interp(oy, hs, half_pixel, H, &dy, &y0, &y1);
+    interp(ox, ws, half_pixel, W, &dx, &x0, &x1);
+    const float* b = x + n * (long)H * W * C;
+    const float* p00 = b + (y0 * W + x0) * C; const float* p10 = b + (y1 * W + x0) * C;
+    const float* p01 = b + (y0 * W + x1) * C; const float* p11 = b + (y1 * W + x1) * C;
+    for (int c = 0; c < C; c++) tile[threadIdx.x * C + c] = bilerp(p00[c], p10[c], p01[c], p11[c], dy, dx);
+  }
+  __syncthreads();
+  const unsigned valid = min((unsigned)kThreads, P - p0) * (unsigned)C;
+  float* o = y + (n * (long)P + p0) * C;
+  for (unsigned i = threadIdx.x; i < valid; i += kThreads) o[i] = tile[i];
+}
+
 // -------------------------------------------------------------------------------------
 // channel concat (up to 4 inputs, channel counts multiples of 4)
 // -------------------------------------------------------------------------------------
@@ -560,6 +586,8 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       if (st.Cin % 4 == 0) {
         long total = (long)n * st.OH * st.OW * (st.Cin / 4);
         resize_k<4><<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), P(st.out), total, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel);
+      } else if (st.Cin <= kResizePxMaxC && n <= 65535) {
+        resize_px_k<<<dim3(blocks_for((long)st.OH * st.OW), n), kThreads, 0, s>>>(P(st.in0), P(st.out), st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel);
       } else {
         long total = (long)n * st.OH * st.OW * st.Cin;
         resize_k<1><<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), P(st.out), total, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel);

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--model", default="lite", help="lite|full|mlkit|deeplab or a .tflite path")
+    ap.add_argument("--host-io", action="store_true", help="also measure the step with per-step H2D of the frames and D2H of the composite (pinned host buffers); reported as host_io, never as value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--profile-iters", type=int, default=5)
@@ -146,6 +147,27 @@ def main():
                        "launches_per_step": mg.info["n_steps"] + 5},
             "checksum": checksum_all,
         }
+
+    # PCIe-inclusive variant: every step uploads its frames and downloads the composite through pinned buffers
+    if rank == 0 and args.host_io:
+        h_in = torch.from_numpy(synth.frames(B, W, H, distinct=distinct)).pin_memory()
+        h_out = torch.empty_like(h_in).pin_memory()
+        def io_step():
+            d_frames.copy_(h_in, non_blocking=True)
+            mg.step(d_frames, d_bg, d_out)
+            h_out.copy_(d_out, non_blocking=True)
+        for _ in range(2):
+            io_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        io_steps = max(3, args.steps // 2)
+        for _ in range(io_steps):
+            io_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        result["host_io"] = {"value": round(B * io_steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / io_steps, 3),
+                             "note": "same step + H2D of %d frames and D2H of %d composites per step (pinned, one stream, no overlap); "
+                                     "%.1f GB/s each way" % (B, B, B * W * H * 3 / (dt / io_steps) / 1e9)}
 
     # per-launch hipEvent timings (rank 0, outside the timed region; advances state like normal steps)
     if rank == 0:
