@@ -59,7 +59,8 @@ hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, i
 // ofinal(in_roi) ↑ roi size, 5x5 box blur (REFLECT_101 on the ROI), write into mask(roi).  libbackscrub.cc:367-371
 hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H,
                                     Rect4 roi, int n, hipStream_t s);
-// mask upscale + blur AND alpha blend of the same tile in one launch (ROI == whole frame, 4-byte aligned images)
+// mask upscale + blur AND alpha blend of the same tile in one launch (W, roi.x, roi.w multiples of 4, 4-byte aligned images;
+// pixels outside the ROI — mask 255 forever — get the background copied)
 bool mask_blend_fusable(int W, int H, Rect4 roi, const uint8_t* bg, size_t bg_stride, const uint8_t* frames, const uint8_t* out);
 hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                              const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s);

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(kThreads) void decode_argmax_k(const float* __restr
 // Steps 2-3 are the separable form of the per-pixel bilinear sample: identical integers, ~4x fewer operations.
 // With BLEND the same workgroup also composites its tile (deepseg.cc:108-134) while the mask bytes are still in
 // registers: the mask is written once and never re-read, and the HBM-bound blend traffic of some workgroups overlaps
-// the LDS/ALU-bound mask phases of others.  (Used when the ROI is the whole frame.)
+// the LDS/ALU-bound mask phases of others.  (Used when W, roi.x and roi.w are multiples of 4; outside the ROI the composite
+// is the background itself, copied by outside_roi_copy_k.)
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));   // v_pk_*_u16 operand
 constexpr int kTW = 128, kTH = 32, kHW = kTW + 4, kHH = kTH + 4, kMaxSrcRows = 40;
 constexpr int kTileItems = kTH * (kTW / 4) / kThreads;     // 4-pixel groups per lane in the last step
@@ -233,7 +234,7 @@ __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, c
                                                          int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid) {
   if constexpr (BLEND) {
     const int ly0 = tid / (kTW / 4), gx = tx0 + (tid % (kTW / 4)) * 4;
-    const long pix0 = (long)(ty0 + ly0) * W + gx;
+    const long pix0 = (long)(roi.y + ty0 + ly0) * W + roi.x + gx;        // frame coordinates of the ROI-relative tile pixel
     const uint8_t* const a0 = bg + (bg_stride ? n * bg_stride : 0) + pix0 * 3;
     const uint8_t* const b0 = frames + ((long)n * W * H + pix0) * 3;
 #pragma unroll
@@ -284,14 +285,14 @@ __device__ __forceinline__ void tile_hsum5(const uint8_t* up, uint16_t* hs, int 
 }
 // Step 5: vertical 5-sums (packed u16 adds: five sums <= 25*255 stay inside a u16 lane), (s + 12) / 25 as
 // ((s + 12) * 5243) >> 17 (exhaustively checked for s <= 25*255), mask store, and with BLEND the composite of the same
-// 4 pixels (ROI == whole frame and W % 4 == 0, checked by the launcher: 12 bytes = 3 aligned words per image).
+// 4 pixels (W, roi.x and roi.w multiples of 4, checked by the launcher: 12 bytes = 3 aligned words per image).
 template <bool BLEND>
 __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __restrict__ mask, uint8_t* __restrict__ outp, const TileBlendOperands& o,
                                                  int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid) {
   const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
   const int gx = tx0 + lx;
   uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx;
-  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(ty0 + ly0) * W + gx) * 3 : nullptr;
+  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx) * 3 : nullptr;
 #pragma unroll
   for (int i = 0; i < kTileItems; i++) {
     const int ly = ly0 + 8 * i, gy = ty0 + ly;
@@ -519,6 +520,24 @@ __global__ __launch_bounds__(kThreads) void blend1_k(const uint8_t* __restrict__
   for (int c = 0; c < 3; c++) o[c] = (uint8_t)((a[c] * m + b[c] * (255 - m)) / 255);
 }
 
+// composite outside the ROI = background: word copies of the row segments left / right of the ROI and of the rows above / below it
+// (W and roi.x, roi.w multiples of 4 → every segment boundary is word aligned)
+constexpr int kOutsideRows = 16;     // rows per workgroup: keeps the launch at a few thousand workgroups per frame batch
+__global__ __launch_bounds__(kThreads) void outside_roi_copy_k(const uint8_t* __restrict__ bg, long bg_stride, uint8_t* __restrict__ out, int W, int H, Rect4 roi) {
+  const int wq = blockIdx.x * kThreads + threadIdx.x;                           // word index inside the row
+  if (wq >= W * 3 / 4) return;
+  const bool col_inside = wq >= roi.x * 3 / 4 && wq < (roi.x + roi.w) * 3 / 4;
+  const long n = blockIdx.z;
+  const uint8_t* src = bg + (bg_stride ? n * bg_stride : 0);
+  uint8_t* dst = out + n * (long)W * H * 3;
+  const int y0 = blockIdx.y * kOutsideRows, y1 = min(y0 + kOutsideRows, H);
+  for (int y = y0; y < y1; y++) {
+    if (col_inside && y >= roi.y && y < roi.y + roi.h) continue;
+    const long off = ((long)y * W) * 3 + (long)wq * 4;
+    *reinterpret_cast<uint32_t*>(dst + off) = *reinterpret_cast<const uint32_t*>(src + off);
+  }
+}
+
 // ---- generic BGR resize -------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void resize_bgr_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ResizeTab tab) {
   const unsigned p = blockIdx.x * kThreads + threadIdx.x;
@@ -632,12 +651,16 @@ hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, R
 }
 
 bool mask_blend_fusable(int W, int H, Rect4 roi, const uint8_t* bg, size_t bg_stride, const uint8_t* frames, const uint8_t* out) {
-  return roi.x == 0 && roi.y == 0 && roi.w == W && roi.h == H && (W % 4) == 0 && (bg_stride % 4) == 0 &&
+  return (W % 4) == 0 && (roi.x % 4) == 0 && (roi.w % 4) == 0 && (bg_stride % 4) == 0 &&
          ((((uintptr_t)bg) | ((uintptr_t)frames) | ((uintptr_t)out)) & 3) == 0;
 }
 
 hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                              const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s) {
+  // outside the ROI the persistent mask is 255 forever (libbackscrub.cc:248-249), i.e. the composite there IS the background
+  // ((a*255 + b*0)/255 == a): those strips are copied, the ROI is composited by the mask tiles
+  if (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H)
+    outside_roi_copy_k<<<dim3(blocks_for((long)W * 3 / 4), (H + kOutsideRows - 1) / kOutsideRows, n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H, roi);
   dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
   if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
   else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
