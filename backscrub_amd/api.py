@@ -68,7 +68,7 @@ SYMBOLS = [
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libbsx.so")
+    return os.environ.get("BSX_LIBRARY") or os.path.join(_HERE, "libbsx.so")   # BSX_LIBRARY: A/B another build of the same ABI
 
 
 def lib():
