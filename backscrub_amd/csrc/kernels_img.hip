@@ -52,6 +52,21 @@ __device__ __forceinline__ void sample_linear(const uint8_t* __restrict__ src, l
   int b0 = t.ya[2 * dy], b1 = t.ya[2 * dy + 1];
   const uint8_t* r0 = src + (long)sy0 * sstride;
   const uint8_t* r1 = src + (long)sy1 * sstride;
+  if constexpr (CN == 3) {
+    // both taps of a row are 6 consecutive bytes: ONE (unaligned) 8-byte load per row instead of six byte loads — the texture
+    // address unit, not HBM, was the limit of the byte form.  Only when the 8 bytes stay inside the row.
+    if (sx1 == sx + 1 && sx * 3 + 8 <= (int)sstride) {
+      struct __attribute__((packed, aligned(1))) U8 { uint64_t v; };
+      const uint64_t q0 = reinterpret_cast<const U8*>(r0 + sx * 3)->v, q1 = reinterpret_cast<const U8*>(r1 + sx * 3)->v;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int h0 = (int)((q0 >> (8 * c)) & 255) * a0 + (int)((q0 >> (8 * (3 + c))) & 255) * a1;
+        const int h1 = (int)((q1 >> (8 * c)) & 255) * a0 + (int)((q1 >> (8 * (3 + c))) & 255) * a1;
+        out[c] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < CN; c++) {
     int h0 = r0[sx * CN + c] * a0 + r0[sx1 * CN + c] * a1;
