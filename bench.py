@@ -62,6 +62,28 @@ def resolve_model(key):
     return key, os.path.basename(key), "user model"
 
 
+def parity_sample(model_path, width, height, frames, bg, gpu_masks, gpu_out, k=4):
+    """The metric's "mask IoU vs CPU ref" on a small sample: the first k streams of the measured job (constant frames, so
+    both sides are in the IIR steady state) against the CPU oracle.  Part of the cpu_baseline leg — the oracle is only the checker."""
+    import numpy as np
+    from oracle import oracle_py
+    ious, max_abs, differing = [], 0, 0
+    for i in range(k):
+        ctx = oracle_py.Ctx(model_path, width, height)
+        for _ in range(4):                                   # 3 frames flush the IIR, the 4th is the steady state
+            want = ctx.process(frames[i])
+        ctx.close()
+        fa, fb = gpu_masks[i] < 128, want < 128
+        union = np.logical_or(fa, fb).sum()
+        ious.append(1.0 if union == 0 else float(np.logical_and(fa, fb).sum() / union))
+        comp = oracle_py.alpha_blend(bg, frames[i], want)
+        d = np.abs(comp.astype(np.int16) - gpu_out[i].astype(np.int16))
+        max_abs = max(max_abs, int(d.max()))
+        differing += int((d > 1).any(axis=-1).sum())
+    return {"streams": k, "mask_iou_min": round(min(ious), 6), "composite_max_abs_diff": max_abs,
+            "composite_pixels_off_by_more_than_1": differing, "pixels": k * width * height}
+
+
 def cpu_baseline(model_path, width, height, target_s):
     """Time the CPU oracle port (all host cores, OpenMP over streams) on a bounded sample."""
     import numpy as np
@@ -129,6 +151,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    masks_k = mg.masks()[:4].cpu().numpy() if rank == 0 else None      # steady-state sample for the parity figure of the cpu_baseline leg
+    out_k = d_out[:4].cpu().numpy() if rank == 0 else None
     # counters: frames (sum), elapsed (max), checksum (sum) — the only collective of the job
     from backscrub_amd.dist import reduce_counters
     checksum = int(d_out[:, ::16, ::16].to(torch.int64).sum().item())
@@ -138,11 +162,12 @@ def main():
     if rank == 0:
         fps = total_frames / max_elapsed
         result = {
-            "metric": "composited frames/sec at 640x480 (batch), whole per-frame hot path, inputs resident in HBM",
+            "metric": "composited frames/sec at 640\u00d7480 (batch), 1/2/4/8 MI355X + mask IoU vs CPU ref",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * max_elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (network) / u8 (image kernels)", "data": "synthetic (%s)" % weights,
-            "config": {"workload": "BASELINE configs[1]: batch=%d %dx%d frames, %s, 1 step = prep+network+decode+mask+blend" % (B, W, H, model_name),
+            "config": {"workload": "BASELINE configs[1]: batch=%d %dx%d frames, %s; 1 step = whole per-frame hot path (prep+network+decode+mask+blend), inputs resident in HBM; "
+                                   "mask IoU vs the CPU oracle: cpu_baseline.parity_sample" % (B, W, H, model_name),
                        "streams_per_gpu": B, "frame": "%dx%d" % (W, H), "network": model_name, "sharding": "streams/%d GPUs, no data-path collective" % world,
                        "launches_per_step": mg.info["n_steps"] + 5},
             "checksum": checksum_all,
@@ -231,6 +256,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(model_path, W, H, args.cpu_seconds)
+                result["cpu_baseline"]["parity_sample"] = parity_sample(model_path, W, H, host, synth.background(W, H, seed=1 + rank), masks_k, out_k)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(result), flush=True)
