@@ -57,6 +57,7 @@ SYMBOLS = [
     ("bsx_resize_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_bgr_to_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_yuyv_to_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("bsx_flip_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_debug_buffer", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("bsx_debug_run_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_plan_describe", C.c_char_p, [C.c_void_p]),
@@ -192,6 +193,14 @@ class MaskGen:
         out = torch.empty((n, h, w, 2), dtype=torch.uint8, device=bgr.device)
         _check(lib().bsx_bgr_to_yuyv(self.h, C.c_void_p(bgr.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, _stream_ptr()),
                self.h, "bsx_bgr_to_yuyv")
+        return out
+
+    def flip_bgr(self, bgr, code):
+        """cv::flip(bgr, out, code) for [n,h,w,3] u8 device frames (deepseg.cc:667-673): 0 vertical, >0 horizontal, <0 both."""
+        torch = _torch()
+        n, h, w, _ = bgr.shape
+        out = torch.empty_like(bgr)
+        _check(lib().bsx_flip_bgr(self.h, C.c_void_p(bgr.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, int(code), _stream_ptr()), self.h, "bsx_flip_bgr")
         return out
 
     def yuyv_to_bgr(self, yuyv):

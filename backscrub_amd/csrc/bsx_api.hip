@@ -430,6 +430,12 @@ int bsx_resize_bgr(bsx_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_
   return BSX_OK;
 }
 
+int bsx_flip_bgr(bsx_ctx* c, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int code, void* stream) {
+  if (!c || !d_src || !d_dst || d_src == d_dst || w <= 0 || h <= 0 || n <= 0) return BSX_EINVAL;
+  BSX_HIP(c, launch_flip_bgr(d_src, d_dst, w, h, code, n, pick(c, stream)));
+  return BSX_OK;
+}
+
 int bsx_bgr_to_yuyv(bsx_ctx* c, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, int h, int n, void* stream) {
   if (!c || !d_bgr || !d_yuyv || w <= 0 || h <= 0 || n <= 0) return BSX_EINVAL;
   BSX_HIP(c, launch_bgr_to_yuyv(d_bgr, d_yuyv, w, h, n, pick(c, stream)));

@@ -73,6 +73,8 @@ hipError_t launch_resize_bgr(const uint8_t* src, uint8_t* dst, ResizeTab tab, in
 hipError_t launch_bgr_to_yuyv(const uint8_t* bgr, uint8_t* yuyv, int w, int h, int n, hipStream_t s);
 // YUYV → BGR ingest.  deepseg.cc:553 (CAP_PROP_CONVERT_RGB), :725
 hipError_t launch_yuyv_to_bgr(const uint8_t* yuyv, uint8_t* bgr, int w, int h, int n, hipStream_t s);
+// cv::flip of the composited frame (code as cv::flip: 0 vertical, >0 horizontal, <0 both).  deepseg.cc:667-673
+hipError_t launch_flip_bgr(const uint8_t* src, uint8_t* dst, int w, int h, int code, int n, hipStream_t s);
 // fill
 hipError_t launch_fill_u8(uint8_t* p, uint8_t v, size_t bytes, hipStream_t s);
 

@@ -598,6 +598,19 @@ __global__ __launch_bounds__(kThreads) void yuyv_to_bgr_k(const uint32_t* __rest
   o[3] = (uint8_t)min(max((yb + buv) >> SH, 0), 255); o[4] = (uint8_t)min(max((yb + guv) >> SH, 0), 255); o[5] = (uint8_t)min(max((yb + ruv) >> SH, 0), 255);
 }
 
+// ---- cv::flip on packed BGR (deepseg.cc:667-673): code 0 = around the x axis (rows reversed), > 0 = around the y axis
+// (columns reversed), < 0 = both.  Out of place; lane = one pixel of frame blockIdx.y.
+__global__ __launch_bounds__(kThreads) void flip_bgr_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int w, int h, int code) {
+  const unsigned p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= (unsigned)(w * h)) return;
+  const int y = (int)(p / (unsigned)w), x = (int)(p - (unsigned)y * (unsigned)w);
+  const int sy = code <= 0 ? h - 1 - y : y, sx = code != 0 ? w - 1 - x : x;
+  const long base = (long)blockIdx.y * w * h * 3;
+  const uint8_t* s = src + base + ((long)sy * w + sx) * 3;
+  uint8_t* d = dst + base + (long)p * 3;
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
 __global__ __launch_bounds__(kThreads) void fill_k(uint4* p, uint4 v, long n16) {
   long i = (long)blockIdx.x * kThreads + threadIdx.x;
   if (i < n16) p[i] = v;
@@ -702,6 +715,14 @@ hipError_t launch_resize_bgr(const uint8_t* src, uint8_t* dst, ResizeTab tab, in
   for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
     const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
     resize_bgr_k<<<dim3(blocks_for((long)tab.dw * tab.dh), nn), kThreads, 0, s>>>(src + (size_t)n0 * tab.sw * tab.sh * 3, dst + (size_t)n0 * tab.dw * tab.dh * 3, tab);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_flip_bgr(const uint8_t* src, uint8_t* dst, int w, int h, int code, int n, hipStream_t s) {
+  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
+    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
+    flip_bgr_k<<<dim3(blocks_for((long)w * h), nn), kThreads, 0, s>>>(src + (size_t)n0 * w * h * 3, dst + (size_t)n0 * w * h * 3, w, h, code);
   }
   return hipGetLastError();
 }

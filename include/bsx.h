@@ -20,6 +20,7 @@
  *   bsx_resize_bgr         grab_background() cv::resize   app/background.cc:178-194
  *   bsx_bgr_to_yuyv        convert_rgb_to_yuyv()          app/deepseg.cc:87-106
  *   bsx_yuyv_to_bgr        VideoCapture's YUYV->BGR       app/deepseg.cc:553,725 (cv::COLOR_YUV2BGR_YUYV)
+ *   bsx_flip_bgr           cv::flip of the output frame   app/deepseg.cc:667-673 (flipHorizontal / flipVertical)
  *   bsx_profile_batch      the per-stage timers           app/deepseg.cc:137-156,701-720 (timinginfo_t)
  *   bsx_get_info           the geometry of backscrub_ctx_t lib/libbackscrub.cc:28-54,234-246
  *
@@ -132,6 +133,10 @@ int bsx_bgr_to_yuyv(bsx_ctx* ctx, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, 
 /* YUYV 4:2:2 (bytes Y0 U Y1 V) [n][h][w][2] -> BGR u8 [n][h][w][3], exactly cv::cvtColor(COLOR_YUV2BGR_YUYV): the conversion
  * cv::VideoCapture applies to raw camera frames for the reference (app/deepseg.cc:553, :725).  Lets a caller upload 2 B/px. */
 int bsx_yuyv_to_bgr(bsx_ctx* ctx, const uint8_t* d_yuyv, uint8_t* d_bgr, int w, int h, int n, void* stream);
+
+/* cv::flip(src, dst, code) on packed BGR u8 [n][h][w][3] (device pointers, dst != src): code 0 flips around the x axis
+ * (-v / flipVertical), code > 0 around the y axis (-h / flipHorizontal), code < 0 both (app/deepseg.cc:667-673). */
+int bsx_flip_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int code, void* stream);
 
 /* ---- introspection used by the parity tests and the bench (stage-by-stage checks) ---- */
 /* Device pointer + element count of: 0 = model input tensor [n_streams][in_h][in_w][in_c] f32,

@@ -123,6 +123,16 @@ def bgr_to_yuyv(img) -> np.ndarray:
     return out
 
 
+def flip_bgr(img: np.ndarray, code: int) -> np.ndarray:
+    """cv::flip(img, out, code) as the app applies it to the composited frame (/root/reference/app/deepseg.cc:667-673):
+    code 0 reverses the rows, code > 0 the columns, code < 0 both."""
+    if code == 0:
+        return np.ascontiguousarray(img[::-1])
+    if code > 0:
+        return np.ascontiguousarray(img[:, ::-1])
+    return np.ascontiguousarray(img[::-1, ::-1])
+
+
 def yuyv_to_bgr(img) -> np.ndarray:
     img = np.ascontiguousarray(img)
     out = np.zeros((img.shape[0], img.shape[1], 3), np.uint8)

@@ -389,6 +389,17 @@ def test_yuyv_to_bgr_matches_oracle(bs, oracle):
 # --------------------------------------------------------------------------------------------
 # size-independent properties at the BASELINE batch size (256 VGA streams, segm_lite)
 # --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("code", [0, 1, -1])
+def test_flip_matches_oracle(bs, oracle, code):
+    from backscrub_amd import synth
+    mg = bs.MaskGen(synthetic_model_path("lite"), 64, 48, n_streams=1)
+    img = synth.random_u8((3, 37, 53, 3), 31)
+    got = mg.flip_bgr(_dev(img), code).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.flip_bgr(img[i], code))
+    mg.close()
+
+
 def test_full_batch_properties(bs, oracle):
     from backscrub_amd import synth
     W, H = VGA
