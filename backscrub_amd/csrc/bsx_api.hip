@@ -581,8 +581,8 @@ int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
     snprintf(head, sizeof head, "ops=%d nodes=%d steps=%d macs=%.0f arena_floats=%zu\n", g.n_file_ops, (int)g.nodes.size(), (int)p.steps.size(),
              p.macs_per_frame, p.arena_floats_per_stream);
     out = head + p.describe();
-    snprintf(head, sizeof head, "program micro-ops=%zu lds_floats=%d lds_tensors=%d hbm_tensors=%d\n", p.program.size(), p.program_lds_floats,
-             p.program_lds_tensors, p.program_global_tensors);
+    snprintf(head, sizeof head, "program micro-ops=%zu lds_floats=%d lds_tensors=%d hbm_tensors=%d lds_blocks=%zu lds_check=%s\n", p.program.size(),
+             p.program_lds_floats, p.program_lds_tensors, p.program_global_tensors, p.program_blocks.size(), p.program_check.c_str());
     out += head;
     for (size_t i = 0; i < p.program_labels.size(); i++) out += "P" + std::to_string(i) + " " + p.program_labels[i] + "\n";
   }

@@ -57,6 +57,8 @@ std::string Plan::describe() const {
 static void build_frame_program(const Graph& g, Plan* plan) {
   plan->program.clear();
   plan->program_labels.clear();
+  plan->program_blocks.clear();
+  plan->program_check.clear();
   const int NS = (int)plan->steps.size();
   const int NT = (int)g.tensors.size();
   std::vector<int> last(NT, -1);
@@ -93,6 +95,7 @@ static void build_frame_program(const Graph& g, Plan* plan) {
       if (pos + need <= cap) {
         l.space = kLocLds; l.off = pos; l.stride = stride;
         live.push_back({pos, need, last[t]});
+        plan->program_blocks.push_back({pos, need, s, last[t], "tensor " + std::to_string(t)});
         high = std::max(high, pos + need);
         plan->program_lds_tensors++;
         loc[t] = l;
@@ -150,7 +153,10 @@ static void build_frame_program(const Graph& g, Plan* plan) {
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
       int pos = kLdsScratchFloats;
       for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
-      if (pos + need <= cap) { slot[s2] = pos; live.push_back({pos, need, s2}); high = std::max(high, pos + need); }
+      if (pos + need <= cap) {
+        slot[s2] = pos; live.push_back({pos, need, s2}); high = std::max(high, pos + need);
+        plan->program_blocks.push_back({pos, need, s, s2, "weights of step " + std::to_string(s2)});
+      }
       else stage[s2] = 0;                       // no room: the op falls back to its unstaged form
     }
     if (tail_pattern(s)) {
@@ -163,7 +169,10 @@ static void build_frame_program(const Graph& g, Plan* plan) {
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
       int pos = kLdsScratchFloats;
       for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
-      if (pos + need <= cap) { tail_ws[s] = pos; tail_rows[s] = R; live.push_back({pos, need, s + 2}); high = std::max(high, pos + need); }
+      if (pos + need <= cap) {
+        tail_ws[s] = pos; tail_rows[s] = R; live.push_back({pos, need, s + 2}); high = std::max(high, pos + need);
+        plan->program_blocks.push_back({pos, need, s, s + 2, "tail band of step " + std::to_string(s)});
+      }
     }
     place(st.out, s);
     MicroOp m;
@@ -204,6 +213,7 @@ static void build_frame_program(const Graph& g, Plan* plan) {
       if (pos + need <= cap && band_floats(band) <= 8192) {
         m.mfma = 1; m.ws_off = pos; m.band_rows = band;
         live.push_back({pos, need, s});          // occupied for this step only
+        plan->program_blocks.push_back({pos, need, s, s, "stem band of step " + std::to_string(s)});
         high = std::max(high, pos + need);
       }
     }
@@ -273,7 +283,32 @@ static void build_frame_program(const Graph& g, Plan* plan) {
   plan->program = std::move(prog);
   plan->program_labels = std::move(labels);
   plan->program_lds_floats = high;
+  plan->program_check = verify_program_lds(*plan);
+  if (plan->program_check != "ok") plan->program.clear();      // never run a program whose LDS reservations collide
 }
+
+// Independent check of the lowering: no two LDS reservations that are alive at the same step may share a float, every block
+// stays inside [kLdsScratchFloats, kLdsTotalFloats), and every LDS operand of every micro-op lies inside the block area.
+std::string verify_program_lds(const Plan& plan) {
+  const auto& b = plan.program_blocks;
+  for (size_t i = 0; i < b.size(); i++) {
+    if (b[i].off < kLdsScratchFloats || b[i].off + b[i].len > kLdsTotalFloats || b[i].len <= 0 || b[i].from > b[i].until)
+      return "block out of range: " + b[i].what;
+    for (size_t j = i + 1; j < b.size(); j++) {
+      const bool time = b[i].from <= b[j].until && b[j].from <= b[i].until;
+      const bool mem = b[i].off < b[j].off + b[j].len && b[j].off < b[i].off + b[i].len;
+      if (time && mem) return "overlap: " + b[i].what + " [" + std::to_string(b[i].from) + "," + std::to_string(b[i].until) + "] and " + b[j].what + " [" +
+                              std::to_string(b[j].from) + "," + std::to_string(b[j].until) + "]";
+    }
+  }
+  for (const MicroOp& m : plan.program) {
+    for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.scale, &m.out})
+      if (l->space == kLocLds && (l->off < kLdsScratchFloats || l->off >= plan.program_lds_floats)) return "operand outside the LDS block area";
+    if (m.stage_floats > 0 && (m.w_lds < kLdsScratchFloats || m.w_lds + m.stage_floats > plan.program_lds_floats)) return "weight slot outside the LDS block area";
+  }
+  return "ok";
+}
+
 
 bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_arena) {
   auto fail = [&](const std::string& m) { if (err) *err = m; return false; };

@@ -55,11 +55,19 @@ struct Plan {
   std::vector<std::string> program_labels;
   int program_lds_floats = 0;         // dynamic LDS the program needs (scratch included)
   int program_lds_tensors = 0, program_global_tensors = 0;
+  // every LDS reservation of the program: [off, off+len) floats, alive for steps [from, until] (tensors, weight slots,
+  // band workspaces) — checked for overlap by verify_program_lds() at the end of the lowering and by the tests
+  struct LdsBlock { int off, len, from, until; std::string what; };
+  std::vector<LdsBlock> program_blocks;
+  std::string program_check;            // "ok" or the first violation found
   std::string describe() const;
 };
 
 // Build the plan.  Returns false with `err` for unsupported graph features.
 // `reuse_arena=false` gives every tensor its own slot (layer-by-layer debugging).
+// "ok", or the first violation among the program's LDS reservations / operands (see Plan::program_blocks)
+std::string verify_program_lds(const Plan& plan);
+
 bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena = true);
 
 }  // namespace bsx

@@ -74,3 +74,19 @@ def test_unsupported_operator_is_reported(bs, tmp_path):
     T.save(m, str(p))
     with pytest.raises(bs.BsxError, match="unsupported builtin operator code 25"):
         bs.model_describe(str(p))
+
+
+@pytest.mark.parametrize("key", ["lite", "full", "mlkit", "deeplab"])
+@pytest.mark.parametrize("real", [True, False])
+def test_frame_program_lds_reservations_do_not_collide(key, real):
+    """Host-only check of the per-frame program's lowering (plan.cpp verify_program_lds): every LDS reservation — tensors, DMA
+    weight slots, band workspaces — with its lifetime; no two that are alive together may overlap, all inside the 160 KiB block."""
+    import backscrub_amd
+    path = model_path(key, prefer_real=real)
+    if real and "synthetic" in os.path.basename(path):
+        pytest.skip("reference model not staged on this box")
+    line = [l for l in backscrub_amd.model_describe(path).splitlines() if l.startswith("program micro-ops=")][0]
+    fields = dict(kv.split("=") for kv in line.split()[1:])
+    assert fields["lds_check"] == "ok", line
+    assert int(fields["micro-ops"]) > 0 and int(fields["lds_blocks"]) >= int(fields["lds_tensors"])
+    assert int(fields["lds_floats"]) <= 160 * 256
