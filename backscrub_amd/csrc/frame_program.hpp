@@ -41,6 +41,7 @@ struct MicroOp {
   int mfma = 0;     // 1: pointwise conv runs on v_mfma_f32_16x16x4_f32 with the weight block staged in LDS
   int gemv = 0;     // 1: ≤4 output pixels → wave-per-output-channel dot products with [co][ci] weights
   int n_cat = 0;
+  int gap_sum = 0;  // pooling ops: the cat[] parts' means are ADDED into the same Cin channels (GAP(a + b)) instead of concatenated
   long long w_off = 0, b_off = 0, w2_off = 0;
   // fused squeeze-excite / gate chain (kind == kMicroSe): GAP(in0 | cat[]) → FC1 (w2_off, b_off, act, Cout=C1) → FC2 (w3_off, b3_off, act2, C2)
   long long w3_off = 0, b3_off = 0;

@@ -796,7 +796,7 @@ __device__ __forceinline__ void mo_dw(cop_t& op, const FrameCtx& c) {
 // partials meet in the scratch once.  Two barriers per channel block instead of a multi-level LDS tree.
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 template <bool XL>
-__device__ __forceinline__ void gap_body(const Ref& x, int HW, int C, const Ref& out, int coff) {
+__device__ __forceinline__ void gap_body(const Ref& x, int HW, int C, const Ref& out, int coff, bool accumulate) {
   lds_f* scratch = lds_base();
   const int C4 = C >> 2;
   int CG = 1;
@@ -829,14 +829,15 @@ __device__ __forceinline__ void gap_body(const Ref& x, int HW, int C, const Ref&
       for (int w = 0; w < kFrameThreads / 64; w++) t = add4(t, ld_lds4(scratch + 4 * (w * CG + threadIdx.x)));
       const float inv = (float)HW;
       t.x /= inv; t.y /= inv; t.z /= inv; t.w /= inv;
+      if (accumulate) t = add4(ld4(out, coff + cq * 4), t);      // GAP(a + b) as GAP(a) + GAP(b): later parts add to the first
       st4(out, coff + cq * 4, t);
     }
     __syncthreads();
   }
 }
 
-__device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& out, int coff) {
-  if (x.lds) gap_body<true>(x, HW, C, out, coff); else gap_body<false>(x, HW, C, out, coff);
+__device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& out, int coff, bool accumulate = false) {
+  if (x.lds) gap_body<true>(x, HW, C, out, coff, accumulate); else gap_body<false>(x, HW, C, out, coff, accumulate);
 }
 
 __device__ __forceinline__ void mo_gap(cop_t& op, const FrameCtx& c) {
@@ -844,7 +845,10 @@ __device__ __forceinline__ void mo_gap(cop_t& op, const FrameCtx& c) {
   const int HW = op.H * op.W;
   if (op.n_cat == 0) { gap_one(make_ref(op.in0, c), HW, op.Cin, out, 0); return; }
   int coff = 0;
-  for (int k = 0; k < op.n_cat; k++) { gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], out, coff); coff += op.cat_c[k]; }
+  for (int k = 0; k < op.n_cat; k++) {
+    gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], out, coff, op.gap_sum && k > 0);
+    if (!op.gap_sum) coff += op.cat_c[k];
+  }
 }
 
 // ---- fused squeeze-excite / decoder-gate chain: GAP → FC(+act) [→ FC(+act)] ---------------------------------------------
@@ -902,7 +906,13 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
   FcPre p2 = p1;
   if (op.n_fc == 2) p2 = fc_preload(op.C1, wts + op.w3_off, wts + op.b3_off, op.C2);
   if (op.n_cat == 0) gap_one(make_ref(op.in0, c), HW, op.Cin, mean, 0);
-  else { int coff = 0; for (int k = 0; k < op.n_cat; k++) { gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], mean, coff); coff += op.cat_c[k]; } }
+  else {
+    int coff = 0;
+    for (int k = 0; k < op.n_cat; k++) {
+      gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], mean, coff, op.gap_sum && k > 0);
+      if (!op.gap_sum) coff += op.cat_c[k];
+    }
+  }
   if (op.n_fc == 1) { fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, out, p1); return; }
   fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, hid, p1);
   __syncthreads();

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void dw_conv_k(const float* __restrict__ 
 // global average pool: block = (frame, channel-quad chunk); rows of lanes stride the pixels
 // -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void gap_k(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int CG, int out_c4_stride,
-                                                 int out_c4_off) {
+                                                 int out_c4_off, int accumulate) {
   __shared__ float4 sm[kThreads];
   const int C4 = C >> 2;
   const int n = blockIdx.x;
@@ -348,7 +348,9 @@ __global__ __launch_bounds__(kThreads) void gap_k(const float* __restrict__ x, f
     for (int r = 1; r < rows; r++) { float4 v = sm[r * CG + cg]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
     float inv = (float)HW;
     t.x /= inv; t.y /= inv; t.z /= inv; t.w /= inv;
-    reinterpret_cast<float4*>(y)[(long)n * out_c4_stride + out_c4_off + cgi] = t;
+    float4* o = reinterpret_cast<float4*>(y) + (long)n * out_c4_stride + out_c4_off + cgi;
+    if (accumulate) { const float4 p = *o; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }   // GAP(a + b) = GAP(a) + GAP(b)
+    *o = t;
   }
 }
 
@@ -557,15 +559,21 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
     }
     case StepKind::Gap: {
       if (st.Cin % 4) return hipErrorInvalidValue;
-      auto one = [&](int tensor, int C, int c_off) {
+      auto one = [&](int tensor, int C, int c_off, int accumulate) {
         int C4 = C / 4;
         int CG = 1;
         while (CG * 2 <= C4 && CG * 2 <= 64) CG *= 2;  // power of two ≤ 64 so rows = 256/CG is exact
         dim3 grid(n, (C4 + CG - 1) / CG);
-        gap_k<<<grid, kThreads, 0, s>>>(P(tensor), P(st.out), st.H * st.W, C, CG, st.Cout / 4, c_off / 4);
+        gap_k<<<grid, kThreads, 0, s>>>(P(tensor), P(st.out), st.H * st.W, C, CG, st.Cout / 4, c_off / 4, accumulate);
       };
-      if (st.concat_in.empty()) one(st.in0, st.Cin, 0);
-      else { int off = 0; for (size_t k = 0; k < st.concat_in.size(); k++) { one(st.concat_in[k], st.concat_c[k], off); off += st.concat_c[k]; } }
+      if (st.concat_in.empty()) one(st.in0, st.Cin, 0, 0);
+      else {
+        int off = 0;
+        for (size_t k = 0; k < st.concat_in.size(); k++) {
+          one(st.concat_in[k], st.concat_c[k], off, st.gap_sum && k > 0);
+          if (!st.gap_sum) off += st.concat_c[k];
+        }
+      }
       break;
     }
     case StepKind::Eltwise: {

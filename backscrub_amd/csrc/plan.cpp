@@ -187,6 +187,7 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     m.in0 = L(st.in0); m.in1 = L(st.in1); m.in2 = L(st.in2); m.res = L(st.residual); m.scale = L(st.in_scale); m.out = L(st.out);
     if (st.concat_in.size() > 4) return;
     m.n_cat = (int)st.concat_in.size();
+    m.gap_sum = st.gap_sum ? 1 : 0;
     for (int k = 0; k < m.n_cat; k++) { m.cat[k] = L(st.concat_in[k]); m.cat_c[k] = st.concat_c[k]; }
     if (st.kind == StepKind::DwConv && !((st.kh == 3 && st.kw == 3) || (st.kh == 5 && st.kw == 5))) return;   // program has 3x3 / 5x5 bodies only
     // weights + bias are contiguous in the arena ([w][pad to 4][b]); the whole range is staged in the slot planned above
@@ -509,6 +510,19 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
               steps.erase(steps.begin() + k);
               st.label = "gapcat#" + std::to_string(n.index);
               break;
+            }
+          // GAP(a + b) == GAP(a) + GAP(b): when the sum feeds nothing but the pool it is never materialised
+          // (MLKit's decoder gates pool skip+up; the full-resolution sum cost a 3 MB/frame HBM round trip)
+          if (st.concat_in.empty())
+            for (size_t k = 0; k < steps.size(); k++) {
+              const Step& e = steps[k];
+              if (e.kind == StepKind::Eltwise && e.out == st.in0 && e.elt == kEltAdd && !e.bcast1 && e.act == kActNone && e.in1 >= 0 &&
+                  !getenv("BSX_NO_GAP_SUM")) {
+                st.concat_in = {e.in0, e.in1}; st.concat_c = {st.Cin, st.Cin}; st.gap_sum = true; st.in0 = e.in0;
+                steps.erase(steps.begin() + k);
+                st.label = "gapsum#" + std::to_string(n.index);
+                break;
+              }
             }
         }
         break;

@@ -39,6 +39,7 @@ struct Step {
   size_t w2_off = 0;                  // [co][ci] copy of the weights for single-pixel (GEMV) steps, 0 if absent
   std::vector<int> concat_in;         // Concat: all inputs
   std::vector<int> concat_c;          // Concat: channels of each input
+  bool gap_sum = false;               // Gap over concat_in as a SUM of the parts' means (GAP(a + b) rewritten), not their concatenation
   double macs = 0;                    // per frame
   int last_node = -1;                 // file operator index of the last fused op
 };
