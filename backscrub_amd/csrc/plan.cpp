@@ -87,6 +87,9 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     int pad = ((C / 4) % 2 == 0) ? 4 : 8;          // (C+pad)/4 odd → 16-byte row reads hit distinct bank quads
     int stride = P > 1 ? C + pad : C;
     int need = (P * stride + 3) / 4 * 4;
+    // a tensor that would leave no room for the weight slots of the ops around it turns those ops into their slow unstaged
+    // forms (MLKit's 16x16x128 tensors are 132 KB): such a tensor goes to HBM instead
+    if (need > kLdsTotalFloats - kLdsScratchFloats - 2 * kLdsMaxStageFloats && !getenv("BSX_PLAN_NO_SLOT_RESERVE")) lds_ok = false;
     if (lds_ok) {
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
