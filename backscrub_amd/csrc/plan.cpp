@@ -164,17 +164,21 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     }
     if (tail_pattern(s)) {
       // z row band: (R+2) rows x W pixels x (C+4) floats, alive for the three fused steps
-      int R = 8;
+      // the largest band that fits the LDS that is free right now: every band recomputes its two halo rows, so taller bands
+      // mean less redundant work and fewer barriers (the kernel keeps a band's 16-pixel tiles in flight 4 per wave: <= 64 tiles)
       auto need_for = [&](int r) { return (r + 2) * st.W * (st.Cout + 4); };
-      while (R > 1 && need_for(R) > 20000) R /= 2;
-      const int need = need_for(R);
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
-      int pos = kLdsScratchFloats;
-      for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
-      if (pos + need <= cap) {
-        tail_ws[s] = pos; tail_rows[s] = R; live.push_back({pos, need, s + 2}); high = std::max(high, pos + need);
-        plan->program_blocks.push_back({pos, need, s, s + 2, "tail band of step " + std::to_string(s)});
+      const int rmax = getenv("BSX_TAIL_ROWS") ? atoi(getenv("BSX_TAIL_ROWS")) : 16;
+      for (int R = rmax; R >= 1 && tail_ws[s] < 0; R = R > 4 ? R - 2 : R - 1) {
+        const int need = need_for(R);
+        if ((R + 2) * st.W > 64 * 16 * 4) continue;           // phase A: <= 4 tiles per wave and band
+        int pos = kLdsScratchFloats;
+        for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
+        if (pos + need <= cap) {
+          tail_ws[s] = pos; tail_rows[s] = R; live.push_back({pos, need, s + 2}); high = std::max(high, pos + need);
+          plan->program_blocks.push_back({pos, need, s, s + 2, "tail band of step " + std::to_string(s)});
+        }
       }
     }
     place(st.out, s);
