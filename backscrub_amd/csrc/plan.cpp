@@ -649,6 +649,32 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
     steps.erase(steps.begin() + i);
     i--;
   }
+  // (c) y = a * s (s a per-channel vector) feeding only a 1x1 convolution — the Meet head's pw(x) * sigmoid(pw(GAP(x))) in front of the
+  //     first decoder convolution, which rewrite (a) has just moved next to it: the same fold as a squeeze-excite MUL
+  for (size_t i = 0; i < steps.size() && !no_rewrites; i++) {
+    if (steps[i].kind != StepKind::Eltwise || steps[i].elt != kEltMul || !steps[i].bcast1 || steps[i].act != kActNone) continue;
+    if (uses_of(steps[i].out) != 1) continue;
+    size_t j = i + 1;
+    for (; j < steps.size(); j++) if (steps[j].in0 == steps[i].out) break;
+    if (j >= steps.size()) continue;
+    Step& Pw = steps[j];
+    if (Pw.kind != StepKind::PwConv || Pw.in_scale >= 0 || Pw.in2 >= 0 || Pw.Cin % 4 || Pw.OH * Pw.OW <= 4) continue;
+    Pw.in0 = steps[i].in0; Pw.in_scale = steps[i].in1;
+    Pw.label += "+mul";
+    steps.erase(steps.begin() + i);
+    i--;
+  }
+  // (d) a global average pool runs right before its first consumer (steps are in file order; the Meet head has an independent
+  //     1x1 convolution between the pool and the FC that reads it): adjacent, the pool and its FC chain fuse into one micro-op
+  for (size_t i = 0; i + 2 < steps.size() && !no_rewrites; i++) {
+    if (steps[i].kind != StepKind::Gap) continue;
+    const int t = steps[i].out;
+    size_t j = i + 1;
+    auto reads = [&](const Step& q) { for (int u : {q.in0, q.in1, q.in2, q.residual, q.in_scale}) if (u == t) return true; for (int u : q.concat_in) if (u == t) return true; return false; };
+    while (j < steps.size() && !reads(steps[j])) j++;
+    if (j >= steps.size() || j == i + 1) continue;
+    std::rotate(steps.begin() + i, steps.begin() + i + 1, steps.begin() + j);   // the pool moves to position j-1
+  }
 
   // ---- activation arena: first-fit over [first def, last use] intervals, in per-stream float units
   plan->tensor_off.assign(NT, -1);
