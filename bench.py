@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--model", default="lite", help="lite|full|mlkit|deeplab or a .tflite path")
+    ap.add_argument("--per-stream-bg", action="store_true", help="every stream composites over its own background frame (animated backgrounds: BASELINE configs[3]) instead of one shared image")
     ap.add_argument("--host-io", action="store_true", help="also measure the step with per-step H2D of the frames and D2H of the composite (pinned host buffers); reported as host_io, never as value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -135,6 +136,8 @@ def main():
     d_base = torch.from_numpy(host).cuda()
     d_frames = d_base.repeat((B + distinct - 1) // distinct, 1, 1, 1)[:B].contiguous()
     d_bg = torch.from_numpy(synth.background(W, H, seed=1 + rank)).cuda()
+    if args.per_stream_bg:      # [B,H,W,3]: one background frame per stream, rolled so that no two streams share bytes
+        d_bg = torch.stack([torch.roll(d_bg, shifts=3 * i, dims=1) for i in range(min(B, 64))]).repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous()
     d_out = torch.empty_like(d_frames)
 
     def barrier():
@@ -273,7 +276,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(model_path, W, H, args.cpu_seconds)
-                result["cpu_baseline"]["parity_sample"] = parity_sample(model_path, W, H, host, synth.background(W, H, seed=1 + rank), masks_k, out_k)
+                if not args.per_stream_bg:
+                    result["cpu_baseline"]["parity_sample"] = parity_sample(model_path, W, H, host, synth.background(W, H, seed=1 + rank), masks_k, out_k)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(result), flush=True)
