@@ -259,7 +259,7 @@ __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, c
         const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0 + (long)(8 * i) * W * 3);
         const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * 3);
         o.a[i][0] = ap[0]; o.a[i][1] = ap[1]; o.a[i][2] = ap[2];
-        o.b[i][0] = bp[0]; o.b[i][1] = bp[1]; o.b[i][2] = bp[2];
+        o.b[i][0] = __builtin_nontemporal_load(bp); o.b[i][1] = __builtin_nontemporal_load(bp + 1); o.b[i][2] = __builtin_nontemporal_load(bp + 2);   // streamed once
       }
     }
   }
@@ -329,7 +329,7 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
       uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * 3);
       uint32_t o3[3];
       blend_quad(o.a[i], o.b[i], packed, o3);
-      op[0] = o3[0]; op[1] = o3[1]; op[2] = o3[2];
+      __builtin_nontemporal_store(o3[0], op); __builtin_nontemporal_store(o3[1], op + 1); __builtin_nontemporal_store(o3[2], op + 2);
     }
   }
 }
