@@ -177,6 +177,24 @@ __global__ __launch_bounds__(kThreads) void decode_k(int type, const float* __re
   out[i] = (uint8_t)((val & 0xE0) | (out[i] >> 3));
 }
 
+// Meet decode, 4 pixels per lane: two 16-byte logit loads, one 4-byte state word read-modified-written.  Same per-pixel
+// arithmetic as decode_k (fast path by margin, exact path for near ties / out-of-range / NaN logits).
+__device__ __forceinline__ uint32_t meet_val(float l0, float l1) {
+  const float d = l1 - l0;
+  if (fabsf(l0) <= 80.f && fabsf(l1) <= 80.f && fabsf(d) >= 1e-4f) return d > 0.f ? 0u : 255u;
+  const float e0 = (float)exp((double)l0), e1 = (float)exp((double)l1);
+  const float s = __fadd_rn(e0, e1);
+  return __fdiv_rn(e0, s) < __fdiv_rn(e1, s) ? 0u : 255u;
+}
+__global__ __launch_bounds__(kThreads) void decode_meet4_k(const float4* __restrict__ t, uint32_t* __restrict__ out, long quads) {
+  const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= quads) return;
+  const float4 a = t[2 * i], b = t[2 * i + 1];               // (l0,l1) of pixels 0,1 | 2,3
+  const uint32_t v = meet_val(a.x, a.y) | (meet_val(a.z, a.w) << 8) | (meet_val(b.x, b.y) << 16) | (meet_val(b.z, b.w) << 24);
+  const uint32_t o = out[i];
+  out[i] = (v & 0xE0E0E0E0u) | ((o >> 3) & 0x1F1F1F1Fu);      // per byte: (val & 0xE0) | (out >> 3)
+}
+
 // DeepLab argmax over nch interleaved classes: the 256 pixels of a workgroup are one contiguous block of 256*nch floats —
 // read it with coalesced 4-byte loads into LDS, then every lane scans its own nch values (stride nch, conflict-free for odd
 // nch).  A lane reading its classes straight from HBM touches 64 cache lines per load instruction.
@@ -647,7 +665,9 @@ hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, int inW, 
 hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, int npix, int nch, int n, hipStream_t s) {
   long total = (long)n * npix;
   int type = model_type == 1 ? 1 : (model_type == 3 ? 3 : 2);
-  if (type == 1 && nch <= kArgmaxMaxCh) decode_argmax_k<<<blocks_for(total), kThreads, 0, s>>>(logits, ofinal, total, nch);
+  if (type == 3 && nch == 2 && (total & 3) == 0 && ((((uintptr_t)logits) & 15) | (((uintptr_t)ofinal) & 3)) == 0)
+    decode_meet4_k<<<blocks_for(total / 4), kThreads, 0, s>>>(reinterpret_cast<const float4*>(logits), reinterpret_cast<uint32_t*>(ofinal), total / 4);
+  else if (type == 1 && nch <= kArgmaxMaxCh) decode_argmax_k<<<blocks_for(total), kThreads, 0, s>>>(logits, ofinal, total, nch);
   else decode_k<<<blocks_for(total), kThreads, 0, s>>>(type, logits, ofinal, total, nch);
   return hipGetLastError();
 }
