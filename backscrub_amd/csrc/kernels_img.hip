@@ -113,13 +113,16 @@ __global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __r
   for (int k = threadIdx.x; k < 768; k += kThreads) lut[k] = bp.color_lut[k];
   __syncthreads();
   const int PW = inW + 2 * kCanvasPad, PH = inH + 2 * kCanvasPad;
-  const long n = blockIdx.y;
+  const long n = blockIdx.z;
   const uint32_t* img = canvas + n * (long)PW * PH;
+  // workgroup = 32 x 32 output pixels (lane = column, 8 rows per pass): no index division anywhere
+  const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x & 31), yb = (int)blockIdx.y * 32 + (int)(threadIdx.x >> 5);
+  if (x >= inW) return;
 #pragma unroll 2
   for (int it = 0; it < kBilPix; it++) {
-    const unsigned p = (blockIdx.x * kBilPix + it) * kThreads + threadIdx.x;
-    if (p >= (unsigned)(inW * inH)) return;
-    const int y = (int)(p / (unsigned)inW), x = (int)(p - (unsigned)y * (unsigned)inW);
+    const int y = yb + 8 * it;
+    if (y >= inH) return;
+    const unsigned p = (unsigned)(y * inW + x);
     const uint32_t* row[5];
 #pragma unroll
     for (int d = 0; d < 5; d++) row[d] = img + (y + d) * PW + (x + kCanvasPad);     // canvas rows y-2 .. y+2 at column x
@@ -656,7 +659,8 @@ hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, int inW, 
   const long per_frame = (long)inW * inH;
   for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
     const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
-    prep_bilateral_k<<<dim3(blocks_for((per_frame + kBilPix - 1) / kBilPix), nn), kThreads, 0, s>>>(canvas + (size_t)n0 * canvas_elems(inW, inH),
+    static_assert(kBilPix * (kThreads / 32) == 32, "32 x 32 pixel workgroup tile");
+    prep_bilateral_k<<<dim3((inW + 31) / 32, (inH + 31) / 32, nn), kThreads, 0, s>>>(canvas + (size_t)n0 * canvas_elems(inW, inH),
                                                                                                     input + (size_t)n0 * per_frame * 3, inW, inH, bp);
   }
   return hipGetLastError();
