@@ -79,6 +79,7 @@ int bsx_device_count(void);
 /* Create a mask generator for `n_streams` independent camera streams of width x height BGR
  * frames on HIP device `device`.  `threads` is accepted for signature parity with
  * bs_maskgen_new (intra-op CPU threads there) and recorded only.  Callbacks may be NULL.
+ * 1 <= n_streams <= 65535 (the stream index rides in a grid dimension).
  * Returns NULL on failure after reporting through ondebug (or stderr), like the reference. */
 bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t height,
                  int n_streams, int device,
