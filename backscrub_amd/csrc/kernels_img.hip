@@ -198,6 +198,17 @@ __global__ __launch_bounds__(kThreads) void decode_meet4_k(const float4* __restr
   out[i] = (v & 0xE0E0E0E0u) | ((o >> 3) & 0x1F1F1F1Fu);      // per byte: (val & 0xE0) | (out >> 3)
 }
 
+// MLKit / BodyPix decode, 4 pixels per lane: `p > 0.65` with the float promoted to double (the literal is a double, libbackscrub.cc:338)
+__global__ __launch_bounds__(kThreads) void decode_thresh4_k(const float4* __restrict__ t, uint32_t* __restrict__ out, long quads) {
+  const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= quads) return;
+  const float4 p = t[i];
+  const uint32_t v = ((double)p.x > 0.65 ? 0u : 255u) | (((double)p.y > 0.65 ? 0u : 255u) << 8) | (((double)p.z > 0.65 ? 0u : 255u) << 16) |
+                     (((double)p.w > 0.65 ? 0u : 255u) << 24);
+  const uint32_t o = out[i];
+  out[i] = (v & 0xE0E0E0E0u) | ((o >> 3) & 0x1F1F1F1Fu);
+}
+
 // DeepLab argmax over nch interleaved classes: the 256 pixels of a workgroup are one contiguous block of 256*nch floats —
 // read it with coalesced 4-byte loads into LDS, then every lane scans its own nch values (stride nch, conflict-free for odd
 // nch).  A lane reading its classes straight from HBM touches 64 cache lines per load instruction.
@@ -671,6 +682,8 @@ hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, i
   int type = model_type == 1 ? 1 : (model_type == 3 ? 3 : 2);
   if (type == 3 && nch == 2 && (total & 3) == 0 && ((((uintptr_t)logits) & 15) | (((uintptr_t)ofinal) & 3)) == 0)
     decode_meet4_k<<<blocks_for(total / 4), kThreads, 0, s>>>(reinterpret_cast<const float4*>(logits), reinterpret_cast<uint32_t*>(ofinal), total / 4);
+  else if (type == 2 && nch == 1 && (total & 3) == 0 && ((((uintptr_t)logits) & 15) | (((uintptr_t)ofinal) & 3)) == 0)
+    decode_thresh4_k<<<blocks_for(total / 4), kThreads, 0, s>>>(reinterpret_cast<const float4*>(logits), reinterpret_cast<uint32_t*>(ofinal), total / 4);
   else if (type == 1 && nch <= kArgmaxMaxCh) decode_argmax_k<<<blocks_for(total), kThreads, 0, s>>>(logits, ofinal, total, nch);
   else decode_k<<<blocks_for(total), kThreads, 0, s>>>(type, logits, ofinal, total, nch);
   return hipGetLastError();
