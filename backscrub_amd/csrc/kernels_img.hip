@@ -567,22 +567,26 @@ __global__ __launch_bounds__(kThreads) void blend1_k(const uint8_t* __restrict__
   for (int c = 0; c < 3; c++) o[c] = (uint8_t)((a[c] * m + b[c] * (255 - m)) / 255);
 }
 
-// composite outside the ROI = background: word copies of the row segments left / right of the ROI and of the rows above / below it
-// (W and roi.x, roi.w multiples of 4 → every segment boundary is word aligned)
-constexpr int kOutsideRows = 16;     // rows per workgroup: keeps the launch at a few thousand workgroups per frame batch
+// composite outside the ROI = background: word copies of the rows above / below the ROI and of the row segments left / right of
+// it (W and roi.x, roi.w multiples of 4 → every segment boundary is word aligned).  Lane = one outside word of frame blockIdx.y.
 __global__ __launch_bounds__(kThreads) void outside_roi_copy_k(const uint8_t* __restrict__ bg, long bg_stride, uint8_t* __restrict__ out, int W, int H, Rect4 roi) {
-  const int wq = blockIdx.x * kThreads + threadIdx.x;                           // word index inside the row
-  if (wq >= W * 3 / 4) return;
-  const bool col_inside = wq >= roi.x * 3 / 4 && wq < (roi.x + roi.w) * 3 / 4;
-  const long n = blockIdx.z;
-  const uint8_t* src = bg + (bg_stride ? n * bg_stride : 0);
-  uint8_t* dst = out + n * (long)W * H * 3;
-  const int y0 = blockIdx.y * kOutsideRows, y1 = min(y0 + kOutsideRows, H);
-  for (int y = y0; y < y1; y++) {
-    if (col_inside && y >= roi.y && y < roi.y + roi.h) continue;
-    const long off = ((long)y * W) * 3 + (long)wq * 4;
-    *reinterpret_cast<uint32_t*>(dst + off) = *reinterpret_cast<const uint32_t*>(src + off);
+  const unsigned wpr = (unsigned)W * 3 / 4;                                   // words per row
+  const unsigned lw = (unsigned)roi.x * 3 / 4, rw0 = (unsigned)(roi.x + roi.w) * 3 / 4, sw = lw + (wpr - rw0);   // strip words per ROI row
+  const unsigned full = (unsigned)(H - roi.h) * wpr;                           // words of the rows entirely outside
+  const unsigned i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= full + (unsigned)roi.h * sw) return;
+  unsigned row, word;
+  if (i < full) {
+    const unsigned r = i / wpr;
+    word = i - r * wpr;
+    row = r < (unsigned)roi.y ? r : r + (unsigned)roi.h;
+  } else {
+    const unsigned j = i - full, r = j / sw, k = j - r * sw;
+    row = (unsigned)roi.y + r;
+    word = k < lw ? k : rw0 + (k - lw);
   }
+  const long n = blockIdx.y, off = ((long)row * W) * 3 + (long)word * 4;
+  *reinterpret_cast<uint32_t*>(out + n * (long)W * H * 3 + off) = *reinterpret_cast<const uint32_t*>(bg + (bg_stride ? n * bg_stride : 0) + off);
 }
 
 // ---- generic BGR resize -------------------------------------------------------------------------
@@ -725,7 +729,8 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   // outside the ROI the persistent mask is 255 forever (libbackscrub.cc:248-249), i.e. the composite there IS the background
   // ((a*255 + b*0)/255 == a): those strips are copied, the ROI is composited by the mask tiles
   if (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H)
-    outside_roi_copy_k<<<dim3(blocks_for((long)W * 3 / 4), (H + kOutsideRows - 1) / kOutsideRows, n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H, roi);
+    outside_roi_copy_k<<<dim3(blocks_for((long)(H - roi.h) * (W * 3 / 4) + (long)roi.h * ((W - roi.w) * 3 / 4)), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H,
+                                                                                                                                 roi);
   dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
   if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
   else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
