@@ -5,13 +5,15 @@
 // and bench.py's `cpu_baseline` leg may load it.  The product (libbsx.so) never links,
 // loads or calls anything in oracle/.
 //
-// PARITY UNPINNED: the reference (/root/reference) ships no tests, golden vectors or
-// fixtures for this path, and its arithmetic lives in two dependencies that are absent
-// from the checkout (TensorFlow-Lite v2.8.0, git submodule `tensorflow` — empty dir,
-// .gitmodules:1-4; and the system OpenCV, 4.2.0 per README.md:63).  This file restates
-// their *published* algorithms (TFLite reference kernels, OpenCV imgproc 8-bit paths)
-// and the in-tree code it can follow line by line; what pins it instead is listed in
-// DESIGN.md §Oracle (PyTorch cross-checks, exhaustive integer identities).
+// PARITY PINNING: every piece of this path whose source IS in the reference tree is pinned to the
+// reference's OWN OBJECT CODE — oracle/_ref/libbs_ref.so compiles lib/libbackscrub.cc, lib/transpose_conv_bias.cc
+// and app/deepseg.cc:87-134 unmodified (oracle/Makefile `ref-lib`) and tests/test_ref_pin.py compares them with the
+// functions below bit for bit (glue + geometry + state, decode + IIR, Convolution2DTransposeBias, alpha_blend, YUYV
+// packing).  PARITY UNPINNED for the rest: the reference ships no tests, golden vectors or fixtures, and the remaining
+// arithmetic lives in two dependencies that are absent from the checkout (TensorFlow-Lite v2.8.0, git submodule
+// `tensorflow` — empty dir, .gitmodules:1-4; and the system OpenCV, 4.2.0 per README.md:63).  Sections 2 and 3 of this
+// file restate their *published* algorithms (TFLite reference kernels, OpenCV imgproc 8-bit paths); what pins those
+// is listed in DESIGN.md §2 (PyTorch cross-checks, exhaustive integer identities, the photo fixture).
 // ***************************************************************************************
 //
 // Every function cites the reference file:line (into /root/reference) it follows.
@@ -421,6 +423,13 @@ static void op_tconv_bias(const OTensor& x, const OTensor& w, const OTensor& b, 
   }
 }
 
+// Optional hook for CUSTOM ops: when set (only by oracle/ref_shim, which routes Convolution2DTransposeBias through the
+// reference's OWN compiled Prepare/Eval, lib/transpose_conv_bias.cc:118-256), it replaces the restatement above.
+// y_out points at hook-owned storage that stays valid until the next call.
+typedef int (*bso_custom_fn)(const char* name, const unsigned char* opts, int n_opts, const float* x, const int* xs4, const float* w,
+                             const int* ws4, const float* b, int nb, float** y_out, int* ys4);
+static bso_custom_fn g_custom_hook = nullptr;
+
 static bool run_op(OModel& m, OOp& op) {
   auto T = [&](int i) -> OTensor& { return m.t[i]; };
   auto opt = [&](size_t k) -> const OTensor* { return (k < op.in.size() && op.in[k] >= 0) ? &m.t[op.in[k]] : nullptr; };
@@ -436,7 +445,18 @@ static bool run_op(OModel& m, OOp& op) {
     case RELU: case RELU6: case HARD_SWISH: case LOGISTIC: op_unary(T(op.in[0]), y, op.code); return true;
     case CONCATENATION: { std::vector<const OTensor*> xs; for (int i : op.in) xs.push_back(&T(i)); op_concat(xs, y, op.axis); return true; }
     case RESIZE_BILINEAR: { const OTensor& sz = T(op.in[1]); if (sz.i.size() < 2) return false; op_resize_bilinear(T(op.in[0]), sz.i[0], sz.i[1], y, op); return true; }
-    case CUSTOM: if (op.custom == "Convolution2DTransposeBias") { op_tconv_bias(T(op.in[0]), T(op.in[1]), T(op.in[2]), y, op); return true; } return false;
+    case CUSTOM:
+      if (g_custom_hook && op.in.size() >= 3) {
+        const OTensor& x = T(op.in[0]); const OTensor& w = T(op.in[1]); const OTensor& b = T(op.in[2]);
+        if (x.shape.size() != 4 || w.shape.size() != 4) return false;
+        float* yp = nullptr; int ys[4] = {0, 0, 0, 0};
+        if (g_custom_hook(op.custom.c_str(), op.custom_opts.data(), (int)op.custom_opts.size(), x.f.data(), x.shape.data(), w.f.data(), w.shape.data(),
+                          b.f.data(), (int)b.f.size(), &yp, ys) != 0 || !yp) return false;
+        y.shape.assign(ys, ys + 4); y.f.assign(yp, yp + y.count());
+        return true;
+      }
+      if (op.custom == "Convolution2DTransposeBias") { op_tconv_bias(T(op.in[0]), T(op.in[1]), T(op.in[2]), y, op); return true; }
+      return false;
     default: return false;
   }
 }
@@ -605,18 +625,23 @@ static void alpha_blend(const uint8_t* a, const uint8_t* b, const uint8_t* m, ui
 // 14-bit fixed point, Y = (R*4899 + G*9617 + B*1868 + 8192)>>14; U = ((B-Y)*8061 + 128<<14 + 8192)>>14;
 // V = ((R-Y)*14369 + ...)>>14, saturated.  Then 4:2:2 packing in byte order Y0,V,Y1,U
 // with (c0+c1)/2 chroma (deepseg.cc:98-103).
-static void bgr_to_yuyv(const uint8_t* in, int w, int h, uint8_t* out) {
+// cv::cvtColor(COLOR_RGB2YUV) on 8-bit 3-channel pixels: channel 0 is taken as R (interleaved Y,U,V out)
+static void rgb2yuv_u8(const uint8_t* in, size_t total, uint8_t* yuv) {
   const int shift = 14, half = 1 << (shift - 1), delta = 128 << shift;
   auto sat = [](int v) { return (uint8_t)std::min(std::max(v, 0), 255); };
-  size_t total = (size_t)w * h;
-  std::vector<uint8_t> Y(total), U(total), V(total);
   for (size_t i = 0; i < total; i++) {
-    int R = in[3 * i], G = in[3 * i + 1], B = in[3 * i + 2];  // RGB2YUV on BGR-ordered bytes
+    int R = in[3 * i], G = in[3 * i + 1], B = in[3 * i + 2];
     int yv = (R * 4899 + G * 9617 + B * 1868 + half) >> shift;
     int u = ((B - yv) * 8061 + delta + half) >> shift;
     int v = ((R - yv) * 14369 + delta + half) >> shift;
-    Y[i] = sat(yv); U[i] = sat(u); V[i] = sat(v);
+    yuv[3 * i] = sat(yv); yuv[3 * i + 1] = sat(u); yuv[3 * i + 2] = sat(v);
   }
+}
+static void bgr_to_yuyv(const uint8_t* in, int w, int h, uint8_t* out) {
+  size_t total = (size_t)w * h;
+  std::vector<uint8_t> yuv(3 * total), Y(total), U(total), V(total);
+  rgb2yuv_u8(in, total, yuv.data());                            // RGB2YUV on BGR-ordered bytes (deepseg.cc:89)
+  for (size_t i = 0; i < total; i++) { Y[i] = yuv[3 * i]; U[i] = yuv[3 * i + 1]; V[i] = yuv[3 * i + 2]; }   // cv::split (:91)
   for (size_t i = 0; i + 1 < total; i += 2) {
     uint8_t u = (uint8_t)(((int)U[i] + (int)U[i + 1]) / 2), v = (uint8_t)(((int)V[i] + (int)V[i + 1]) / 2);
     out[2 * i] = Y[i]; out[2 * i + 1] = v; out[2 * i + 2] = Y[i + 1]; out[2 * i + 3] = u;
@@ -754,7 +779,7 @@ static bool ctx_process(OCtx& c, const uint8_t* frame, uint8_t* mask_out) {
 // =======================================================================================
 extern "C" {
 
-const char* bso_version(void) { return "bs_oracle 1 (CPU restatement; parity unpinned)"; }
+const char* bso_version(void) { return "bs_oracle 2 (CPU restatement; in-tree reference code pinned by oracle/_ref, OpenCV/TFLite semantics unpinned)"; }
 
 void* bso_model_load(const char* path) {
   OModel* m = new OModel;
@@ -801,6 +826,21 @@ void bso_bilateral_c3(const uint8_t* src, int w, int h, uint8_t* dst, int d, dou
 void bso_blur5_u8(const uint8_t* src, int w, int h, long sstride, uint8_t* dst, long dstride) { blur5_u8(src, w, h, (size_t)sstride, dst, (size_t)dstride); }
 void bso_alpha_blend(const uint8_t* bg, const uint8_t* fr, const uint8_t* m, uint8_t* out, long npix) { alpha_blend(bg, fr, m, out, (size_t)npix); }
 void bso_bgr_to_yuyv(const uint8_t* in, int w, int h, uint8_t* out) { bgr_to_yuyv(in, w, h, out); }
+void bso_rgb2yuv_u8(const uint8_t* in, long npix, uint8_t* yuv) { rgb2yuv_u8(in, (size_t)npix, yuv); }
+void bso_set_custom_op_hook(bso_custom_fn fn) { g_custom_hook = fn; }
+// the Convolution2DTransposeBias restatement on its own (custom options = padding, stride_w, stride_h); y == NULL queries the shape
+int bso_tconv_bias(const float* x, const int* xs4, const float* w, const int* ws4, const float* b, int padding, int stride_w, int stride_h, float* y, int* ys4) {
+  OTensor tx, tw, tb, ty; OOp op;
+  tx.shape.assign(xs4, xs4 + 4); tx.f.assign(x, x + tx.count());
+  tw.shape.assign(ws4, ws4 + 4); tw.f.assign(w, w + tw.count());
+  tb.shape = {ws4[0]}; tb.f.assign(b, b + ws4[0]);
+  const int32_t v[3] = {padding, stride_w, stride_h};
+  op.custom_opts.assign((const uint8_t*)v, (const uint8_t*)v + 12);
+  op_tconv_bias(tx, tw, tb, ty, op);
+  for (int k = 0; k < 4; k++) ys4[k] = ty.shape[k];
+  if (y) memcpy(y, ty.f.data(), ty.f.size() * sizeof(float));
+  return 0;
+}
 void bso_yuyv_to_bgr(const uint8_t* in, int w, int h, uint8_t* out) { yuyv_to_bgr(in, w, h, out); }
 void bso_decode_iir(int type, const float* t, long npix, int nch, uint8_t* out) { decode_iir(type, t, (size_t)npix, nch, out); }
 void bso_convert_f32(const uint8_t* in, long n, float scale, float off, float* out) { for (long i = 0; i < n; i++) out[i] = (float)in[i] * scale + off; }

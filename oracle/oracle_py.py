@@ -17,7 +17,7 @@ _f32p = C.POINTER(C.c_float)
 
 
 def build(quiet=True):
-    subprocess.check_call(["make", "-C", _HERE, "libbs_oracle.so", "libbs_oracle_fast.so", "ref-models"],
+    subprocess.check_call(["make", "-C", _HERE, "libbs_oracle.so", "libbs_oracle_fast.so", "ref-models", "ref-lib"],
                           stdout=subprocess.DEVNULL if quiet else None)
 
 
@@ -45,6 +45,7 @@ def _load(name):
     lib.bso_yuyv_to_bgr.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
     lib.bso_decode_iir.argtypes = [C.c_int, _f32p, C.c_long, C.c_int, _u8p]
     lib.bso_convert_f32.argtypes = [_u8p, C.c_long, C.c_float, C.c_float, _f32p]
+    lib.bso_tconv_bias.argtypes = [_f32p, C.POINTER(C.c_int), _f32p, C.POINTER(C.c_int), _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int)]
     lib.bso_ctx_new.restype = C.c_void_p
     lib.bso_ctx_new.argtypes = [C.c_char_p, C.c_int, C.c_int]
     lib.bso_ctx_delete.argtypes = [C.c_void_p]
@@ -138,6 +139,16 @@ def yuyv_to_bgr(img) -> np.ndarray:
     out = np.zeros((img.shape[0], img.shape[1], 3), np.uint8)
     lib().bso_yuyv_to_bgr(_u8(img), img.shape[1], img.shape[0], _u8(out))
     return out
+
+
+def tconv_bias(x, w, b, padding=1, stride=(2, 2)) -> np.ndarray:
+    """Convolution2DTransposeBias restatement: x [1,H,W,Ci], w [Co,kh,kw,Ci], b [Co] → [1,OH,OW,Co]."""
+    x, w, b = (np.ascontiguousarray(a, np.float32) for a in (x, w, b))
+    xs, ws, ys = (C.c_int * 4)(*x.shape), (C.c_int * 4)(*w.shape), (C.c_int * 4)()
+    lib().bso_tconv_bias(_f32(x), xs, _f32(w), ws, _f32(b), padding, stride[0], stride[1], None, ys)
+    y = np.empty(tuple(ys), np.float32)
+    lib().bso_tconv_bias(_f32(x), xs, _f32(w), ws, _f32(b), padding, stride[0], stride[1], _f32(y), ys)
+    return y
 
 
 def decode_iir(modeltype: int, logits: np.ndarray, ofinal: np.ndarray) -> np.ndarray:
