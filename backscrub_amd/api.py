@@ -219,6 +219,10 @@ class MaskGen:
             frame = np.ascontiguousarray(frame)
         if mask_out is None:
             mask_out = np.empty((self.height, self.width), np.uint8)
+        elif (not isinstance(mask_out, np.ndarray) or mask_out.dtype != np.uint8 or mask_out.shape != (self.height, self.width)
+              or mask_out.strides[1] != 1 or mask_out.strides[0] < self.width or not mask_out.flags.writeable):
+            # the C side writes height rows of width bytes: anything else would scribble over the host heap
+            raise BsxError("mask_out must be a writable uint8 [%d,%d] array with unit inner stride" % (self.height, self.width))
         _check(lib().bsx_process_host(self.h, stream_idx, frame.ctypes.data, frame.strides[0], mask_out.ctypes.data, mask_out.strides[0]),
                self.h, "bsx_process_host")
         return mask_out

@@ -13,6 +13,7 @@
 // order prep, infer, mask on the calling thread (:303,311,363).  Added check: a frame whose size or
 // type differs from the geometry given to new() returns false instead of throwing cv::Exception.
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/bs_maskgen.h"

@@ -107,6 +107,7 @@ struct bsx_ctx {
   DevResizeTab tab_down, tab_up;
   std::map<std::pair<std::pair<int, int>, std::pair<int, int>>, DevResizeTab> bg_tabs;
   std::string last_error, plan_text;
+  bool no_mask_blend_fusion = false;   // BSX_NO_MASK_BLEND_FUSION, read once at bsx_new (no getenv on the per-step path)
 
   // stream-0 view of a graph tensor (network input/output have dedicated buffers; intermediates are batch-major in
   // the per-launch path and frame-major — frame 0 first — in the per-frame program)
@@ -118,6 +119,17 @@ struct bsx_ctx {
 };
 
 namespace {
+
+// HIP's current device is per THREAD and defaults to 0: the reference application creates the context on its main thread
+// (app/deepseg.cc:246) and calls bs_maskgen_process on a worker thread (:203,258), so every entry point that touches the
+// GPU switches to the context's device for its duration and restores the caller's device afterwards.
+struct DeviceGuard {
+  int prev = -1, dev;
+  explicit DeviceGuard(int d) : dev(d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+  ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 void report(bsx_ctx* c, bsx_debug_fn fn, void* user, const char* fmt, ...) {
   char buf[1024];
@@ -165,7 +177,6 @@ int model_type_from_name(const std::string& n) {  // lib/libbackscrub.cc:116-130
 }
 
 int init_device_state(bsx_ctx* c) {
-  BSX_HIP(c, hipSetDevice(c->device));
   BSX_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   const size_t N = (size_t)c->n_streams;
   BSX_HIP(c, hipMalloc(&c->d_arena, c->plan.arena_floats_per_stream * N * sizeof(float)));
@@ -235,13 +246,26 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s) {
   for (const Step& st : c->plan.steps) BSX_HIP(c, launch_step(st, c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s));
   return BSX_OK;
 }
-int run_decode(bsx_ctx* c, int n, hipStream_t s) {
-  BSX_HIP(c, launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
+// `slot` = first state slot (stream index) of the batch: frame i uses ofinal / mask slot `slot + i`
+int run_decode(bsx_ctx* c, int n, hipStream_t s, int slot = 0) {
+  BSX_HIP(c, launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal + (size_t)slot * c->outW * c->outH, c->outW * c->outH, c->outC, n, s));
   return BSX_OK;
 }
-int run_mask(bsx_ctx* c, int n, hipStream_t s) {
-  BSX_HIP(c, launch_mask_upscale_blur(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, n, s));
+int run_mask(bsx_ctx* c, int n, hipStream_t s, int slot = 0) {
+  BSX_HIP(c, launch_mask_upscale_blur(c->d_ofinal + (size_t)slot * c->outW * c->outH, c->outW, c->outH, c->in_roi, c->tab_up.tab,
+                                      c->d_masks + (size_t)slot * c->width * c->height, c->width, c->height, c->roi, n, s));
   return BSX_OK;
+}
+// bs_maskgen_process for n frames whose per-stream state lives in slots [slot, slot + n)
+int process_impl(bsx_ctx* c, const uint8_t* d_frames, int n, int slot, hipStream_t s) {
+  int rc;
+  if ((rc = run_prep(c, d_frames, n, s))) return rc;
+  if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }   // :303
+  if ((rc = run_infer(c, n, s))) return rc;
+  if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); } // :311
+  if ((rc = run_decode(c, n, s, slot))) return rc;
+  if (c->onmask) { BSX_HIP(c, hipStreamSynchronize(s)); c->onmask(c->caller_ctx); }   // :363
+  return run_mask(c, n, s, slot);
 }
 
 }  // namespace
@@ -262,6 +286,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
                  bsx_stage_fn onprep, bsx_stage_fn oninfer, bsx_stage_fn onmask, void* caller_ctx) {
   if (!model_path || !width || !height || n_streams <= 0 || n_streams > 65535) {   // grid.z of the mask kernel carries the stream index
     report(nullptr, ondebug, caller_ctx, "error: bad arguments to bsx_new\n"); return nullptr; }
+  try {   // nothing may throw across the C ABI (std::bad_alloc / length_error from a hostile model file included)
   std::unique_ptr<bsx_ctx> c(new bsx_ctx);
   c->ondebug = ondebug; c->onprep = onprep; c->oninfer = oninfer; c->onmask = onmask; c->caller_ctx = caller_ctx;
   c->threads = threads; c->width = (int)width; c->height = (int)height; c->n_streams = n_streams; c->device = device;
@@ -302,6 +327,11 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     report(nullptr, ondebug, caller_ctx, "error: frame/model geometry yields an empty or out-of-range ROI\n");
     return nullptr;
   }
+  c->no_mask_blend_fusion = getenv("BSX_NO_MASK_BLEND_FUSION") != nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    report(nullptr, ondebug, caller_ctx, "error: HIP device %d not available (%d visible)\n", device, ndev); return nullptr; }
+  DeviceGuard guard(device);    // the caller's current device is restored on return
   if (init_device_state(c.get()) != BSX_OK) { bsx_ctx* raw = c.release(); bsx_delete(raw); return nullptr; }
   c->plan_text = c->plan.describe();
   {
@@ -313,11 +343,18 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     for (size_t i = 0; i < c->plan.program_labels.size(); i++) { c->plan_text += "P" + std::to_string(i) + " " + c->plan.program_labels[i] + "\n"; }
   }
   return c.release();
+  } catch (const std::exception& e) {
+    report(nullptr, ondebug, caller_ctx, "error: %s while creating the context\n", e.what());
+    return nullptr;
+  } catch (...) {
+    report(nullptr, ondebug, caller_ctx, "error: unknown exception while creating the context\n");
+    return nullptr;
+  }
 }
 
 void bsx_delete(bsx_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceGuard guard(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -342,6 +379,7 @@ int bsx_get_info(const bsx_ctx* c, bsx_info* o) {
 
 int bsx_reset(bsx_ctx* c, void* stream) {
   if (!c) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   const size_t N = (size_t)c->n_streams;
   BSX_HIP(c, hipMemsetAsync(c->d_ofinal, 0, N * c->outW * c->outH, s));
@@ -353,15 +391,10 @@ uint8_t* bsx_masks_device(bsx_ctx* c) { return c ? c->d_masks : nullptr; }
 
 int bsx_process_batch(bsx_ctx* c, const uint8_t* d_frames, int n, uint8_t* d_masks, void* stream) {
   if (!c || !d_frames || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   int rc;
-  if ((rc = run_prep(c, d_frames, n, s))) return rc;
-  if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }   // :303
-  if ((rc = run_infer(c, n, s))) return rc;
-  if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); } // :311
-  if ((rc = run_decode(c, n, s))) return rc;
-  if (c->onmask) { BSX_HIP(c, hipStreamSynchronize(s)); c->onmask(c->caller_ctx); }   // :363
-  if ((rc = run_mask(c, n, s))) return rc;
+  if ((rc = process_impl(c, d_frames, n, 0, s))) return rc;
   if (d_masks) BSX_HIP(c, hipMemcpyAsync(d_masks, c->d_masks, (size_t)n * c->width * c->height, hipMemcpyDeviceToDevice, s));
   return BSX_OK;
 }
@@ -369,18 +402,15 @@ int bsx_process_batch(bsx_ctx* c, const uint8_t* d_frames, int n, uint8_t* d_mas
 int bsx_process_host(bsx_ctx* c, int stream_idx, const uint8_t* h_bgr, size_t bgr_stride, uint8_t* h_mask, size_t mask_stride) {
   if (!c || !h_bgr || !h_mask || stream_idx < 0 || stream_idx >= c->n_streams) return BSX_EINVAL;
   if (bgr_stride < (size_t)c->width * 3 || mask_stride < (size_t)c->width) return BSX_ESIZE;
+  DeviceGuard guard(c->device);
   hipStream_t s = c->own_stream;
   const size_t fbytes = (size_t)c->width * c->height * 3;
   if (!c->d_host_frame) BSX_HIP(c, hipMalloc(&c->d_host_frame, fbytes));
   BSX_HIP(c, hipMemcpy2DAsync(c->d_host_frame, (size_t)c->width * 3, h_bgr, bgr_stride, (size_t)c->width * 3, c->height, hipMemcpyHostToDevice, s));
-  // run the single stream in its own state slot: temporarily view slot `stream_idx` as slot 0
-  uint8_t* ofinal0 = c->d_ofinal; uint8_t* masks0 = c->d_masks;
-  c->d_ofinal += (size_t)stream_idx * c->outW * c->outH;
-  c->d_masks += (size_t)stream_idx * c->width * c->height;
-  int rc = bsx_process_batch(c, c->d_host_frame, 1, nullptr, s);
-  uint8_t* my_mask = c->d_masks;
-  c->d_ofinal = ofinal0; c->d_masks = masks0;
+  // the single frame runs against the temporal state of slot `stream_idx` (the context itself is never modified)
+  int rc = process_impl(c, c->d_host_frame, 1, stream_idx, s);
   if (rc) return rc;
+  const uint8_t* my_mask = c->d_masks + (size_t)stream_idx * c->width * c->height;
   BSX_HIP(c, hipMemcpy2DAsync(h_mask, mask_stride, my_mask, (size_t)c->width, (size_t)c->width, c->height, hipMemcpyDeviceToHost, s));
   BSX_HIP(c, hipStreamSynchronize(s));
   return BSX_OK;
@@ -390,13 +420,15 @@ int bsx_composite_batch(bsx_ctx* c, const uint8_t* d_bg, size_t bg_frame_stride,
                         int n, void* stream) {
   if (!c || !d_bg || !d_frames || !d_out || n <= 0) return BSX_EINVAL;
   if (!d_masks) { if (n > c->n_streams) return BSX_EINVAL; d_masks = c->d_masks; }
+  DeviceGuard guard(c->device);
   BSX_HIP(c, launch_blend(d_bg, bg_frame_stride, d_frames, d_masks, d_out, (size_t)c->width * c->height, n, pick(c, stream)));
   return BSX_OK;
 }
 
 int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream) {
   if (!c || !d_frames || !d_bg || !d_out || n <= 0 || n > c->n_streams) return BSX_EINVAL;
-  const bool fuse = !c->onmask && getenv("BSX_NO_MASK_BLEND_FUSION") == nullptr &&
+  DeviceGuard guard(c->device);
+  const bool fuse = !c->onmask && !c->no_mask_blend_fusion &&
                     mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, d_out);
   if (!fuse) {
     int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
@@ -418,6 +450,7 @@ int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, siz
 
 int bsx_resize_bgr(bsx_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream) {
   if (!c || !d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || n <= 0) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   auto key = std::make_pair(std::make_pair(sw, sh), std::make_pair(dw, dh));
   auto it = c->bg_tabs.find(key);
   if (it == c->bg_tabs.end()) {
@@ -432,18 +465,21 @@ int bsx_resize_bgr(bsx_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_
 
 int bsx_flip_bgr(bsx_ctx* c, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int code, void* stream) {
   if (!c || !d_src || !d_dst || d_src == d_dst || w <= 0 || h <= 0 || n <= 0) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   BSX_HIP(c, launch_flip_bgr(d_src, d_dst, w, h, code, n, pick(c, stream)));
   return BSX_OK;
 }
 
 int bsx_bgr_to_yuyv(bsx_ctx* c, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, int h, int n, void* stream) {
   if (!c || !d_bgr || !d_yuyv || w <= 0 || h <= 0 || n <= 0) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   BSX_HIP(c, launch_bgr_to_yuyv(d_bgr, d_yuyv, w, h, n, pick(c, stream)));
   return BSX_OK;
 }
 
 int bsx_yuyv_to_bgr(bsx_ctx* c, const uint8_t* d_yuyv, uint8_t* d_bgr, int w, int h, int n, void* stream) {
   if (!c || !d_yuyv || !d_bgr || w <= 0 || h <= 0 || n <= 0 || (((long)w * h) & 1)) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   BSX_HIP(c, launch_yuyv_to_bgr(d_yuyv, d_bgr, w, h, n, pick(c, stream)));
   return BSX_OK;
 }
@@ -463,6 +499,7 @@ int bsx_debug_buffer(bsx_ctx* c, int which, void** d_ptr, size_t* bytes) {
 
 int bsx_debug_run_stage(bsx_ctx* c, int stage, const uint8_t* d_frames, int n, void* stream) {
   if (!c || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   switch (stage) {
     case 0: if (!d_frames) return BSX_EINVAL; return run_prep(c, d_frames, n, s);
@@ -476,9 +513,10 @@ int bsx_debug_run_stage(bsx_ctx* c, int stage, const uint8_t* d_frames, int n, v
 int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_stride, uint8_t* d_out, int n, int iters,
                       bsx_launch_stat* out, int cap, void* stream) {
   if (!c || !d_frames || !d_bg || !d_out || !out || n <= 0 || n > c->n_streams || iters <= 0) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   const int n_net = c->use_program ? 1 : (int)c->plan.steps.size();
-  const bool fuse_tail = !c->onmask && getenv("BSX_NO_MASK_BLEND_FUSION") == nullptr &&
+  const bool fuse_tail = !c->onmask && !c->no_mask_blend_fusion &&
                          mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
   const int L = 2 + n_net + (fuse_tail ? 2 : 3) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
   if (cap < L) return BSX_EINVAL;
@@ -556,6 +594,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
 
 int bsx_debug_program_timeline(bsx_ctx* c, int n, unsigned long long* ticks, int cap, void* stream) {
   if (!c || !ticks || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   if (!c->use_program) return 0;
   const int L = (int)c->plan.program.size();
   if (cap < L + 1 || L + 1 > 256) return BSX_EINVAL;
@@ -573,8 +612,10 @@ int bsx_debug_program_timeline(bsx_ctx* c, int n, unsigned long long* ticks, int
 
 int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
   if (!model_path || !buf || !cap) return BSX_EINVAL;
-  Graph g; Plan p; std::string err, out;
+  std::string err, out;
   int rc = BSX_OK;
+  try {
+  Graph g; Plan p;
   if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { out = err; rc = BSX_EMODEL; }
   else {
     char head[256];
@@ -586,6 +627,8 @@ int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
     out += head;
     for (size_t i = 0; i < p.program_labels.size(); i++) out += "P" + std::to_string(i) + " " + p.program_labels[i] + "\n";
   }
+  } catch (const std::exception& e) { out = std::string("exception while reading the model: ") + e.what(); rc = BSX_EMODEL; }
+  catch (...) { out = "unknown exception while reading the model"; rc = BSX_EMODEL; }
   snprintf(buf, cap, "%s", out.c_str());
   return rc;
 }
@@ -594,6 +637,7 @@ const char* bsx_plan_describe(bsx_ctx* c) { return c ? c->plan_text.c_str() : ""
 
 long bsx_debug_tensor(bsx_ctx* c, int t, float* h_out, long cap) {
   if (!c || t < 0 || t >= (int)c->graph.tensors.size() || c->plan.tensor_off[t] < 0) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
   long n = (long)c->graph.tensors[t].elems();
   if (!h_out) return n;
   if (hipDeviceSynchronize() != hipSuccess) return BSX_EDEVICE;

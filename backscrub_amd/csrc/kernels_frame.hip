@@ -1082,7 +1082,10 @@ __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* 
 }  // namespace
 
 hipError_t frame_program_prepare(int lds_floats) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(frame_program_k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * (int)sizeof(float));
+  // The attribute belongs to the process-global kernel, not to a context: always raise it to the full 160 KiB so that a
+  // context with a small program can never lower the limit under a live context with a larger one.
+  if (lds_floats > kLdsTotalFloats) return hipErrorInvalidValue;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(frame_program_k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotalFloats * (int)sizeof(float));
 }
 
 hipError_t launch_frame_program(const MicroOp* d_ops, int n_ops, int lds_floats, float* arena, long per_frame_floats, float* net_in, float* net_out,

@@ -90,7 +90,9 @@ float f16_to_f32(uint16_t h) {
   return f;
 }
 
-int map_fused_act(int a) { return a == 1 ? kActRelu : a == 3 ? kActRelu6 : kActNone; }
+// ActivationFunctionType: 0 NONE, 1 RELU, 3 RELU6 are implemented; RELU_N1_TO_1 (2), TANH (4), SIGN_BIT (5) are not —
+// -1 makes the load fail instead of silently computing the wrong network.
+int map_fused_act(int a) { return a == 0 ? kActNone : a == 1 ? kActRelu : a == 3 ? kActRelu6 : -1; }
 
 }  // namespace
 
@@ -113,6 +115,7 @@ bool load_tflite(const std::string& path, Graph* g, std::string* err) {
   std::vector<Code> codes;
   {
     auto v = r.vec(root, 1);
+    if (!r.in_range(v.at, 4ull * v.len)) return fail("operator-code table out of file range");
     for (uint32_t i = 0; i < v.len; i++) {
       size_t t = r.follow(v.at + 4ull * i);
       int legacy = r.field<int8_t>(t, 0, 0), full = r.field<int32_t>(t, 3, 0);
@@ -122,8 +125,12 @@ bool load_tflite(const std::string& path, Graph* g, std::string* err) {
   std::vector<Reader::Span> buffers;
   {
     auto v = r.vec(root, 4);
+    if (!r.in_range(v.at, 4ull * v.len)) return fail("buffer table out of file range");
     for (uint32_t i = 0; i < v.len; i++) buffers.push_back(r.vec(r.follow(v.at + 4ull * i), 0));
   }
+  // every flatbuffer vector element occupies at least one byte of the file: a length beyond the file size is malformed
+  // (and would otherwise turn into an unbounded resize below)
+  const size_t file_n = bytes.size();
   auto sgs = r.vec(root, 2);
   if (!sgs.len) return fail("model has no subgraph");
   size_t sg = r.follow(sgs.at);
@@ -131,6 +138,7 @@ bool load_tflite(const std::string& path, Graph* g, std::string* err) {
   // ---- tensors
   {
     auto v = r.vec(sg, 0);
+    if (!r.in_range(v.at, 4ull * v.len) || v.len > file_n) return fail("tensor table out of file range");
     g->tensors.resize(v.len);
     for (uint32_t i = 0; i < v.len; i++) {
       size_t t = r.follow(v.at + 4ull * i);
@@ -138,9 +146,12 @@ bool load_tflite(const std::string& path, Graph* g, std::string* err) {
       ti.shape = r.ints(t, 0);
       ti.name = r.text(t, 3);
       if (ti.shape.size() > 4) return fail("tensor rank > 4 unsupported");
+      uint64_t prod = 1;
       for (size_t k = 0; k < ti.shape.size(); k++) {
         if (ti.shape[k] <= 0) return fail("dynamic / empty tensor shape unsupported");
         ti.dims[4 - ti.shape.size() + k] = ti.shape[k];
+        prod *= (uint64_t)ti.shape[k];
+        if (prod > (1ull << 31)) return fail("tensor #" + std::to_string(i) + " has more than 2^31 elements");
       }
       int type = r.field<int8_t>(t, 1, 0);
       uint32_t b = r.field<uint32_t>(t, 2, 0);
@@ -178,6 +189,7 @@ bool load_tflite(const std::string& path, Graph* g, std::string* err) {
 
   // ---- operators
   auto ops = r.vec(sg, 3);
+  if (!r.in_range(ops.at, 4ull * ops.len)) return fail("operator table out of file range");
   g->n_file_ops = (int)ops.len;
   for (uint32_t i = 0; i < ops.len; i++) {
     size_t o = r.follow(ops.at + 4ull * i);
@@ -189,7 +201,7 @@ bool load_tflite(const std::string& path, Graph* g, std::string* err) {
     auto oo = r.ints(o, 2);
     if (oo.size() != 1) return fail("operator with != 1 outputs unsupported");
     n.output = oo[0];
-    for (int t : n.inputs) if (t >= (int)g->tensors.size()) return fail("operator input index out of range");
+    for (int t : n.inputs) if (t >= (int)g->tensors.size() || t < -1) return fail("operator input index out of range");
     if (n.output < 0 || n.output >= (int)g->tensors.size()) return fail("operator output index out of range");
     size_t opt = r.sub(o, 4);
     int code = codes[ci].builtin;
@@ -228,7 +240,7 @@ bool load_tflite(const std::string& path, Graph* g, std::string* err) {
         break;
       case 2:
         n.type = OpType::Concat;
-        if (opt) n.axis = r.field<int32_t>(opt, 0, 0);
+        if (opt) { n.axis = r.field<int32_t>(opt, 0, 0); n.act = map_fused_act(r.field<int8_t>(opt, 1, 0)); if (n.act != kActNone) return fail("fused activation on CONCATENATION unsupported (op #" + std::to_string(i) + ")"); }
         break;
       case 0: n.type = OpType::Add; if (opt) n.act = map_fused_act(r.field<int8_t>(opt, 0, 0)); break;
       case 18: n.type = OpType::Mul; if (opt) n.act = map_fused_act(r.field<int8_t>(opt, 0, 0)); break;
@@ -258,6 +270,22 @@ bool load_tflite(const std::string& path, Graph* g, std::string* err) {
         return fail("unsupported builtin operator code " + std::to_string(code) + " at op #" + std::to_string(i));
     }
     if (!r.ok()) return fail("malformed flatbuffer (read out of range) at op #" + std::to_string(i));
+    if (n.act < 0) return fail("unsupported fused activation at op #" + std::to_string(i));
+    if (n.stride_w < 1 || n.stride_h < 1 || n.dil_w < 1 || n.dil_h < 1 || n.depth_mult < 1 || n.tconv_stride_w < 1 || n.tconv_stride_h < 1 ||
+        n.stride_w > 4096 || n.stride_h > 4096 || n.dil_w > 4096 || n.dil_h > 4096 || n.tconv_stride_w > 4096 || n.tconv_stride_h > 4096 || n.filter_w < 0 || n.filter_h < 0)
+      return fail("operator #" + std::to_string(i) + " has a non-positive / absurd stride, dilation or filter size");
+    // -1 marks an OPTIONAL operand (a bias); the data operands every kernel dereferences must exist
+    {
+      size_t mandatory = 1;
+      switch (n.type) {
+        case OpType::Conv: case OpType::DwConv: case OpType::FullyConnected: case OpType::Add: case OpType::Mul: case OpType::ResizeBilinear: mandatory = 2; break;
+        case OpType::TransposeConvBias: mandatory = 3; break;
+        case OpType::Concat: mandatory = n.inputs.size(); break;
+        default: mandatory = 1; break;
+      }
+      if (n.inputs.size() < mandatory) return fail("operator #" + std::to_string(i) + " has too few inputs");
+      for (size_t k = 0; k < mandatory; k++) if (n.inputs[k] < 0) return fail("operator #" + std::to_string(i) + " lacks a mandatory input");
+    }
 
     // fold constant-only DEQUANTIZE (weights): the f16 payload was already widened on load
     if (n.type == OpType::Dequantize) {

@@ -306,7 +306,7 @@ def _opts_table(b: Builder, op: Op):
     if c == OPCODES["FULLY_CONNECTED"]:
         return OPT_FC, b.table([(0, "i8", o.get("act", 0)), (1, "i8", 0), (2, "bool", o.get("keep_num_dims", 0))])
     if c == OPCODES["CONCATENATION"]:
-        return OPT_CONCAT, b.table([(0, "i32", o.get("axis", 3)), (1, "i8", 0)])
+        return OPT_CONCAT, b.table([(0, "i32", o.get("axis", 3)), (1, "i8", o.get("act", 0))])
     if c == OPCODES["ADD"]:
         return OPT_ADD, b.table([(0, "i8", o.get("act", 0))])
     if c == OPCODES["MUL"]:

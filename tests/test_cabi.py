@@ -51,3 +51,20 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_py" not in txt and "bs_oracle" not in txt and "libbs_oracle" not in txt, f
+
+
+def test_process_host_rejects_a_bad_mask_out_before_reaching_c(built):
+    """The C side writes height rows of width bytes into mask_out: wrong dtype / shape / inner stride must raise here."""
+    import numpy as np
+    from backscrub_amd import api
+
+    class Fake(api.MaskGen):
+        def __init__(self):          # no context: validation happens before any library call
+            self.width, self.height, self.h = 8, 4, None
+
+    mg = Fake()
+    frame = np.zeros((4, 8, 3), np.uint8)
+    for bad in (np.zeros((4, 8), np.float32), np.zeros((4, 7), np.uint8), np.zeros((4, 16), np.uint8)[:, ::2], np.zeros((3, 8), np.uint8)):
+        with pytest.raises(api.BsxError, match="mask_out"):
+            mg.process_host(frame, 0, bad)
+    assert api.bs_maskgen_process(mg, frame, np.zeros((4, 7), np.uint8)) is False

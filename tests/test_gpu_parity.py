@@ -30,9 +30,12 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _iou_fg(a, b):
-    """IoU of the person region (mask < 128) — 1.0 when both are empty"""
+def _iou_fg(a, b, need_person=False):
+    """IoU of the person region (mask < 128) — 1.0 when both are empty, unless the caller says the oracle mask (b) must
+    contain a person (end-to-end tests on the photo fixture): an empty expectation then FAILS instead of passing vacuously."""
     fa, fb = a < 128, b < 128
+    if need_person:
+        assert fb.mean() > 0.05, "oracle mask has no person region (%.4f): the test would be vacuous" % fb.mean()
     union = np.logical_or(fa, fb).sum()
     return 1.0 if union == 0 else np.logical_and(fa, fb).sum() / union
 
@@ -280,6 +283,38 @@ def test_end_to_end_iou_and_composite(bs, oracle, key, res, real):
             # composite: <= 1 LSB except where a decision pixel flipped (bounded by the IoU bar)
             diff = np.abs(got_out[i].astype(np.int16) - want_out.astype(np.int16)).max(-1)
             assert (diff > 1).mean() <= 1e-3, "t=%d stream %d: %.5f of pixels differ by > 1 LSB" % (t, i, (diff > 1).mean())
+    for c in oc:
+        c.close()
+    mg.close()
+
+
+@pytest.mark.parametrize("key", ["deeplab", "lite", "full", "mlkit"])
+def test_end_to_end_on_the_photo_fixture(bs, oracle, key):
+    """End to end on REAL pixels with the reference's REAL weights: the two 640x480 webcam screenshots of the reference's
+    backgrounds/screenshot.jpg (tests/golden/photo_2x640x480.png).  All four networks segment the person (~24 % of the frame),
+    so the IoU here is over a real person region — in particular for DeepLab, which finds nobody in the synthetic frames."""
+    from backscrub_amd import synth
+    from tools import make_photo_fixture as P
+    path = model_path(key)
+    if "synthetic" in os.path.basename(path):
+        pytest.skip("reference model not staged on this box")
+    W, H = VGA
+    frames = P.load_frames()
+    n = frames.shape[0]
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    oc = [oracle.Ctx(path, W, H) for _ in range(n)]
+    bg = synth.background(W, H)
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    for t in range(3):
+        mg.step(_dev(frames), _dev(bg), out)
+        got_mask, got_out = mg.masks().cpu().numpy(), out.cpu().numpy()
+        for i in range(n):
+            want_mask = oc[i].process(frames[i])
+            iou = _iou_fg(got_mask[i], want_mask, need_person=(t == 2))
+            assert iou >= 0.999, "%s t=%d frame %d IoU %.5f" % (key, t, i, iou)
+            want_out = oracle.alpha_blend(bg, frames[i], want_mask)
+            diff = np.abs(got_out[i].astype(np.int16) - want_out.astype(np.int16)).max(-1)
+            assert (diff > 1).mean() <= 1e-3, "%s t=%d frame %d: %.5f of pixels differ by > 1 LSB" % (key, t, i, (diff > 1).mean())
     for c in oc:
         c.close()
     mg.close()

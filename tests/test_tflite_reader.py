@@ -90,3 +90,77 @@ def test_frame_program_lds_reservations_do_not_collide(key, real):
     assert fields["lds_check"] == "ok", line
     assert int(fields["micro-ops"]) > 0 and int(fields["lds_blocks"]) >= int(fields["lds_tensors"])
     assert int(fields["lds_floats"]) <= 160 * 256
+
+
+# ---- hostile / unsupported files: an error string, never a crash, an exception across the C ABI or a wrong network ----
+def _describe_bytes(tmp_path, data, name="segm_hostile.tflite"):
+    import ctypes
+
+    import backscrub_amd
+    p = tmp_path / name
+    p.write_bytes(bytes(data))
+    buf = ctypes.create_string_buffer(1 << 16)
+    rc = backscrub_amd.lib().bsx_model_describe(str(p).encode(), buf, len(buf))
+    return rc, buf.value.decode(errors="replace")
+
+
+def test_loader_survives_mutated_files(tmp_path):
+    """400 seeded mutations of a valid model (single bytes, 0xFFFFFFFF words = -1 indices / huge lengths, random words):
+    bsx_model_describe must return 0 or BSX_EMODEL every time."""
+    import numpy as np
+    from tools import make_synthetic_model
+    src = open(make_synthetic_model.ensure("lite"), "rb").read()
+    rng = np.random.default_rng(5)
+    seen = set()
+    for _ in range(400):
+        b = bytearray(src)
+        for _ in range(int(rng.integers(1, 4))):
+            region = int(rng.integers(0, 3))
+            pos = int(rng.integers(0, 64)) if region == 0 else int(rng.integers(len(b) - 20000, len(b))) if region == 1 else int(rng.integers(0, len(b)))
+            kind = int(rng.integers(0, 3))
+            if kind == 0 or pos + 4 > len(b):
+                b[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b[pos:pos + 4] = (0xFFFFFFFF).to_bytes(4, "little")
+            else:
+                b[pos:pos + 4] = int(rng.integers(0, 1 << 31)).to_bytes(4, "little")
+        rc, _ = _describe_bytes(tmp_path, b)
+        seen.add(rc)
+        assert rc in (0, -2)
+    assert seen == {0, -2}      # the mutations really did reach both outcomes
+
+
+def test_unsupported_fused_activation_and_missing_operands_are_rejected(tmp_path):
+    """A conv whose options carry TANH (4) / RELU_N1_TO_1 (2), a CONCATENATION with a fused activation, or an operator whose
+    mandatory data operand is -1 must fail the load with a reason — not run as a different network / read tensors[-1]."""
+    import copy
+
+    from backscrub_amd import tflite_io as T
+    from tools import make_synthetic_model
+    base = make_synthetic_model.build("deeplab")      # DeepLab keeps its activations fused in the conv options
+
+    def describe(model, name="deeplab_hostile.tflite"):
+        path = str(tmp_path / name)
+        T.save(model, path)
+        return _describe_bytes(tmp_path, open(path, "rb").read(), name)
+
+    rc, msg = describe(base)
+    assert rc == 0, msg
+    conv = next(i for i, o in enumerate(base.ops) if o.name == "CONV_2D" and o.opts.get("act", 0) in (1, 3))
+    for bad in (2, 4, 5):
+        m = copy.deepcopy(base)
+        m.ops[conv].opts["act"] = bad
+        rc, msg = describe(m)
+        assert rc == -2 and "fused activation" in msg, msg
+    cat = next(i for i, o in enumerate(base.ops) if o.name == "CONCATENATION")
+    m = copy.deepcopy(base)
+    m.ops[cat].opts["act"] = 1
+    rc, msg = describe(m)
+    assert rc == -2 and "CONCATENATION" in msg, msg
+    for victim in ("CONV_2D", "DEPTHWISE_CONV_2D", "ADD", "RESIZE_BILINEAR", "AVERAGE_POOL_2D"):
+        k = next(i for i, o in enumerate(base.ops) if o.name == victim)
+        for operand in range(2 if victim != "AVERAGE_POOL_2D" else 1):
+            m = copy.deepcopy(base)
+            m.ops[k].inputs[operand] = -1
+            rc, msg = describe(m)
+            assert rc == -2 and "mandatory input" in msg, (victim, operand, msg)
