@@ -2,26 +2,30 @@
 """bench.py — composited frames/s of the backscrub hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the whole per-frame hot path over one batch of device-resident
-synthetic camera frames: ROI resize + BGR2RGB + bilateral + normalise, the segmentation
-network, decode + temporal IIR, mask upscale + 5x5 blur, alpha blend with the background
-(`bsx_step_batch`).  Workload at N=1 = BASELINE.json configs[1]: batch of 256 640x480
-frames, segm_lite_v681 (Google Meet 160x96).  Streams are independent, so N GPUs run N
-such batches (weak scaling, no data-path collective); the only RCCL traffic is the
-all-reduce of the throughput counters.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU, RCCL);
+launched that way by someone else it just reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+A "step" is one pass of the whole per-frame hot path over one batch of device-resident synthetic camera frames: ROI
+resize + BGR2RGB + bilateral + normalise, the segmentation network, decode + temporal IIR, mask upscale + 5x5 blur, alpha
+blend with the background (`bsx_step_batch`).  `value` = BASELINE.json configs[1]: batch of 256 640x480 frames,
+segm_lite_v681 (Google Meet 160x96).  Streams are independent, so N GPUs run N such batches (weak scaling, no data-path
+collective); the only RCCL traffic is the all-reduce of the throughput counters.
 
 Rank 0 prints ONE JSON line (contract in the task statement) that additionally carries
-`roofline` (dominant kernel, hipEvent-timed per launch inside this process through
-bsx_profile_batch), `roofline_blend` (the kernel the north star names) and `cpu_baseline`
-(the CPU oracle port timed on this box's host cores — test infrastructure used only as the
-baseline leg, never in the measured path).
+  roofline / roofline_blend   dominant kernel and the blend kernel, hipEvent-timed per launch (bsx_profile_batch)
+  cpu_baseline                the CPU oracle port timed on this box's host cores (+ parity_sample: mask IoU vs the oracle)
+  configs                     (N = 1 only) the other single-GPU BASELINE configurations, measured the same way:
+                              configs[2] 256 x 1280x720 mlkit, configs[3] 1024 x 640x480 deeplab with a per-step H2D upload +
+                              GPU resize of an animated background frame, configs[4]'s per-GPU slice 1024 x 1280x720 segm_full
+  single_stream               latency of the drop-in path (bsx_process_host = what bs_maskgen_process forwards to)
+The oracle is used only in the cpu_baseline / parity legs — never in the measured path.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -30,7 +34,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-FP32_PEAK_TFLOPS = 157.3   # f32 vector/matrix peak — the network kernels compute in f32
+FP32_PEAK_TFLOPS = 157.3   # f32 vector/matrix peak
+F16_PEAK_TFLOPS = 2500.0   # dense f16 MFMA peak
+METRIC = "composited frames/sec at 640×480 (batch), 1/2/4/8 MI355X + mask IoU vs CPU ref"
+NAMES = {"lite": "segm_lite_v681.tflite", "full": "segm_full_v679.tflite",
+         "mlkit": "selfiesegmentation_mlkit-256x256-2021_01_19-v1215.f16.tflite", "deeplab": "deeplabv3_257_mv_gpu.tflite"}
+PMC_NAMES = {"frame_program": "frame_program_k", "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
+             "mask_upscale_blur": "mask_tile_k<false>", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k"}
 
 
 def parse():
@@ -42,52 +52,77 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--model", default="lite", help="lite|full|mlkit|deeplab or a .tflite path")
-    ap.add_argument("--per-stream-bg", action="store_true", help="every stream composites over its own background frame (animated backgrounds: BASELINE configs[3]) instead of one shared image")
+    ap.add_argument("--per-stream-bg", action="store_true", help="every stream composites over its own background frame instead of one shared image")
+    ap.add_argument("--bg-ring", action="store_true", help="animated background: every step uploads the next frame of a pinned 36-frame 480x360 ring (H2D) and resizes it on the GPU (grab_background), inside the timed region")
     ap.add_argument("--host-io", action="store_true", help="also measure the step with per-step H2D of the frames and D2H of the composite (pinned host buffers); reported as host_io, never as value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` / `single_stream` legs (N = 1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--profile-iters", type=int, default=5)
     ap.add_argument("--dump-launches", default="", help="write the per-launch hipEvent table to this file")
+    ap.add_argument("--selftest-dist", action="store_true", help="CPU plumbing test of the multi-process path (gloo): launch, rendezvous, counter all-reduce, JSON line — no GPU work")
     return ap.parse_args()
 
 
 def resolve_model(key):
-    names = {"lite": "segm_lite_v681.tflite", "full": "segm_full_v679.tflite",
-             "mlkit": "selfiesegmentation_mlkit-256x256-2021_01_19-v1215.f16.tflite", "deeplab": "deeplabv3_257_mv_gpu.tflite"}
-    if key in names:
-        real = os.path.join(ROOT, "oracle", "_ref", "models", names[key])
+    if key in NAMES:
+        real = os.path.join(ROOT, "oracle", "_ref", "models", NAMES[key])    # model DATA staged from the reference checkout
         if os.path.exists(real):
-            return real, names[key], "reference weights"
+            return real, NAMES[key], "reference weights"
         from tools import make_synthetic_model
-        return make_synthetic_model.ensure(key), names[key], "random-init weights, reference architecture"
+        return make_synthetic_model.ensure(key), NAMES[key], "random-init weights, reference architecture"
     return key, os.path.basename(key), "user model"
 
 
-def parity_sample(model_path, width, height, frames, bg, gpu_masks, gpu_out, k=4):
-    """The metric's "mask IoU vs CPU ref" on a small sample: the first k streams of the measured job (constant frames, so
-    both sides are in the IIR steady state) against the CPU oracle.  Part of the cpu_baseline leg — the oracle is only the checker."""
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """--gpus N without a launcher: become `torch.distributed.run` with N ranks on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# CPU legs (test infrastructure: the oracle is the checker / the baseline, never the measured path)
+# ------------------------------------------------------------------------------------------------------------------------------
+def parity_sample(model_path, width, height, frames, bg, gpu_masks, gpu_out, need_person):
+    """The metric's "mask IoU vs CPU ref" on a small sample: the first streams of the measured job (constant frames, so both
+    sides are in the IIR steady state) against the CPU oracle."""
     import numpy as np
     from oracle import oracle_py
-    ious, max_abs, differing = [], 0, 0
+    ious, max_abs, differing, fg = [], 0, 0, []
+    k = len(frames)
     for i in range(k):
         ctx = oracle_py.Ctx(model_path, width, height)
         for _ in range(4):                                   # 3 frames flush the IIR, the 4th is the steady state
             want = ctx.process(frames[i])
         ctx.close()
         fa, fb = gpu_masks[i] < 128, want < 128
+        fg.append(float(fb.mean()))
         union = np.logical_or(fa, fb).sum()
         ious.append(1.0 if union == 0 else float(np.logical_and(fa, fb).sum() / union))
         comp = oracle_py.alpha_blend(bg, frames[i], want)
         d = np.abs(comp.astype(np.int16) - gpu_out[i].astype(np.int16))
         max_abs = max(max_abs, int(d.max()))
         differing += int((d > 1).any(axis=-1).sum())
-    return {"streams": k, "mask_iou_min": round(min(ious), 6), "composite_max_abs_diff": max_abs,
-            "composite_pixels_off_by_more_than_1": differing, "pixels": k * width * height}
+    out = {"streams": k, "mask_iou_min": round(min(ious), 6), "composite_max_abs_diff": max_abs,
+           "composite_pixels_off_by_more_than_1": differing, "pixels": k * width * height,
+           "oracle_person_fraction": [round(v, 4) for v in fg]}
+    if need_person and max(fg) < 0.05:
+        out["warning"] = "oracle masks contain no person: IoU is vacuous"
+    return out
 
 
 def cpu_baseline(model_path, width, height, target_s):
     """Time the CPU oracle port (all host cores, OpenMP over streams) on a bounded sample."""
-    import numpy as np
     from backscrub_amd import synth
     from oracle import oracle_py
     cores = os.cpu_count() or 1
@@ -106,81 +141,249 @@ def cpu_baseline(model_path, width, height, target_s):
             "stage_share": {k: round(v / tot, 3) for k, v in zip(("prep", "infer", "mask", "blend"), stages)}}
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------------------------------------
+# one measured configuration
+# ------------------------------------------------------------------------------------------------------------------------------
+def load_pmc(B, W, H, model_name):
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        wl = pj.get("workload", {})
+        if (wl.get("batch"), wl.get("width"), wl.get("height"), wl.get("model")) == (B, W, H, model_name):
+            return pj["kernels"]
+    except Exception:
+        pass
+    return {}
+
+
+def roofline_of(s, pmc, mode_dtype):
+    """achieved = ALGORITHMIC bytes (or flops) of the launch / its mean hipEvent duration; traffic = HBM bytes per launch from
+    the committed rocprofv3 PMC passes (profiles/pmc_latest.json): (2*FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE doubled per
+    MI355X_MICROARCH.md §HBM (gfx950 counts 128-B reads at 64 B)."""
+    k = pmc.get(PMC_NAMES.get(s["name"], ""))
+    traffic = int((2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024) if k and "FETCH_SIZE_KiB" in k and "WRITE_SIZE_KiB" in k else None
+    peak_tf = F16_PEAK_TFLOPS if mode_dtype == "f16" else FP32_PEAK_TFLOPS
+    if s["flops"] > 0 and s["flops"] / max(s["bytes"], 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
+        a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
+        return {"kernel": s["name"], "bound": "mfma", "achieved": round(a, 3), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(a / peak_tf, 4),
+                "traffic": traffic, "avg_ms": round(s["avg_ms"], 4), "algorithmic_flops_per_launch": int(s["flops"]),
+                "algorithmic_bytes_per_launch": int(s["bytes"])}
+    return {"kernel": s["name"], "bound": "hbm", "achieved": round(s["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(s["avg_ms"], 4),
+            "algorithmic_bytes_per_launch": int(s["bytes"])}
+
+
+def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stream_bg=False, bg_ring=False, profile_iters=5, dump_launches=""):
+    """Run one configuration on this rank's GPU.  Returns a dict with the timed result and (rank 0) the per-launch profile and
+    the samples the parity leg needs."""
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        sys.exit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
-
     import backscrub_amd
     from backscrub_amd import synth
+    from backscrub_amd.dist import reduce_counters
 
-    model_path, model_name, weights = resolve_model(args.model)
-    W, H, B = args.width, args.height, args.batch
+    model_path, model_name, weights = resolve_model(model_key)
     mg = backscrub_amd.MaskGen(model_path, W, H, n_streams=B, device=local_rank)
-
-    # synthetic, device-resident inputs: each GPU owns its own B streams (seeded by global stream id)
+    # synthetic, device-resident inputs: each GPU owns its own B streams (seeded by global stream id); at 640x480 the first two
+    # streams carry the two REAL webcam frames of tests/golden/photo_2x640x480.png so that the parity sample has a real person
     distinct = 16
     host = synth.frames(distinct, W, H, t=rank)
+    photo = False
+    if (W, H) == (640, 480):
+        try:
+            from tools import make_photo_fixture
+            host[:2] = make_photo_fixture.load_frames()
+            photo = True
+        except Exception:
+            pass
     d_base = torch.from_numpy(host).cuda()
     d_frames = d_base.repeat((B + distinct - 1) // distinct, 1, 1, 1)[:B].contiguous()
-    d_bg = torch.from_numpy(synth.background(W, H, seed=1 + rank)).cuda()
-    if args.per_stream_bg:      # [B,H,W,3]: one background frame per stream, rolled so that no two streams share bytes
+    bg_host = synth.background(W, H, seed=1 + rank)
+    d_bg = torch.from_numpy(bg_host).cuda()
+    if per_stream_bg:      # [B,H,W,3]: one background frame per stream, rolled so that no two streams share bytes
         d_bg = torch.stack([torch.roll(d_bg, shifts=3 * i, dims=1) for i in range(min(B, 64))]).repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous()
     d_out = torch.empty_like(d_frames)
+    ring = None
+    if bg_ring:
+        # animated background (configs[3]): the reference decodes the video on a host thread (app/background.cc:29-104) and
+        # grab_background() resizes the current frame to the camera size EVERY frame (:186).  webm cannot be decoded in this image:
+        # the decode is emulated by a ring of 36 pre-decoded 480x360 frames (the size of backgrounds/animated.gif) in PINNED host
+        # memory; per step: H2D of the next frame + bsx_resize_bgr on the GPU, both inside the timed region.
+        ring = torch.from_numpy(np.stack([synth.background(480, 360, seed=100 + i) for i in range(36)])).pin_memory()
+        d_small = torch.empty((1, 360, 480, 3), dtype=torch.uint8, device="cuda")
+
+    def one_step(t):
+        if ring is not None:
+            d_small[0].copy_(ring[t % 36], non_blocking=True)
+            bg = mg.resize_bgr(d_small, W, H)[0]
+            mg.step(d_frames, bg, d_out)
+        else:
+            mg.step(d_frames, d_bg, d_out)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        mg.step(d_frames, d_bg, d_out)
+    for t in range(warmup):
+        one_step(t)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mg.step(d_frames, d_bg, d_out)
+    for t in range(steps):
+        one_step(warmup + t)
     barrier()
     elapsed = time.perf_counter() - t0
 
-    masks_k = mg.masks()[:4].cpu().numpy() if rank == 0 else None      # steady-state sample for the parity figure of the cpu_baseline leg
-    out_k = d_out[:4].cpu().numpy() if rank == 0 else None
-    # counters: frames (sum), elapsed (max), checksum (sum) — the only collective of the job
-    from backscrub_amd.dist import reduce_counters
     checksum = int(d_out[:, ::16, ::16].to(torch.int64).sum().item())
-    total_frames, max_elapsed, checksum_all = reduce_counters(B * args.steps, elapsed, checksum, device="cuda")
+    total_frames, max_elapsed, checksum_all = reduce_counters(B * steps, elapsed, checksum, device="cuda")   # the only collective of the job
+    res = {"model_path": model_path, "model_name": model_name, "weights": weights, "B": B, "W": W, "H": H, "photo": photo,
+           "fps": total_frames / max_elapsed, "ms_per_step": 1e3 * max_elapsed / steps, "checksum": checksum_all, "mg": mg,
+           "d_frames": d_frames, "d_bg": d_bg, "d_out": d_out, "host": host, "bg_host": bg_host}
+    if rank == 0:
+        k = 4
+        if ring is not None:                 # parity needs ONE known background: re-run the last step over the still image
+            mg.step(d_frames, d_bg, d_out)
+            torch.cuda.synchronize()
+        res["masks_k"] = mg.masks()[:k].cpu().numpy()
+        res["out_k"] = d_out[:k].cpu().numpy()
+        stats = mg.profile(d_frames, d_bg, d_out, iters=profile_iters)
+        for s in stats:
+            s["GBps"] = s["bytes"] / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
+        extra = [s for s in stats if s["name"].endswith("(standalone)")]   # measured for its roofline line, not part of the step
+        stats = [s for s in stats if not s["name"].endswith("(standalone)")]
+        if dump_launches:
+            with open(dump_launches, "w") as f:
+                f.write(mg.plan())
+                for i, s in enumerate(stats):
+                    f.write("%3d %-22s %8.2f us %9.1f GB/s %8.2f GFLOP/s\n" % (i, s["name"], s["avg_ms"] * 1e3, s["GBps"], s["flops"] / max(s["avg_ms"], 1e-9) / 1e6))
+        groups = {"prep": 0.0, "network": 0.0, "decode": 0.0, "mask": 0.0, "blend": 0.0}
+        for s in stats:
+            g = {"prep_resize": "prep", "prep_bilateral": "prep", "prep": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend",
+                 "mask_blend": "blend"}.get(s["name"], "network")
+            groups[g] += s["avg_ms"]
+        net = [s for s in stats if {"prep_resize": 1, "prep_bilateral": 1, "prep": 1, "decode_iir": 1, "mask_upscale_blur": 1, "blend": 1, "mask_blend": 1}.get(s["name"]) is None]
+        res.update(stats=stats, extra=extra, groups=groups, net_ms=sum(s["avg_ms"] for s in net), net_flops=sum(s["flops"] for s in net),
+                   net_launches=len(net))
+    return res
 
+
+def summarize(res, pmc, mode_dtype="f32"):
+    """→ the JSON fragment of one measured configuration (rank 0)."""
+    stats, extra = res["stats"], res["extra"]
+    dom = max(stats, key=lambda s: s["avg_ms"])
+    blend = dict((extra or [s for s in stats if s["name"] in ("blend", "mask_blend")])[0], name="blend")
+    out = {"value": round(res["fps"], 1), "unit": "frames/s", "ms_per_step": round(res["ms_per_step"], 4),
+           "roofline": roofline_of(dom, pmc, mode_dtype), "roofline_blend": roofline_of(blend, pmc, mode_dtype)}
+    if extra:
+        out["roofline_blend"]["note"] = "bsx_composite_batch kernel timed stand-alone; inside the step the blend is fused with mask upscale+blur (mask_blend)"
+    if res["net_launches"] > 1:              # per-launch network (DeepLab): the whole network as one roofline line as well
+        a = res["net_flops"] / (res["net_ms"] * 1e-3) / 1e12
+        out["roofline_network"] = {"kernel": "network (%d launches)" % res["net_launches"], "bound": "mfma", "achieved": round(a, 3), "peak": FP32_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(a / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_ms": round(res["net_ms"], 4)}
+    out["stage_ms"] = {k: round(v, 4) for k, v in res["groups"].items()}
+    out["stage_ms"]["sum_of_launches"] = round(sum(s["avg_ms"] for s in stats), 4)
+    out["top_launches"] = [{"name": s["name"], "ms": round(s["avg_ms"], 4), "GBps": round(s["GBps"], 1)} for s in sorted(stats, key=lambda s: -s["avg_ms"])[:8]]
+    return out
+
+
+def release(res):
+    import torch
+    res["mg"].close()
+    for k in ("mg", "d_frames", "d_bg", "d_out"):
+        res.pop(k, None)
+    torch.cuda.empty_cache()
+
+
+def single_stream_latency(model_key, W, H, calls):
+    """The drop-in path an unchanged deepseg.cc would take: bs_maskgen_process → bsx_process_host (H2D of one frame, the whole
+    mask pipeline for one stream, D2H of the mask, synchronous).  Context: the reference's README quotes ~10 FPS for DeepLab on two
+    CPU cores (README.md:177) and the Meet model card ~120 FPS inference on a laptop CPU — neither measured here."""
+    import numpy as np
+
+    import backscrub_amd
+    from backscrub_amd import synth
+    path, name, _ = resolve_model(model_key)
+    mg = backscrub_amd.MaskGen(path, W, H, n_streams=1)
+    f = synth.frame(W, H, 0)
+    mask = np.empty((H, W), np.uint8)
+    for _ in range(5):
+        mg.process_host(f, 0, mask)
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        mg.process_host(f, 0, mask)
+        ts.append(1e3 * (time.perf_counter() - t0))
+    mg.close()
+    ts.sort()
+    return {"network": name, "frame": "%dx%d" % (W, H), "calls": calls, "p50_ms": round(ts[len(ts) // 2], 3), "p99_ms": round(ts[min(len(ts) - 1, int(len(ts) * 0.99))], 3),
+            "fps_at_p50": round(1e3 / ts[len(ts) // 2], 1)}
+
+
+def selftest_dist(args):
+    """CPU plumbing check of the multi-process path (tests/test_dist_gloo.py): same launch, rendezvous and counter reduction as
+    the GPU run, gloo instead of RCCL, no GPU work."""
+    import torch.distributed as dist
+    from backscrub_amd.dist import reduce_counters, shard_streams
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    a, b = shard_streams(args.batch * world, world, rank)
+    frames, elapsed, checksum = reduce_counters((b - a) * args.steps, 1.0 + 0.25 * rank, 1000 + rank)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "selftest": "dist", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "frames": frames,
+                          "elapsed_max": elapsed, "checksum": checksum, "value": frames / elapsed, "unit": "frames/s", "scaling": "weak"}), flush=True)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                     # does not return
+    if args.selftest_dist:
+        return selftest_dist(args)
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("--gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+
+    W, H, B = args.width, args.height, args.batch
+    res = measure(args.model, W, H, B, args.steps, args.warmup, rank, world, local_rank, per_stream_bg=args.per_stream_bg, bg_ring=args.bg_ring,
+                  profile_iters=args.profile_iters, dump_launches=args.dump_launches)
     result = None
     if rank == 0:
-        fps = total_frames / max_elapsed
+        import backscrub_amd
+        mode = backscrub_amd.bs_tensorflow_version()
         result = {
-            "metric": "composited frames/sec at 640\u00d7480 (batch), 1/2/4/8 MI355X + mask IoU vs CPU ref",
-            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * max_elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (network) / u8 (image kernels)", "data": "synthetic (%s)" % weights,
+            "metric": METRIC, "value": round(res["fps"], 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (network) / u8 (image kernels)", "data": "synthetic (%s)" % res["weights"],
             "config": {"workload": "BASELINE configs[1]: batch=%d %dx%d frames, %s; 1 step = whole per-frame hot path (prep+network+decode+mask+blend), inputs resident in HBM; "
-                                   "mask IoU vs the CPU oracle: cpu_baseline.parity_sample" % (B, W, H, model_name),
-                       "streams_per_gpu": B, "frame": "%dx%d" % (W, H), "network": model_name, "sharding": "streams/%d GPUs, no data-path collective" % world,
-                       "launches_per_step": mg.info["n_steps"] + 5},
-            "checksum": checksum_all,
+                                   "mask IoU vs the CPU oracle: cpu_baseline.parity_sample" % (B, W, H, res["model_name"]),
+                       "streams_per_gpu": B, "frame": "%dx%d" % (W, H), "network": res["model_name"], "sharding": "streams/%d GPUs, no data-path collective" % world,
+                       "library": mode},
+            "checksum": res["checksum"],
         }
+        result.update({k: v for k, v in summarize(res, load_pmc(B, W, H, res["model_name"])).items() if k not in ("value", "unit", "ms_per_step")})
 
     # PCIe-inclusive variant (SURVEY §8d): every step uploads its frames and downloads its composites through pinned buffers.
     # Copies run on their own HIP streams with double-buffered device frames / composites, so the upload of step t+1 and the
     # download of step t-1 overlap the compute of step t (the per-stream mask state keeps the compute steps in order).
     if rank == 0 and args.host_io:
-        h_in = torch.from_numpy(synth.frames(B, W, H, distinct=distinct)).pin_memory()
+        from backscrub_amd import synth
+        mg, d_frames, d_bg, d_out = res["mg"], res["d_frames"], res["d_bg"], res["d_out"]
+        h_in = torch.from_numpy(synth.frames(B, W, H, distinct=16)).pin_memory()
         h_out = torch.empty_like(h_in).pin_memory()
         s_in, s_out, s_cmp = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
         bufs = [(torch.empty_like(d_frames), torch.empty_like(d_out)) for _ in range(2)]
@@ -213,75 +416,53 @@ def main():
         result["host_io"] = {"value": round(B * io_steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / io_steps, 3),
                              "note": "same step + H2D of %d frames and D2H of %d composites per step (pinned buffers, copy streams overlapped with "
                                      "compute, double-buffered); %.1f GB/s each way" % (B, B, B * W * H * 3 / (dt / io_steps) / 1e9)}
+        del bufs, h_in, h_out
 
-    # per-launch hipEvent timings (rank 0, outside the timed region; advances state like normal steps)
+    main_samples = None
     if rank == 0:
-        stats = mg.profile(d_frames, d_bg, d_out, iters=args.profile_iters)
-        for s in stats:
-            s["GBps"] = s["bytes"] / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
-        extra = [s for s in stats if s["name"].endswith("(standalone)")]   # measured for its roofline line, not part of the step
-        stats = [s for s in stats if not s["name"].endswith("(standalone)")]
-        tot_ms = sum(s["avg_ms"] for s in stats)
-        if args.dump_launches:
-            with open(args.dump_launches, "w") as f:
-                f.write(mg.plan())
-                for i, s in enumerate(stats):
-                    f.write("%3d %-22s %8.2f us %9.1f GB/s %8.2f GFLOP/s\n" % (i, s["name"], s["avg_ms"] * 1e3, s["GBps"], s["flops"] / max(s["avg_ms"], 1e-9) / 1e6))
-        groups = {"prep": 0.0, "network": 0.0, "decode": 0.0, "mask": 0.0, "blend": 0.0}
-        for s in stats:
-            k = {"prep_resize": "prep", "prep_bilateral": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend",
-                 "mask_blend": "blend"}.get(s["name"], "network")
-            groups[k] += s["avg_ms"]
-        dom = max(stats, key=lambda s: s["avg_ms"])
-        blend = (extra or [s for s in stats if s["name"] in ("blend", "mask_blend")])[0]
-        blend = dict(blend, name="blend")
+        main_samples = (res["model_path"], res["host"][:4].copy(), res["bg_host"], res["masks_k"], res["out_k"], res["photo"])
+    release(res)
 
-        pmc = {}
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            wl = pj.get("workload", {})
-            if (wl.get("batch"), wl.get("width"), wl.get("height"), wl.get("model")) == (B, W, H, model_name):
-                pmc = pj["kernels"]
-        except Exception:
-            pass
-        pmc_names = {"frame_program": "frame_program_k", "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
-                     "mask_upscale_blur": "mask_tile_k<false>", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k"}
-
-        def traffic(s):
-            """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json):
-            (2*FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 counts 128-B reads at 64 B)."""
-            k = pmc.get(pmc_names.get(s["name"], ""))
-            if not k or "FETCH_SIZE_KiB" not in k or "WRITE_SIZE_KiB" not in k:
-                return None
-            return int((2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
-
-        def roof(s):
-            if s["flops"] > 0 and s["flops"] / max(s["bytes"], 1) > FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
-                a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
-                return {"kernel": s["name"], "bound": "mfma", "achieved": round(a, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(a / FP32_PEAK_TFLOPS, 4), "traffic": traffic(s), "avg_ms": round(s["avg_ms"], 4),
-                        "note": "f32 MFMA/VALU peak; the fused network launch is issue/latency bound, see DESIGN.md"}
-            return {"kernel": s["name"], "bound": "hbm", "achieved": round(s["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic(s), "avg_ms": round(s["avg_ms"], 4),
-                    "algorithmic_bytes_per_launch": int(s["bytes"])}
-
-        result["roofline"] = roof(dom)
-        result["roofline_blend"] = roof(blend)
-        if extra:
-            result["roofline_blend"]["note"] = "bsx_composite_batch kernel timed stand-alone; inside the step the blend is fused with mask upscale+blur (mask_blend)"
-        result["stage_ms"] = {k: round(v, 4) for k, v in groups.items()}
-        result["stage_ms"]["sum_of_launches"] = round(tot_ms, 4)
-        result["top_launches"] = [{"name": s["name"], "ms": round(s["avg_ms"], 4), "GBps": round(s["GBps"], 1)}
-                                  for s in sorted(stats, key=lambda s: -s["avg_ms"])[:8]]
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(model_path, W, H, args.cpu_seconds)
+                result["cpu_baseline"] = cpu_baseline(main_samples[0], W, H, args.cpu_seconds)
                 if not args.per_stream_bg:
-                    result["cpu_baseline"]["parity_sample"] = parity_sample(model_path, W, H, host, synth.background(W, H, seed=1 + rank), masks_k, out_k)
+                    mp_, fr_, bg_, mk_, out_, photo_ = main_samples
+                    result["cpu_baseline"]["parity_sample"] = parity_sample(mp_, W, H, fr_, bg_, mk_, out_, need_person=photo_)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        default_job = (args.model, W, H, B) == ("lite", 640, 480, 256) and not args.per_stream_bg and not args.bg_ring
+        if world == 1 and default_job and not args.no_extra_configs:
+            # the other single-GPU BASELINE configurations, same protocol with fewer steps (they are 3-70x longer per step)
+            extra_cfgs = [
+                ("configs[2]", "batch=256 1280x720 frames, %s" % NAMES["mlkit"], dict(model_key="mlkit", W=1280, H=720, B=256)),
+                ("configs[3]", "batch=1024 640x480 frames, %s, animated background: per-step H2D upload of a 480x360 frame from a pinned 36-frame ring + GPU resize "
+                               "(grab_background) inside the timed region" % NAMES["deeplab"], dict(model_key="deeplab", W=640, H=480, B=1024, bg_ring=True)),
+                ("configs[4] per-GPU slice", "batch=1024 1280x720 frames, %s (8192 streams / 8 GPUs)" % NAMES["full"], dict(model_key="full", W=1280, H=720, B=1024)),
+            ]
+            result["configs"] = []
+            for tag, desc, kw in extra_cfgs:
+                try:
+                    n_steps = max(3, args.steps // 4)
+                    r = measure(steps=n_steps, warmup=2, rank=0, world=1, local_rank=local_rank, profile_iters=2, **kw)
+                    frag = summarize(r, {})
+                    frag = {"baseline_config": tag, "workload": desc, "steps": n_steps, "warmup": 2, **frag}
+                    samples = (r["model_path"], r["host"][:2].copy(), r["bg_host"], r["masks_k"], r["out_k"], r["photo"])
+                    release(r)
+                    if not args.no_cpu_baseline:
+                        mp_, fr_, bg_, mk_, out_, photo_ = samples
+                        frag["parity_sample"] = parity_sample(mp_, kw["W"], kw["H"], fr_, bg_, mk_, out_, need_person=photo_)
+                    result["configs"].append(frag)
+                except Exception as e:
+                    result["configs"].append({"baseline_config": tag, "workload": desc, "error": repr(e)})
+            try:
+                result["single_stream"] = {"what": "bsx_process_host per call (= bs_maskgen_process through the C++ shim): H2D frame, whole mask pipeline, D2H mask, synchronous",
+                                           "runs": [single_stream_latency("lite", 640, 480, 200), single_stream_latency("deeplab", 640, 480, 60)],
+                                           "published_context_not_measured_here": "reference README.md:177 ~10 FPS DeepLab on two i5 cores; Meet model card ~120 FPS inference on a laptop CPU"}
+            except Exception as e:
+                result["single_stream"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
-    mg.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -50,3 +50,21 @@ def test_counter_allreduce_world2():
 
 def test_reduce_counters_without_group():
     assert reduce_counters(5, 2.0, 7) == (5.0, 2.0, 7)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must spawn its own ranks (torch.distributed.run, 127.0.0.1) —
+    the plumbing leg (--selftest-dist: gloo, no GPU work) goes through exactly that launch, rendezvous and counter reduction."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-dist", "--batch", "8", "--steps", "5"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["frames"] == 80.0 and d["elapsed_max"] == 1.25 and d["checksum"] == 2001
+    assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"]
