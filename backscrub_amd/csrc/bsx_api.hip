@@ -107,6 +107,7 @@ struct bsx_ctx {
   DevResizeTab tab_down, tab_up;
   std::map<std::pair<std::pair<int, int>, std::pair<int, int>>, DevResizeTab> bg_tabs;
   std::string last_error, plan_text;
+  bool keep_logits = false;            // BSX_KEEP_LOGITS: segmented plans write the logits and run the stand-alone decode (A/B, debugging)
   bool no_mask_blend_fusion = false;   // BSX_NO_MASK_BLEND_FUSION, read once at bsx_new (no getenv on the per-step path)
 
   // stream-0 view of a graph tensor (network input/output have dedicated buffers; intermediates are batch-major in
@@ -187,11 +188,12 @@ int init_device_state(bsx_ctx* c) {
   // The per-frame program pays off when most tensors stay in LDS (Meet / MLKit families); graphs whose tensors mostly
   // spill (DeepLab: 33x33x480) run faster as one batch-wide launch per step.  BSX_FORCE_FRAME_PROGRAM / BSX_NO_FRAME_PROGRAM override.
   c->use_program = !c->plan.program.empty() && getenv("BSX_NO_FRAME_PROGRAM") == nullptr &&
-                   (c->plan.program_lds_tensors >= c->plan.program_global_tensors || getenv("BSX_FORCE_FRAME_PROGRAM") != nullptr);
+                   (c->plan.seg.on || c->plan.program_lds_tensors >= c->plan.program_global_tensors || getenv("BSX_FORCE_FRAME_PROGRAM") != nullptr);
   if (c->use_program) {
     BSX_HIP(c, hipMalloc(&c->d_program, c->plan.program.size() * sizeof(MicroOp)));
     BSX_HIP(c, hipMemcpy(c->d_program, c->plan.program.data(), c->plan.program.size() * sizeof(MicroOp), hipMemcpyHostToDevice));
     BSX_HIP(c, frame_program_prepare(c->plan.program_lds_floats));
+    if (c->plan.seg.on) BSX_HIP(c, seg_prepare());
   }
   BSX_HIP(c, hipMalloc(&c->d_canvas, N * canvas_elems(c->inW, c->inH) * sizeof(uint32_t)));
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
@@ -237,7 +239,21 @@ int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s) {
   BSX_HIP(c, launch_prep_bilateral(c->d_canvas, c->tensor_ptr(c->plan.input), c->inW, c->inH, c->bilateral, n, s));
   return BSX_OK;
 }
-int run_infer(bsx_ctx* c, int n, hipStream_t s) {
+// logits = true: the network output tensor is written (stage tests, the stand-alone decode follows); false: the tail kernel of a
+// segmented plan decodes straight into the temporal state of slots [slot, slot + n) and no logits exist
+bool infer_decodes(const bsx_ctx* c) { return c->use_program && c->plan.seg.on && !c->keep_logits; }
+int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0) {
+  if (c->use_program && c->plan.seg.on) {
+    const SegPlan& sp = c->plan.seg;
+    const long pf = (long)c->plan.arena_floats_per_stream;
+    BSX_HIP(c, launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s));
+    BSX_HIP(c, launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s));
+    BSX_HIP(c, launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out,
+                                    c->d_weights, n, s));
+    BSX_HIP(c, launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s));
+    BSX_HIP(c, launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal + (size_t)slot * c->outW * c->outH, c->d_weights, logits, n, s));
+    return BSX_OK;
+  }
   if (c->use_program) {
     BSX_HIP(c, launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena,
                                     (long)c->plan.arena_floats_per_stream, c->d_net_in, c->d_net_out, c->d_weights, n, s));
@@ -261,9 +277,10 @@ int process_impl(bsx_ctx* c, const uint8_t* d_frames, int n, int slot, hipStream
   int rc;
   if ((rc = run_prep(c, d_frames, n, s))) return rc;
   if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }   // :303
-  if ((rc = run_infer(c, n, s))) return rc;
+  const bool fused_decode = infer_decodes(c);
+  if ((rc = run_infer(c, n, s, !fused_decode, slot))) return rc;
   if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); } // :311
-  if ((rc = run_decode(c, n, s, slot))) return rc;
+  if (!fused_decode && (rc = run_decode(c, n, s, slot))) return rc;
   if (c->onmask) { BSX_HIP(c, hipStreamSynchronize(s)); c->onmask(c->caller_ctx); }   // :363
   return run_mask(c, n, s, slot);
 }
@@ -311,7 +328,9 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     return nullptr;
   }
   bool no_reuse = getenv("BSX_ARENA_NO_REUSE") != nullptr;
-  if (!build_plan(c->graph, &c->plan, &err, !no_reuse)) { report(nullptr, ondebug, caller_ctx, "error: unable to build GPU plan: %s\n", err.c_str()); return nullptr; }
+  // the per-launch path (BSX_NO_FRAME_PROGRAM) executes the plain step list: it needs the unsegmented plan
+  const bool segments = getenv("BSX_NO_SEGMENTS") == nullptr && getenv("BSX_NO_FRAME_PROGRAM") == nullptr;
+  if (!build_plan(c->graph, &c->plan, &err, !no_reuse, segments)) { report(nullptr, ondebug, caller_ctx, "error: unable to build GPU plan: %s\n", err.c_str()); return nullptr; }
   // ROI geometry, float arithmetic truncated to int exactly as lib/libbackscrub.cc:230-246
   float ratio = (float)c->inH / (float)c->inW;
   float frameratio = (float)height / (float)width;
@@ -328,6 +347,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     return nullptr;
   }
   c->no_mask_blend_fusion = getenv("BSX_NO_MASK_BLEND_FUSION") != nullptr;
+  c->keep_logits = getenv("BSX_KEEP_LOGITS") != nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
     report(nullptr, ondebug, caller_ctx, "error: HIP device %d not available (%d visible)\n", device, ndev); return nullptr; }
@@ -340,6 +360,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
              c->use_program ? "ON" : "off", c->plan.program.size(), c->plan.program_lds_floats, c->plan.program_lds_floats / 256.0,
              c->plan.program_lds_tensors, c->plan.program_global_tensors);
     c->plan_text += line;
+    if (c->use_program && c->plan.seg.on) c->plan_text += c->plan.seg_text;
     for (size_t i = 0; i < c->plan.program_labels.size(); i++) { c->plan_text += "P" + std::to_string(i) + " " + c->plan.program_labels[i] + "\n"; }
   }
   return c.release();
@@ -370,7 +391,7 @@ int bsx_get_info(const bsx_ctx* c, bsx_info* o) {
   o->in_w = c->inW; o->in_h = c->inH; o->in_c = c->inC; o->out_w = c->outW; o->out_h = c->outH; o->out_c = c->outC;
   int r[4] = {c->roi.x, c->roi.y, c->roi.w, c->roi.h}, q[4] = {c->in_roi.x, c->in_roi.y, c->in_roi.w, c->in_roi.h};
   memcpy(o->roi, r, sizeof r); memcpy(o->in_roi, q, sizeof q);
-  o->n_ops = c->graph.n_file_ops; o->n_steps = c->use_program ? 1 : (int)c->plan.steps.size(); o->device = c->device;
+  o->n_ops = c->graph.n_file_ops; o->n_steps = c->use_program ? (c->plan.seg.on ? 5 : 1) : (int)c->plan.steps.size(); o->device = c->device;
   o->norm_scale = c->norm_scale; o->norm_offset = c->norm_offset;
   o->nn_flops_per_frame = 2.0 * c->plan.macs_per_frame;
   o->act_bytes_per_stream = c->plan.arena_floats_per_stream * sizeof(float);
@@ -440,9 +461,10 @@ int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, siz
   int rc;
   if ((rc = run_prep(c, d_frames, n, s))) return rc;
   if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }
-  if ((rc = run_infer(c, n, s))) return rc;
+  const bool fused_decode = infer_decodes(c);
+  if ((rc = run_infer(c, n, s, !fused_decode, 0))) return rc;
   if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); }
-  if ((rc = run_decode(c, n, s))) return rc;
+  if (!fused_decode && (rc = run_decode(c, n, s))) return rc;
   BSX_HIP(c, launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg,
                                bg_frame_stride, d_frames, d_out, n, s));
   return BSX_OK;
@@ -515,10 +537,12 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   if (!c || !d_frames || !d_bg || !d_out || !out || n <= 0 || n > c->n_streams || iters <= 0) return BSX_EINVAL;
   DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
-  const int n_net = c->use_program ? 1 : (int)c->plan.steps.size();
+  const bool seg = c->use_program && c->plan.seg.on;
+  const bool fused_decode = infer_decodes(c);
+  const int n_net = c->use_program ? (seg ? 5 : 1) : (int)c->plan.steps.size();
   const bool fuse_tail = !c->onmask && !c->no_mask_blend_fusion &&
                          mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
-  const int L = 2 + n_net + (fuse_tail ? 2 : 3) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
+  const int L = 2 + n_net + (fused_decode ? 0 : 1) + (fuse_tail ? 1 : 2) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
   if (cap < L) return BSX_EINVAL;
   std::vector<hipEvent_t> ev((size_t)2 * L);
   for (auto& e : ev) BSX_HIP(c, hipEventCreate(&e));
@@ -535,12 +559,21 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     } while (0)
     BSX_TIMED(launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
     BSX_TIMED(launch_prep_bilateral(c->d_canvas, c->tensor_ptr(c->plan.input), c->inW, c->inH, c->bilateral, n, s));
-    if (c->use_program)
-      BSX_TIMED(launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena,
-                                     (long)c->plan.arena_floats_per_stream, c->d_net_in, c->d_net_out, c->d_weights, n, s));
+    const long pf = (long)c->plan.arena_floats_per_stream;
+    if (seg) {
+      const SegPlan& sp = c->plan.seg;
+      BSX_TIMED(launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s));
+      BSX_TIMED(launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s));
+      BSX_TIMED(launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out,
+                                     c->d_weights, n, s));
+      BSX_TIMED(launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s));
+      BSX_TIMED(launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal, c->d_weights, !fused_decode, n, s));
+    } else if (c->use_program)
+      BSX_TIMED(launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out,
+                                     c->d_weights, n, s));
     else
       for (const Step& st : c->plan.steps) BSX_TIMED(launch_step(st, c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s));
-    BSX_TIMED(launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
+    if (!fused_decode) BSX_TIMED(launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
     if (fuse_tail) {
       BSX_TIMED(launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg, bg_stride,
                                   d_frames, d_out, n, s));
@@ -565,7 +598,21 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   // prep_resize: reads the touched part of the ROI (<= 3 B/px of the ROI), writes the 4 B/px canvas
   put(j++, "prep_resize", N * (3.0 * c->roi.w * c->roi.h + 4.0 * canvas), 0);
   put(j++, "prep_bilateral", N * (4.0 * canvas + 12.0 * canvas), 0);
-  if (c->use_program) {
+  if (seg) {
+    // algorithmic bytes of each segment = the tensors it must read once + write once (f32); flops from the fused steps it covers
+    const std::vector<Step>& S = c->plan.steps;
+    const int NS = (int)S.size();
+    auto macs = [&](int a, int b) { double m = 0; for (int i = a; i <= b; i++) m += S[i].macs; return m; };
+    const SegPlan& sp = c->plan.seg;
+    const double eA = 16.0 * sp.head.H1 * sp.head.W1, eb0 = 16.0 * sp.head.H2 * sp.head.W2, ec0 = (double)sp.k2.dw.C * sp.k2.H3 * sp.k2.W3;
+    const double elo2 = 16.0 * sp.k3.HL * sp.k3.WL, elo = 16.0 * sp.k3.H2 * sp.k3.W2;
+    const double ein = (double)c->inW * c->inH * c->inC, eout = (double)c->outW * c->outH * c->outC;
+    put(j++, "seg_head", N * 4.0 * (ein + eA + eb0), N * 2.0 * macs(0, 2));
+    put(j++, "seg_k2", N * 4.0 * (eb0 + eb0 + ec0), N * 2.0 * macs(3, 8));
+    put(j++, "frame_program", N * 4.0 * (ec0 + elo2) + 4.0 * c->plan.weights.size(), N * 2.0 * macs(9, NS - 11));
+    put(j++, "seg_k3", N * 4.0 * (eb0 + elo2 + elo), N * 2.0 * macs(NS - 10, NS - 8));
+    put(j++, fused_decode ? "seg_tail+decode" : "seg_tail", N * (4.0 * (eA + elo) + (fused_decode ? 2.0 * c->outW * c->outH : 4.0 * eout)), N * 2.0 * macs(NS - 7, NS - 1));
+  } else if (c->use_program) {
     // algorithmic bytes of the fused network = its input tensor + its output tensor + the weights once
     double io = (double)c->inW * c->inH * c->inC + (double)c->outW * c->outH * c->outC;
     put(j++, "frame_program", N * io * 4.0 + 4.0 * c->plan.weights.size(), N * 2.0 * c->plan.macs_per_frame);
@@ -580,7 +627,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     }
     put(j++, st.label, N * b * 4.0, N * 2.0 * st.macs);
   }
-  put(j++, "decode_iir", N * ((double)c->outW * c->outH * c->outC * 4.0 + 2.0 * c->outW * c->outH), 0);
+  if (!fused_decode) put(j++, "decode_iir", N * ((double)c->outW * c->outH * c->outC * 4.0 + 2.0 * c->outW * c->outH), 0);
   if (fuse_tail) {
     // fused: model-res mask in, full-res mask out (1 B/px), bg + frame in (6 B/px), composite out (3 B/px)
     put(j++, "mask_blend", N * ((double)c->in_roi.w * c->in_roi.h + 10.0 * px), 0);

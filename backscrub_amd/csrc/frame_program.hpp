@@ -54,6 +54,8 @@ struct MicroOp {
   Loc in0, in1, in2, res, scale, out;
   Loc cat[4];
   int cat_c[4] = {0, 0, 0, 0};
+  int cat_hw[4] = {0, 0, 0, 0};      // pixels each pooled part is averaged over
+  int cat_parts[4] = {0, 0, 0, 0};   // > 0: the part arrives as that many per-tile partial sums [n][C] (written by a segment kernel) instead of a tensor
 };
 
 constexpr int kMicroTail = 101;              // MicroOp::kind of the fused pw → dw(+residual) → transpose-conv tail

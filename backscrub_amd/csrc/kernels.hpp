@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "plan.hpp"
+#include "segments.hpp"
 
 namespace bsx {
 
@@ -21,6 +22,14 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
 hipError_t frame_program_prepare(int lds_floats);
 hipError_t launch_frame_program(const MicroOp* d_ops, int n_ops, int lds_floats, float* arena, long per_frame_floats, float* net_in, float* net_out,
                                 const float* weights, int n, hipStream_t s, unsigned long long* timeline = nullptr);
+
+// Spatially-parallel segment kernels around the per-frame program (kernels_seg.hip, segments.hpp)
+hipError_t seg_prepare();
+hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const float* net_in, const float* weights, int n, hipStream_t s);
+hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s);
+hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s);
+// logits = true: write the network output tensor (debug / stage tests); false: decode + temporal IIR straight into `ofinal`
+hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s);
 
 // ---- image path ----------------------------------------------------------------------
 // Fixed-point bilinear tables of cv::resize(INTER_LINEAR, 8u) for one (src,dst) size pair

@@ -840,13 +840,38 @@ __device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& 
   if (x.lds) gap_body<true>(x, HW, C, out, coff, accumulate); else gap_body<false>(x, HW, C, out, coff, accumulate);
 }
 
+// one pooled part of a (possibly concatenated / summed) global average pool: a tensor, or per-tile partial sums written by
+// a segment kernel (segments.hpp) — [n][C] floats in the frame's arena slice, mean = sum / hw
+__device__ __forceinline__ void gap_part(cop_t& op, int k, const FrameCtx& c, const Ref& out, int coff, bool accumulate) {
+  const Ref x = make_ref(op.cat[k], c);
+  const int C = op.cat_c[k], np = op.cat_parts[k];
+  if (np == 0) { gap_one(x, op.cat_hw[k], C, out, coff, accumulate); return; }
+  // slices of the partial sums are added by different lanes (independent loads), then the C channel totals by the first C lanes
+  lds_f* scratch = lds_base();
+  const int S = min(kFrameThreads / C, np), tid = (int)threadIdx.x, ch = tid % C, slice = tid / C;
+  if (slice < S) {
+    float s = 0.f;
+    for (int i = slice; i < np; i += S) s += x.g[i * C + ch];
+    scratch[slice * C + ch] = s;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float s = 0.f;
+    for (int j = 0; j < S; j++) s += scratch[j * C + tid];
+    float m = s / (float)op.cat_hw[k];
+    if (accumulate) m += ld1(out, coff + tid);
+    st1(out, coff + tid, m);
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ void mo_gap(cop_t& op, const FrameCtx& c) {
   const Ref out = make_ref(op.out, c);
   const int HW = op.H * op.W;
   if (op.n_cat == 0) { gap_one(make_ref(op.in0, c), HW, op.Cin, out, 0); return; }
   int coff = 0;
   for (int k = 0; k < op.n_cat; k++) {
-    gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], out, coff, op.gap_sum && k > 0);
+    gap_part(op, k, c, out, coff, op.gap_sum && k > 0);
     if (!op.gap_sum) coff += op.cat_c[k];
   }
 }
@@ -909,7 +934,7 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
   else {
     int coff = 0;
     for (int k = 0; k < op.n_cat; k++) {
-      gap_one(make_ref(op.cat[k], c), HW, op.cat_c[k], mean, coff, op.gap_sum && k > 0);
+      gap_part(op, k, c, mean, coff, op.gap_sum && k > 0);
       if (!op.gap_sum) coff += op.cat_c[k];
     }
   }

@@ -2,6 +2,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -54,16 +55,20 @@ std::string Plan::describe() const {
 
 // Lower the step list into the per-frame program: one MicroOp per step, every tensor that fits placed in
 // LDS (liveness-based first fit inside the 160 KiB block), the rest in the frame's slice of the HBM arena.
-static void build_frame_program(const Graph& g, Plan* plan) {
+// `steps`: the step list to lower (the whole network, or the middle of a segmented plan).  `ext`: tensors that cross the
+// program's boundary (produced or consumed by a segment kernel) — they live at their arena offset, never in LDS.
+// `part_n[t]` > 0 marks tensor t of a pooling step as "already pooled per tile": [part_n][C] partial sums at tensor_off[t].
+static void build_frame_program(const Graph& g, Plan* plan, const std::vector<Step>& steps, const std::vector<int>& ext = {},
+                                const std::map<int, int>& part_n = {}, const std::map<int, int>& part_hw = {}) {
   plan->program.clear();
   plan->program_labels.clear();
   plan->program_blocks.clear();
   plan->program_check.clear();
-  const int NS = (int)plan->steps.size();
+  const int NS = (int)steps.size();
   const int NT = (int)g.tensors.size();
   std::vector<int> last(NT, -1);
   for (int s = 0; s < NS; s++) {
-    const Step& st = plan->steps[s];
+    const Step& st = steps[s];
     // steps without a micro-op form → no program (the per-launch path is used instead)
     if ((st.kind == StepKind::PwConv || st.kind == StepKind::Eltwise || st.kind == StepKind::DwConv || st.kind == StepKind::Gap ||
          st.kind == StepKind::TConv) && (st.Cin % 4)) return;
@@ -71,6 +76,7 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     for (int t : st.concat_in) last[t] = s;
   }
   last[g.output] = NS + 1;
+  for (int t : ext) if (t >= 0) last[t] = NS + 1;          // consumed after the program ends
   const bool no_lds = getenv("BSX_PROGRAM_NO_LDS") != nullptr;  // debugging: every tensor in the HBM arena
   std::vector<Loc> loc(NT);
   struct Blk { int off, len, until; };
@@ -112,13 +118,21 @@ static void build_frame_program(const Graph& g, Plan* plan) {
   };
   plan->program_lds_tensors = plan->program_global_tensors = 0;
   place(g.input, -1);
+  for (int t : ext) {
+    if (t < 0 || loc[t].space != kLocNone) continue;
+    const TensorInfo& ti = g.tensors[t];
+    Loc l;
+    l.elems = (int)ti.elems(); l.space = kLocGlobal; l.off = (int)plan->tensor_off[t]; l.stride = ti.dims[3];
+    loc[t] = l;
+    plan->program_global_tensors++;
+  }
   // Weight staging slots.  stage[s] floats of step s are DMA'd to LDS while the PREVIOUS micro-op runs, so the slot must be
   // free from the first step of that previous micro-op (q) to s.  q is conservative: a GAP → FC.. chain may fuse into one op.
   auto gemv_form = [&](const Step& st) { return st.kind == StepKind::PwConv && st.OH * st.OW <= 4 && st.OH * st.OW * st.Cout * 16 <= kLdsScratchFloats; };
   std::vector<int> stage(NS, 0), slot(NS, 0);
   std::vector<std::vector<int>> slots_from(NS);
   for (int s = 0; s < NS; s++) {
-    const Step& st = plan->steps[s];
+    const Step& st = steps[s];
     long nb = st.kind == StepKind::DwConv ? st.Cout : (st.kind == StepKind::TConv ? st.Cout : st.cout_pad);
     long range = ((long)st.b_off - (long)st.w_off) + ((nb + 3) / 4) * 4;
     bool uses = (st.kind == StepKind::PwConv && !gemv_form(st)) || st.kind == StepKind::Conv || st.kind == StepKind::DwConv || st.kind == StepKind::TConv;
@@ -126,12 +140,12 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     if (!(uses && st.b_off > st.w_off && range <= kLdsMaxStageFloats)) continue;
     stage[s] = (int)range;
     int q = s > 0 ? s - 1 : 0;
-    auto fc_like = [&](int k) { const Step& f = plan->steps[k]; return f.kind == StepKind::PwConv && f.OH * f.OW == 1; };
+    auto fc_like = [&](int k) { const Step& f = steps[k]; return f.kind == StepKind::PwConv && f.OH * f.OW == 1; };
     if (s > 0 && fc_like(q)) {
       while (q > 0 && fc_like(q - 1)) q--;
-      if (q > 0 && plan->steps[q - 1].kind == StepKind::Gap) q--;
+      if (q > 0 && steps[q - 1].kind == StepKind::Gap) q--;
     }
-    if (s > 2 && plan->steps[s - 1].kind == StepKind::TConv && plan->steps[s - 2].kind == StepKind::DwConv) q = std::min(q, s - 3);
+    if (s > 2 && steps[s - 1].kind == StepKind::TConv && steps[s - 2].kind == StepKind::DwConv) q = std::min(q, s - 3);
     slots_from[q].push_back(s);
   }
   std::vector<MicroOp> prog;
@@ -139,9 +153,9 @@ static void build_frame_program(const Graph& g, Plan* plan) {
   std::vector<int> tail_ws(NS, -1), tail_rows(NS, 0);
   auto tail_pattern = [&](int s) {
     if (s + 2 >= NS || getenv("BSX_PROGRAM_NO_TAIL")) return false;
-    const Step& a = plan->steps[s];
-    const Step& b = plan->steps[s + 1];
-    const Step& c2 = plan->steps[s + 2];
+    const Step& a = steps[s];
+    const Step& b = steps[s + 1];
+    const Step& c2 = steps[s + 2];
     return a.kind == StepKind::PwConv && a.residual < 0 && a.Cin == 16 && a.cout_pad == 16 && a.Cout == 16 &&
            a.OH * a.OW > 1024 && last[a.out] == s + 1 &&
            b.kind == StepKind::DwConv && b.in0 == a.out && b.residual == a.out && b.kh == 3 && b.kw == 3 && b.sh == 1 && b.sw == 1 && b.dh == 1 &&
@@ -149,7 +163,7 @@ static void build_frame_program(const Graph& g, Plan* plan) {
            c2.kind == StepKind::TConv && c2.in0 == b.out && c2.kh == 2 && c2.kw == 2 && c2.Cout <= 4;
   };
   for (int s = 0; s < NS; s++) {
-    const Step& st = plan->steps[s];
+    const Step& st = steps[s];
     for (int s2 : slots_from[s]) {
       const int need = (stage[s2] + 3) / 4 * 4;
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
@@ -195,7 +209,13 @@ static void build_frame_program(const Graph& g, Plan* plan) {
     if (st.concat_in.size() > 4) return;
     m.n_cat = (int)st.concat_in.size();
     m.gap_sum = st.gap_sum ? 1 : 0;
-    for (int k = 0; k < m.n_cat; k++) { m.cat[k] = L(st.concat_in[k]); m.cat_c[k] = st.concat_c[k]; }
+    for (int k = 0; k < m.n_cat; k++) {
+      const int ct = st.concat_in[k];
+      m.cat[k] = L(ct); m.cat_c[k] = st.concat_c[k];
+      m.cat_hw[k] = g.tensors[ct].dims[1] * g.tensors[ct].dims[2];
+      auto pn = part_n.find(ct);
+      if (pn != part_n.end()) { m.cat_parts[k] = pn->second; m.cat_hw[k] = part_hw.at(ct); }
+    }
     if (st.kind == StepKind::DwConv && !((st.kh == 3 && st.kw == 3) || (st.kh == 5 && st.kw == 5))) return;   // program has 3x3 / 5x5 bodies only
     // weights + bias are contiguous in the arena ([w][pad to 4][b]); the whole range is staged in the slot planned above
     m.stage_floats = stage[s]; m.w_lds = slot[s];
@@ -245,11 +265,11 @@ static void build_frame_program(const Graph& g, Plan* plan) {
       auto is_fc = [&](size_t k, const Loc& in) {
         if (k >= prog.size()) return false;
         const MicroOp& f = prog[k];
-        const Step& st = plan->steps[k];
+        const Step& st = steps[k];
         return f.kind == (int)StepKind::PwConv && f.OH * f.OW == 1 && st.w2_off != 0 && f.res.space == kLocNone && f.scale.space == kLocNone &&
-               f.in0.space == kLocLds && f.in0.off == in.off && f.out.space == kLocLds && f.Cin % 4 == 0;
+               f.in0.space == kLocLds && f.in0.off == in.off && (f.out.space == kLocLds || f.out.space == kLocGlobal) && f.Cin % 4 == 0;
       };
-      auto single_use = [&](size_t k) { const Step& st = plan->steps[k]; return last[st.out] == (int)k + 1; };
+      auto single_use = [&](size_t k) { const Step& st = steps[k]; return last[st.out] == (int)k + 1; };
       if (tail_ws[i] >= 0 && prog[i].mfma && prog[i].out.space == kLocGlobal && prog[i].scale.space != kLocGlobal) {
         // pw(+muladd) → dw 3x3 (+act, + z) → tconv 2x2: z never leaves LDS, t never leaves registers
         MicroOp m = prog[i];
@@ -270,11 +290,11 @@ static void build_frame_program(const Graph& g, Plan* plan) {
         MicroOp m = g0;
         const MicroOp& f1 = prog[i + 1];
         m.kind = kMicroSe; m.in1 = g0.out; m.in2 = f1.out; m.n_fc = 1;
-        m.w2_off = (long long)plan->steps[i + 1].w2_off; m.b_off = f1.b_off; m.act = f1.act; m.C1 = f1.Cout; m.out = f1.out;
+        m.w2_off = (long long)steps[i + 1].w2_off; m.b_off = f1.b_off; m.act = f1.act; m.C1 = f1.Cout; m.out = f1.out;
         size_t used = 2;
         if (is_fc(i + 2, f1.out) && single_use(i + 1)) {
           const MicroOp& f2 = prog[i + 2];
-          m.n_fc = 2; m.w3_off = (long long)plan->steps[i + 2].w2_off; m.b3_off = f2.b_off; m.act2 = f2.act; m.C2 = f2.Cout; m.out = f2.out;
+          m.n_fc = 2; m.w3_off = (long long)steps[i + 2].w2_off; m.b3_off = f2.b_off; m.act2 = f2.act; m.C2 = f2.Cout; m.out = f2.out;
           used = 3;
         }
         fusedp.push_back(m);
@@ -318,7 +338,199 @@ std::string verify_program_lds(const Plan& plan) {
 }
 
 
-bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_arena) {
+// ---- segmentation of the Meet / MLKit family (segments.hpp) ------------------------------------------------------------------
+namespace {
+
+// total interpolation weight every source row/column receives from RESIZE_BILINEAR in -> out (same clamping as the kernels);
+// GAP(resize(x)) == GAP(x) iff the weights are uniform
+bool resize_weights_uniform(int in, int out, bool align, bool half_pixel) {
+  std::vector<double> wsum(in, 0.0);
+  const float scale = (align && out > 1) ? (float)(in - 1) / (float)(out - 1) : (float)in / (float)out;
+  for (int o = 0; o < out; o++) {
+    const float v = half_pixel ? ((float)o + 0.5f) * scale - 0.5f : (float)o * scale;
+    const float fl = std::floor(v);
+    const int lo = std::max((int)fl, 0), hi = std::min((int)std::ceil(v), in - 1);
+    const float frac = v - (float)lo;
+    wsum[lo] += 1.0 - frac; wsum[hi] += frac;
+  }
+  const double want = (double)out / (double)in;
+  for (double x : wsum) if (std::fabs(x - want) > 1e-5) return false;
+  return true;
+}
+
+SegConvW conv_w(const Step& st) { SegConvW c; c.w_off = (long long)st.w_off; c.b_off = (long long)st.b_off; c.Cin = st.kh * st.kw * st.Cin; c.Cout = st.Cout; c.cout_pad = st.cout_pad; c.act = st.act; return c; }
+SegDwW dw_w(const Step& st) { SegDwW c; c.w_off = (long long)st.w_off; c.b_off = (long long)st.b_off; c.C = st.Cout; c.act = st.act; return c; }
+SegFc fc_w(const Step& st) { SegFc c; c.w_off = (long long)st.w2_off; c.b_off = (long long)st.b_off; c.Cin = st.Cin; c.Cout = st.Cout; c.act = st.act; return c; }
+
+bool is_pw16(const Step& st) { return st.kind == StepKind::PwConv && st.Cin == 16 && st.Cout == 16 && st.cout_pad == 16 && st.OH * st.OW > 4; }
+bool is_fc_step(const Step& st) { return st.kind == StepKind::PwConv && st.OH * st.OW == 1 && st.w2_off != 0 && st.residual < 0 && st.in_scale < 0 && st.in2 < 0 && st.Cin <= 32 && st.Cout <= 32; }
+bool is_dw3(const Step& st, int stride) {
+  return st.kind == StepKind::DwConv && st.kh == 3 && st.kw == 3 && st.sh == stride && st.sw == stride && st.dh == 1 && st.dw == 1;
+}
+int tiles_for(int extent, int target) { return (extent + target - 1) / target; }
+
+}  // namespace
+
+// Recognise  head | k2 | middle | k3 | tail  in the fused step list and lower it: four segment descriptors + the per-frame
+// program for the middle.  Returns false (plan untouched apart from scratch) when the graph does not have this shape.
+static bool seg_fail(int where) { if (getenv("BSX_SEG_DEBUG")) fprintf(stderr, "segmentation: check %d failed\n", where); return false; }
+static bool build_segments(Graph& g, Plan* plan) {
+  const std::vector<Step>& S = plan->steps;
+  const int NS = (int)S.size();
+  if (NS < 9 + 15) return seg_fail(1);
+  // operand slots that read tensor t (a pooling step lists its parts in concat_in; its in0 merely repeats the first part)
+  auto uses_of = [&](int t) {
+    int n = 0;
+    for (const Step& q : S) {
+      for (int u : {q.concat_in.empty() ? q.in0 : -1, q.in1, q.in2, q.residual, q.in_scale}) n += (u == t);
+      for (int u : q.concat_in) n += (u == t);
+    }
+    return n + (t == g.output);
+  };
+  auto dims = [&](int t, int k) { return g.tensors[t].dims[k]; };
+
+  // ---- head: stem → 1x1 → dw/s2
+  const Step &stem = S[0], &hpw = S[1], &hdw = S[2];
+  if (!(stem.kind == StepKind::Conv && stem.in0 == g.input && stem.kh == 3 && stem.kw == 3 && stem.sh == 2 && stem.sw == 2 && stem.dh == 1 && stem.dw == 1 &&
+        stem.Cin == 3 && stem.Cout == 16 && stem.cout_pad == 16 && stem.residual < 0)) return seg_fail(2);
+  const int A = stem.out;
+  if (!(is_pw16(hpw) && hpw.in0 == A && hpw.residual < 0 && hpw.in_scale < 0 && hpw.in2 < 0 && uses_of(hpw.out) == 1)) return seg_fail(3);
+  if (!(is_dw3(hdw, 2) && hdw.in0 == hpw.out && hdw.Cout == 16 && hdw.residual < 0)) return seg_fail(4);
+  const int b0 = hdw.out;
+  // ---- k2: GAP(b0) → FC → FC → 1x1 (scaled) → 1x1 expand → dw/s2
+  const Step &g1 = S[3], &f1a = S[4], &f1b = S[5], &pwa = S[6], &pwb = S[7], &kdw = S[8];
+  if (!(g1.kind == StepKind::Gap && g1.concat_in.empty() && g1.in0 == b0 && is_fc_step(f1a) && f1a.in0 == g1.out && is_fc_step(f1b) && f1b.in0 == f1a.out &&
+        f1a.Cin == 16 && f1b.Cout == 16 && uses_of(b0) == 2)) return seg_fail(5);
+  if (!(is_pw16(pwa) && pwa.in0 == b0 && pwa.in_scale == f1b.out && pwa.residual < 0 && pwa.in2 < 0 && uses_of(f1b.out) == 1)) return seg_fail(6);
+  const int B = pwa.out;
+  if (!(pwb.kind == StepKind::PwConv && pwb.in0 == B && pwb.Cin == 16 && pwb.cout_pad % 16 == 0 && pwb.residual < 0 && pwb.in_scale < 0 && pwb.in2 < 0 &&
+        uses_of(pwb.out) == 1 && pwb.Cout % 4 == 0)) return seg_fail(7);
+  if (!(is_dw3(kdw, 2) && kdw.in0 == pwb.out && kdw.residual < 0)) return seg_fail(8);
+  const int c0 = kdw.out;
+  // ---- tail: resize → GAP(A, up) → FC → FC → 1x1 (A*g + up) → dw + residual → tconv
+  const Step &tr = S[NS - 7], &tg = S[NS - 6], &tf1 = S[NS - 5], &tf2 = S[NS - 4], &tpw = S[NS - 3], &tdw = S[NS - 2], &ttc = S[NS - 1];
+  if (!(tr.kind == StepKind::Resize && tr.Cin == 16 && tr.OH == dims(A, 1) && tr.OW == dims(A, 2))) return seg_fail(9);
+  const int lo = tr.in0, up = tr.out;
+  auto pools = [](const Step& q, int a, int b) { return q.kind == StepKind::Gap && q.concat_in.size() == 2 && ((q.concat_in[0] == a && q.concat_in[1] == b) || (q.gap_sum && q.concat_in[0] == b && q.concat_in[1] == a)); };
+  if (!(pools(tg, A, up) && is_fc_step(tf1) && tf1.in0 == tg.out &&
+        is_fc_step(tf2) && tf2.in0 == tf1.out && tf2.Cout == 16)) return seg_fail(10);
+  if (!(is_pw16(tpw) && tpw.in0 == A && tpw.in_scale == tf2.out && tpw.in2 == up && tpw.residual < 0)) return seg_fail(11);
+  if (!(is_dw3(tdw, 1) && tdw.in0 == tpw.out && tdw.residual == tpw.out && tdw.Cout == 16 && tdw.pad_t == 1 && tdw.pad_l == 1)) return seg_fail(12);
+  if (!(ttc.kind == StepKind::TConv && ttc.in0 == tdw.out && ttc.kh == 2 && ttc.kw == 2 && ttc.Cin == 16 && (ttc.Cout == 1 || ttc.Cout == 2) && ttc.out == g.output)) return seg_fail(13);
+  if (uses_of(A) != 3 || uses_of(up) != 2 || uses_of(tpw.out) != 2 || uses_of(tdw.out) != 1 || uses_of(tf2.out) != 1) return seg_fail(14);
+  if (!resize_weights_uniform(tr.H, tr.OH, tr.align_corners, tr.half_pixel) || !resize_weights_uniform(tr.W, tr.OW, tr.align_corners, tr.half_pixel)) return seg_fail(15);
+  // ---- k3: resize → GAP(B, up2) → FC → FC → 1x1 (B*g + up2) → dw + residual → 1x1 → lo
+  const Step &kr = S[NS - 14], &kg = S[NS - 13], &kf1 = S[NS - 12], &kf2 = S[NS - 11], &kp1 = S[NS - 10], &kd = S[NS - 9], &kp2 = S[NS - 8];
+  if (!(kr.kind == StepKind::Resize && kr.Cin == 16 && kr.OH == dims(B, 1) && kr.OW == dims(B, 2))) return seg_fail(16);
+  const int lo2 = kr.in0, up2 = kr.out;
+  if (!(pools(kg, B, up2) && is_fc_step(kf1) && kf1.in0 == kg.out &&
+        is_fc_step(kf2) && kf2.in0 == kf1.out && kf2.Cout == 16)) return seg_fail(17);
+  if (!(is_pw16(kp1) && kp1.in0 == B && kp1.in_scale == kf2.out && kp1.in2 == up2 && kp1.residual < 0)) return seg_fail(18);
+  if (!(is_dw3(kd, 1) && kd.in0 == kp1.out && kd.residual == kp1.out && kd.Cout == 16 && kd.pad_t == 1 && kd.pad_l == 1)) return seg_fail(19);
+  if (!(is_pw16(kp2) && kp2.in0 == kd.out && kp2.out == lo && kp2.residual < 0 && kp2.in_scale < 0 && kp2.in2 < 0)) return seg_fail(20);
+  if (uses_of(B) != 3 || uses_of(up2) != 2 || uses_of(kp1.out) != 2 || uses_of(kd.out) != 1 || uses_of(kf2.out) != 1 || uses_of(lo) != 1 || uses_of(lo2) != 1) return seg_fail(21);
+  if (!resize_weights_uniform(kr.H, kr.OH, kr.align_corners, kr.half_pixel) || !resize_weights_uniform(kr.W, kr.OW, kr.align_corners, kr.half_pixel)) return seg_fail(22);
+  if (uses_of(c0) != 1) return seg_fail(23);
+
+  // ---- dedicated, never-reused arena space for everything that crosses a kernel boundary (a segment kernel reads and writes
+  //      different tiles of its tensors concurrently, so liveness-based sharing inside one kernel would be a race)
+  size_t top = plan->arena_floats_per_stream;
+  auto reserve = [&](size_t floats) { size_t at = top; top += (floats + 63) / 64 * 64; return (long long)at; };
+  auto synth = [&](const char* name, int n, int C) {
+    TensorInfo t; t.dims[0] = 1; t.dims[1] = n; t.dims[2] = 1; t.dims[3] = C; t.shape = {1, n, 1, C}; t.name = name;
+    g.tensors.push_back(t);
+    plan->tensor_off.push_back(-1);
+    return (int)g.tensors.size() - 1;
+  };
+  SegPlan sp;
+  // tile geometry (BSX_SEG_TILES="hTR,hTC,k2TR,k2TC,k3TR,k3TC,tTR,tTC" overrides the targets)
+  int tgt[8] = {2, 20, 3, 20, 8, 20, 16, 20};
+  if (const char* e = getenv("BSX_SEG_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &tgt[0], &tgt[1], &tgt[2], &tgt[3], &tgt[4], &tgt[5], &tgt[6], &tgt[7]);
+  auto split = [&](int extent, int target, int* tile, int* n) { *n = tiles_for(extent, std::max(1, target)); *tile = (extent + *n - 1) / *n; };
+
+  SegHead& h = sp.head;
+  h.H0 = stem.H; h.W0 = stem.W; h.H1 = stem.OH; h.W1 = stem.OW; h.H2 = hdw.OH; h.W2 = hdw.OW;
+  h.stem_pt = stem.pad_t; h.stem_pl = stem.pad_l; h.dw_pt = hdw.pad_t; h.dw_pl = hdw.pad_l;
+  h.stem = conv_w(stem); h.pw = conv_w(hpw); h.dw = dw_w(hdw);
+  split(h.H2, tgt[0], &h.TR, &h.tiles_y); split(h.W2, tgt[1], &h.TC, &h.tiles_x);
+  h.lds_floats = seg_head_lds_floats(h);
+  h.m_rowf = seg_magic((4 * h.TC + 3) * 3); h.m_ac = seg_magic(2 * h.TC + 1); h.m_tc = seg_magic(h.TC);
+  SegK2& k2 = sp.k2;
+  k2.H2 = hdw.OH; k2.W2 = hdw.OW; k2.H3 = kdw.OH; k2.W3 = kdw.OW; k2.dw_pt = kdw.pad_t; k2.dw_pl = kdw.pad_l;
+  k2.pw_a = conv_w(pwa); k2.pw_b = conv_w(pwb); k2.dw = dw_w(kdw);
+  split(k2.H3, tgt[2], &k2.TR, &k2.tiles_y); split(k2.W3, tgt[3], &k2.TC, &k2.tiles_x);
+  k2.lds_floats = seg_k2_lds_floats(k2);
+  k2.m_bc = seg_magic(2 * k2.TC + 1); k2.m_tc = seg_magic(k2.TC);
+  SegK3& k3 = sp.k3;
+  k3.H2 = kp1.OH; k3.W2 = kp1.OW; k3.HL = kr.H; k3.WL = kr.W; k3.half_pixel = kr.half_pixel; k3.align_corners = kr.align_corners;
+  k3.pw1 = conv_w(kp1); k3.pw2 = conv_w(kp2); k3.dw = dw_w(kd);
+  split(k3.H2, tgt[4], &k3.TR, &k3.tiles_y); split(k3.W2, tgt[5], &k3.TC, &k3.tiles_x);
+  k3.lds_floats = seg_k3_lds_floats(k3);
+  k3.m_zw = seg_magic(k3.TC + 2); k3.m_tc = seg_magic(k3.TC);
+  SegTail& tl = sp.tail;
+  tl.H1 = tpw.OH; tl.W1 = tpw.OW; tl.HL = tr.H; tl.WL = tr.W; tl.H0 = ttc.OH; tl.W0 = ttc.OW; tl.half_pixel = tr.half_pixel; tl.align_corners = tr.align_corners;
+  tl.pw = conv_w(tpw); tl.dw = dw_w(tdw); tl.tc_w_off = (long long)ttc.w_off; tl.tc_b_off = (long long)ttc.b_off; tl.Co = ttc.Cout; tl.act3 = ttc.act;
+  split(tl.H1, tgt[6], &tl.TR, &tl.tiles_y); split(tl.W1, tgt[7], &tl.TC, &tl.tiles_x);
+  tl.lds_floats = seg_tail_lds_floats(tl);
+  tl.m_zw = seg_magic(tl.TC + 2); tl.m_tc = seg_magic(tl.TC);
+  const int lds_cap = 160 * 256;
+  if (h.lds_floats > lds_cap || k2.lds_floats > lds_cap || k3.lds_floats > lds_cap || tl.lds_floats > lds_cap) return seg_fail(24);
+  if (ttc.OH != 2 * tpw.OH || ttc.OW != 2 * tpw.OW || h.H2 != k3.H2 || h.W2 != k3.W2) return seg_fail(25);
+  if (h.tiles_y * h.tiles_x > 1024 || k2.tiles_y * k2.tiles_x > 1024 || k3.tiles_y * k3.tiles_x > 1024) return seg_fail(26);
+
+  const int pA = synth("partials(A)", h.tiles_y * h.tiles_x, 16), pb0 = synth("partials(b0)", h.tiles_y * h.tiles_x, 16);
+  const int pB = synth("partials(B)", k2.tiles_y * k2.tiles_x, 16), plo = synth("partials(lo)", k3.tiles_y * k3.tiles_x, 16);
+  for (int t : {A, b0, B, c0, lo2, lo, kf2.out, pA, pb0, pB, plo}) plan->tensor_off[t] = reserve(g.tensors[t].elems());
+  // tensors that exist only inside a segment kernel are never materialised
+  for (int t : {hpw.out, g1.out, f1a.out, f1b.out, pwb.out, up2, kg.out, kf1.out, kp1.out, kd.out, up, tg.out, tf1.out, tf2.out, tpw.out, tdw.out})
+    if (t != g.output) plan->tensor_off[t] = -1;
+  plan->arena_floats_per_stream = top;
+
+  h.a_off = plan->tensor_off[A]; h.b0_off = plan->tensor_off[b0]; h.part_a_off = plan->tensor_off[pA]; h.part_b0_off = plan->tensor_off[pb0];
+  k2.b0_off = plan->tensor_off[b0]; k2.B_off = plan->tensor_off[B]; k2.c0_off = plan->tensor_off[c0]; k2.part_B_off = plan->tensor_off[pB];
+  k2.gate.n_parts = 1; k2.gate.n_fc = 2; k2.gate.sum_parts = 0;
+  k2.gate.part[0].off = plan->tensor_off[pb0]; k2.gate.part[0].n = h.tiles_y * h.tiles_x; k2.gate.part[0].C = 16; k2.gate.part[0].hw = (float)(h.H2 * h.W2);
+  k2.gate.fc[0] = fc_w(f1a); k2.gate.fc[1] = fc_w(f1b);
+  k3.skip_off = plan->tensor_off[B]; k3.lo2_off = plan->tensor_off[lo2]; k3.g_off = plan->tensor_off[kf2.out]; k3.lo_off = plan->tensor_off[lo];
+  k3.part_lo_off = plan->tensor_off[plo];
+  tl.skip_off = plan->tensor_off[A]; tl.lo_off = plan->tensor_off[lo];
+  tl.gate.n_parts = 2; tl.gate.n_fc = 2; tl.gate.sum_parts = tg.gap_sum ? 1 : 0;
+  tl.gate.part[0].off = plan->tensor_off[pA]; tl.gate.part[0].n = h.tiles_y * h.tiles_x; tl.gate.part[0].C = 16; tl.gate.part[0].hw = (float)(h.H1 * h.W1);
+  tl.gate.part[1].off = plan->tensor_off[plo]; tl.gate.part[1].n = k3.tiles_y * k3.tiles_x; tl.gate.part[1].C = 16; tl.gate.part[1].hw = (float)(k3.H2 * k3.W2);
+  tl.gate.fc[0] = fc_w(tf1); tl.gate.fc[1] = fc_w(tf2);
+  if (tl.gate.fc[0].Cin != (tl.gate.sum_parts ? 16 : 32) || k2.gate.fc[0].Cin != 16) return seg_fail(27);
+
+  // ---- the middle: steps 9 .. NS-15, then the level-2 gate with its pooled inputs replaced: GAP(B) arrives as partial sums
+  //      from k2, GAP(up2) == GAP(lo2) (uniform 2x interpolation weights)
+  std::vector<Step> mid(S.begin() + 9, S.begin() + (NS - 14));
+  Step gate = kg;
+  gate.concat_in = {B, lo2};
+  gate.in0 = B;
+  gate.label += "*";
+  mid.push_back(gate); mid.push_back(kf1); mid.push_back(kf2);
+  std::map<int, int> part_n, part_hw;
+  part_n[B] = k2.tiles_y * k2.tiles_x; part_hw[B] = k2.H2 * k2.W2;
+  // the program sees the partial sums of B under B's tensor id: point that id at the partials for the duration of the lowering
+  const long B_real = plan->tensor_off[B];
+  plan->tensor_off[B] = plan->tensor_off[pB];
+  build_frame_program(g, plan, mid, {c0, B, lo2, kf2.out}, part_n, part_hw);
+  plan->tensor_off[B] = B_real;
+  if (plan->program.empty()) return seg_fail(28);
+  sp.on = true;
+  plan->seg = sp;
+  char line[256];
+  plan->seg_text.clear();
+  auto add = [&](const char* name, int TR, int TC, int ty, int tx, int lds) {
+    snprintf(line, sizeof line, "segment %-5s tile %dx%d, %dx%d tiles per frame, LDS %.1f KiB\n", name, TR, TC, ty, tx, lds / 256.0);
+    plan->seg_text += line;
+  };
+  add("head", h.TR, h.TC, h.tiles_y, h.tiles_x, h.lds_floats); add("k2", k2.TR, k2.TC, k2.tiles_y, k2.tiles_x, k2.lds_floats);
+  add("k3", k3.TR, k3.TC, k3.tiles_y, k3.tiles_x, k3.lds_floats); add("tail", tl.TR, tl.TC, tl.tiles_y, tl.tiles_x, tl.lds_floats);
+  return true;
+}
+
+
+bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_arena, bool segments) {
   auto fail = [&](const std::string& m) { if (err) *err = m; return false; };
   Graph g = g_in;                       // local copy: the rewrite passes below may append synthetic tensors
   int NT = (int)g.tensors.size();
@@ -714,7 +926,11 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   plan->macs_per_frame = 0;
   for (const Step& st : steps) plan->macs_per_frame += st.macs;
   plan->steps = std::move(steps);
-  build_frame_program(g, plan);
+  plan->seg = SegPlan();
+  if (!segments || getenv("BSX_NO_SEGMENTS") || !build_segments(g, plan)) {
+    plan->seg = SegPlan();
+    build_frame_program(g, plan, plan->steps);
+  }
   return true;
 }
 

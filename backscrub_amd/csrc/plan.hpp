@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "frame_program.hpp"
+#include "segments.hpp"
 #include "tflite_model.hpp"
 
 namespace bsx {
@@ -61,6 +62,9 @@ struct Plan {
   struct LdsBlock { int off, len, from, until; std::string what; };
   std::vector<LdsBlock> program_blocks;
   std::string program_check;            // "ok" or the first violation found
+  // spatially-parallel segment kernels around the program (segments.hpp); when seg.on, `program` is only the MIDDLE of the network
+  SegPlan seg;
+  std::string seg_text;                 // one line per segment kernel (tiles, LDS) for bsx_plan_describe
   std::string describe() const;
 };
 
@@ -69,6 +73,8 @@ struct Plan {
 // "ok", or the first violation among the program's LDS reservations / operands (see Plan::program_blocks)
 std::string verify_program_lds(const Plan& plan);
 
-bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena = true);
+// `segments`: allow the head | k2 | middle | k3 | tail segmentation (segments.hpp) where the graph has that shape; the per-launch
+// path executes the plain step list and needs segments = false.
+bool build_plan(const Graph& g, Plan* plan, std::string* err, bool reuse_arena = true, bool segments = true);
 
 }  // namespace bsx

@@ -1,0 +1,111 @@
+// segments.hpp — the spatially-parallel "segment" kernels around the per-frame program.
+//
+// Interpreter::Invoke() (/root/reference/lib/libbackscrub.cc:307) for the Meet / MLKit family is cut where the
+// graph has GLOBAL dependencies (squeeze-excite and decoder-gate average pools).  Between two such cuts every
+// operator is spatially local, so the high-resolution ends of the network — where a frame offers thousands of
+// independent pixels — run as ordinary tiled kernels (many 256-lane workgroups per frame, halo recompute through
+// LDS, several workgroups per CU hiding each other's latency), and only the low-resolution middle, whose tensors
+// fit one CU's LDS, stays a one-workgroup-per-frame program (frame_program.hpp):
+//
+//   head   stem conv3x3/s2 → 1x1 → depthwise3x3/s2                       (+ pooled partial sums of A and b0)
+//   k2     SE gate(b0) → 1x1 (skip B) → 1x1 expand → depthwise3x3/s2     (+ partial sums of B)
+//   middle per-frame LDS program: the rest of the encoder, head, decoder levels 3 and 2 (gate of level 2 included)
+//   k3     B·g + up(lo2) → 1x1 → dw3x3 + residual → 1x1 (lo)            (+ partial sums of lo)
+//   tail   gate(A, lo) → A·g + up(lo) → 1x1 → dw3x3 + residual → Convolution2DTransposeBias 2x2 [→ decode + IIR]
+//
+// The pooled means the gates need are produced as per-tile partial sums by the kernel that writes the pooled tensor
+// and reduced by the consumer; GAP(resize2x(x)) == GAP(x) for the half-pixel 2x up-sampling these graphs use (every
+// source pixel carries the same total interpolation weight — verified on the host, otherwise the plan stays unsegmented),
+// so the up-sampled tensors are never materialised: each consumer interpolates the low-resolution tensor on the fly.
+//
+// Plain PODs shared by the planner (plan.cpp) and the device code (kernels_seg.hip); passed to the kernels BY VALUE
+// (kernarg → SGPRs: no descriptor fetches on the critical path).
+#pragma once
+#include <cstdint>
+
+namespace bsx {
+
+struct SegConvW { long long w_off = 0, b_off = 0; int Cin = 0, Cout = 0, cout_pad = 0, act = 0; };   // dense / 1x1: [k][cout_pad], bias [cout_pad]
+struct SegDwW { long long w_off = 0, b_off = 0; int C = 0, act = 0; };                               // depthwise 3x3: [fy][fx][C], bias [C]
+struct SegFc { long long w_off = 0, b_off = 0; int Cin = 0, Cout = 0, act = 0; };                    // [co][ci] rows
+struct SegPart { long long off = 0; int n = 0, C = 0; float hw = 1.f; };                             // partial sums [n][C] in the frame's arena slice; mean = sum / hw
+struct SegGate {                                                                                      // mean parts (concatenated or summed) → FC → [FC]
+  int n_parts = 0, sum_parts = 0, n_fc = 0;
+  SegPart part[2];
+  SegFc fc[2];
+};
+
+constexpr int kSegThreads = 256;
+constexpr int kSegMaxC = 16;        // channel count of every tensor at the segment boundaries (A, b0, B, lo2, lo)
+
+struct SegHead {
+  int H0 = 0, W0 = 0, H1 = 0, W1 = 0, H2 = 0, W2 = 0;     // network input, A (stem output), b0 (depthwise output)
+  int stem_pt = 0, stem_pl = 0, dw_pt = 0, dw_pl = 0;
+  SegConvW stem, pw;
+  SegDwW dw;
+  long long a_off = 0, b0_off = 0, part_a_off = 0, part_b0_off = 0;
+  int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;           // tile of b0 pixels per workgroup
+  int lds_floats = 0;
+  unsigned m_rowf = 0, m_ac = 0, m_tc = 0;                // ceil(2^32 / d) for the in-kernel divisions by (4TC+3)*3, 2TC+1, TC
+};
+
+struct SegK2 {
+  int H2 = 0, W2 = 0, H3 = 0, W3 = 0;                     // b0 / B resolution, c0 resolution
+  int dw_pt = 0, dw_pl = 0;
+  SegGate gate;                                           // s1 = gate(GAP(b0))
+  SegConvW pw_a, pw_b;                                    // B = pw_a(b0 * s1); x = act(pw_b(B))
+  SegDwW dw;                                              // c0 = act(dw3x3/s2(x))
+  long long b0_off = 0, B_off = 0, c0_off = 0, part_B_off = 0;
+  int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;           // tile of c0 pixels
+  int lds_floats = 0;
+  unsigned m_bc = 0, m_tc = 0;
+};
+
+struct SegK3 {
+  int H2 = 0, W2 = 0, HL = 0, WL = 0;                     // output resolution, resolution of lo2
+  int half_pixel = 0, align_corners = 0;
+  SegConvW pw1, pw2;                                      // z = act(pw1(skip*g + up(lo2))); lo = pw2(z + act(dw(z)))
+  SegDwW dw;
+  long long skip_off = 0, lo2_off = 0, g_off = 0, lo_off = 0, part_lo_off = 0;
+  int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
+  int lds_floats = 0;
+  unsigned m_zw = 0, m_tc = 0;
+};
+
+struct SegTail {
+  int H1 = 0, W1 = 0, HL = 0, WL = 0, H0 = 0, W0 = 0;     // A resolution, lo resolution, network output resolution
+  int half_pixel = 0, align_corners = 0;
+  SegGate gate;                                           // g = gate(GAP(A) | GAP(lo))
+  SegConvW pw;                                            // z = act(pw(A*g + up(lo)))
+  SegDwW dw;                                              // t = z + act(dw(z))
+  long long tc_w_off = 0, tc_b_off = 0;                   // Convolution2DTransposeBias 2x2: [fy][fx][oc][ic], bias [oc]
+  int Co = 0, act3 = 0, model_type = 0;
+  long long skip_off = 0, lo_off = 0;
+  int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
+  int lds_floats = 0;
+  unsigned m_zw = 0, m_tc = 0;
+};
+
+// LDS floats each kernel needs for the tile sizes in its descriptor (the planner picks the tiles against these; the kernels
+// carve the same regions)
+constexpr int kSegScratchFloats = 256;   // gate vector / means / hidden / partial-sum meeting points
+constexpr int kSegGateStageFloats = 512 + 2 * (32 * 32 + 32);   // gate prologue staging (aliases the first tile region)
+inline unsigned seg_magic(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
+inline int seg_head_lds_floats(const SegHead& d) {
+  const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, IR = 2 * AR + 1, IC = 2 * AC + 1;
+  const int a = IR * IC * 3, b = AR * AC * 16, r1 = a > b ? a : b;
+  return kSegScratchFloats + ((r1 + 3) & ~3) + AR * AC * 16;
+}
+inline int seg_k2_lds_floats(const SegK2& d) { const int v = 2 * (2 * d.TR + 1) * (2 * d.TC + 1) * 16; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats); }
+inline int seg_k3_lds_floats(const SegK3& d) { return kSegScratchFloats + (d.TR + 2) * (d.TC + 2) * 16 + d.TR * d.TC * 16; }
+inline int seg_tail_lds_floats(const SegTail& d) { const int v = (d.TR + 2) * (d.TC + 2) * 16; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats); }
+
+struct SegPlan {
+  bool on = false;
+  SegHead head;
+  SegK2 k2;
+  SegK3 k3;
+  SegTail tail;
+};
+
+}  // namespace bsx
