@@ -27,7 +27,7 @@ namespace {
 extern __shared__ __attribute__((aligned(16))) float seg_smem[];
 
 constexpr int kScrGate = 0;      // [0,16) gate vector, [16,48) means, [48,80) hidden
-constexpr int kScrRed = 96;      // [96, 96 + 2*64) partial-sum meeting points (two sets of 4 waves x 16 channels)
+constexpr int kScrRed = 96;      // [96, 96 + 2*256) partial-sum meeting points (two sets of 16 slots x 16 channels)
 constexpr int kScrFloats = kSegScratchFloats;  // tiles start here
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -36,19 +36,32 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) { return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)); }
 
-// same forms as the per-frame program (hardware exp2 / rcp)
+// Activations.  none / relu / relu6 are ONE branch-free v_med3_f32 with kernel-uniform bounds (the first version switched on the
+// activation code per element: a dozen scalar branches per MFMA tile were most of its SALU stream and of its stalls); hard-swish
+// (stems) and the logistic (MLKit's output) are compile-time variants of the kernels that need them.  Same arithmetic forms as the
+// per-frame program (hardware exp2 / rcp).
+struct Clamp { float lo, hi; };
+__device__ __forceinline__ Clamp clamp_of(int act) {               // planner guarantees act in {none, relu, relu6} wherever this is used
+  Clamp c;
+  c.lo = act == kActNone ? -__builtin_huge_valf() : 0.f;
+  c.hi = act == kActRelu6 ? 6.f : __builtin_huge_valf();
+  return c;
+}
+__device__ __forceinline__ float4 clamp4(float4 v, Clamp c) {
+  return make_float4(__builtin_amdgcn_fmed3f(v.x, c.lo, c.hi), __builtin_amdgcn_fmed3f(v.y, c.lo, c.hi), __builtin_amdgcn_fmed3f(v.z, c.lo, c.hi),
+                     __builtin_amdgcn_fmed3f(v.w, c.lo, c.hi));
+}
+__device__ __forceinline__ float hswish1(float v) { return v * __builtin_amdgcn_fmed3f(v + 3.f, 0.f, 6.f) * 0.16666667163372040f; }
+__device__ __forceinline__ float4 hswish4(float4 v) { return make_float4(hswish1(v.x), hswish1(v.y), hswish1(v.z), hswish1(v.w)); }
+__device__ __forceinline__ float sigmoid1(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); }
+// gate prologue only (a handful of lanes, once per workgroup)
 __device__ __forceinline__ float sg_act(float v, int act) {
   if (act == kActNone) return v;
-  if (act == kActSigmoid) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
-  const float hi = act == kActRelu ? 3.0e38f : 6.f;
-  if (act == kActHswish) return v * fminf(hi, fmaxf(0.f, v + 3.f)) * 0.16666667163372040f;
-  return fminf(fmaxf(v, 0.f), hi);
+  if (act == kActSigmoid) return sigmoid1(v);
+  if (act == kActHswish) return hswish1(v);
+  if (act == kActRelu) return fmaxf(v, 0.f);
+  return __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
 }
-__device__ __forceinline__ float4 sg_act4(float4 v, int act) { return make_float4(sg_act(v.x, act), sg_act(v.y, act), sg_act(v.z, act), sg_act(v.w, act)); }
-
-// n / d for 0 <= n < 65536 with m = ceil(2^32 / d)
-__device__ __forceinline__ int div_magic(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
-__host__ __device__ inline unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
 
 // one 16-pixel x 16-channel tile of a 1x1 convolution with Cin = 16: 4 MFMAs
 __device__ __forceinline__ f4acc mma16(const float4 a, const float (&wr)[4]) {
@@ -128,42 +141,41 @@ __device__ __forceinline__ void seg_gate(const SegGate& gt, const float* __restr
 }
 
 // ---- per-tile partial sums of a 16-channel tensor → partials[tile][16] -------------------------------------------------------
-// mode 0: MFMA-epilogue lanes (lane (g, li) owns channel quad li >> 2); mode 1: item lanes (lane owns channel quad tid & 3).
+// Lanes hold float4 partial sums of their channel quad.  MODE 0: MFMA-epilogue lanes (lane (g, li): channel quad li >> 2, the four
+// lanes li & 3 differ in pixel); MODE 1: depthwise lanes (lane = 4 * pixel + quad inside a 16-lane DPP row).  Two DPP steps leave
+// 16 partial float4 per wave; they meet in s_red[16 slots][16 channels] and the first 16 lanes of the workgroup finish the sum.
+template <int SHR>
+__device__ __forceinline__ float dpp_row_shr(float v) {        // lane i <- lane i - SHR inside its row of 16 (0 where there is none)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SHR, 0xf, 0xf, true));
+}
 template <int MODE>
-__device__ __forceinline__ void wave_reduce16(float4 v, float* s_red /* [4 waves][16] */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  auto fold = [&](int o) { v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o); };
+__device__ __forceinline__ void wave_reduce16(float4 v, float* s_red, int wave, int lane) {
   if (MODE == 0) {
-    fold(1); fold(2); fold(16); fold(32);
-    if ((lane & 3) == 0 && lane < 16) st4(s_red + wave * 16 + (lane >> 2) * 4, v);
+    v.x += dpp_quad(v.x, 1); v.y += dpp_quad(v.y, 1); v.z += dpp_quad(v.z, 1); v.w += dpp_quad(v.w, 1);
+    v.x += dpp_quad(v.x, 2); v.y += dpp_quad(v.y, 2); v.z += dpp_quad(v.z, 2); v.w += dpp_quad(v.w, 2);
+    if ((lane & 3) == 0) st4(s_red + (wave * 4 + (lane >> 4)) * 16 + (lane & 12), v);          // slot (wave, g), channels 4 * (li >> 2)
   } else {
-    fold(4); fold(8); fold(16); fold(32);
-    if (lane < 4) st4(s_red + wave * 16 + lane * 4, v);
+    v.x += dpp_row_shr<4>(v.x); v.y += dpp_row_shr<4>(v.y); v.z += dpp_row_shr<4>(v.z); v.w += dpp_row_shr<4>(v.w);
+    v.x += dpp_row_shr<8>(v.x); v.y += dpp_row_shr<8>(v.y); v.z += dpp_row_shr<8>(v.z); v.w += dpp_row_shr<8>(v.w);
+    if ((lane & 12) == 12) st4(s_red + (wave * 4 + (lane >> 4)) * 16 + 4 * (lane & 3), v);     // slot (wave, row), channels 4 * quad
   }
 }
 __device__ __forceinline__ void store_partials(const float* s_red, float* dst /* 16 floats */) {   // after a barrier
-  if (threadIdx.x < 16) dst[threadIdx.x] = (s_red[threadIdx.x] + s_red[16 + threadIdx.x]) + (s_red[32 + threadIdx.x] + s_red[48 + threadIdx.x]);
+  if (threadIdx.x < 16) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) s += s_red[j * 16 + threadIdx.x];
+    dst[threadIdx.x] = s;
+  }
 }
 
-// ---- bilinear sample of a [HL][WL][16] tensor at output pixel (oy, ox), channels c0..c0+3 (TFLite reference association) ---------
-struct UpCoef { int y0, y1, x0, x1; float dy, dx; };
+// ---- bilinear up-sampling (RESIZE_BILINEAR) as per-axis tables: index pair + fraction, TFLite's clamping ----------------------
 __device__ __forceinline__ void up_axis(int o, float scale, bool half_pixel, int in_size, int* lo, int* hi, float* frac) {
   const float v = half_pixel ? __fadd_rn(__fmul_rn((float)o + 0.5f, scale), -0.5f) : __fmul_rn((float)o, scale);
   const float fl = floorf(v);
   *lo = max((int)fl, 0);
   *hi = min((int)ceilf(v), in_size - 1);
   *frac = v - (float)*lo;
-}
-__device__ __forceinline__ float up_lerp(float x00, float x10, float x01, float x11, float dy, float dx) {
-  const float a = __fmul_rn(__fmul_rn(x00, 1.f - dy), 1.f - dx), b = __fmul_rn(__fmul_rn(x10, dy), 1.f - dx);
-  const float c = __fmul_rn(__fmul_rn(x01, 1.f - dy), dx), d = __fmul_rn(__fmul_rn(x11, dy), dx);
-  return __fadd_rn(__fadd_rn(__fadd_rn(a, b), c), d);
-}
-__device__ __forceinline__ float4 up_sample(const float* __restrict__ lo, int WL, const UpCoef& u, int ch) {
-  const float4 a = ld4(lo + (u.y0 * WL + u.x0) * 16 + ch), b = ld4(lo + (u.y1 * WL + u.x0) * 16 + ch);
-  const float4 c = ld4(lo + (u.y0 * WL + u.x1) * 16 + ch), d = ld4(lo + (u.y1 * WL + u.x1) * 16 + ch);
-  return make_float4(up_lerp(a.x, b.x, c.x, d.x, u.dy, u.dx), up_lerp(a.y, b.y, c.y, d.y, u.dy, u.dx), up_lerp(a.z, b.z, c.z, d.z, u.dy, u.dx),
-                     up_lerp(a.w, b.w, c.w, d.w, u.dy, u.dx));
 }
 __device__ __forceinline__ float up_scale(int in, int out, bool align) { return (align && out > 1) ? (float)(in - 1) / (float)(out - 1) : (float)in / (float)out; }
 
@@ -175,14 +187,19 @@ __device__ __forceinline__ float quad_reduce_scatter(float p0, float p1, float p
   return (b1 ? khi : klo) + dpp_quad(b1 ? klo : khi, 2);
 }
 
-// depthwise 3x3 (stride S) at tile pixel (py, px) of a dense [rows][ZW][16] LDS tile, channel quad `q`
+// depthwise 3x3 (stride S) at pixel (py, px) of a [rows][RW][16] LDS tile, channel quad `q`; packed FMAs (v_pk_fma_f32)
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v ldv(const float* p) { return *reinterpret_cast<const f4v*>(p); }
+__device__ __forceinline__ f4v tov(float4 a) { f4v r = {a.x, a.y, a.z, a.w}; return r; }
+__device__ __forceinline__ float4 tof4(f4v a) { return make_float4(a.x, a.y, a.z, a.w); }
 template <int S>
-__device__ __forceinline__ float4 dw3x3(const float* __restrict__ zt, int ZW, int py, int px, int q, const float4 (&wd)[9]) {
-  float4 acc = f4zero();
+__device__ __forceinline__ f4v dw3x3(const float* __restrict__ zt, int RW, int py, int px, int q, const f4v (&wd)[9]) {
+  f4v acc = {0.f, 0.f, 0.f, 0.f};
+  const float* base = zt + ((S * py) * RW + S * px) * 16 + 4 * q;
 #pragma unroll
   for (int fy = 0; fy < 3; fy++)
 #pragma unroll
-    for (int fx = 0; fx < 3; fx++) acc = f4fma(ld4(zt + ((S * py + fy) * ZW + S * px + fx) * 16 + 4 * q), wd[fy * 3 + fx], acc);
+    for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(ldv(base + (fy * RW + fx) * 16), wd[fy * 3 + fx], acc);
   return acc;
 }
 
@@ -195,40 +212,59 @@ __device__ __forceinline__ uint32_t seg_meet_val(float l0, float l1) {
   return __fdiv_rn(e0, s) < __fdiv_rn(e1, s) ? 0u : 255u;
 }
 
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// MFMA phases walk ROW-ALIGNED tiles: tile t = (row t / ctiles, 16 columns 16 * (t % ctiles) ..) of a [rows][RW = 16 * ctiles][16]
+// LDS tile.  The row is wave-uniform (scalar index math, scalar in-image tests), the column of a lane is 16 * ct + its fixed lane
+// offset: no per-pixel divisions, which were most of the VALU work of the first (linear-index) version of these kernels.
+struct RowTile { int row, ct; };
+__device__ __forceinline__ RowTile row_tile(int t, int ctiles, unsigned m_ct) {
+  RowTile r;
+  r.row = (int)(((unsigned)t * m_ct) >> 16);           // t / ctiles for t < 4096 (m_ct = ceil(65536 / ctiles))
+  r.ct = t - r.row * ctiles;
+  return r;
+}
+
 // ==================================================================================================================================
 // head: stem conv3x3/s2 (3 → 16) → 1x1 (16 → 16) → depthwise 3x3/s2; writes A (skip of the last decoder level), b0, and the
-// pooled partial sums of both.  Tile = TR x TC pixels of b0.
+// pooled partial sums of both.  Tile = TR (<= 4) x TC (<= 15) pixels of b0.
 // ==================================================================================================================================
+template <bool STEM_HSWISH>
 __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float* __restrict__ arena, long per_frame, const float* __restrict__ net_in,
                                                           const float* __restrict__ w) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC;
-  const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, ar0 = 2 * r0 - d.dw_pt, ac0 = 2 * c0 - d.dw_pl;
-  const int IR = 2 * AR + 1, IC = 2 * AC + 1, ir0 = 2 * ar0 - d.stem_pt, ic0 = 2 * ac0 - d.stem_pl;
+  const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, ar0 = 2 * r0 - d.dw_pt, ac0 = 2 * c0 - d.dw_pl, RW = d.rw, ctiles = RW >> 4;
+  const int IR = 2 * AR + 1, IC = 2 * AC + 1, ir0 = 2 * ar0 - d.stem_pt, ic0 = 2 * ac0 - d.stem_pl, rowf = IC * 3;
   float* fa = arena + (size_t)f * (size_t)per_frame;
-  float* in_t = seg_smem + kScrFloats;                              // [IR][IC][3]; later x_t = act(pw(A)) [AR*AC][16]
-  const int r1 = max(IR * IC * 3, AR * AC * 16);
-  float* a_t = in_t + ((r1 + 3) & ~3);                              // [AR*AC][16]
+  float* in_t = seg_smem + kScrFloats;                              // [IR][IC * 3]; later x_t = act(pw(A)) [AR][RW][16]
+  const int r1 = max(IR * rowf, AR * RW * 16);
+  float* a_t = in_t + ((r1 + 3) & ~3);                              // [AR][RW][16]
   float* x_t = in_t;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
 
-  // 1. input tile (zero outside the image: SAME padding of the stem); a lane's loads are all issued before its first LDS store
+  // 1. input tile (zero outside the image: SAME padding of the stem): wave = rows, lane = row elements; every load of the lane is
+  //    in flight before its first LDS store
   {
     const float* src = net_in + (size_t)f * (size_t)(d.H0 * d.W0 * 3);
-    const int rowf = IC * 3, lo_rem = max(0, -ic0) * 3, hi_rem = min(IC, d.W0 - ic0) * 3;
-    const unsigned mrow = d.m_rowf;
-    constexpr int kB = 12;
-    for (int base = 0; base < IR * rowf; base += kB * kSegThreads) {
-      float v[kB];
+    const int lo_rem = max(0, -ic0) * 3, hi_rem = min(IC, d.W0 - ic0) * 3;
+    float v[5][3];
 #pragma unroll
-      for (int j = 0; j < kB; j++) {
-        const int i = base + j * kSegThreads + tid;
-        const int row = div_magic(i, mrow), rem = i - row * rowf, gy = ir0 + row;
-        v[j] = 0.f;
-        if (i < IR * rowf && gy >= 0 && gy < d.H0 && rem >= lo_rem && rem < hi_rem) v[j] = src[((long)gy * d.W0 + ic0) * 3 + rem];
+    for (int j = 0; j < 5; j++) {
+      const int row = wave + 4 * j, gy = ir0 + row;
+      const bool rowok = row < IR && gy >= 0 && gy < d.H0;
+#pragma unroll
+      for (int e3 = 0; e3 < 3; e3++) {
+        const int e = lane + 64 * e3;
+        v[j][e3] = 0.f;
+        if (rowok && e >= lo_rem && e < hi_rem) v[j][e3] = src[((long)gy * d.W0 + ic0) * 3 + e];
       }
+    }
 #pragma unroll
-      for (int j = 0; j < kB; j++) { const int i = base + j * kSegThreads + tid; if (i < IR * rowf) in_t[i] = v[j]; }
+    for (int j = 0; j < 5; j++) {
+      const int row = wave + 4 * j;
+#pragma unroll
+      for (int e3 = 0; e3 < 3; e3++) { const int e = lane + 64 * e3; if (row < IR && e < rowf) in_t[row * rowf + e] = v[j][e3]; }
     }
   }
   // stem operand tables of this lane: k = 4s + g over the im2col axis (fy, fx, ci), 27 valid entries
@@ -239,80 +275,99 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
     const int k = 4 * s + g;
     const bool valid = k < 27;
     const int fy = k / 9, r9 = k - 9 * fy, fx = r9 / 3, ci = r9 - 3 * fx;
-    koff[s] = valid ? (fy * IC + fx) * 3 + ci : 0;
+    koff[s] = valid ? fy * rowf + fx * 3 + ci : 0;
     ws[s] = valid ? w[d.stem.w_off + (long long)k * d.stem.cout_pad + li] : 0.f;
   }
   const float4 bias_s = ld4(w + d.stem.b_off + cq4);
+  const Clamp cl_stem = clamp_of(d.stem.act), cl_pw = clamp_of(d.pw.act), cl_dw = clamp_of(d.dw.act);
+  const int ntile = AR * ctiles;
+  const int xe = 4 * g + q;                                        // column of the pixel this lane owns after the quad transpose
   __syncthreads();
 
-  // 2. stem on the A region
-  const int npix = AR * AC, ntile = (npix + 15) >> 4;
-  const unsigned mac = d.m_ac;
+  // 2. stem on the A region, two tiles per iteration: their MFMA chains (7 dependent instructions each) interleave
   float4 sumA = f4zero();
-  for (int t = wave; t < ntile; t += 4) {
-    const int p = min(16 * t + li, npix - 1);
-    const int ay = div_magic(p, mac), ax = p - ay * AC;
-    const float* base = in_t + ((2 * ay) * IC + 2 * ax) * 3;
-    float av[7];
-#pragma unroll
-    for (int s = 0; s < 7; s++) av[s] = base[koff[s]];
-    f4acc acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 7; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], ws[s], acc, 0, 0, 0);
-    const int pp = 16 * t + 4 * g + q;
+  auto stem_epilogue = [&](const f4acc acc, const RowTile rt) {
     float4 v = quad_transpose(acc, q);
-    if (pp < npix) {
-      const int y2 = div_magic(pp, mac), x2 = pp - y2 * AC, gy = ar0 + y2, gx = ac0 + x2;
-      v = sg_act4(f4add(v, bias_s), d.stem.act);
-      st4(a_t + pp * 16 + cq4, v);
-      const bool inside = gy >= 0 && gy < d.H1 && gx >= 0 && gx < d.W1;
-      if (inside && gy >= 2 * r0 && gy < 2 * r0 + 2 * d.TR && gx >= 2 * c0 && gx < 2 * c0 + 2 * d.TC) {   // each A pixel is stored by exactly one tile
+    const int x2 = 16 * rt.ct + xe, gy = ar0 + rt.row, gx = ac0 + x2;
+    if (x2 < AC) {
+      v = f4add(v, bias_s);
+      v = STEM_HSWISH ? hswish4(v) : clamp4(v, cl_stem);
+      st4(a_t + (rt.row * RW + x2) * 16 + cq4, v);
+      const bool row_owned = gy >= max(2 * r0, 0) && gy < min(2 * r0 + 2 * d.TR, d.H1);          // scalar
+      if (row_owned && gx >= 2 * c0 && gx < min(2 * c0 + 2 * d.TC, d.W1)) {                      // each A pixel is stored by exactly one tile
         st4(fa + d.a_off + ((long)gy * d.W1 + gx) * 16 + cq4, v);
         sumA = f4add(sumA, v);
       }
     }
+  };
+  for (int t = wave; t < ntile; t += 8) {
+    const bool two = t + 4 < ntile;                                  // scalar
+    const RowTile r0t = row_tile(t, ctiles, d.m_ct), r1t = row_tile(two ? t + 4 : t, ctiles, d.m_ct);
+    const float* base0 = in_t + (2 * r0t.row) * rowf + 6 * min(16 * r0t.ct + li, AC - 1);
+    const float* base1 = in_t + (2 * r1t.row) * rowf + 6 * min(16 * r1t.ct + li, AC - 1);
+    float av0[7], av1[7];
+#pragma unroll
+    for (int s7 = 0; s7 < 7; s7++) { av0[s7] = base0[koff[s7]]; av1[s7] = base1[koff[s7]]; }
+    f4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s7 = 0; s7 < 7; s7++) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[s7], ws[s7], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[s7], ws[s7], acc1, 0, 0, 0);
+    }
+    stem_epilogue(acc0, r0t);
+    if (two) stem_epilogue(acc1, r1t);
   }
   float wr[4];
   load_wtile(wr, w, d.pw, 0, li, g);
   const float4 bias_p = ld4(w + d.pw.b_off + cq4);
   __syncthreads();
 
-  // 3. x = act(pw(A)) on the same region; zero outside the image (SAME padding of the depthwise)
-  for (int t = wave; t < ntile; t += 4) {
-    const int p = min(16 * t + li, npix - 1);
-    const f4acc acc = mma16(ld4(a_t + p * 16 + 4 * g), wr);
-    const int pp = 16 * t + 4 * g + q;
+  // 3. x = act(pw(A)) on the same region; zero outside the image (SAME padding of the depthwise); two tiles per iteration
+  auto pw_epilogue = [&](const f4acc acc, const RowTile rt) {
     float4 v = quad_transpose(acc, q);
-    if (pp < npix) {
-      const int y2 = div_magic(pp, mac), x2 = pp - y2 * AC, gy = ar0 + y2, gx = ac0 + x2;
+    const int x2 = 16 * rt.ct + xe, gy = ar0 + rt.row, gx = ac0 + x2;
+    if (x2 < AC) {
       const bool inside = gy >= 0 && gy < d.H1 && gx >= 0 && gx < d.W1;
-      v = inside ? sg_act4(f4add(v, bias_p), d.pw.act) : f4zero();
-      st4(x_t + pp * 16 + cq4, v);
+      v = inside ? clamp4(f4add(v, bias_p), cl_pw) : f4zero();
+      st4(x_t + (rt.row * RW + x2) * 16 + cq4, v);
     }
+  };
+  for (int t = wave; t < ntile; t += 8) {
+    const bool two = t + 4 < ntile;
+    const RowTile r0t = row_tile(t, ctiles, d.m_ct), r1t = row_tile(two ? t + 4 : t, ctiles, d.m_ct);
+    const float4 a0 = ld4(a_t + (r0t.row * RW + min(16 * r0t.ct + li, AC - 1)) * 16 + 4 * g);
+    const float4 a1 = ld4(a_t + (r1t.row * RW + min(16 * r1t.ct + li, AC - 1)) * 16 + 4 * g);
+    f4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wr[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wr[0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wr[1], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wr[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wr[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wr[2], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wr[3], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wr[3], acc1, 0, 0, 0);
+    pw_epilogue(acc0, r0t);
+    if (two) pw_epilogue(acc1, r1t);
   }
-  const int quad = tid & 3;
-  float4 wd[9];
+  const int quad = lane & 3, px = lane >> 2;                        // depthwise lanes: (pixel of the row, channel quad)
+  f4v wd[9];
 #pragma unroll
-  for (int k = 0; k < 9; k++) wd[k] = ld4(w + d.dw.w_off + k * 16 + 4 * quad);
-  const float4 bias_d = ld4(w + d.dw.b_off + 4 * quad);
+  for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + 4 * quad);
+  const f4v bias_d = ldv(w + d.dw.b_off + 4 * quad);
   __syncthreads();
 
-  // 4. depthwise 3x3 / stride 2 → b0
+  // 4. depthwise 3x3 / stride 2 → b0: one tile row per wave iteration
   float4 sumB = f4zero();
-  const unsigned mtc = d.m_tc;
-  for (int i = tid; i < d.TR * d.TC * 4; i += kSegThreads) {
-    const int pix = i >> 2, py = div_magic(pix, mtc), px = pix - py * d.TC;
-    if (r0 + py >= d.H2 || c0 + px >= d.W2) continue;
-    const float4 v = sg_act4(f4add(dw3x3<2>(x_t, AC, py, px, quad, wd), bias_d), d.dw.act);
-    st4(fa + d.b0_off + ((long)(r0 + py) * d.W2 + c0 + px) * 16 + 4 * quad, v);
-    sumB = f4add(sumB, v);
+  for (int py = wave; py < d.TR; py += 4) {
+    if (r0 + py >= d.H2) break;
+    if (px < d.TC && c0 + px < d.W2) {
+      const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
+      st4(fa + d.b0_off + ((long)(r0 + py) * d.W2 + c0 + px) * 16 + 4 * quad, v);
+      sumB = f4add(sumB, v);
+    }
   }
   float* s_red = seg_smem + kScrRed;
-  wave_reduce16<0>(sumA, s_red);
-  wave_reduce16<1>(sumB, s_red + 64);
+  wave_reduce16<0>(sumA, s_red, wave, lane);
+  wave_reduce16<1>(sumB, s_red + 256, wave, lane);
   __syncthreads();
   store_partials(s_red, fa + d.part_a_off + (long)blockIdx.x * 16);
-  store_partials(s_red + 64, fa + d.part_b0_off + (long)blockIdx.x * 16);
+  store_partials(s_red + 256, fa + d.part_b0_off + (long)blockIdx.x * 16);
 }
 
 // ==================================================================================================================================
@@ -322,196 +377,227 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC;
-  const int BR = 2 * d.TR + 1, BC = 2 * d.TC + 1, br0 = 2 * r0 - d.dw_pt, bc0 = 2 * c0 - d.dw_pl;
+  const int BR = 2 * d.TR + 1, BC = 2 * d.TC + 1, br0 = 2 * r0 - d.dw_pt, bc0 = 2 * c0 - d.dw_pl, RW = d.rw, ctiles = RW >> 4;
   float* fa = arena + (size_t)f * (size_t)per_frame;
-  const int npix = BR * BC, ntile = (npix + 15) >> 4;
-  float* B_t = seg_smem + kScrFloats;
-  float* x_t = B_t + npix * 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+  float* B_t = seg_smem + kScrFloats;                               // [BR][RW][16]
+  float* x_t = B_t + BR * RW * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+  const int ntile = BR * ctiles, xe = 4 * g + q;
+  // all of this wave's b0 operands are requested before the gate prologue (one memory round trip for the whole workgroup)
+  constexpr int kB0 = 6;                                            // planner: ceil(BR * ctiles / 4) <= 6
+  float4 b0v[kB0];
+#pragma unroll
+  for (int j = 0; j < kB0; j++) {
+    const int t = wave + 4 * j;
+    b0v[j] = f4zero();
+    if (t < ntile) {
+      const RowTile rt = row_tile(t, ctiles, d.m_ct);
+      const int gy = br0 + rt.row, gx = bc0 + 16 * rt.ct + li;
+      if (gy >= 0 && gy < d.H2 && gx >= 0 && gx < d.W2) b0v[j] = ld4(fa + d.b0_off + ((long)gy * d.W2 + gx) * 16 + 4 * g);
+    }
+  }
   seg_gate(d.gate, fa, w, seg_smem, B_t);
   const float4 sv = ld4(seg_smem + kScrGate + 4 * g);
   float wr[4];
   load_wtile(wr, w, d.pw_a, 0, li, g);
   const float4 bias_a = ld4(w + d.pw_a.b_off + cq4);
-  const unsigned mbc = d.m_bc;
+  const Clamp cl_a = clamp_of(d.pw_a.act), cl_b = clamp_of(d.pw_b.act), cl_dw = clamp_of(d.dw.act);
 
-  // 1. B on the region the depthwise needs (the next tile's operand is requested before this tile's MFMAs)
+  // 1. B on the region the depthwise needs
   float4 sumB = f4zero();
-  auto load_b0 = [&](int t) {
-    float4 a = f4zero();
-    if (t < ntile) {
-      const int p = min(16 * t + li, npix - 1);
-      const int by = div_magic(p, mbc), bx = p - by * BC, gy = br0 + by, gx = bc0 + bx;
-      if (gy >= 0 && gy < d.H2 && gx >= 0 && gx < d.W2) a = ld4(fa + d.b0_off + ((long)gy * d.W2 + gx) * 16 + 4 * g);
-    }
-    return a;
-  };
-  float4 a_next = load_b0(wave);
-  for (int t = wave; t < ntile; t += 4) {
-    float4 a = a_next;
-    a_next = load_b0(t + 4);
+#pragma unroll
+  for (int j = 0; j < kB0; j++) {
+    const int t = wave + 4 * j;
+    if (t >= ntile) break;
+    const RowTile rt = row_tile(t, ctiles, d.m_ct);
+    float4 a = b0v[j];
     a = make_float4(__fmul_rn(a.x, sv.x), __fmul_rn(a.y, sv.y), __fmul_rn(a.z, sv.z), __fmul_rn(a.w, sv.w));
     const f4acc acc = mma16(a, wr);
-    const int pp = 16 * t + 4 * g + q;
     float4 v = quad_transpose(acc, q);
-    if (pp < npix) {
-      const int y2 = div_magic(pp, mbc), x2 = pp - y2 * BC, hy = br0 + y2, hx = bc0 + x2;
-      v = sg_act4(f4add(v, bias_a), d.pw_a.act);
-      st4(B_t + pp * 16 + cq4, v);
-      const bool inside = hy >= 0 && hy < d.H2 && hx >= 0 && hx < d.W2;
-      if (inside && hy >= 2 * r0 && hy < 2 * r0 + 2 * d.TR && hx >= 2 * c0 && hx < 2 * c0 + 2 * d.TC) {
+    const int x2 = 16 * rt.ct + xe, hy = br0 + rt.row, hx = bc0 + x2;
+    if (x2 < BC) {
+      v = clamp4(f4add(v, bias_a), cl_a);
+      st4(B_t + (rt.row * RW + x2) * 16 + cq4, v);
+      const bool row_owned = hy >= max(2 * r0, 0) && hy < min(2 * r0 + 2 * d.TR, d.H2);
+      if (row_owned && hx >= 2 * c0 && hx < min(2 * c0 + 2 * d.TC, d.W2)) {
         st4(fa + d.B_off + ((long)hy * d.W2 + hx) * 16 + cq4, v);
         sumB = f4add(sumB, v);
       }
     }
   }
   float* s_red = seg_smem + kScrRed;
-  wave_reduce16<0>(sumB, s_red);
+  wave_reduce16<0>(sumB, s_red, wave, lane);
   __syncthreads();
   store_partials(s_red, fa + d.part_B_off + (long)blockIdx.x * 16);
 
   // 2. 16 expanded channels at a time: x = act(pw_b(B)) → depthwise 3x3/s2 → c0
-  const int C = d.dw.C, ngrp = (C + 15) >> 4, quad = tid & 3;
-  const unsigned mtc = d.m_tc;
+  const int C = d.dw.C, ngrp = (C + 15) >> 4, quad = lane & 3, px = lane >> 2;
   for (int grp = 0; grp < ngrp; grp++) {
     load_wtile(wr, w, d.pw_b, 16 * grp, li, g);
     const float4 bias_b = ld4(w + d.pw_b.b_off + 16 * grp + cq4);
     for (int t = wave; t < ntile; t += 4) {
-      const int p = min(16 * t + li, npix - 1);
-      const f4acc acc = mma16(ld4(B_t + p * 16 + 4 * g), wr);
-      const int pp = 16 * t + 4 * g + q;
+      const RowTile rt = row_tile(t, ctiles, d.m_ct);
+      const int bx = min(16 * rt.ct + li, BC - 1);
+      const f4acc acc = mma16(ld4(B_t + (rt.row * RW + bx) * 16 + 4 * g), wr);
       float4 v = quad_transpose(acc, q);
-      if (pp < npix) {
-        const int y2 = div_magic(pp, mbc), x2 = pp - y2 * BC, hy = br0 + y2, hx = bc0 + x2;
+      const int x2 = 16 * rt.ct + xe, hy = br0 + rt.row, hx = bc0 + x2;
+      if (x2 < BC) {
         const bool inside = hy >= 0 && hy < d.H2 && hx >= 0 && hx < d.W2;
-        v = inside ? sg_act4(f4add(v, bias_b), d.pw_b.act) : f4zero();
-        st4(x_t + pp * 16 + cq4, v);
+        v = inside ? clamp4(f4add(v, bias_b), cl_b) : f4zero();
+        st4(x_t + (rt.row * RW + x2) * 16 + cq4, v);
       }
     }
     const int ch = 16 * grp + 4 * quad;
-    float4 wd[9];
-    float4 bias_d = f4zero();
+    f4v wd[9];
+    f4v bias_d = {0.f, 0.f, 0.f, 0.f};
     if (ch < C) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) wd[k] = ld4(w + d.dw.w_off + (long long)k * C + ch);
-      bias_d = ld4(w + d.dw.b_off + ch);
+      for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + (long long)k * C + ch);
+      bias_d = ldv(w + d.dw.b_off + ch);
     }
     __syncthreads();
-    if (ch < C)
-      for (int i = tid; i < d.TR * d.TC * 4; i += kSegThreads) {
-        const int pix = i >> 2, py = div_magic(pix, mtc), px = pix - py * d.TC;
-        if (r0 + py >= d.H3 || c0 + px >= d.W3) continue;
-        const float4 v = sg_act4(f4add(dw3x3<2>(x_t, BC, py, px, quad, wd), bias_d), d.dw.act);
+    if (ch < C && px < d.TC && c0 + px < d.W3)
+      for (int py = wave; py < d.TR && r0 + py < d.H3; py += 4) {
+        const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
         st4(fa + d.c0_off + ((long)(r0 + py) * d.W3 + c0 + px) * C + ch, v);
       }
     __syncthreads();
   }
 }
 
-// z = act(pw(skip * g + up(lo))) on the (TR+2) x (TC+2) halo region of a tile, zero outside the image — shared by k3 and the tail.
-// A tile's five 16-byte operands (skip + four interpolation taps) are requested one tile AHEAD of the arithmetic that uses them.
-struct GatedOperand { float4 s, a, b, c, d; float dy, dx; bool in; };
-__device__ __forceinline__ void seg_gated_pw(const float* __restrict__ skip, const float* __restrict__ lo, int H, int W, int HL, int WL, bool half_pixel, bool align,
-                                             const float* s_gate, const SegConvW& pw, const float* __restrict__ w, int r0, int c0, int ZH, int ZW, unsigned mzw,
-                                             float* z_t) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+// z = act(pw(skip * g + up(lo))) on the (TR+2) x (TC+2 <= 16) halo region of a tile, zero outside the image — shared by k3 and the
+// tail.  One MFMA tile = one region row (16 columns): the row's interpolation pair is scalar, the column's a per-lane constant;
+// up = a*w00 + b*w10 + c*w01 + d*w11 with w = products of the two axis fractions (differs from the reference association
+// ((a*(1-dy))*(1-dx) + ...) by float rounding only).
+// Memory: at 3-4 workgroups per CU a dependent global load costs 1-2 us, so EVERYTHING the phase reads is requested in the first
+// instructions of the kernel (gated_prefetch): the lane's skip operand of each of its <= kGatedRows rows into registers, the
+// low-resolution rows/columns the tile interpolates from into LDS (l_t, [LR][LC][20]); the compute part then never touches HBM.
+constexpr int kGatedRows = 5;           // region rows per wave: (TR + 2 + 3) / 4 <= 5  →  TR <= 18
+constexpr int kLoStride = 20;           // floats per staged low-resolution pixel (16 + 4: spreads the 16-byte tap reads over the banks)
+struct GatedPre { float4 s[kGatedRows]; int ly0, lx0, LC; };
+__device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ skip, const float* __restrict__ lo, int H, int W, int HL, int WL, bool half_pixel,
+                                                   bool align, int r0, int c0, int ZH, int ZC, float* l_t) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4;
+  GatedPre pre;
+  const int ix = c0 - 1 + li;
+  const bool col_in = li < ZC && ix >= 0 && ix < W;
+#pragma unroll
+  for (int j = 0; j < kGatedRows; j++) {
+    const int zy = wave + 4 * j, iy = r0 - 1 + zy;
+    pre.s[j] = f4zero();
+    if (zy < ZH && iy >= 0 && iy < H && col_in) pre.s[j] = ld4(skip + ((long)iy * W + ix) * 16 + 4 * g);
+  }
+  // low-resolution window: rows y0(first image row of the region) .. y1(last), columns likewise (monotone maps)
+  const float hs = up_scale(HL, H, align), wsc = up_scale(WL, W, align);
+  int ly0, ly1, lx0, lx1, t0, t1;
+  float fr;
+  up_axis(max(r0 - 1, 0), hs, half_pixel, HL, &ly0, &t1, &fr);
+  up_axis(min(r0 - 2 + ZH, H - 1), hs, half_pixel, HL, &t0, &ly1, &fr);
+  up_axis(max(c0 - 1, 0), wsc, half_pixel, WL, &lx0, &t1, &fr);
+  up_axis(min(c0 - 2 + ZC, W - 1), wsc, half_pixel, WL, &t0, &lx1, &fr);
+  const int LR = ly1 - ly0 + 1, LC = lx1 - lx0 + 1;                 // planner: LR <= 12, LC * 4 <= 64
+  pre.ly0 = ly0; pre.lx0 = lx0; pre.LC = LC;
+  float4 v[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int ly = wave + 4 * j;
+    v[j] = f4zero();
+    if (ly < LR && lane < LC * 4) v[j] = ld4(lo + ((long)(ly0 + ly) * WL + lx0 + (lane >> 2)) * 16 + 4 * (lane & 3));
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int ly = wave + 4 * j;
+    if (ly < LR && lane < LC * 4) st4(l_t + (ly * LC + (lane >> 2)) * kLoStride + 4 * (lane & 3), v[j]);
+  }
+  return pre;
+}
+__device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* l_t, int H, int W, int HL, int WL, bool half_pixel, bool align, const float* s_gate,
+                                              const SegConvW& pw, const float* __restrict__ w, int r0, int c0, int ZH, int ZC, float* z_t) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
   float wr[4];
   load_wtile(wr, w, pw, 0, li, g);
   const float4 bias = ld4(w + pw.b_off + cq4);
   const float4 gv = ld4(s_gate + 4 * g);
+  const Clamp cl = clamp_of(pw.act);
   const float hs = up_scale(HL, H, align), wsc = up_scale(WL, W, align);
-  const int npix = ZH * ZW, ntile = (npix + 15) >> 4;
-  auto fetch = [&](int t) {
-    GatedOperand o;
-    o.in = false; o.dy = o.dx = 0.f;
-    o.s = o.a = o.b = o.c = o.d = f4zero();
-    if (t < ntile) {
-      const int p = min(16 * t + li, npix - 1);
-      const int zy = div_magic(p, mzw), zx = p - zy * ZW, iy = r0 - 1 + zy, ix = c0 - 1 + zx;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-        o.in = true;
-        o.s = ld4(skip + ((long)iy * W + ix) * 16 + 4 * g);
-        UpCoef u;
-        up_axis(iy, hs, half_pixel, HL, &u.y0, &u.y1, &u.dy);
-        up_axis(ix, wsc, half_pixel, WL, &u.x0, &u.x1, &u.dx);
-        o.dy = u.dy; o.dx = u.dx;
-        o.a = ld4(lo + (u.y0 * WL + u.x0) * 16 + 4 * g); o.b = ld4(lo + (u.y1 * WL + u.x0) * 16 + 4 * g);
-        o.c = ld4(lo + (u.y0 * WL + u.x1) * 16 + 4 * g); o.d = ld4(lo + (u.y1 * WL + u.x1) * 16 + 4 * g);
-      }
-    }
-    return o;
-  };
-  GatedOperand nx = fetch(wave);
-  for (int t = wave; t < ntile; t += 4) {
-    const GatedOperand o = nx;
-    nx = fetch(t + 4);
-    float4 a = f4zero();
-    if (o.in) {
-      const float4 up = make_float4(up_lerp(o.a.x, o.b.x, o.c.x, o.d.x, o.dy, o.dx), up_lerp(o.a.y, o.b.y, o.c.y, o.d.y, o.dy, o.dx),
-                                    up_lerp(o.a.z, o.b.z, o.c.z, o.d.z, o.dy, o.dx), up_lerp(o.a.w, o.b.w, o.c.w, o.d.w, o.dy, o.dx));
-      a = make_float4(__fadd_rn(__fmul_rn(o.s.x, gv.x), up.x), __fadd_rn(__fmul_rn(o.s.y, gv.y), up.y), __fadd_rn(__fmul_rn(o.s.z, gv.z), up.z),
-                      __fadd_rn(__fmul_rn(o.s.w, gv.w), up.w));
-    }
+  // column constants of this lane: operand side (pixel li) and epilogue side (pixel 4g + q)
+  const int ix = c0 - 1 + li;
+  int x0, x1;
+  float dx;
+  up_axis(min(max(ix, 0), W - 1), wsc, half_pixel, WL, &x0, &x1, &dx);
+  const int xo0 = (x0 - pre.lx0) * kLoStride + 4 * g, xo1 = (x1 - pre.lx0) * kLoStride + 4 * g;
+  const int xe = 4 * g + q, hx = c0 - 1 + xe;
+  const bool ecol_in = xe < ZC && hx >= 0 && hx < W;
+#pragma unroll
+  for (int j = 0; j < kGatedRows; j++) {
+    const int zy = wave + 4 * j, iy = r0 - 1 + zy;
+    if (zy >= ZH) break;
+    const bool row_in = iy >= 0 && iy < H;                           // scalar
+    int y0, y1;
+    float dy;
+    up_axis(min(max(iy, 0), H - 1), hs, half_pixel, HL, &y0, &y1, &dy);
+    const float* l0 = l_t + (y0 - pre.ly0) * pre.LC * kLoStride;
+    const float* l1 = l_t + (y1 - pre.ly0) * pre.LC * kLoStride;
+    const float4 ta = ld4(l0 + xo0), tb = ld4(l1 + xo0), tc = ld4(l0 + xo1), td = ld4(l1 + xo1);
+    const float w00 = (1.f - dy) * (1.f - dx), w10 = dy * (1.f - dx), w01 = (1.f - dy) * dx, w11 = dy * dx;
+    const float4 sk = pre.s[j];
+    float4 a;
+    a.x = fmaf(sk.x, gv.x, fmaf(td.x, w11, fmaf(tc.x, w01, fmaf(tb.x, w10, ta.x * w00))));
+    a.y = fmaf(sk.y, gv.y, fmaf(td.y, w11, fmaf(tc.y, w01, fmaf(tb.y, w10, ta.y * w00))));
+    a.z = fmaf(sk.z, gv.z, fmaf(td.z, w11, fmaf(tc.z, w01, fmaf(tb.z, w10, ta.z * w00))));
+    a.w = fmaf(sk.w, gv.w, fmaf(td.w, w11, fmaf(tc.w, w01, fmaf(tb.w, w10, ta.w * w00))));
     const f4acc acc = mma16(a, wr);
-    const int pp = 16 * t + 4 * g + q;
     float4 v = quad_transpose(acc, q);
-    if (pp < npix) {
-      const int y2 = div_magic(pp, mzw), x2 = pp - y2 * ZW, hy = r0 - 1 + y2, hx = c0 - 1 + x2;
-      const bool inside = hy >= 0 && hy < H && hx >= 0 && hx < W;
-      v = inside ? sg_act4(f4add(v, bias), pw.act) : f4zero();
-      st4(z_t + pp * 16 + cq4, v);
-    }
+    v = (ecol_in && row_in) ? clamp4(f4add(v, bias), cl) : f4zero();
+    if (xe < ZC) st4(z_t + (zy * 16 + xe) * 16 + cq4, v);
   }
 }
 
 // ==================================================================================================================================
-// k3 (decoder level 2): z = act(pw1(B * g + up(lo2))); t = z + act(dw3x3(z)); lo = pw2(t).  Tile = TR x TC at the B resolution.
+// k3 (decoder level 2): z = act(pw1(B * g + up(lo2))); t = z + act(dw3x3(z)); lo = pw2(t).  Tile = TR x TC (<= 14) at the B resolution.
 // ==================================================================================================================================
 __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
-  const int r0 = ty * d.TR, c0 = tx * d.TC, ZH = d.TR + 2, ZW = d.TC + 2;
+  const int r0 = ty * d.TR, c0 = tx * d.TC, ZH = d.TR + 2, ZC = d.TC + 2;
   float* fa = arena + (size_t)f * (size_t)per_frame;
-  float* z_t = seg_smem + kScrFloats;
-  float* t_t = z_t + ZH * ZW * 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+  float* z_t = seg_smem + kScrFloats;                               // [ZH][16][16]
+  float* t_t = z_t + ZH * 256;                                      // [TR][16][16]
+  float* l_t = t_t + d.TR * 256;                                    // staged window of lo2
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+  const GatedPre pre = gated_prefetch(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
   if (tid < 16) seg_smem[kScrGate + tid] = fa[d.g_off + tid];
   __syncthreads();
-  seg_gated_pw(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw1, w, r0, c0, ZH, ZW, d.m_zw, z_t);
-  const int quad = tid & 3;
-  float4 wd[9];
+  gated_compute(pre, l_t, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw1, w, r0, c0, ZH, ZC, z_t);
+  const int quad = lane & 3, px = lane >> 2;
+  f4v wd[9];
 #pragma unroll
-  for (int k = 0; k < 9; k++) wd[k] = ld4(w + d.dw.w_off + k * 16 + 4 * quad);
-  const float4 bias_d = ld4(w + d.dw.b_off + 4 * quad);
+  for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + 4 * quad);
+  const f4v bias_d = ldv(w + d.dw.b_off + 4 * quad);
+  const Clamp cl_dw = clamp_of(d.dw.act), cl_2 = clamp_of(d.pw2.act);
   __syncthreads();
-  const unsigned mtc = d.m_tc;
-  for (int i = tid; i < d.TR * d.TC * 4; i += kSegThreads) {
-    const int pix = i >> 2, py = div_magic(pix, mtc), px = pix - py * d.TC;
-    const float4 zc = ld4(z_t + ((py + 1) * ZW + px + 1) * 16 + 4 * quad);
-    const float4 dv = sg_act4(f4add(dw3x3<1>(z_t, ZW, py, px, quad, wd), bias_d), d.dw.act);
-    st4(t_t + pix * 16 + 4 * quad, f4add(dv, zc));                 // dw epilogue: activation, then + residual z
-  }
+  if (px < d.TC)
+    for (int py = wave; py < d.TR; py += 4) {
+      const f4v zc = ldv(z_t + ((py + 1) * 16 + px + 1) * 16 + 4 * quad);
+      const float4 dv = clamp4(tof4(dw3x3<1>(z_t, 16, py, px, quad, wd) + bias_d), cl_dw);
+      st4(t_t + (py * 16 + px) * 16 + 4 * quad, f4add(dv, tof4(zc)));       // dw epilogue: activation, then + residual z
+    }
   float wr[4];
   load_wtile(wr, w, d.pw2, 0, li, g);
   const float4 bias2 = ld4(w + d.pw2.b_off + cq4);
   __syncthreads();
-  const int npix = d.TR * d.TC, ntile = (npix + 15) >> 4;
   float4 sum = f4zero();
-  for (int t = wave; t < ntile; t += 4) {
-    const int p = min(16 * t + li, npix - 1);
-    const f4acc acc = mma16(ld4(t_t + p * 16 + 4 * g), wr);
-    const int pp = 16 * t + 4 * g + q;
+  const int xe = 4 * g + q;
+  for (int py = wave; py < d.TR && r0 + py < d.H2; py += 4) {
+    const f4acc acc = mma16(ld4(t_t + (py * 16 + min(li, d.TC - 1)) * 16 + 4 * g), wr);
     float4 v = quad_transpose(acc, q);
-    if (pp < npix) {
-      const int py = div_magic(pp, mtc), px = pp - py * d.TC;
-      if (r0 + py < d.H2 && c0 + px < d.W2) {
-        v = sg_act4(f4add(v, bias2), d.pw2.act);
-        st4(fa + d.lo_off + ((long)(r0 + py) * d.W2 + c0 + px) * 16 + cq4, v);
-        sum = f4add(sum, v);
-      }
+    if (xe < d.TC && c0 + xe < d.W2) {
+      v = clamp4(f4add(v, bias2), cl_2);
+      st4(fa + d.lo_off + ((long)(r0 + py) * d.W2 + c0 + xe) * 16 + cq4, v);
+      sum = f4add(sum, v);
     }
   }
   float* s_red = seg_smem + kScrRed;
-  wave_reduce16<0>(sum, s_red);
+  wave_reduce16<0>(sum, s_red, wave, lane);
   __syncthreads();
   store_partials(s_red, fa + d.part_lo_off + (long)blockIdx.x * 16);
 }
@@ -519,24 +605,39 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
 // ==================================================================================================================================
 // tail (decoder level 1 + output): g = gate(GAP(A), GAP(lo)); z = act(pw(A * g + up(lo))); t = z + act(dw3x3(z));
 // out = act3(Convolution2DTransposeBias 2x2 (t)) → logits (LOGITS) or straight into decode + temporal IIR on `ofinal`.
-// Tile = TR x TC at the A resolution = 2TR x 2TC output pixels.  Phase B lanes = (pixel, channel quad): the depthwise runs on the
-// lane's 4 channels, the 4 x CO transpose-conv dot products are split over the quad and reduce-scattered so that lane `quad`
-// ends up with output position (fy, fx) = (quad >> 1, quad & 1) of its pixel.
+// Tile = TR x TC (<= 14) at the A resolution = 2TR x 2TC output pixels.  Phase B lanes = (pixel of the row, channel quad): the
+// depthwise runs on the lane's 4 channels, the 4 x CO transpose-conv dot products are split over the quad and reduce-scattered so
+// that lane `quad` ends up with output position (fy, fx) = (quad >> 1, quad & 1) of its pixel.
 // ==================================================================================================================================
-template <int CO, bool LOGITS>
+template <int CO, bool LOGITS, bool SIGMOID>
 __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float* __restrict__ arena, long per_frame, float* __restrict__ net_out,
                                                           uint8_t* __restrict__ ofinal, const float* __restrict__ w) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
-  const int r0 = ty * d.TR, c0 = tx * d.TC, ZH = d.TR + 2, ZW = d.TC + 2;
+  const int r0 = ty * d.TR, c0 = tx * d.TC, ZH = d.TR + 2, ZC = d.TC + 2;
   float* fa = arena + (size_t)f * (size_t)per_frame;
-  float* z_t = seg_smem + kScrFloats;
-  seg_gate(d.gate, fa, w, seg_smem, z_t);
-  seg_gated_pw(fa + d.skip_off, fa + d.lo_off, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw, w, r0, c0, ZH, ZW, d.m_zw, z_t);
-  const int tid = threadIdx.x, quad = tid & 3;
-  float4 wd[9];
+  float* z_t = seg_smem + kScrFloats;                               // [ZH][16][16]
+  float* l_t = z_t + max(ZH * 256, kGateStageFloats);               // staged window of lo
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), quad = lane & 3, px = lane >> 2;
+  const int fy = quad >> 1, fx = quad & 1, ix = c0 + px;
+  // every global read of the workgroup is requested here, before the first wait: skip operands, the window of lo, the temporal
+  // state bytes this lane will update, then (inside seg_gate) the pooled partial sums and the gate weights
+  const GatedPre pre = gated_prefetch(fa + d.skip_off, fa + d.lo_off, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
+  constexpr int kRowsB = 5;                                          // TR <= 18 → <= 5 tile rows per wave in phase B
+  uint8_t prev[kRowsB];
+  if (!LOGITS) {
 #pragma unroll
-  for (int k = 0; k < 9; k++) wd[k] = ld4(w + d.dw.w_off + k * 16 + 4 * quad);
-  const float4 bias_d = ld4(w + d.dw.b_off + 4 * quad);
+    for (int j = 0; j < kRowsB; j++) {
+      const int py = wave + 4 * j, iy = r0 + py;
+      prev[j] = 0;
+      if (py < d.TR && iy < d.H1 && px < d.TC && ix < d.W1) prev[j] = ofinal[(long)f * d.H0 * d.W0 + (long)(2 * iy + fy) * d.W0 + 2 * ix + fx];
+    }
+  }
+  seg_gate(d.gate, fa, w, seg_smem, z_t);
+  gated_compute(pre, l_t, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw, w, r0, c0, ZH, ZC, z_t);
+  f4v wd[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + 4 * quad);
+  const f4v bias_d = ldv(w + d.dw.b_off + 4 * quad);
   float4 wt[4][CO];
   float bt[CO];
 #pragma unroll
@@ -545,38 +646,39 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
     for (int oc = 0; oc < CO; oc++) wt[pos][oc] = ld4(w + d.tc_w_off + (long long)(pos * CO + oc) * 16 + 4 * quad);
 #pragma unroll
   for (int oc = 0; oc < CO; oc++) bt[oc] = w[d.tc_b_off + oc];
+  const Clamp cl_dw = clamp_of(d.dw.act);
   __syncthreads();
-  const unsigned mtc = d.m_tc;
-  const int fy = quad >> 1, fx = quad & 1;
-  for (int i = tid; i < d.TR * d.TC * 4; i += kSegThreads) {
-    const int pix = i >> 2, py = div_magic(pix, mtc), px = pix - py * d.TC;
-    const int iy = r0 + py, ix = c0 + px;
-    if (iy >= d.H1 || ix >= d.W1) continue;                         // uniform inside a quad (all four lanes share the pixel)
-    const float4 zc = ld4(z_t + ((py + 1) * ZW + px + 1) * 16 + 4 * quad);
-    const float4 t4 = f4add(sg_act4(f4add(dw3x3<1>(z_t, ZW, py, px, quad, wd), bias_d), d.dw.act), zc);
-    float o[CO];
+  if (px < d.TC && ix < d.W1)                                        // uniform inside a quad (all four lanes share the pixel)
 #pragma unroll
-    for (int oc = 0; oc < CO; oc++) {
-      float pp[4];
+    for (int j = 0; j < kRowsB; j++) {
+      const int py = wave + 4 * j, iy = r0 + py;
+      if (py >= d.TR || iy >= d.H1) break;
+      const f4v zc = ldv(z_t + ((py + 1) * 16 + px + 1) * 16 + 4 * quad);
+      const float4 t4 = f4add(clamp4(tof4(dw3x3<1>(z_t, 16, py, px, quad, wd) + bias_d), cl_dw), tof4(zc));
+      float o[CO];
 #pragma unroll
-      for (int pos = 0; pos < 4; pos++) {
-        const float4 wv = wt[pos][oc];
-        pp[pos] = fmaf(t4.w, wv.w, fmaf(t4.z, wv.z, fmaf(t4.y, wv.y, t4.x * wv.x)));
+      for (int oc = 0; oc < CO; oc++) {
+        float pp[4];
+#pragma unroll
+        for (int pos = 0; pos < 4; pos++) {
+          const float4 wv = wt[pos][oc];
+          pp[pos] = fmaf(t4.w, wv.w, fmaf(t4.z, wv.z, fmaf(t4.y, wv.y, t4.x * wv.x)));
+        }
+        o[oc] = bt[oc] + quad_reduce_scatter(pp[0], pp[1], pp[2], pp[3], quad);
+        if (SIGMOID) o[oc] = sigmoid1(o[oc]);
       }
-      o[oc] = sg_act(bt[oc] + quad_reduce_scatter(pp[0], pp[1], pp[2], pp[3], quad), d.act3);
-    }
-    const int oy = 2 * iy + fy, ox = 2 * ix + fx;
-    const long opix = (long)f * d.H0 * d.W0 + (long)oy * d.W0 + ox;
-    if (LOGITS) {
+      const int oy = 2 * iy + fy, ox = 2 * ix + fx;
+      const long opix = (long)f * d.H0 * d.W0 + (long)oy * d.W0 + ox;
+      if (LOGITS) {
 #pragma unroll
-      for (int oc = 0; oc < CO; oc++) net_out[opix * CO + oc] = o[oc];
-    } else {
-      uint32_t val;
-      if (CO == 2) val = seg_meet_val(o[0], o[CO - 1]);
-      else val = ((double)o[0] > 0.65) ? 0u : 255u;                // MLKit: float promoted to double against the double literal (libbackscrub.cc:338)
-      ofinal[opix] = (uint8_t)((val & 0xE0u) | (ofinal[opix] >> 3));
+        for (int oc = 0; oc < CO; oc++) net_out[opix * CO + oc] = o[oc];
+      } else {
+        uint32_t val;
+        if (CO == 2) val = seg_meet_val(o[0], o[CO - 1]);
+        else val = ((double)o[0] > 0.65) ? 0u : 255u;                // MLKit: float promoted to double against the double literal (libbackscrub.cc:338)
+        ofinal[opix] = (uint8_t)((val & 0xE0u) | ((uint32_t)prev[j] >> 3));
+      }
     }
-  }
 }
 
 template <class K>
@@ -589,17 +691,22 @@ hipError_t allow_lds(K kernel, int lds_bytes) {
 hipError_t seg_prepare() {
   const int full = 160 * 1024;     // process-global kernel attributes: always the full LDS (cf. frame_program_prepare)
   hipError_t e;
-  if ((e = allow_lds(seg_head_k, full)) != hipSuccess) return e;
+  if ((e = allow_lds(seg_head_k<true>, full)) != hipSuccess) return e;
+  if ((e = allow_lds(seg_head_k<false>, full)) != hipSuccess) return e;
   if ((e = allow_lds(seg_k2_k, full)) != hipSuccess) return e;
   if ((e = allow_lds(seg_k3_k, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_tail_k<1, false>, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_tail_k<1, true>, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_tail_k<2, false>, full)) != hipSuccess) return e;
-  return allow_lds(seg_tail_k<2, true>, full);
+  if ((e = allow_lds(seg_tail_k<1, false, true>, full)) != hipSuccess) return e;
+  if ((e = allow_lds(seg_tail_k<1, true, true>, full)) != hipSuccess) return e;
+  if ((e = allow_lds(seg_tail_k<1, false, false>, full)) != hipSuccess) return e;
+  if ((e = allow_lds(seg_tail_k<1, true, false>, full)) != hipSuccess) return e;
+  if ((e = allow_lds(seg_tail_k<2, false, false>, full)) != hipSuccess) return e;
+  return allow_lds(seg_tail_k<2, true, false>, full);
 }
 
 hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const float* net_in, const float* weights, int n, hipStream_t s) {
-  seg_head_k<<<dim3(d.tiles_y * d.tiles_x, n), kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, net_in, weights);
+  const dim3 grid(d.tiles_y * d.tiles_x, n);
+  if (d.stem.act == kActHswish) seg_head_k<true><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, net_in, weights);
+  else seg_head_k<false><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, net_in, weights);
   return hipGetLastError();
 }
 hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s) {
@@ -613,12 +720,16 @@ hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const flo
 hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s) {
   const dim3 grid(d.tiles_y * d.tiles_x, n);
   const size_t lds = (size_t)d.lds_floats * sizeof(float);
-  if (d.Co == 2) {
-    if (logits) seg_tail_k<2, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
-    else seg_tail_k<2, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+  const bool sig = d.act3 == kActSigmoid;
+  if (d.Co == 2 && !sig) {
+    if (logits) seg_tail_k<2, true, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    else seg_tail_k<2, false, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+  } else if (d.Co == 1 && sig) {
+    if (logits) seg_tail_k<1, true, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    else seg_tail_k<1, false, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
   } else if (d.Co == 1) {
-    if (logits) seg_tail_k<1, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
-    else seg_tail_k<1, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    if (logits) seg_tail_k<1, true, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    else seg_tail_k<1, false, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
   } else {
     return hipErrorInvalidValue;
   }

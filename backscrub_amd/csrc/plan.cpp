@@ -431,6 +431,10 @@ static bool build_segments(Graph& g, Plan* plan) {
   if (uses_of(B) != 3 || uses_of(up2) != 2 || uses_of(kp1.out) != 2 || uses_of(kd.out) != 1 || uses_of(kf2.out) != 1 || uses_of(lo) != 1 || uses_of(lo2) != 1) return seg_fail(21);
   if (!resize_weights_uniform(kr.H, kr.OH, kr.align_corners, kr.half_pixel) || !resize_weights_uniform(kr.W, kr.OW, kr.align_corners, kr.half_pixel)) return seg_fail(22);
   if (uses_of(c0) != 1) return seg_fail(23);
+  // activations the kernels implement: a clamp (none / relu / relu6) everywhere, hard-swish also on the stem, the logistic also on the output
+  auto clampish = [](int a) { return a == kActNone || a == kActRelu || a == kActRelu6; };
+  if (!(clampish(stem.act) || stem.act == kActHswish) || !(clampish(ttc.act) || ttc.act == kActSigmoid) || (ttc.act == kActSigmoid && ttc.Cout != 1)) return seg_fail(34);
+  for (const Step* q : {&hpw, &hdw, &pwa, &pwb, &kdw, &kp1, &kd, &kp2, &tpw, &tdw}) if (!clampish(q->act)) return seg_fail(35);
 
   // ---- dedicated, never-reused arena space for everything that crosses a kernel boundary (a segment kernel reads and writes
   //      different tiles of its tensors concurrently, so liveness-based sharing inside one kernel would be a race)
@@ -444,7 +448,9 @@ static bool build_segments(Graph& g, Plan* plan) {
   };
   SegPlan sp;
   // tile geometry (BSX_SEG_TILES="hTR,hTC,k2TR,k2TC,k3TR,k3TC,tTR,tTC" overrides the targets)
-  int tgt[8] = {2, 20, 3, 20, 8, 20, 16, 20};
+  // kernel limits: head TR <= 4, TC <= 15 (one depthwise row per wave, 2TC+1 <= 32 columns of 6 floats per input row lane chunk);
+  // k2 TC <= 15; k3 / tail TC <= 14 (TC + 2 <= 16: one MFMA tile per halo-region row)
+  int tgt[8] = {4, 14, 4, 7, 16, 14, 16, 14};
   if (const char* e = getenv("BSX_SEG_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &tgt[0], &tgt[1], &tgt[2], &tgt[3], &tgt[4], &tgt[5], &tgt[6], &tgt[7]);
   auto split = [&](int extent, int target, int* tile, int* n) { *n = tiles_for(extent, std::max(1, target)); *tile = (extent + *n - 1) / *n; };
 
@@ -454,25 +460,27 @@ static bool build_segments(Graph& g, Plan* plan) {
   h.stem = conv_w(stem); h.pw = conv_w(hpw); h.dw = dw_w(hdw);
   split(h.H2, tgt[0], &h.TR, &h.tiles_y); split(h.W2, tgt[1], &h.TC, &h.tiles_x);
   h.lds_floats = seg_head_lds_floats(h);
-  h.m_rowf = seg_magic((4 * h.TC + 3) * 3); h.m_ac = seg_magic(2 * h.TC + 1); h.m_tc = seg_magic(h.TC);
+  h.rw = seg_row_width(2 * h.TC + 1); h.m_ct = (65536u + (unsigned)(h.rw / 16) - 1) / (unsigned)(h.rw / 16);
+  if (h.TR > 4 || h.TC > 15 || (4 * h.TC + 3) * 3 > 192) return seg_fail(30);
   SegK2& k2 = sp.k2;
   k2.H2 = hdw.OH; k2.W2 = hdw.OW; k2.H3 = kdw.OH; k2.W3 = kdw.OW; k2.dw_pt = kdw.pad_t; k2.dw_pl = kdw.pad_l;
   k2.pw_a = conv_w(pwa); k2.pw_b = conv_w(pwb); k2.dw = dw_w(kdw);
   split(k2.H3, tgt[2], &k2.TR, &k2.tiles_y); split(k2.W3, tgt[3], &k2.TC, &k2.tiles_x);
   k2.lds_floats = seg_k2_lds_floats(k2);
-  k2.m_bc = seg_magic(2 * k2.TC + 1); k2.m_tc = seg_magic(k2.TC);
+  k2.rw = seg_row_width(2 * k2.TC + 1); k2.m_ct = (65536u + (unsigned)(k2.rw / 16) - 1) / (unsigned)(k2.rw / 16);
+  if (k2.TC > 15 || ((2 * k2.TR + 1) * (k2.rw / 16) + 3) / 4 > 6) return seg_fail(31);
   SegK3& k3 = sp.k3;
   k3.H2 = kp1.OH; k3.W2 = kp1.OW; k3.HL = kr.H; k3.WL = kr.W; k3.half_pixel = kr.half_pixel; k3.align_corners = kr.align_corners;
   k3.pw1 = conv_w(kp1); k3.pw2 = conv_w(kp2); k3.dw = dw_w(kd);
   split(k3.H2, tgt[4], &k3.TR, &k3.tiles_y); split(k3.W2, tgt[5], &k3.TC, &k3.tiles_x);
   k3.lds_floats = seg_k3_lds_floats(k3);
-  k3.m_zw = seg_magic(k3.TC + 2); k3.m_tc = seg_magic(k3.TC);
+  if (k3.TC > 14 || k3.TR > 18) return seg_fail(32);
   SegTail& tl = sp.tail;
   tl.H1 = tpw.OH; tl.W1 = tpw.OW; tl.HL = tr.H; tl.WL = tr.W; tl.H0 = ttc.OH; tl.W0 = ttc.OW; tl.half_pixel = tr.half_pixel; tl.align_corners = tr.align_corners;
   tl.pw = conv_w(tpw); tl.dw = dw_w(tdw); tl.tc_w_off = (long long)ttc.w_off; tl.tc_b_off = (long long)ttc.b_off; tl.Co = ttc.Cout; tl.act3 = ttc.act;
   split(tl.H1, tgt[6], &tl.TR, &tl.tiles_y); split(tl.W1, tgt[7], &tl.TC, &tl.tiles_x);
   tl.lds_floats = seg_tail_lds_floats(tl);
-  tl.m_zw = seg_magic(tl.TC + 2); tl.m_tc = seg_magic(tl.TC);
+  if (tl.TC > 14 || tl.TR > 18) return seg_fail(33);
   const int lds_cap = 160 * 256;
   if (h.lds_floats > lds_cap || k2.lds_floats > lds_cap || k3.lds_floats > lds_cap || tl.lds_floats > lds_cap) return seg_fail(24);
   if (ttc.OH != 2 * tpw.OH || ttc.OW != 2 * tpw.OW || h.H2 != k3.H2 || h.W2 != k3.W2) return seg_fail(25);

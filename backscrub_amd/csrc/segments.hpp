@@ -46,7 +46,8 @@ struct SegHead {
   long long a_off = 0, b0_off = 0, part_a_off = 0, part_b0_off = 0;
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;           // tile of b0 pixels per workgroup
   int lds_floats = 0;
-  unsigned m_rowf = 0, m_ac = 0, m_tc = 0;                // ceil(2^32 / d) for the in-kernel divisions by (4TC+3)*3, 2TC+1, TC
+  int rw = 0;                                             // LDS row width of the A region: 16 * ceil((2TC+1) / 16)
+  unsigned m_ct = 0;                                      // ceil(65536 / (rw / 16))
 };
 
 struct SegK2 {
@@ -58,7 +59,8 @@ struct SegK2 {
   long long b0_off = 0, B_off = 0, c0_off = 0, part_B_off = 0;
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;           // tile of c0 pixels
   int lds_floats = 0;
-  unsigned m_bc = 0, m_tc = 0;
+  int rw = 0;                                             // LDS row width of the B region: 16 * ceil((2TC+1) / 16)
+  unsigned m_ct = 0;
 };
 
 struct SegK3 {
@@ -69,7 +71,6 @@ struct SegK3 {
   long long skip_off = 0, lo2_off = 0, g_off = 0, lo_off = 0, part_lo_off = 0;
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
-  unsigned m_zw = 0, m_tc = 0;
 };
 
 struct SegTail {
@@ -83,22 +84,22 @@ struct SegTail {
   long long skip_off = 0, lo_off = 0;
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
-  unsigned m_zw = 0, m_tc = 0;
 };
 
 // LDS floats each kernel needs for the tile sizes in its descriptor (the planner picks the tiles against these; the kernels
 // carve the same regions)
-constexpr int kSegScratchFloats = 256;   // gate vector / means / hidden / partial-sum meeting points
+constexpr int kSegScratchFloats = 640;   // gate vector / means / hidden / partial-sum meeting points
 constexpr int kSegGateStageFloats = 512 + 2 * (32 * 32 + 32);   // gate prologue staging (aliases the first tile region)
-inline unsigned seg_magic(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
+inline int seg_row_width(int cols) { return (cols + 15) / 16 * 16; }
 inline int seg_head_lds_floats(const SegHead& d) {
-  const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, IR = 2 * AR + 1, IC = 2 * AC + 1;
-  const int a = IR * IC * 3, b = AR * AC * 16, r1 = a > b ? a : b;
-  return kSegScratchFloats + ((r1 + 3) & ~3) + AR * AC * 16;
+  const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, IR = 2 * AR + 1, IC = 2 * AC + 1, RW = seg_row_width(AC);
+  const int a = IR * IC * 3, b = AR * RW * 16, r1 = a > b ? a : b;
+  return kSegScratchFloats + ((r1 + 3) & ~3) + AR * RW * 16;
 }
-inline int seg_k2_lds_floats(const SegK2& d) { const int v = 2 * (2 * d.TR + 1) * (2 * d.TC + 1) * 16; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats); }
-inline int seg_k3_lds_floats(const SegK3& d) { return kSegScratchFloats + (d.TR + 2) * (d.TC + 2) * 16 + d.TR * d.TC * 16; }
-inline int seg_tail_lds_floats(const SegTail& d) { const int v = (d.TR + 2) * (d.TC + 2) * 16; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats); }
+inline int seg_k2_lds_floats(const SegK2& d) { const int v = 2 * (2 * d.TR + 1) * seg_row_width(2 * d.TC + 1) * 16; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats); }
+constexpr int kSegLoTileFloats = 12 * 16 * 20;   // staged window of the low-resolution tensor a k3 / tail tile interpolates from: <= 12 rows x 16 columns x 20 floats
+inline int seg_k3_lds_floats(const SegK3& d) { return kSegScratchFloats + (d.TR + 2) * 256 + d.TR * 256 + kSegLoTileFloats; }
+inline int seg_tail_lds_floats(const SegTail& d) { const int v = (d.TR + 2) * 256; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats) + kSegLoTileFloats; }
 
 struct SegPlan {
   bool on = false;
