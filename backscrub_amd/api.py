@@ -164,12 +164,14 @@ class MaskGen:
     def program_timeline(self, n=None):
         """per-micro-op durations (microseconds, workgroup 0) of the per-frame network program"""
         n = n or self.n_streams
-        cap = 512
+        cap = 1024 + 64 * 16 * 4
         arr = (C.c_ulonglong * cap)()
         k = lib().bsx_debug_program_timeline(self.h, n, arr, cap, _stream_ptr())
         if k < 0:
             _check(k, self.h, "bsx_debug_program_timeline")
         self.last_subphase_us = [arr[256 + i] / 100.0 for i in range(12)]   # debug accumulators of instrumented micro-ops
+        # fine[op][wave] = (wait+barrier, weight-DMA issue, body) in shader cycles, lane 0 of each wave of workgroup 0
+        self.last_fine = [[tuple(arr[1024 + (i * 16 + w) * 4 + j] for j in range(4)) for w in range(16)] for i in range(min(k, 64))]
         return [(arr[i + 1] - arr[i]) / 100.0 for i in range(k)]
 
     def masks(self):

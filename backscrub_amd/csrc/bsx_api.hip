@@ -646,13 +646,14 @@ int bsx_debug_program_timeline(bsx_ctx* c, int n, unsigned long long* ticks, int
   const int L = (int)c->plan.program.size();
   if (cap < L + 1 || L + 1 > 256) return BSX_EINVAL;
   unsigned long long* d = nullptr;
-  BSX_HIP(c, hipMalloc(&d, 512 * sizeof(unsigned long long)));
-  BSX_HIP(c, hipMemset(d, 0, 512 * sizeof(unsigned long long)));
+  const size_t kTl = 1024 + 64 * 16 * 4;       // coarse stamps [0,256), sub-phase accumulators [256,512), fine per-wave stamps [1024, ..)
+  BSX_HIP(c, hipMalloc(&d, kTl * sizeof(unsigned long long)));
+  BSX_HIP(c, hipMemset(d, 0, kTl * sizeof(unsigned long long)));
   hipStream_t s = pick(c, stream);
   BSX_HIP(c, launch_frame_program(c->d_program, L, c->plan.program_lds_floats, c->d_arena, (long)c->plan.arena_floats_per_stream, c->d_net_in,
                                   c->d_net_out, c->d_weights, n, s, d));
   BSX_HIP(c, hipStreamSynchronize(s));
-  BSX_HIP(c, hipMemcpy(ticks, d, (size_t)std::min(cap, 512) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  BSX_HIP(c, hipMemcpy(ticks, d, std::min((size_t)cap, kTl) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   (void)hipFree(d);
   return L;
 }

@@ -75,7 +75,7 @@ __device__ __forceinline__ f4acc mma16(const float4 a, const float (&wr)[4]) {
 // B-operand registers of the [16][cout_pad] block at output channels n0..n0+15: lane (li, g) holds w[4g + r][n0 + li]
 __device__ __forceinline__ void load_wtile(float (&wr)[4], const float* __restrict__ w, const SegConvW& c, int n0, int li, int g) {
 #pragma unroll
-  for (int r = 0; r < 4; r++) wr[r] = w[c.w_off + (long long)(4 * g + r) * c.cout_pad + n0 + li];
+  for (int r = 0; r < 4; r++) wr[r] = (w + c.w_off)[(unsigned)((4 * g + r) * c.cout_pad + n0 + li)];
 }
 
 // ---- gate prologue: means from partial sums → FC → [FC] → s_gate[0..C) ---------------------------------------------------
@@ -99,17 +99,21 @@ __device__ __forceinline__ void seg_gate(const SegGate& gt, const float* __restr
   {
     const int c = tid & 15, slice = tid >> 4;
     for (int k = 0; k < gt.n_parts; k++) {
-      const float* src = fa + gt.part[k].off + c;
+      const float* src = fa + gt.part[k].off;
       float s = 0.f;
 #pragma unroll 4
-      for (int i = slice; i < gt.part[k].n; i += 16) s += src[i * 16];
+      for (int i = slice; i < gt.part[k].n; i += 16) s += src[(unsigned)(i * 16 + c)];
       ps[k * 256 + slice * 16 + c] = s;
     }
   }
-  for (int i = tid; i < w1n; i += kSegThreads) w1[i] = w[f1.w_off + i];
-  for (int i = tid; i < w2n; i += kSegThreads) w2[i] = w[f2.w_off + i];
-  if (tid < f1.Cout) b1[tid] = w[f1.b_off + tid];
-  if (gt.n_fc == 2 && tid < f2.Cout) b2[tid] = w[f2.b_off + tid];
+  {
+    const float* g1 = w + f1.w_off;
+    const float* g2 = w + f2.w_off;
+    for (int i = tid; i < w1n; i += kSegThreads) w1[i] = g1[(unsigned)i];
+    for (int i = tid; i < w2n; i += kSegThreads) w2[i] = g2[(unsigned)i];
+    if (tid < f1.Cout) b1[tid] = (w + f1.b_off)[(unsigned)tid];
+    if (gt.n_fc == 2 && tid < f2.Cout) b2[tid] = (w + f2.b_off)[(unsigned)tid];
+  }
   __syncthreads();
   const int Cm = gt.sum_parts ? 16 : 16 * gt.n_parts;
   if (tid < Cm) {
@@ -241,6 +245,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   const int r1 = max(IR * rowf, AR * RW * 16);
   float* a_t = in_t + ((r1 + 3) & ~3);                              // [AR][RW][16]
   float* x_t = in_t;
+  float* A_out = fa + d.a_off;                                      // uniform bases + 32-bit lane offsets (global_load/store saddr forms)
+  float* b0_out = fa + d.b0_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
 
   // 1. input tile (zero outside the image: SAME padding of the stem): wave = rows, lane = row elements; every load of the lane is
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
       for (int e3 = 0; e3 < 3; e3++) {
         const int e = lane + 64 * e3;
         v[j][e3] = 0.f;
-        if (rowok && e >= lo_rem && e < hi_rem) v[j][e3] = src[((long)gy * d.W0 + ic0) * 3 + e];
+        if (rowok && e >= lo_rem && e < hi_rem) v[j][e3] = src[(unsigned)((gy * d.W0 + ic0) * 3 + e)];
       }
     }
 #pragma unroll
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
     const bool valid = k < 27;
     const int fy = k / 9, r9 = k - 9 * fy, fx = r9 / 3, ci = r9 - 3 * fx;
     koff[s] = valid ? fy * rowf + fx * 3 + ci : 0;
-    ws[s] = valid ? w[d.stem.w_off + (long long)k * d.stem.cout_pad + li] : 0.f;
+    ws[s] = valid ? (w + d.stem.w_off)[(unsigned)(k * d.stem.cout_pad + li)] : 0.f;
   }
   const float4 bias_s = ld4(w + d.stem.b_off + cq4);
   const Clamp cl_stem = clamp_of(d.stem.act), cl_pw = clamp_of(d.pw.act), cl_dw = clamp_of(d.dw.act);
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
       st4(a_t + (rt.row * RW + x2) * 16 + cq4, v);
       const bool row_owned = gy >= max(2 * r0, 0) && gy < min(2 * r0 + 2 * d.TR, d.H1);          // scalar
       if (row_owned && gx >= 2 * c0 && gx < min(2 * c0 + 2 * d.TC, d.W1)) {                      // each A pixel is stored by exactly one tile
-        st4(fa + d.a_off + ((long)gy * d.W1 + gx) * 16 + cq4, v);
+        st4(A_out + (unsigned)((gy * d.W1 + gx) * 16 + cq4), v);
         sumA = f4add(sumA, v);
       }
     }
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
     if (r0 + py >= d.H2) break;
     if (px < d.TC && c0 + px < d.W2) {
       const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
-      st4(fa + d.b0_off + ((long)(r0 + py) * d.W2 + c0 + px) * 16 + 4 * quad, v);
+      st4(b0_out + (unsigned)(((r0 + py) * d.W2 + c0 + px) * 16 + 4 * quad), v);
       sumB = f4add(sumB, v);
     }
   }
@@ -381,6 +387,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
   float* fa = arena + (size_t)f * (size_t)per_frame;
   float* B_t = seg_smem + kScrFloats;                               // [BR][RW][16]
   float* x_t = B_t + BR * RW * 16;
+  const float* b0_in = fa + d.b0_off;
+  float* B_out = fa + d.B_off;
+  float* c0_out = fa + d.c0_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
   const int ntile = BR * ctiles, xe = 4 * g + q;
   // all of this wave's b0 operands are requested before the gate prologue (one memory round trip for the whole workgroup)
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
     if (t < ntile) {
       const RowTile rt = row_tile(t, ctiles, d.m_ct);
       const int gy = br0 + rt.row, gx = bc0 + 16 * rt.ct + li;
-      if (gy >= 0 && gy < d.H2 && gx >= 0 && gx < d.W2) b0v[j] = ld4(fa + d.b0_off + ((long)gy * d.W2 + gx) * 16 + 4 * g);
+      if (gy >= 0 && gy < d.H2 && gx >= 0 && gx < d.W2) b0v[j] = ld4(b0_in + (unsigned)((gy * d.W2 + gx) * 16 + 4 * g));
     }
   }
   seg_gate(d.gate, fa, w, seg_smem, B_t);
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
       st4(B_t + (rt.row * RW + x2) * 16 + cq4, v);
       const bool row_owned = hy >= max(2 * r0, 0) && hy < min(2 * r0 + 2 * d.TR, d.H2);
       if (row_owned && hx >= 2 * c0 && hx < min(2 * c0 + 2 * d.TC, d.W2)) {
-        st4(fa + d.B_off + ((long)hy * d.W2 + hx) * 16 + cq4, v);
+        st4(B_out + (unsigned)((hy * d.W2 + hx) * 16 + cq4), v);
         sumB = f4add(sumB, v);
       }
     }
@@ -452,14 +461,14 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
     f4v bias_d = {0.f, 0.f, 0.f, 0.f};
     if (ch < C) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + (long long)k * C + ch);
+      for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + (unsigned)(k * C + ch));
       bias_d = ldv(w + d.dw.b_off + ch);
     }
     __syncthreads();
     if (ch < C && px < d.TC && c0 + px < d.W3)
       for (int py = wave; py < d.TR && r0 + py < d.H3; py += 4) {
         const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
-        st4(fa + d.c0_off + ((long)(r0 + py) * d.W3 + c0 + px) * C + ch, v);
+        st4(c0_out + (unsigned)(((r0 + py) * d.W3 + c0 + px) * C + ch), v);
       }
     __syncthreads();
   }
@@ -485,7 +494,7 @@ __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ ski
   for (int j = 0; j < kGatedRows; j++) {
     const int zy = wave + 4 * j, iy = r0 - 1 + zy;
     pre.s[j] = f4zero();
-    if (zy < ZH && iy >= 0 && iy < H && col_in) pre.s[j] = ld4(skip + ((long)iy * W + ix) * 16 + 4 * g);
+    if (zy < ZH && iy >= 0 && iy < H && col_in) pre.s[j] = ld4(skip + (unsigned)((iy * W + ix) * 16 + 4 * g));
   }
   // low-resolution window: rows y0(first image row of the region) .. y1(last), columns likewise (monotone maps)
   const float hs = up_scale(HL, H, align), wsc = up_scale(WL, W, align);
@@ -502,7 +511,7 @@ __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ ski
   for (int j = 0; j < 3; j++) {
     const int ly = wave + 4 * j;
     v[j] = f4zero();
-    if (ly < LR && lane < LC * 4) v[j] = ld4(lo + ((long)(ly0 + ly) * WL + lx0 + (lane >> 2)) * 16 + 4 * (lane & 3));
+    if (ly < LR && lane < LC * 4) v[j] = ld4(lo + (unsigned)(((ly0 + ly) * WL + lx0 + (lane >> 2)) * 16 + 4 * (lane & 3)));
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) {
@@ -563,6 +572,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
   float* z_t = seg_smem + kScrFloats;                               // [ZH][16][16]
   float* t_t = z_t + ZH * 256;                                      // [TR][16][16]
   float* l_t = t_t + d.TR * 256;                                    // staged window of lo2
+  float* lo_out = fa + d.lo_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
   const GatedPre pre = gated_prefetch(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
   if (tid < 16) seg_smem[kScrGate + tid] = fa[d.g_off + tid];
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
     float4 v = quad_transpose(acc, q);
     if (xe < d.TC && c0 + xe < d.W2) {
       v = clamp4(f4add(v, bias2), cl_2);
-      st4(fa + d.lo_off + ((long)(r0 + py) * d.W2 + c0 + xe) * 16 + cq4, v);
+      st4(lo_out + (unsigned)(((r0 + py) * d.W2 + c0 + xe) * 16 + cq4), v);
       sum = f4add(sum, v);
     }
   }
@@ -617,6 +627,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
   float* fa = arena + (size_t)f * (size_t)per_frame;
   float* z_t = seg_smem + kScrFloats;                               // [ZH][16][16]
   float* l_t = z_t + max(ZH * 256, kGateStageFloats);               // staged window of lo
+  uint8_t* of = ofinal + (size_t)f * (size_t)(d.H0 * d.W0);
+  float* no = net_out + (size_t)f * (size_t)(d.H0 * d.W0 * CO);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), quad = lane & 3, px = lane >> 2;
   const int fy = quad >> 1, fx = quad & 1, ix = c0 + px;
   // every global read of the workgroup is requested here, before the first wait: skip operands, the window of lo, the temporal
@@ -629,7 +641,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
     for (int j = 0; j < kRowsB; j++) {
       const int py = wave + 4 * j, iy = r0 + py;
       prev[j] = 0;
-      if (py < d.TR && iy < d.H1 && px < d.TC && ix < d.W1) prev[j] = ofinal[(long)f * d.H0 * d.W0 + (long)(2 * iy + fy) * d.W0 + 2 * ix + fx];
+      if (py < d.TR && iy < d.H1 && px < d.TC && ix < d.W1) prev[j] = of[(unsigned)((2 * iy + fy) * d.W0 + 2 * ix + fx)];
     }
   }
   seg_gate(d.gate, fa, w, seg_smem, z_t);
@@ -643,7 +655,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
 #pragma unroll
   for (int pos = 0; pos < 4; pos++)
 #pragma unroll
-    for (int oc = 0; oc < CO; oc++) wt[pos][oc] = ld4(w + d.tc_w_off + (long long)(pos * CO + oc) * 16 + 4 * quad);
+    for (int oc = 0; oc < CO; oc++) wt[pos][oc] = ld4(w + d.tc_w_off + (unsigned)((pos * CO + oc) * 16 + 4 * quad));
 #pragma unroll
   for (int oc = 0; oc < CO; oc++) bt[oc] = w[d.tc_b_off + oc];
   const Clamp cl_dw = clamp_of(d.dw.act);
@@ -668,15 +680,15 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
         if (SIGMOID) o[oc] = sigmoid1(o[oc]);
       }
       const int oy = 2 * iy + fy, ox = 2 * ix + fx;
-      const long opix = (long)f * d.H0 * d.W0 + (long)oy * d.W0 + ox;
+      const unsigned opix = (unsigned)(oy * d.W0 + ox);
       if (LOGITS) {
 #pragma unroll
-        for (int oc = 0; oc < CO; oc++) net_out[opix * CO + oc] = o[oc];
+        for (int oc = 0; oc < CO; oc++) no[opix * CO + oc] = o[oc];
       } else {
         uint32_t val;
         if (CO == 2) val = seg_meet_val(o[0], o[CO - 1]);
         else val = ((double)o[0] > 0.65) ? 0u : 255u;                // MLKit: float promoted to double against the double literal (libbackscrub.cc:338)
-        ofinal[opix] = (uint8_t)((val & 0xE0u) | ((uint32_t)prev[j] >> 3));
+        of[opix] = (uint8_t)((val & 0xE0u) | ((uint32_t)prev[j] >> 3));
       }
     }
 }
