@@ -96,6 +96,8 @@ struct bsx_ctx {
   float* d_net_in = nullptr;        // network input  [n][inH][inW][inC] f32 (written by the prep kernels)
   float* d_net_out = nullptr;       // network output [n][outH][outW][outC] f32 (read by the decode kernel)
   float* d_weights = nullptr;
+  uint16_t* d_weights16 = nullptr;   // split-f16 copies of the large pointwise-conv weights (Plan::weights16)
+  int f16_terms = 3;                 // per-launch path: 3 = split-f16 MFMA GEMM (f32-grade, default), 1 = plain f16 inputs (BSX_F16_GEMM=fast), 0 = f32 MFMA (BSX_F16_GEMM=off)
   uint32_t* d_canvas = nullptr;
   uint8_t* d_ofinal = nullptr;
   uint8_t* d_masks = nullptr;
@@ -185,6 +187,9 @@ int init_device_state(bsx_ctx* c) {
   BSX_HIP(c, hipMalloc(&c->d_net_out, N * c->outW * c->outH * c->outC * sizeof(float)));
   BSX_HIP(c, hipMalloc(&c->d_weights, std::max<size_t>(c->plan.weights.size(), 4) * sizeof(float)));
   BSX_HIP(c, hipMemcpy(c->d_weights, c->plan.weights.data(), c->plan.weights.size() * sizeof(float), hipMemcpyHostToDevice));
+  BSX_HIP(c, hipMalloc(&c->d_weights16, std::max<size_t>(c->plan.weights16.size(), 8) * sizeof(uint16_t)));
+  BSX_HIP(c, hipMemcpy(c->d_weights16, c->plan.weights16.data(), c->plan.weights16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  if (const char* m = getenv("BSX_F16_GEMM")) c->f16_terms = !strcmp(m, "off") ? 0 : (!strcmp(m, "fast") ? 1 : 3);
   // The per-frame program pays off when most tensors stay in LDS (Meet / MLKit families); graphs whose tensors mostly
   // spill (DeepLab: 33x33x480) run faster as one batch-wide launch per step.  BSX_FORCE_FRAME_PROGRAM / BSX_NO_FRAME_PROGRAM override.
   c->use_program = !c->plan.program.empty() && getenv("BSX_NO_FRAME_PROGRAM") == nullptr &&
@@ -241,7 +246,12 @@ int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s) {
 }
 // logits = true: the network output tensor is written (stage tests, the stand-alone decode follows); false: the tail kernel of a
 // segmented plan decodes straight into the temporal state of slots [slot, slot + n) and no logits exist
-bool infer_decodes(const bsx_ctx* c) { return c->use_program && c->plan.seg.on && !c->keep_logits; }
+// per-launch path (DeepLab): the graph's final RESIZE_BILINEAR runs fused with the argmax decode + IIR — no full-resolution logits
+bool argmax_tail(const bsx_ctx* c) {
+  return !c->use_program && !c->keep_logits && c->model_type == BSX_MODEL_DEEPLAB && !c->plan.steps.empty() && c->plan.steps.back().out == c->plan.output &&
+         resize_argmax_fusable(c->plan.steps.back());
+}
+bool infer_decodes(const bsx_ctx* c) { return (c->use_program && c->plan.seg.on && !c->keep_logits) || argmax_tail(c); }
 int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0) {
   if (c->use_program && c->plan.seg.on) {
     const SegPlan& sp = c->plan.seg;
@@ -259,7 +269,15 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
                                     (long)c->plan.arena_floats_per_stream, c->d_net_in, c->d_net_out, c->d_weights, n, s));
     return BSX_OK;
   }
-  for (const Step& st : c->plan.steps) BSX_HIP(c, launch_step(st, c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s));
+  const bool fused_tail = !logits && argmax_tail(c);
+  const size_t ns = c->plan.steps.size() - (fused_tail ? 1 : 0);
+  for (size_t i = 0; i < ns; i++)
+    BSX_HIP(c, launch_step(c->plan.steps[i], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms));
+  if (fused_tail) {
+    const Step& last = c->plan.steps.back();
+    BSX_HIP(c, launch_resize_argmax_iir(last, c->d_arena + (size_t)c->plan.tensor_off[last.in0] * (size_t)c->n_streams,
+                                        c->d_ofinal + (size_t)slot * c->outW * c->outH, n, s));
+  }
   return BSX_OK;
 }
 // `slot` = first state slot (stream index) of the batch: frame i uses ofinal / mask slot `slot + i`
@@ -377,7 +395,7 @@ void bsx_delete(bsx_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program};
+  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -539,6 +557,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   hipStream_t s = pick(c, stream);
   const bool seg = c->use_program && c->plan.seg.on;
   const bool fused_decode = infer_decodes(c);
+  const bool atail = argmax_tail(c);
   const int n_net = c->use_program ? (seg ? 5 : 1) : (int)c->plan.steps.size();
   const bool fuse_tail = !c->onmask && !c->no_mask_blend_fusion &&
                          mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
@@ -571,8 +590,12 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     } else if (c->use_program)
       BSX_TIMED(launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out,
                                      c->d_weights, n, s));
-    else
-      for (const Step& st : c->plan.steps) BSX_TIMED(launch_step(st, c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s));
+    else {
+      for (size_t si = 0; si + (atail ? 1 : 0) < c->plan.steps.size(); si++)
+        BSX_TIMED(launch_step(c->plan.steps[si], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms));
+      if (atail) BSX_TIMED(launch_resize_argmax_iir(c->plan.steps.back(), c->d_arena + (size_t)c->plan.tensor_off[c->plan.steps.back().in0] * (size_t)c->n_streams,
+                                                    c->d_ofinal, n, s));
+    }
     if (!fused_decode) BSX_TIMED(launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
     if (fuse_tail) {
       BSX_TIMED(launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg, bg_stride,
@@ -625,7 +648,8 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       case StepKind::Gap: b = in + st.Cin; break;
       default: b = in + o + (st.residual >= 0 ? o : 0) + (st.in_scale >= 0 ? st.Cin : 0); break;
     }
-    put(j++, st.label, N * b * 4.0, N * 2.0 * st.macs);
+    const bool is_tail = atail && &st == &c->plan.steps.back();
+    put(j++, is_tail ? st.label + "+argmax" : st.label, is_tail ? N * (4.0 * in + 2.0 * st.OH * st.OW) : N * b * 4.0, N * 2.0 * st.macs);
   }
   if (!fused_decode) put(j++, "decode_iir", N * ((double)c->outW * c->outH * c->outC * 4.0 + 2.0 * c->outW * c->outH), 0);
   if (fuse_tail) {

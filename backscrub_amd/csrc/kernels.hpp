@@ -15,8 +15,14 @@ namespace bsx {
 // Executes one fused step for `n` streams.  `arena` holds every activation tensor at
 // arena + plan.tensor_off[t] * n_cap (frame i of tensor t at + i * elems(t)).
 // The network input / output tensors live in their own batch-major buffers (net_in / net_out).
+// weights16 / f16_terms: the split-f16 MFMA form of the large pointwise convolutions (Step::w16_off, plan.weights16):
+// 3 = hi/lo split of both operands (f32-grade results, the default), 1 = plain f16 inputs (IoU-gated fast mode), 0 = f32 MFMA
 hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
-                       hipStream_t s);
+                       hipStream_t s, const uint16_t* weights16 = nullptr, int f16_terms = 0);
+
+// DeepLab tail: the graph's final RESIZE_BILINEAR fused with the 21-way argmax + temporal IIR (the full-resolution logits never exist)
+bool resize_argmax_fusable(const Step& st);
+hipError_t launch_resize_argmax_iir(const Step& st, const float* lowres_logits, uint8_t* ofinal, int n, hipStream_t s);
 
 // Whole-network per-frame program (kernels_frame.hip): one 1024-lane workgroup per stream.
 hipError_t frame_program_prepare(int lds_floats);

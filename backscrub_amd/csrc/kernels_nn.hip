@@ -125,7 +125,8 @@ constexpr int kGemmSA = kGemmBK + 4;      // (SA / 4) odd: the 16-byte A reads o
 constexpr int kGemmSB = kGemmBN + 4;      // 4 * SB = 16 (mod 32): the four k-rows a wave reads per MFMA split over both bank halves
 __global__ __launch_bounds__(kThreads) void pw_gemm_mfma_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
-                                                          float* __restrict__ y, long M, int HW, int Cin, int Cout, int cout_pad, int act) {
+                                                          float* __restrict__ y, long M, int HW, int Cin, int Cout, int cout_pad, int act,
+                                                          const float* __restrict__ fbias) {
   __shared__ __attribute__((aligned(16))) float As[kGemmBM * kGemmSA];
   __shared__ __attribute__((aligned(16))) float Bs[kGemmBK * kGemmSB];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -208,13 +209,153 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_mfma_k(const float* __restri
       if (m >= M || c0 >= Cout) continue;
       const float vv[4] = {v.x, v.y, v.z, v.w};
       if ((Cout & 3) == 0) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+        float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+        if (fbias) { const float4 fb = *reinterpret_cast<const float4*>(fbias + (m / HW) * (long)Cout + c0); bv.x += fb.x; bv.y += fb.y; bv.z += fb.z; bv.w += fb.w; }
         float4 o = make_float4(act_fn(vv[0] + bv.x, act), act_fn(vv[1] + bv.y, act), act_fn(vv[2] + bv.z, act), act_fn(vv[3] + bv.w, act));
         if (res) { const float4 r = *reinterpret_cast<const float4*>(res + m * Cout + c0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         *reinterpret_cast<float4*>(y + m * Cout + c0) = o;
       } else {
         for (int e = 0; e < 4 && c0 + e < Cout; e++) {
-          float o = act_fn(vv[e] + bias[c0 + e], act);
+          float o = act_fn(vv[e] + bias[c0 + e] + (fbias ? fbias[(m / HW) * (long)Cout + c0 + e] : 0.f), act);
+          if (res) o += res[m * Cout + c0 + e];
+          y[m * Cout + c0 + e] = o;
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------
+// 1x1 convolution as a SPLIT-f16 MFMA GEMM (the "fp16 MFMA pointwise" mode): same tiling as pw_gemm_mfma_k, but on
+// v_mfma_f32_16x16x32_f16 — 16x the f32 MFMA rate — with every f32 operand carried as TWO halves, x = xh + xl:
+//     x*w  ≈  xh*wh + xl*wh + xh*wl          (products of halves are exact in the f32 accumulator; the dropped xl*wl is 2^-22 relative)
+// so the result keeps ~22 significant bits: the logits stay inside the 1e-4 parity bar against the f32 oracle (measured),
+// unlike plain f16 activations.  3 MFMAs of K = 32 replace 8 f32 MFMAs of K = 4: ~5x less matrix-pipe time per MAC.
+// Activations are split while the A tile is staged into LDS (v_cvt_pkrtz: round-toward-zero never overflows to inf; the low
+// half absorbs the larger rounding error); the weights were split once on the host (plan.cpp, [hi | lo][cout_pad][Kp] halves,
+// k contiguous so that a lane's 8 consecutive k of one output channel are one 16-byte LDS read).
+// TERMS = 1 keeps only xh*wh (plain f16 inputs, f32 accumulate): the IoU-gated fast mode.
+// -------------------------------------------------------------------------------------
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+constexpr int kHSA = kGemmBK + 8;        // halves per LDS row: 80 B → the 16-byte reads of 16 consecutive rows hit distinct bank quads
+template <int TERMS>
+__global__ __launch_bounds__(kThreads) void pw_gemm_f16s_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
+                                                          const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
+                                                          float* __restrict__ y, long M, int HW, int Cin, int Kp, int Cout, int cout_pad, int act,
+                                                          const float* __restrict__ fbias) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[kGemmBM * kHSA];
+  __shared__ __attribute__((aligned(16))) _Float16 Al[kGemmBM * kHSA];
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[kGemmBN * kHSA];
+  __shared__ __attribute__((aligned(16))) _Float16 Bl[kGemmBN * kHSA];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const long m_base = (long)blockIdx.x * kGemmBM;
+  const int n_base = blockIdx.y * kGemmBN;
+  const int nt = min(4, (cout_pad - n_base) >> 4);
+  const _Float16* wh = w16;
+  const _Float16* wl = w16 + (size_t)cout_pad * Kp;
+  // loader mapping: A = 128 rows x 8 float4 (4 per lane); B = 64 channels x 32 halves = 4 x 16-byte chunks per channel (1 per lane, hi and lo)
+  float4 ra[4];
+  h8v rbh, rbl;
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int f = tid + i * kThreads, row = f >> 3, kq = (f & 7) * 4;
+      const long m = m_base + row;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M && k0 + kq < Cin) {
+        float4 v = *reinterpret_cast<const float4*>(x + m * Cin + k0 + kq);
+        if (scale) {
+          const float4 sv = *reinterpret_cast<const float4*>(scale + (m / HW) * (long)Cin + k0 + kq);
+          v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w);
+        }
+        if (addx) {
+          const float4 av = *reinterpret_cast<const float4*>(addx + m * Cin + k0 + kq);
+          v.x = __fadd_rn(v.x, av.x); v.y = __fadd_rn(v.y, av.y); v.z = __fadd_rn(v.z, av.z); v.w = __fadd_rn(v.w, av.w);
+        }
+        ra[i] = v;
+      }
+    }
+    const int ch = tid >> 2, kc = (tid & 3) * 8;
+    rbh = h8v{0, 0, 0, 0, 0, 0, 0, 0}; rbl = rbh;
+    if (n_base + ch < cout_pad) {
+      rbh = *reinterpret_cast<const h8v*>(wh + (size_t)(n_base + ch) * Kp + k0 + kc);
+      if (TERMS == 3) rbl = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + ch) * Kp + k0 + kc);
+    }
+  };
+  f4acc acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = f4acc{0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  for (int k0 = 0; k0 < Kp; k0 += kGemmBK) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int f = tid + i * kThreads, row = f >> 3, kq = (f & 7) * 4;
+      const float4 v = ra[i];
+      const h2v h01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)), h23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
+      const h4v hi = {h01.x, h01.y, h23.x, h23.y};
+      *reinterpret_cast<h4v*>(&Ah[row * kHSA + kq]) = hi;
+      if (TERMS == 3) {
+        const h2v l01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01.x, v.y - (float)h01.y));
+        const h2v l23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23.x, v.w - (float)h23.y));
+        const h4v lo = {l01.x, l01.y, l23.x, l23.y};
+        *reinterpret_cast<h4v*>(&Al[row * kHSA + kq]) = lo;
+      }
+    }
+    {
+      const int ch = tid >> 2, kc = (tid & 3) * 8;
+      *reinterpret_cast<h8v*>(&Bh[ch * kHSA + kc]) = rbh;
+      if (TERMS == 3) *reinterpret_cast<h8v*>(&Bl[ch * kHSA + kc]) = rbl;
+    }
+    __syncthreads();
+    if (k0 + kGemmBK < Kp) fetch(k0 + kGemmBK);              // in flight while this tile is multiplied
+    h8v ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++) {
+      ah[mi] = *reinterpret_cast<const h8v*>(&Ah[(32 * wave + 16 * mi + li) * kHSA + 8 * g]);
+      if (TERMS == 3) al[mi] = *reinterpret_cast<const h8v*>(&Al[(32 * wave + 16 * mi + li) * kHSA + 8 * g]);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      if (ni < nt) {
+        const h8v bh = *reinterpret_cast<const h8v*>(&Bh[(16 * ni + li) * kHSA + 8 * g]);
+        h8v bl = bh;
+        if (TERMS == 3) bl = *reinterpret_cast<const h8v*>(&Bl[(16 * ni + li) * kHSA + 8 * g]);
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+          if (TERMS == 3) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int q = li & 3;
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++) {
+    const long m = m_base + 32 * wave + 16 * mi + 4 * g + q;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      if (ni >= nt) continue;
+      const int c0 = n_base + 16 * ni + (li & ~3);
+      const float4 v = quad_transpose(acc[mi][ni], q);
+      if (m >= M || c0 >= Cout) continue;
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      if ((Cout & 3) == 0) {
+        float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+        if (fbias) { const float4 fb = *reinterpret_cast<const float4*>(fbias + (m / HW) * (long)Cout + c0); bv.x += fb.x; bv.y += fb.y; bv.z += fb.z; bv.w += fb.w; }
+        float4 o = make_float4(act_fn(vv[0] + bv.x, act), act_fn(vv[1] + bv.y, act), act_fn(vv[2] + bv.z, act), act_fn(vv[3] + bv.w, act));
+        if (res) { const float4 r = *reinterpret_cast<const float4*>(res + m * Cout + c0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        *reinterpret_cast<float4*>(y + m * Cout + c0) = o;
+      } else {
+        for (int e = 0; e < 4 && c0 + e < Cout; e++) {
+          float o = act_fn(vv[e] + bias[c0 + e] + (fbias ? fbias[(m / HW) * (long)Cout + c0 + e] : 0.f), act);
           if (res) o += res[m * Cout + c0 + e];
           y[m * Cout + c0 + e] = o;
         }
@@ -227,7 +368,8 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_mfma_k(const float* __restri
 // 256-stream batch still fills thousands of lanes instead of one workgroup.
 __global__ __launch_bounds__(kThreads) void pw_small_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                       const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
-                                                      float* __restrict__ y, long total, int HW, int Cin, int Cout, int cout_pad, int act) {
+                                                      float* __restrict__ y, long total, int HW, int Cin, int Cout, int cout_pad, int act,
+                                                      const float* __restrict__ fbias = nullptr) {
   long i = (long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= total) return;
   int co = (int)(i % Cout);
@@ -235,13 +377,27 @@ __global__ __launch_bounds__(kThreads) void pw_small_k(const float* __restrict__
   const float* xp = x + p * Cin;
   const float* sp = scale ? scale + (p / HW) * (long)Cin : nullptr;
   float acc = 0.f;
-  for (int ci = 0; ci < Cin; ci++) {
+  int ci = 0;
+  if (!sp && !addx) {
+    // plain GEMV (the per-frame FC / pool-branch steps): eight weight loads in flight per lane — one load per iteration made the
+    // 256-long dot products of DeepLab's ASPP cost one L2 round trip per element (63-98 us for 17 MFLOP)
+    for (; ci + 8 <= Cin; ci += 8) {
+      float wv[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { wv[u] = w[(long)(ci + u) * cout_pad + co]; xv[u] = xp[ci + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc = fmaf(xv[u], wv[u], acc);
+    }
+  }
+  for (; ci < Cin; ci++) {
     float xv = xp[ci];
     if (sp) xv = __fmul_rn(xv, sp[ci]);
     if (addx) xv = __fadd_rn(xv, addx[p * Cin + ci]);
     acc = fmaf(xv, w[(long)ci * cout_pad + co], acc);
   }
-  float v = act_fn(acc + bias[co], act);
+  float bb = bias[co];
+  if (fbias) bb += fbias[(p / HW) * (long)Cout + co];        // per-frame bias vector (a broadcast concat branch folded into this conv)
+  float v = act_fn(acc + bb, act);
   if (res) v += res[i];
   y[i] = v;
 }
@@ -466,6 +622,47 @@ __global__ __launch_bounds__(kThreads) void resize_px_k(const float* __restrict_
 }
 
 // -------------------------------------------------------------------------------------
+// DeepLab tail: RESIZE_BILINEAR (33 → 257, align_corners) + 21-way argmax + "person" test + temporal IIR in one pass
+// (lib/libbackscrub.cc:318-332 on the output of the graph's last op).  The 257x257x21 logits — 5.5 MB per frame, written and
+// read back once each by the unfused pair resize_px_k + decode_argmax_k — never exist: a workgroup stages the few low-resolution
+// pixels its 64 x 4 output pixels interpolate from in LDS and every lane scans the 21 classes of its pixel from there.
+// Same interpolation arithmetic (interp / bilerp) and the same first-maximum-wins scan as the unfused kernels.
+// -------------------------------------------------------------------------------------
+constexpr int kFusedTW = 64, kFusedTH = 4, kFusedMaxSrc = 160;    // source pixels per tile (rows x cols), C <= kResizePxMaxC
+__global__ __launch_bounds__(kThreads) void resize_argmax_iir_k(const float* __restrict__ x, uint8_t* __restrict__ ofinal, int H, int W, int C, int OH, int OW,
+                                                               float hs, float ws, int half_pixel, int person) {
+  __shared__ float src[kFusedMaxSrc * kResizePxMaxC];
+  const long n = blockIdx.z;
+  const int ox0 = blockIdx.x * kFusedTW, oy0 = blockIdx.y * kFusedTH;
+  const int tx = threadIdx.x & (kFusedTW - 1), ty = threadIdx.x >> 6;
+  // source window of the tile (monotone maps)
+  float fr; int a0, a1, sy0, sy1, sx0, sx1;
+  interp(oy0, hs, half_pixel, H, &fr, &sy0, &a1);
+  interp(min(oy0 + kFusedTH - 1, OH - 1), hs, half_pixel, H, &fr, &a0, &sy1);
+  interp(ox0, ws, half_pixel, W, &fr, &sx0, &a1);
+  interp(min(ox0 + kFusedTW - 1, OW - 1), ws, half_pixel, W, &fr, &a0, &sx1);
+  const int SR = sy1 - sy0 + 1, SC = sx1 - sx0 + 1;
+  const float* b = x + n * (long)H * W * C;
+  for (int r = 0; r < SR; r++) {
+    const float* row = b + ((long)(sy0 + r) * W + sx0) * C;
+    for (int i = threadIdx.x; i < SC * C; i += kThreads) src[r * SC * C + i] = row[i];
+  }
+  __syncthreads();
+  const int ox = ox0 + tx, oy = oy0 + ty;
+  if (ox >= OW || oy >= OH) return;
+  float dy, dx; int y0, y1, x0, x1;
+  interp(oy, hs, half_pixel, H, &dy, &y0, &y1);
+  interp(ox, ws, half_pixel, W, &dx, &x0, &x1);
+  const float* p00 = src + ((y0 - sy0) * SC + (x0 - sx0)) * C; const float* p10 = src + ((y1 - sy0) * SC + (x0 - sx0)) * C;
+  const float* p01 = src + ((y0 - sy0) * SC + (x1 - sx0)) * C; const float* p11 = src + ((y1 - sy0) * SC + (x1 - sx0)) * C;
+  float maxval = -10000.f; int maxpos = 0;                         // first maximum wins, as the reference loop
+  for (int c = 0; c < C; c++) { const float v = bilerp(p00[c], p10[c], p01[c], p11[c], dy, dx); if (v > maxval) { maxval = v; maxpos = c; } }
+  const uint8_t val = maxpos == person ? 0 : 255;
+  uint8_t* o = ofinal + n * (long)OH * OW + (long)oy * OW + ox;
+  *o = (uint8_t)((val & 0xE0) | (*o >> 3));
+}
+
+// -------------------------------------------------------------------------------------
 // channel concat (up to 4 inputs, channel counts multiples of 4)
 // -------------------------------------------------------------------------------------
 struct ConcatArgs { const float4* in[4]; int c4[4]; int n_in; };
@@ -512,8 +709,24 @@ inline unsigned blocks_for(long total) { return (unsigned)((total + kThreads - 1
 
 }  // namespace
 
+// → false when the source window of some tile would not fit the staging area (the caller then keeps the unfused pair)
+bool resize_argmax_fusable(const Step& st) {
+  if (st.kind != StepKind::Resize || st.Cin > kResizePxMaxC || st.OH < st.H || st.OW < st.W) return false;
+  // up-sampling: a 64 x 4 tile touches at most ceil(4 * H / OH) + 2 rows and ceil(64 * W / OW) + 2 columns
+  const int rows = (kFusedTH * st.H + st.OH - 1) / st.OH + 2, cols = (kFusedTW * st.W + st.OW - 1) / st.OW + 2;
+  return rows * cols <= kFusedMaxSrc;
+}
+hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofinal, int n, hipStream_t s) {
+  float hs = (float)st.H / (float)st.OH, ws = (float)st.W / (float)st.OW;
+  if (st.align_corners && st.OH > 1) hs = (float)(st.H - 1) / (float)(st.OH - 1);
+  if (st.align_corners && st.OW > 1) ws = (float)(st.W - 1) / (float)(st.OW - 1);
+  dim3 grid((st.OW + kFusedTW - 1) / kFusedTW, (st.OH + kFusedTH - 1) / kFusedTH, n);
+  resize_argmax_iir_k<<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, 15);
+  return hipGetLastError();
+}
+
 hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
-                       hipStream_t s) {
+                       hipStream_t s, const uint16_t* weights16, int f16_terms) {
   auto P = [&](int t) -> float* {
     if (t < 0) return nullptr;
     if (t == plan.input) return net_in;
@@ -529,7 +742,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       int HW = st.OH * st.OW;
       if (M <= 4096) {
         long total = M * st.Cout;
-        pw_small_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), total, HW, st.Cin, st.Cout, st.cout_pad, st.act);
+        pw_small_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), total, HW, st.Cin, st.Cout, st.cout_pad, st.act, P(st.out_bias));
         break;
       }
       // enough rows and channels to fill 128 x 64 MFMA tiles → the GEMM form (BSX_NO_PW_GEMM=1 keeps the lane-per-pixel form)
@@ -537,9 +750,16 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       // (even K = 8 / N = 16 layers: the tiles are mostly padding, but A is read once and coalesced — measured faster than the lane-per-pixel form)
       if (!no_gemm && M >= 8192 && (st.Cin & 3) == 0 && st.Cin >= 8 && st.cout_pad % 16 == 0 && st.cout_pad >= 16) {
         dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);
-        pw_gemm_mfma_k<<<gg, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act);
+        if (weights16 && st.k16_pad > 0 && f16_terms > 0) {        // split-f16 (3 terms, f32-grade) or plain f16-input (1 term) MFMA
+          const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
+          if (f16_terms == 3) pw_gemm_f16s_k<3><<<gg, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias));
+          else pw_gemm_f16s_k<1><<<gg, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias));
+          break;
+        }
+        pw_gemm_mfma_k<<<gg, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act, P(st.out_bias));
         break;
       }
+      if (st.out_bias >= 0) return hipErrorInvalidValue;          // the planner only folds a concat branch into convs that take one of the forms above
 #define BSX_PW(CT) pw_conv_k<CT><<<grid, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act)
       if (st.cout_tile == 16) BSX_PW(16); else BSX_PW(32);
 #undef BSX_PW

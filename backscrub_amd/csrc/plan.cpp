@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 
 namespace bsx {
@@ -17,6 +18,38 @@ void conv_geometry(int in, int k, int s, int d, bool same, int* out, int* pad) {
   *out = same ? (in + s - 1) / s : (in + s - eff) / s;
   int total = (*out - 1) * s + eff - in;
   *pad = total > 0 ? total / 2 : 0;
+}
+
+// float → IEEE half, round to nearest even (host side, weights only)
+uint16_t f32_to_f16_rn(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0));       // inf / nan
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);                                          // clamps to the largest finite half
+  if (x < 0x33000001u) return (uint16_t)sign;                                                        // below half of the smallest subnormal
+  if (x < 0x38800000u) {                                                                             // subnormal half
+    const int e = (int)(x >> 23);
+    const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    const int shift = 126 - e;                    // 14..24
+    uint32_t h = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1))) h++;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((x - 0x38000000u) >> 13);
+  const uint32_t rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+  return (uint16_t)(sign | h);
+}
+float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 1023;
+  uint32_t bits;
+  if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+  else if (e) bits = sign | ((e + 112) << 23) | (m << 13);
+  else if (!m) bits = sign;
+  else { int sh = 0; uint32_t mm = m; while (!(mm & 1024)) { mm <<= 1; sh++; } bits = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 1023) << 13); }
+  float f; memcpy(&f, &bits, 4); return f;
 }
 
 bool is_unary(OpType t) { return t == OpType::Relu || t == OpType::Relu6 || t == OpType::HardSwish || t == OpType::Logistic; }
@@ -72,6 +105,7 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
     // steps without a micro-op form → no program (the per-launch path is used instead)
     if ((st.kind == StepKind::PwConv || st.kind == StepKind::Eltwise || st.kind == StepKind::DwConv || st.kind == StepKind::Gap ||
          st.kind == StepKind::TConv) && (st.Cin % 4)) return;
+    if (st.out_bias >= 0) return;                          // per-frame output bias exists in the per-launch kernels only
     for (int t : {st.in0, st.in1, st.in2, st.residual, st.in_scale, st.out}) if (t >= 0) last[t] = s;
     for (int t : st.concat_in) last[t] = s;
   }
@@ -822,7 +856,8 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   std::stable_sort(steps.begin(), steps.end(), [](const Step& a, const Step& b) { return a.last_node < b.last_node; });
 
   // ---- linear-algebra rewrites on the step list ------------------------------------------------------------------
-  auto uses_of = [&](int t) { int n = 0; for (const Step& q : steps) { for (int u : {q.in0, q.in1, q.in2, q.residual, q.in_scale}) n += (u == t); for (int u : q.concat_in) n += (u == t); } return n + (t == g.output); };
+  // operand slots reading tensor t (steps that list their parts in concat_in repeat the first part in in0: counted once)
+  auto uses_of = [&](int t) { int n = 0; for (const Step& q : steps) { for (int u : {q.concat_in.empty() ? q.in0 : -1, q.in1, q.in2, q.residual, q.in_scale, q.out_bias}) n += (u == t); for (int u : q.concat_in) n += (u == t); } return n + (t == g.output); };
   const bool no_rewrites = getenv("BSX_NO_REWRITES") != nullptr;
   // (a) pw(resize(x)) → resize(pw(x)): a 1x1 convolution without activation commutes with bilinear interpolation (both
   //     are linear and the interpolation weights sum to 1, so the bias passes through); done at the LOW resolution the
@@ -896,6 +931,73 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
     std::rotate(steps.begin() + i, steps.begin() + i + 1, steps.begin() + j);   // the pool moves to position j-1
   }
 
+  // (e) RESIZE_BILINEAR to the same size is the identity (DeepLab's 33 → 33 resize in front of the final 33 → 257 one): its
+  //     consumers read its input directly
+  for (size_t i = 0; i < steps.size() && !no_rewrites; i++) {
+    const Step R = steps[i];
+    if (R.kind != StepKind::Resize || R.H != R.OH || R.W != R.OW || R.out == g.output) continue;
+    for (Step& q : steps) {
+      for (int* u : {&q.in0, &q.in1, &q.in2, &q.residual, &q.in_scale}) if (*u == R.out) *u = R.in0;
+      for (int& u : q.concat_in) if (u == R.out) u = R.in0;
+    }
+    steps.erase(steps.begin() + i);
+    i--;
+  }
+  // (f) concat(broadcast(p), X) feeding only a 1x1 convolution, p a per-frame [1,1,Ca] vector up-sampled to X's size (DeepLab's ASPP
+  //     image-pooling branch): the convolution is linear, so  conv(concat(bcast p, X)) = W[0:Ca]·p + W[Ca:]·X + b.  The first term is
+  //     one GEMV per frame (a per-frame bias vector); the 512-channel concat and the broadcast tensor are never built and the
+  //     convolution's K halves.  Weight rows are [ci][cout_pad], so both halves are views of the packed block: no repacking.
+  for (size_t i = 0; i + 1 < steps.size() && !no_rewrites; i++) {
+    if (steps[i].kind != StepKind::Concat || steps[i].concat_in.size() != 2 || uses_of(steps[i].out) != 1) continue;
+    size_t j = i + 1;
+    for (; j < steps.size(); j++) if (steps[j].in0 == steps[i].out) break;
+    if (j >= steps.size()) continue;
+    if (steps[j].kind != StepKind::PwConv || steps[j].in_scale >= 0 || steps[j].in2 >= 0 || steps[j].residual >= 0 || steps[j].OH * steps[j].OW <= 4) continue;
+    const int tb = steps[i].concat_in[0], tx = steps[i].concat_in[1];
+    size_t r = steps.size();
+    for (size_t k = 0; k < i; k++) if (steps[k].kind == StepKind::Resize && steps[k].out == tb && steps[k].H == 1 && steps[k].W == 1) r = k;
+    if (r >= steps.size() || uses_of(tb) != 1) continue;
+    const int p = steps[r].in0, Ca = steps[i].concat_c[0], Cb = steps[i].concat_c[1];
+    if (Ca % 4 || Cb % 4) continue;
+    Step conv = steps[j];
+    TensorInfo nt;
+    nt.dims[0] = 1; nt.dims[1] = 1; nt.dims[2] = 1; nt.dims[3] = conv.Cout; nt.shape = {1, 1, 1, conv.Cout}; nt.name = "frame_bias";
+    g.tensors.push_back(nt);
+    const int tbias = (int)g.tensors.size() - 1;
+    Step gemv = conv;                                  // W[0:Ca]·p + b, no activation
+    gemv.in0 = p; gemv.H = gemv.W = gemv.OH = gemv.OW = 1; gemv.Cin = Ca; gemv.act = kActNone; gemv.out = tbias; gemv.w2_off = 0;
+    gemv.macs = (double)Ca * conv.Cout; gemv.label = conv.label + "[pool branch]";
+    conv.in0 = tx; conv.Cin = Cb; conv.w_off = conv.w_off + (size_t)Ca * conv.cout_pad; conv.out_bias = tbias;
+    align_w();
+    conv.b_off = W.size(); W.resize(W.size() + conv.cout_pad, 0.f);      // its bias moved into the per-frame vector
+    conv.macs = (double)conv.OH * conv.OW * conv.Cout * Cb; conv.label += "-pool";
+    // the resize and the concat disappear; the GEMV takes the concat's place (p exists by then)
+    steps[j] = conv;
+    steps[i] = gemv;
+    steps.erase(steps.begin() + r);
+    i--;
+  }
+
+  NT = (int)g.tensors.size();
+  // ---- split-f16 copies of the large pointwise-conv weights: w = hi + lo (+ 2^-22 relative), [hi | lo][cout_pad][Kp], k contiguous
+  plan->weights16.clear();
+  for (Step& st : steps) {
+    st.w16_off = 0; st.k16_pad = 0;
+    if (st.kind != StepKind::PwConv || st.Cin < 32 || st.cout_pad % 16 != 0 || st.OH * st.OW <= 4) continue;
+    const int Kp = round_up(st.Cin, 32);
+    while (plan->weights16.size() % 8) plan->weights16.push_back(0);          // 16-byte aligned rows
+    st.w16_off = plan->weights16.size(); st.k16_pad = Kp;
+    plan->weights16.resize(plan->weights16.size() + 2 * (size_t)st.cout_pad * Kp, 0);
+    uint16_t* hi = plan->weights16.data() + st.w16_off;
+    uint16_t* lo = hi + (size_t)st.cout_pad * Kp;
+    for (int k = 0; k < st.Cin; k++) for (int o = 0; o < st.Cout; o++) {
+      const float wv = W[st.w_off + (size_t)k * st.cout_pad + o];
+      const uint16_t h = f32_to_f16_rn(wv);
+      hi[(size_t)o * Kp + k] = h;
+      lo[(size_t)o * Kp + k] = f32_to_f16_rn(wv - f16_to_f32(h));
+    }
+  }
+
   // ---- activation arena: first-fit over [first def, last use] intervals, in per-stream float units
   plan->tensor_off.assign(NT, -1);
   std::vector<int> first(NT, -1), last(NT, -1);
@@ -904,7 +1006,7 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   touch(g.input, -1);
   for (int s = 0; s < NS; s++) {
     const Step& st = steps[s];
-    touch(st.in0, s); touch(st.in1, s); touch(st.in2, s); touch(st.residual, s); touch(st.in_scale, s);
+    touch(st.in0, s); touch(st.in1, s); touch(st.in2, s); touch(st.residual, s); touch(st.in_scale, s); touch(st.out_bias, s);
     for (int t : st.concat_in) touch(t, s);
     touch(st.out, s);
   }

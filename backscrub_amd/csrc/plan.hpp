@@ -28,6 +28,8 @@ struct Step {
   int out = -1;
   int residual = -1;                  // tensor added after the activation (conv-type steps)
   int in_scale = -1;                  // [N,1,1,Cin] tensor multiplied into the input (PwConv only)
+  int out_bias = -1;                  // [N,1,1,Cout] per-frame vector added to the accumulator before the activation (PwConv only:
+                                      // a spatially constant concat branch folded into the consuming 1x1 convolution)
   int H = 1, W = 1, Cin = 1, OH = 1, OW = 1, Cout = 1;
   int kh = 1, kw = 1, sh = 1, sw = 1, dh = 1, dw = 1, pad_t = 0, pad_l = 0;
   int act = kActNone;
@@ -38,6 +40,8 @@ struct Step {
   int cout_tile = 16;                 // output channels per thread in the conv kernels
   size_t w_off = 0, b_off = 0;        // float offsets into the weight arena
   size_t w2_off = 0;                  // [co][ci] copy of the weights for single-pixel (GEMV) steps, 0 if absent
+  size_t w16_off = 0;                 // Plan::weights16 offset (halves) of the split-f16 copy [hi | lo][cout_pad][k16_pad], k contiguous
+  int k16_pad = 0;                    // Cin rounded up to 32 (0: the step has no f16 copy)
   std::vector<int> concat_in;         // Concat: all inputs
   std::vector<int> concat_c;          // Concat: channels of each input
   bool gap_sum = false;               // Gap over concat_in as a SUM of the parts' means (GAP(a + b) rewritten), not their concatenation
@@ -48,6 +52,7 @@ struct Step {
 struct Plan {
   std::vector<Step> steps;
   std::vector<float> weights;         // packed weight arena (host copy)
+  std::vector<uint16_t> weights16;    // IEEE half bit patterns: hi/lo split of the large pointwise-conv weights (split-f16 MFMA GEMM)
   std::vector<long> tensor_off;       // per graph tensor: float offset per stream-slot unit, -1 if not materialised
   size_t arena_floats_per_stream = 0; // arena size = this * n_streams
   int input = -1, output = -1;

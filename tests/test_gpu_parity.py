@@ -219,10 +219,22 @@ def test_generic_mask_kernel_matches_tile_kernel(bs, oracle, res, monkeypatch):
     monkeypatch.delenv("BSX_NO_MASK_TILE", raising=False)
 
 
+NETWORK_PATHS = {
+    # the Meet / MLKit graphs have three executions of the same fused plan; all must meet the logit tolerance against the oracle
+    "lite": [("segments + middle program", {}, "segment head"), ("whole-network program", {"BSX_NO_SEGMENTS": "1"}, "frame program: ON"),
+             ("one launch per step", {"BSX_NO_FRAME_PROGRAM": "1"}, "frame program: off")],
+    "mlkit": [("segments + middle program", {}, "segment head"), ("whole-network program", {"BSX_NO_SEGMENTS": "1"}, "frame program: ON"),
+              ("one launch per step", {"BSX_NO_FRAME_PROGRAM": "1"}, "frame program: off")],
+    # DeepLab runs per launch: the split-f16 MFMA GEMM (default) and the f32 MFMA GEMM, with and without the planner's rewrites
+    "deeplab": [("split-f16 MFMA GEMM", {}, "conv#66-pool"), ("f32 MFMA GEMM", {"BSX_F16_GEMM": "off"}, "conv#66-pool"),
+                ("no graph rewrites", {"BSX_NO_REWRITES": "1"}, "concat#65")],
+}
+
+
 @pytest.mark.parametrize("key", ["lite", "mlkit", "deeplab"])
-def test_per_launch_path_agrees_with_frame_program(bs, oracle, key, monkeypatch):
-    """The network has two executions of the same fused plan: the per-frame LDS program (default) and one
-    launch per step (BSX_NO_FRAME_PROGRAM=1).  Both must meet the logit tolerance against the oracle."""
+def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, key, monkeypatch):
+    """Same plan, different executions (segment kernels + per-frame middle program / whole-network program / one launch per
+    step; f32 vs split-f16 MFMA GEMMs; with and without the linear-algebra rewrites): every one within 1e-4 of the oracle's logits."""
     from backscrub_amd import synth
     path = model_path(key)
     W, H = VGA
@@ -230,24 +242,46 @@ def test_per_launch_path_agrees_with_frame_program(bs, oracle, key, monkeypatch)
     oc = oracle.Ctx(path, W, H)
     oc.prep(f)
     want = oc.infer()
-    outs = []
-    monkeypatch.setenv("BSX_FORCE_FRAME_PROGRAM", "1")   # DeepLab defaults to the per-launch path; exercise both here
-    for no_prog in ("", "1"):
-        if no_prog:
-            monkeypatch.setenv("BSX_NO_FRAME_PROGRAM", "1")
-        else:
-            monkeypatch.delenv("BSX_NO_FRAME_PROGRAM", raising=False)
+    knobs = ("BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM")
+    for name, env, marker in NETWORK_PATHS[key]:
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         mg = bs.MaskGen(path, W, H, n_streams=2)
-        assert ("frame program: ON" in mg.plan()) == (not no_prog)
+        assert marker in mg.plan(), "%s: expected %r in the plan" % (name, marker)
         mg.run_stage(0, _dev(np.stack([f, f])))
         mg.run_stage(1, n=2)
         got = mg.output_tensor().cpu().numpy()
         assert np.array_equal(got[0], got[1])
         err = float(np.abs(got[0] - want).max()) / max(1.0, float(np.abs(want).max()))
-        assert err < 1e-4, "%s path: rel err %g" % ("per-launch" if no_prog else "program", err)
-        outs.append(got[0])
+        assert err < 1e-4, "%s: rel err %g" % (name, err)
         mg.close()
+    for k in knobs:
+        monkeypatch.delenv(k, raising=False)
     oc.close()
+
+
+def test_deeplab_fast_f16_mode_is_close_but_not_parity_grade(bs, oracle, monkeypatch):
+    """BSX_F16_GEMM=fast (plain f16 MFMA inputs, f32 accumulate — what SetAllowFp16PrecisionForFp32 permits, lib/libbackscrub.cc:225)
+    is an opt-in mode: its logits are close (1e-2) but it is NOT held to the 1e-4 parity bar; the default split-f16 mode is."""
+    from backscrub_amd import synth
+    path = model_path("deeplab")
+    W, H = VGA
+    f = synth.frame(W, H, 5)
+    oc = oracle.Ctx(path, W, H)
+    oc.prep(f)
+    want = oc.infer()
+    monkeypatch.setenv("BSX_F16_GEMM", "fast")
+    mg = bs.MaskGen(path, W, H, n_streams=1)
+    mg.run_stage(0, _dev(f[None]))
+    mg.run_stage(1, n=1)
+    got = mg.output_tensor().cpu().numpy()[0]
+    err = float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max()))
+    assert err < 1e-2, err
+    assert (got.argmax(-1) == want.argmax(-1)).mean() > 0.99
+    mg.close(); oc.close()
+    monkeypatch.delenv("BSX_F16_GEMM", raising=False)
 
 
 # --------------------------------------------------------------------------------------------
