@@ -57,6 +57,7 @@ SYMBOLS = [
     ("bsx_resize_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_bgr_to_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_yuyv_to_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("bsx_gaussian_blur_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_flip_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_debug_buffer", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("bsx_debug_run_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -203,6 +204,15 @@ class MaskGen:
         n, h, w, _ = bgr.shape
         out = torch.empty_like(bgr)
         _check(lib().bsx_flip_bgr(self.h, C.c_void_p(bgr.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, int(code), _stream_ptr()), self.h, "bsx_flip_bgr")
+        return out
+
+    def gaussian_blur(self, bgr, ksize=25):
+        """cv::GaussianBlur(bgr, out, Size(ksize, ksize), 0) for [n,h,w,3] u8 device frames (deepseg.cc:657-658, -p bgblur:<ksize>)."""
+        torch = _torch()
+        n, h, w, _ = bgr.shape
+        out = torch.empty_like(bgr)
+        _check(lib().bsx_gaussian_blur_bgr(self.h, C.c_void_p(bgr.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, int(ksize), _stream_ptr()),
+               self.h, "bsx_gaussian_blur_bgr")
         return out
 
     def yuyv_to_bgr(self, yuyv):

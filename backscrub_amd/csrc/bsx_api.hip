@@ -510,6 +510,13 @@ int bsx_flip_bgr(bsx_ctx* c, const uint8_t* d_src, uint8_t* d_dst, int w, int h,
   return BSX_OK;
 }
 
+int bsx_gaussian_blur_bgr(bsx_ctx* c, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int ksize, void* stream) {
+  if (!c || !d_src || !d_dst || d_src == d_dst || w <= 0 || h <= 0 || n <= 0 || ksize < 1 || ksize > 31 || !(ksize & 1)) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
+  BSX_HIP(c, launch_gauss_blur(d_src, d_dst, w, h, ksize, n, pick(c, stream)));
+  return BSX_OK;
+}
+
 int bsx_bgr_to_yuyv(bsx_ctx* c, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, int h, int n, void* stream) {
   if (!c || !d_bgr || !d_yuyv || w <= 0 || h <= 0 || n <= 0) return BSX_EINVAL;
   DeviceGuard guard(c->device);

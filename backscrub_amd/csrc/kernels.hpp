@@ -90,6 +90,8 @@ hipError_t launch_bgr_to_yuyv(const uint8_t* bgr, uint8_t* yuyv, int w, int h, i
 hipError_t launch_yuyv_to_bgr(const uint8_t* yuyv, uint8_t* bgr, int w, int h, int n, hipStream_t s);
 // cv::flip of the composited frame (code as cv::flip: 0 vertical, >0 horizontal, <0 both).  deepseg.cc:667-673
 hipError_t launch_flip_bgr(const uint8_t* src, uint8_t* dst, int w, int h, int code, int n, hipStream_t s);
+// cv::GaussianBlur(Size(ksize, ksize), sigma 0) of packed BGR u8 images (dst != src), ksize odd <= 31.  deepseg.cc:657-658 (-p bgblur:N)
+hipError_t launch_gauss_blur(const uint8_t* src, uint8_t* dst, int w, int h, int ksize, int n, hipStream_t s);
 // fill
 hipError_t launch_fill_u8(uint8_t* p, uint8_t v, size_t bytes, hipStream_t s);
 

@@ -761,6 +761,127 @@ hipError_t launch_resize_bgr(const uint8_t* src, uint8_t* dst, ResizeTab tab, in
   return hipGetLastError();
 }
 
+// ---- cv::GaussianBlur(bg, bg, Size(n, n), 0) on packed BGR u8 (app/deepseg.cc:657-658, `-p bgblur:<n>`) ------------------------------
+// OpenCV's 8-bit Gaussian is an integer separable filter: u8-valued coefficients c[k] = cvRound(kernel * 256) (host table), the
+// horizontal pass Σ c·src in u16 (8 fractional bits), the vertical pass Σ c·h in u32 (16 fractional bits), (v + 2^15) >> 16,
+// BORDER_REFLECT_101.  With Σc <= 257 neither intermediate can overflow, so the saturating adds of the reference never trigger.
+// Tile = 64 x 16 output pixels per workgroup.  The source tile (+ radius r <= 15 on every side) is de-interleaved into three byte
+// planes in LDS so that consecutive taps of one channel are consecutive bytes: the horizontal pass then does 4 taps per
+// v_dot4_u32_u8 on windows shifted out of aligned dwords with v_alignbyte; its u16 results are stored transposed ([col][row]) so the
+// vertical pass does 2 taps per v_dot2_u32_u16 the same way.  HBM traffic = the image once in, once out.
+constexpr int kGTW = 64, kGTH = 16, kGMaxR = 15, kGSW = kGTW + 2 * kGMaxR, kGSH = kGTH + 2 * kGMaxR;    // 94 x 46 source tile
+constexpr int kGSrcStride = 96;                  // bytes per plane row (multiple of 4)
+constexpr int kGHStride = 48;                    // u16 per hbuf column (rows of the source tile, even)
+struct GaussCoef { uint32_t c4[8]; uint32_t c2[16]; int n, r; };   // c[k] packed 4 per dword (bytes) and 2 per dword (u16), zero padded
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int reflect101_far(int p, int len) {   // cv::borderInterpolate(BORDER_REFLECT_101) for overshoots beyond one period
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+  return p;
+}
+__global__ __launch_bounds__(kThreads) void gauss_blur_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H, GaussCoef gc) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[3 * kGSH * kGSrcStride];          // [plane][row][col]
+  __shared__ __attribute__((aligned(16))) uint16_t s_h[3 * kGTW * kGHStride];             // [plane][col][row]
+  const size_t img = (size_t)blockIdx.z * (size_t)W * H * 3;
+  const uint8_t* in = src + img;
+  uint8_t* out = dst + img;
+  const int x0 = blockIdx.x * kGTW, y0 = blockIdx.y * kGTH, r = gc.r, n = gc.n;
+  const int SW = kGTW + 2 * r, SH = kGTH + 2 * r;                                          // live part of the source tile
+  // 1. stage + de-interleave (reflected at the image border)
+  for (int i = threadIdx.x; i < SH * SW; i += kThreads) {
+    const int row = i / SW, col = i - row * SW;
+    const int gy = reflect101_far(y0 - r + row, H), gx = reflect101_far(x0 - r + col, W);
+    const uint8_t* p = in + ((size_t)gy * W + gx) * 3;
+    const uint8_t b = p[0], g = p[1], rr = p[2];
+    s_src[(0 * kGSH + row) * kGSrcStride + col] = b;
+    s_src[(1 * kGSH + row) * kGSrcStride + col] = g;
+    s_src[(2 * kGSH + row) * kGSrcStride + col] = rr;
+  }
+  __syncthreads();
+  // 2. horizontal pass: item = (plane, source row, group of 4 output columns)
+  const int NT = (n + 3) >> 2;
+  for (int i = threadIdx.x; i < 3 * SH * (kGTW / 4); i += kThreads) {
+    const int grp = i & (kGTW / 4 - 1), pr = i / (kGTW / 4), row = pr % SH, plane = pr / SH;
+    const uint32_t* rowp = reinterpret_cast<const uint32_t*>(s_src + (plane * kGSH + row) * kGSrcStride) + grp;   // bytes 4*grp ..
+    uint32_t d[10];
+#pragma unroll
+    for (int t = 0; t < 10; t++) d[t] = (t <= NT) ? rowp[t] : 0u;          // stays inside the 96-byte row: 4*15 + 4*10 = 100 > 96 only for t = 9, never needed (NT <= 8)
+    uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      if (t < NT) {
+        const uint32_t c = gc.c4[t];
+        acc[0] = __builtin_amdgcn_udot4(d[t], c, acc[0], false);
+        acc[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d[t + 1], d[t], 1), c, acc[1], false);
+        acc[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d[t + 1], d[t], 2), c, acc[2], false);
+        acc[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d[t + 1], d[t], 3), c, acc[3], false);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) s_h[(plane * kGTW + 4 * grp + j) * kGHStride + row] = (uint16_t)min(acc[j], 0xFFFFu);
+  }
+  __syncthreads();
+  // 3. vertical pass: item = (plane, output column, pair of output rows)
+  const int NP = (n + 1) >> 1;
+  for (int i = threadIdx.x; i < 3 * kGTW * (kGTH / 2); i += kThreads) {
+    const int m = i & (kGTH / 2 - 1), pc = i / (kGTH / 2), col = pc & (kGTW - 1), plane = pc / kGTW;
+    const uint32_t* colp = reinterpret_cast<const uint32_t*>(s_h + (plane * kGTW + col) * kGHStride) + m;        // rows 2m ..
+    uint32_t hd[17];
+#pragma unroll
+    for (int t = 0; t < 17; t++) hd[t] = (t <= NP) ? colp[t] : 0u;          // 2m + 2*16 + 1 <= 47 < kGHStride
+    uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      if (t < NP) {
+        const us2v c = __builtin_bit_cast(us2v, gc.c2[t]);
+        a0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, hd[t]), c, a0, false);
+        a1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, __builtin_amdgcn_alignbyte(hd[t + 1], hd[t], 2)), c, a1, false);
+      }
+    }
+    const int gx = x0 + col, gy = y0 + 2 * m;
+    if (gx < W) {
+      if (gy < H) out[((size_t)gy * W + gx) * 3 + plane] = (uint8_t)min((a0 + (1u << 15)) >> 16, 255u);
+      if (gy + 1 < H) out[((size_t)(gy + 1) * W + gx) * 3 + plane] = (uint8_t)min((a1 + (1u << 15)) >> 16, 255u);
+    }
+  }
+}
+
+// Coefficients of cv::GaussianBlur(ksize = n, sigma = 0) for 8-bit images (OpenCV 3.4 - 4.4 rule; DESIGN.md records the
+// version ambiguity): fixed tables for n <= 7, else cvRound(exp(-x^2 / (2 sigma^2)) / sum * 256), sigma = 0.3 * ((n-1)/2 - 1) + 0.8.
+bool gauss_coefficients(int n, GaussCoef* gc) {
+  if (n < 1 || n > 2 * kGMaxR + 1 || !(n & 1)) return false;
+  unsigned c[32] = {0};
+  if (n == 1) c[0] = 256;
+  else if (n == 3) { c[0] = 64; c[1] = 128; c[2] = 64; }
+  else if (n == 5) { const unsigned t[] = {16, 64, 96, 64, 16}; for (int i = 0; i < 5; i++) c[i] = t[i]; }
+  else if (n == 7) { const unsigned t[] = {8, 28, 56, 72, 56, 28, 8}; for (int i = 0; i < 7; i++) c[i] = t[i]; }
+  else {
+    const double sigma = ((n - 1) * 0.5 - 1) * 0.3 + 0.8, scale2x = (-0.5 * 0.25) / (sigma * sigma);
+    double v[32], sum = 0;
+    for (int i = 0, x = 1 - n; i < n; i++, x += 2) { v[i] = std::exp((double)(x * x) * scale2x); sum += v[i]; }
+    const double inv = 1.0 / sum;
+    for (int i = 0; i < n; i++) c[i] = (unsigned)std::lrint(v[i] * inv * 256.0);
+  }
+  unsigned total = 0;
+  for (int i = 0; i < n; i++) { if (c[i] > 255 && n > 1) return false; total += c[i]; }
+  if (total > 257) return false;                          // the kernel relies on Σc·255 fitting 16 bits
+  *gc = GaussCoef{};
+  gc->n = n; gc->r = n / 2;
+  if (n == 1) { gc->c4[0] = 0; gc->c2[0] = 256; return true; }   // 256 does not fit a byte: n = 1 is served as a copy by the caller
+  for (int i = 0; i < n; i++) { gc->c4[i >> 2] |= c[i] << (8 * (i & 3)); gc->c2[i >> 1] |= c[i] << (16 * (i & 1)); }
+  return true;
+}
+hipError_t launch_gauss_blur(const uint8_t* src, uint8_t* dst, int w, int h, int ksize, int n, hipStream_t s) {
+  GaussCoef gc;
+  if (!gauss_coefficients(ksize, &gc)) return hipErrorInvalidValue;
+  if (ksize == 1) return hipMemcpyAsync(dst, src, (size_t)n * w * h * 3, hipMemcpyDeviceToDevice, s);
+  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
+    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
+    gauss_blur_k<<<dim3((w + kGTW - 1) / kGTW, (h + kGTH - 1) / kGTH, nn), kThreads, 0, s>>>(src + (size_t)n0 * w * h * 3, dst + (size_t)n0 * w * h * 3, w, h, gc);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_flip_bgr(const uint8_t* src, uint8_t* dst, int w, int h, int code, int n, hipStream_t s) {
   for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
     const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;

@@ -21,6 +21,8 @@
  *   bsx_bgr_to_yuyv        convert_rgb_to_yuyv()          app/deepseg.cc:87-106
  *   bsx_yuyv_to_bgr        VideoCapture's YUYV->BGR       app/deepseg.cc:553,725 (cv::COLOR_YUV2BGR_YUYV)
  *   bsx_flip_bgr           cv::flip of the output frame   app/deepseg.cc:667-673 (flipHorizontal / flipVertical)
+ *   bsx_gaussian_blur_bgr  cv::GaussianBlur of the background app/deepseg.cc:415-431,652-658 (-p bgblur:<n>: blur the camera frame itself
+ *                          (or the background image) and composite over it)
  *   bsx_profile_batch      the per-stage timers           app/deepseg.cc:137-156,701-720 (timinginfo_t)
  *   bsx_get_info           the geometry of backscrub_ctx_t lib/libbackscrub.cc:28-54,234-246
  *
@@ -138,6 +140,11 @@ int bsx_yuyv_to_bgr(bsx_ctx* ctx, const uint8_t* d_yuyv, uint8_t* d_bgr, int w, 
 /* cv::flip(src, dst, code) on packed BGR u8 [n][h][w][3] (device pointers, dst != src): code 0 flips around the x axis
  * (-v / flipVertical), code > 0 around the y axis (-h / flipHorizontal), code < 0 both (app/deepseg.cc:667-673). */
 int bsx_flip_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int code, void* stream);
+
+/* cv::GaussianBlur(src, dst, Size(ksize, ksize), 0) on packed BGR u8 [n][h][w][3] (device pointers, dst != src), BORDER_REFLECT_101,
+ * OpenCV's 8-bit fixed-point coefficients; ksize odd, 1 <= ksize <= 31 (the reference's default strength is 25, app/deepseg.cc:429).
+ * The "blur my own room" mode of the reference = this on the camera frames, then bsx_step_batch with bg_frame_stride = one frame. */
+int bsx_gaussian_blur_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int ksize, void* stream);
 
 /* ---- introspection used by the parity tests and the bench (stage-by-stage checks) ---- */
 /* Device pointer + element count of: 0 = model input tensor [n_streams][in_h][in_w][in_c] f32,

@@ -612,6 +612,58 @@ static void blur5_u8(const uint8_t* src, int w, int h, size_t sstride, uint8_t* 
   }
 }
 
+// cv::GaussianBlur(src, dst, Size(n, n), 0) for CV_8UC3, BORDER_REFLECT_101 — app/deepseg.cc:657-658 (`-p bgblur:<n>`, n odd,
+// default 25, :420-429).  OpenCV's 8-bit path is a FIXED-POINT separable filter (imgproc smooth.dispatch.cpp / smooth.simd.hpp,
+// "bit-exact" since 3.4): coefficients ufixedpoint16 (8 fractional bits) = cvRound(k[i] * 256) of the normalised kernel
+// k[i] = exp(-x^2 / (2 sigma^2)) / sum, sigma = 0.3 * ((n-1) * 0.5 - 1) + 0.8 for sigma <= 0, with the exact tables
+// {1}, {1,2,1}/4, {1,4,6,4,1}/16, {1,3.5,7,9,7,3.5,1}/32 for n = 1, 3, 5, 7; horizontal pass Σ c·src in saturating u16
+// (8 fractional bits), vertical pass Σ c·h in saturating u32 (16 fractional bits), result = sat_u8((v + 2^15) >> 16).
+// Recorded ambiguities (unpinned: OpenCV is absent from the checkout): (1) the kernel is evaluated in SOFTWARE double
+// (softdouble) there, in libm double here — a coefficient could differ only if k*256 sits within 1e-13 of a rounding tie;
+// (2) this is the coefficient rule of OpenCV 3.4 - 4.4 (README.md:63 names 4.2.0); 4.5+ diffuses the rounding error so that
+// the coefficients sum to exactly 256.
+static std::vector<uint16_t> gaussian_coeffs_u16(int n) {
+  std::vector<uint16_t> c(n);
+  if (n == 1) { c[0] = 256; return c; }
+  if (n == 3) { c = {64, 128, 64}; return c; }
+  if (n == 5) { c = {16, 64, 96, 64, 16}; return c; }
+  if (n == 7) { c = {8, 28, 56, 72, 56, 28, 8}; return c; }
+  const double sigma = ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+  const double scale2x = (-0.5 * 0.25) / (sigma * sigma);
+  std::vector<double> v(n);
+  double sum = 0;
+  for (int i = 0, x = 1 - n; i < n; i++, x += 2) { v[i] = std::exp((double)(x * x) * scale2x); sum += v[i]; }
+  const double inv = 1.0 / sum;
+  for (int i = 0; i < n; i++) c[i] = (uint16_t)cv_round(v[i] * inv * 256.0);
+  return c;
+}
+static void gaussian_blur_c3(const uint8_t* src, int w, int h, int n, uint8_t* dst) {
+  const std::vector<uint16_t> c = gaussian_coeffs_u16(n);
+  const int r = n / 2;
+  std::vector<uint16_t> hbuf((size_t)w * h * 3);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++)
+      for (int ch = 0; ch < 3; ch++) {
+        uint32_t acc = 0;
+        for (int k = 0; k < n; k++) {
+          acc += (uint32_t)c[k] * src[((size_t)y * w + reflect101(x + k - r, w)) * 3 + ch];
+          if (acc > 0xFFFFu) acc = 0xFFFFu;                      // ufixedpoint16 saturating add
+        }
+        hbuf[((size_t)y * w + x) * 3 + ch] = (uint16_t)acc;
+      }
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++)
+      for (int ch = 0; ch < 3; ch++) {
+        uint64_t acc = 0;
+        for (int k = 0; k < n; k++) {
+          acc += (uint64_t)c[k] * hbuf[((size_t)reflect101(y + k - r, h) * w + x) * 3 + ch];
+          if (acc > 0xFFFFFFFFull) acc = 0xFFFFFFFFull;          // ufixedpoint32 saturating add
+        }
+        const uint64_t v = (acc + (1u << 15)) >> 16;
+        dst[((size_t)y * w + x) * 3 + ch] = (uint8_t)std::min<uint64_t>(v, 255);
+      }
+}
+
 // alpha_blend — follows app/deepseg.cc:108-134 (int math, truncating /255; a=bg, b=frame).
 static void alpha_blend(const uint8_t* a, const uint8_t* b, const uint8_t* m, uint8_t* o, size_t npix) {
   for (size_t p = 0; p < npix; p++) {
@@ -828,6 +880,8 @@ void bso_alpha_blend(const uint8_t* bg, const uint8_t* fr, const uint8_t* m, uin
 void bso_bgr_to_yuyv(const uint8_t* in, int w, int h, uint8_t* out) { bgr_to_yuyv(in, w, h, out); }
 void bso_rgb2yuv_u8(const uint8_t* in, long npix, uint8_t* yuv) { rgb2yuv_u8(in, (size_t)npix, yuv); }
 void bso_set_custom_op_hook(bso_custom_fn fn) { g_custom_hook = fn; }
+void bso_gaussian_blur_c3(const uint8_t* src, int w, int h, int n, uint8_t* dst) { gaussian_blur_c3(src, w, h, n, dst); }
+int bso_gaussian_coeffs(int n, uint16_t* out) { const std::vector<uint16_t> c = gaussian_coeffs_u16(n); memcpy(out, c.data(), c.size() * 2); return (int)c.size(); }
 // the Convolution2DTransposeBias restatement on its own (custom options = padding, stride_w, stride_h); y == NULL queries the shape
 int bso_tconv_bias(const float* x, const int* xs4, const float* w, const int* ws4, const float* b, int padding, int stride_w, int stride_h, float* y, int* ys4) {
   OTensor tx, tw, tb, ty; OOp op;

@@ -45,6 +45,8 @@ def _load(name):
     lib.bso_yuyv_to_bgr.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
     lib.bso_decode_iir.argtypes = [C.c_int, _f32p, C.c_long, C.c_int, _u8p]
     lib.bso_convert_f32.argtypes = [_u8p, C.c_long, C.c_float, C.c_float, _f32p]
+    lib.bso_gaussian_blur_c3.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p]
+    lib.bso_gaussian_coeffs.argtypes = [C.c_int, C.POINTER(C.c_uint16)]
     lib.bso_tconv_bias.argtypes = [_f32p, C.POINTER(C.c_int), _f32p, C.POINTER(C.c_int), _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int)]
     lib.bso_ctx_new.restype = C.c_void_p
     lib.bso_ctx_new.argtypes = [C.c_char_p, C.c_int, C.c_int]
@@ -121,6 +123,20 @@ def bgr_to_yuyv(img) -> np.ndarray:
     img = np.ascontiguousarray(img)
     out = np.zeros((img.shape[0], img.shape[1], 2), np.uint8)
     lib().bso_bgr_to_yuyv(_u8(img), img.shape[1], img.shape[0], _u8(out))
+    return out
+
+
+def gaussian_blur(img: np.ndarray, ksize: int) -> np.ndarray:
+    """cv::GaussianBlur(img, out, Size(ksize, ksize), 0) on packed 8-bit BGR (/root/reference/app/deepseg.cc:657-658)."""
+    img = np.ascontiguousarray(img)
+    out = np.empty_like(img)
+    lib().bso_gaussian_blur_c3(_u8(img), img.shape[1], img.shape[0], int(ksize), _u8(out))
+    return out
+
+
+def gaussian_coeffs(ksize: int) -> np.ndarray:
+    out = np.zeros(ksize, np.uint16)
+    lib().bso_gaussian_coeffs(int(ksize), out.ctypes.data_as(C.POINTER(C.c_uint16)))
     return out
 
 

@@ -458,6 +458,52 @@ def test_yuyv_to_bgr_matches_oracle(bs, oracle):
 # --------------------------------------------------------------------------------------------
 # size-independent properties at the BASELINE batch size (256 VGA streams, segm_lite)
 # --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ksize,res", [(25, VGA), (3, (322, 242)), (5, (64, 16)), (7, (65, 17)), (9, (33, 47)), (31, (130, 70)), (1, (40, 30)), (25, (20, 12))])
+def test_gaussian_blur_matches_oracle(bs, oracle, ksize, res):
+    """bsx_gaussian_blur_bgr (the -p bgblur:<n> step, app/deepseg.cc:657-658) is integer arithmetic: bit-exact against the oracle,
+    including images smaller than the kernel radius (multiple reflections) and sizes that are not multiples of the 64x16 tile."""
+    from backscrub_amd import synth
+    W, H = res
+    img = synth.random_u8((2, H, W, 3), 60 + ksize)
+    img[0, : H // 3] = 255
+    mg = bs.MaskGen(synthetic_model_path("lite"), 640, 480, n_streams=1)
+    got = mg.gaussian_blur(_dev(img), ksize).cpu().numpy()
+    for i in range(2):
+        want = oracle.gaussian_blur(img[i], ksize)
+        assert np.array_equal(got[i], want), "ksize %d image %d: %d bytes differ" % (ksize, i, (got[i] != want).sum())
+    with pytest.raises(bs.BsxError):
+        mg.gaussian_blur(_dev(img), 4)
+    with pytest.raises(bs.BsxError):
+        mg.gaussian_blur(_dev(img), 33)
+    mg.close()
+
+
+def test_blur_own_frame_as_background(bs, oracle):
+    """The reference's most used mode (-p bgblur without -b, app/deepseg.cc:652-661): background = GaussianBlur(camera frame),
+    then alpha_blend — as bsx_gaussian_blur_bgr + bsx_step_batch with one background per stream."""
+    from backscrub_amd import synth
+    path = model_path("lite")
+    W, H = VGA
+    n = 2
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    oc = [oracle.Ctx(path, W, H) for _ in range(n)]
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    for t in range(3):
+        frames = np.stack([synth.frame(W, H, s, t) for s in range(n)])
+        d_frames = _dev(frames)
+        d_bg = mg.gaussian_blur(d_frames, 25)
+        mg.step(d_frames, d_bg, out)
+        got_m, got_o = mg.masks().cpu().numpy(), out.cpu().numpy()
+        for i in range(n):
+            want_m = oc[i].process(frames[i])
+            assert _iou_fg(got_m[i], want_m) >= 0.999
+            if np.array_equal(got_m[i], want_m):
+                assert np.array_equal(got_o[i], oracle.alpha_blend(oracle.gaussian_blur(frames[i], 25), frames[i], want_m))
+    for c in oc:
+        c.close()
+    mg.close()
+
+
 @pytest.mark.parametrize("code", [0, 1, -1])
 def test_flip_matches_oracle(bs, oracle, code):
     from backscrub_amd import synth

@@ -208,3 +208,49 @@ def test_yuyv_to_bgr_formula_and_roundtrip_bound(oracle):
     out = oracle.yuyv_to_bgr(grey)[0]
     assert (out[:, 0] == out[:, 1]).all() and (out[:, 1] == out[:, 2]).all()
     assert out[16, 0] == 0 and out[235, 0] == 255
+
+
+# ---- cv::GaussianBlur 8-bit fixed-point path (app/deepseg.cc:657-658, -p bgblur:<n>) -------------------------------------------
+def _gauss_numpy(img, n):
+    """Independent numpy statement of OpenCV's 8-bit Gaussian: ufixedpoint16 coefficients, u16 horizontal / u32 vertical passes."""
+    if n == 1:
+        c = np.array([256])
+    elif n == 3:
+        c = np.array([64, 128, 64])
+    elif n == 5:
+        c = np.array([16, 64, 96, 64, 16])
+    elif n == 7:
+        c = np.array([8, 28, 56, 72, 56, 28, 8])
+    else:
+        sigma = ((n - 1) * 0.5 - 1) * 0.3 + 0.8
+        x = np.arange(1 - n, n, 2, dtype=np.float64)
+        v = np.exp(x * x * (-0.125 / (sigma * sigma)))
+        c = np.rint(v / v.sum() * 256.0).astype(np.int64)
+    r = n // 2
+    pad = np.pad(img.astype(np.int64), ((r, r), (r, r), (0, 0)), mode="reflect")      # numpy "reflect" == BORDER_REFLECT_101
+    h = sum(c[k] * pad[:, k:k + img.shape[1]] for k in range(n))
+    h = np.minimum(h, 0xFFFF)
+    v = sum(c[k] * h[k:k + img.shape[0]] for k in range(n))
+    v = np.minimum(v, 0xFFFFFFFF)
+    return np.minimum((v + (1 << 15)) >> 16, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 7, 9, 25, 31])
+def test_gaussian_blur_restatement(oracle, n):
+    from backscrub_amd import synth
+    img = synth.random_u8((37, 53, 3), 40 + n)
+    img[:6, :6] = 255                                   # saturation corner: with sum(c) = 257 the result must clamp at 255, not wrap
+    got = oracle.gaussian_blur(img, n)
+    assert np.array_equal(got, _gauss_numpy(img, n))
+    c = oracle.gaussian_coeffs(n)
+    assert 255 <= int(c.sum()) <= 257 and (c == c[::-1]).all() and (n == 1 or int(c.max()) < 256)
+    if n >= 3:
+        # it IS a Gaussian of the sigma OpenCV derives from the kernel size: within 3 grey levels of the float filter
+        from scipy.ndimage import gaussian_filter1d
+        sigma = 0.3 * ((n - 1) * 0.5 - 1) + 0.8
+        f = img.astype(np.float64)
+        for ax in (0, 1):
+            f = gaussian_filter1d(f, sigma, axis=ax, mode="mirror", truncate=(n // 2) / sigma)
+        if n > 7:
+            assert np.abs(f - got).max() <= 3.0     # 8-bit coefficients (sum 256 or 257) on a pure-noise image
+    assert got[:3, :3].min() == 255
