@@ -240,24 +240,26 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 constexpr int kHSA = kGemmBK + 8;        // halves per LDS row: 80 B → the 16-byte reads of 16 consecutive rows hit distinct bank quads
-template <int TERMS>
+// NTW = 16-channel tiles per workgroup (4: a 128 x 64 tile; a 128 x 160 variant for the projection layers measured 25 % slower: registers)
+template <int TERMS, int NTW>
 __global__ __launch_bounds__(kThreads) void pw_gemm_f16s_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                           const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
                                                           float* __restrict__ y, long M, int HW, int Cin, int Kp, int Cout, int cout_pad, int act,
                                                           const float* __restrict__ fbias) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[kGemmBM * kHSA];
   __shared__ __attribute__((aligned(16))) _Float16 Al[kGemmBM * kHSA];
-  __shared__ __attribute__((aligned(16))) _Float16 Bh[kGemmBN * kHSA];
-  __shared__ __attribute__((aligned(16))) _Float16 Bl[kGemmBN * kHSA];
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[NTW * 16 * kHSA];
+  __shared__ __attribute__((aligned(16))) _Float16 Bl[NTW * 16 * kHSA];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
-  const long m_base = (long)blockIdx.x * kGemmBM;
-  const int n_base = blockIdx.y * kGemmBN;
-  const int nt = min(4, (cout_pad - n_base) >> 4);
+  const long m_base = (long)blockIdx.y * kGemmBM;
+  const int n_base = blockIdx.x * (NTW * 16);
+  const int nt = min(NTW, (cout_pad - n_base) >> 4);
   const _Float16* wh = w16;
   const _Float16* wl = w16 + (size_t)cout_pad * Kp;
   // loader mapping: A = 128 rows x 8 float4 (4 per lane); B = 64 channels x 32 halves = 4 x 16-byte chunks per channel (1 per lane, hi and lo)
+  constexpr int kBP = (NTW * 64 + kThreads - 1) / kThreads;       // 16-byte weight pieces per lane and K step
   float4 ra[4];
-  h8v rbh, rbl;
+  h8v rbh[kBP], rbl[kBP];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -277,18 +279,21 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_f16s_k(const float* __restri
         ra[i] = v;
       }
     }
-    const int ch = tid >> 2, kc = (tid & 3) * 8;
-    rbh = h8v{0, 0, 0, 0, 0, 0, 0, 0}; rbl = rbh;
-    if (n_base + ch < cout_pad) {
-      rbh = *reinterpret_cast<const h8v*>(wh + (size_t)(n_base + ch) * Kp + k0 + kc);
-      if (TERMS == 3) rbl = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + ch) * Kp + k0 + kc);
+#pragma unroll
+    for (int i = 0; i < kBP; i++) {
+      const int f = tid + i * kThreads, ch = f >> 2, kc = (f & 3) * 8;
+      rbh[i] = h8v{0, 0, 0, 0, 0, 0, 0, 0}; rbl[i] = rbh[i];
+      if (ch < NTW * 16 && n_base + ch < cout_pad) {
+        rbh[i] = *reinterpret_cast<const h8v*>(wh + (size_t)(n_base + ch) * Kp + k0 + kc);
+        if (TERMS == 3) rbl[i] = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + ch) * Kp + k0 + kc);
+      }
     }
   };
-  f4acc acc[2][4];
+  f4acc acc[2][NTW];
 #pragma unroll
   for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = f4acc{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = f4acc{0.f, 0.f, 0.f, 0.f};
   fetch(0);
   for (int k0 = 0; k0 < Kp; k0 += kGemmBK) {
 #pragma unroll
@@ -305,10 +310,13 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_f16s_k(const float* __restri
         *reinterpret_cast<h4v*>(&Al[row * kHSA + kq]) = lo;
       }
     }
-    {
-      const int ch = tid >> 2, kc = (tid & 3) * 8;
-      *reinterpret_cast<h8v*>(&Bh[ch * kHSA + kc]) = rbh;
-      if (TERMS == 3) *reinterpret_cast<h8v*>(&Bl[ch * kHSA + kc]) = rbl;
+#pragma unroll
+    for (int i = 0; i < kBP; i++) {
+      const int f = tid + i * kThreads, ch = f >> 2, kc = (f & 3) * 8;
+      if (ch < NTW * 16) {
+        *reinterpret_cast<h8v*>(&Bh[ch * kHSA + kc]) = rbh[i];
+        if (TERMS == 3) *reinterpret_cast<h8v*>(&Bl[ch * kHSA + kc]) = rbl[i];
+      }
     }
     __syncthreads();
     if (k0 + kGemmBK < Kp) fetch(k0 + kGemmBK);              // in flight while this tile is multiplied
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_f16s_k(const float* __restri
       if (TERMS == 3) al[mi] = *reinterpret_cast<const h8v*>(&Al[(32 * wave + 16 * mi + li) * kHSA + 8 * g]);
     }
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++) {
+    for (int ni = 0; ni < NTW; ni++) {
       if (ni < nt) {
         const h8v bh = *reinterpret_cast<const h8v*>(&Bh[(16 * ni + li) * kHSA + 8 * g]);
         h8v bl = bh;
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_f16s_k(const float* __restri
   for (int mi = 0; mi < 2; mi++) {
     const long m = m_base + 32 * wave + 16 * mi + 4 * g + q;
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++) {
+    for (int ni = 0; ni < NTW; ni++) {
       if (ni >= nt) continue;
       const int c0 = n_base + 16 * ni + (li & ~3);
       const float4 v = quad_transpose(acc[mi][ni], q);
@@ -480,6 +488,56 @@ __global__ __launch_bounds__(kThreads) void dw_conv_k(const float* __restrict__ 
   long o = p * g.Cin + c;
   if (res) { float4 r = *reinterpret_cast<const float4*>(res + o); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
   *reinterpret_cast<float4*>(y + o) = v;
+}
+
+// Stride-1 3x3 depthwise with dilation d (DeepLab's 33x33 layers, d = 1 / 2 / 4): lane = (channel quad, column x, row residue ry)
+// and walks the rows ry, ry + d, ry + 2d, …  Consecutive outputs of that walk share two of their three tap rows, so the lane keeps
+// a 3 x 3 window of float4 in registers and loads ONE new tap row (3 x 16 bytes) per output instead of nine taps: the lane-per-output
+// form ran at the L2's 9x read amplification (2.2 TB/s algorithmic, 38 % of DeepLab's network time).  Lanes of a wave are
+// consecutive channel quads of one pixel: every load is a contiguous kilobyte.  FMA order per output = (fy, fx) ascending, as dw_conv_k.
+__global__ __launch_bounds__(kThreads) void dw_col_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                    const float* __restrict__ res, float* __restrict__ y, long total, int H, int W, int C, int d, int act) {
+  const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total) return;
+  const int C4 = C >> 2;
+  const int c = (int)(idx % C4) * 4;
+  long q = idx / C4;
+  const int ox = (int)(q % W);
+  q /= W;
+  const int ry = (int)(q % d);
+  const long n = q / d;
+  float4 wv[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) wv[k] = *reinterpret_cast<const float4*>(w + (long)k * C + c);
+  const float4 b = *reinterpret_cast<const float4*>(bias + c);
+  const float* base = x + n * (long)H * W * C + c;
+  const bool vl = ox - d >= 0, vr = ox + d < W;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_row = [&](int iy, float4& l, float4& m, float4& r) {
+    l = m = r = z;
+    if (iy >= 0 && iy < H) {
+      const float* p = base + ((long)iy * W + ox) * C;
+      m = *reinterpret_cast<const float4*>(p);
+      if (vl) l = *reinterpret_cast<const float4*>(p - (long)d * C);
+      if (vr) r = *reinterpret_cast<const float4*>(p + (long)d * C);
+    }
+  };
+  float4 t0, t1, t2, m0, m1, m2, b0, b1, b2;
+  load_row(ry - d, t0, t1, t2);
+  load_row(ry, m0, m1, m2);
+  for (int oy = ry; oy < H; oy += d) {
+    load_row(oy + d, b0, b1, b2);
+    float4 acc = z;
+#define BSX_TAP(v, k) acc.x = fmaf(v.x, wv[k].x, acc.x); acc.y = fmaf(v.y, wv[k].y, acc.y); acc.z = fmaf(v.z, wv[k].z, acc.z); acc.w = fmaf(v.w, wv[k].w, acc.w);
+    BSX_TAP(t0, 0) BSX_TAP(t1, 1) BSX_TAP(t2, 2) BSX_TAP(m0, 3) BSX_TAP(m1, 4) BSX_TAP(m2, 5) BSX_TAP(b0, 6) BSX_TAP(b1, 7) BSX_TAP(b2, 8)
+#undef BSX_TAP
+    float4 v;
+    v.x = act_fn(acc.x + b.x, act); v.y = act_fn(acc.y + b.y, act); v.z = act_fn(acc.z + b.z, act); v.w = act_fn(acc.w + b.w, act);
+    const long o = ((n * H + oy) * (long)W + ox) * C + c;
+    if (res) { const float4 r = *reinterpret_cast<const float4*>(res + o); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    *reinterpret_cast<float4*>(y + o) = v;
+    t0 = m0; t1 = m1; t2 = m2; m0 = b0; m1 = b1; m2 = b2;
+  }
 }
 
 // -------------------------------------------------------------------------------------
@@ -752,8 +810,13 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);
         if (weights16 && st.k16_pad > 0 && f16_terms > 0) {        // split-f16 (3 terms, f32-grade) or plain f16-input (1 term) MFMA
           const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
-          if (f16_terms == 3) pw_gemm_f16s_k<3><<<gg, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias));
-          else pw_gemm_f16s_k<1><<<gg, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias));
+          // grid.x = column tile (fastest in dispatch order): the workgroups sharing one 128-row A tile run back to back, so the tile
+          // comes from HBM once and from L2 for the other column tiles (expand layers have up to 8 of them)
+          const dim3 gw(gg.y, gg.x);
+          if (gg.x > 65535) return hipErrorInvalidValue;
+#define BSX_F16S(T, N) pw_gemm_f16s_k<T, N><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias))
+          if (f16_terms == 3) BSX_F16S(3, 4); else BSX_F16S(1, 4);
+#undef BSX_F16S
           break;
         }
         pw_gemm_mfma_k<<<gg, kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.Cout, st.cout_pad, st.act, P(st.out_bias));
@@ -775,6 +838,13 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
     case StepKind::DwConv: {
       long total = (long)n * st.OH * st.OW * (st.Cin / 4);
       ConvGeom g{st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.cout_pad, st.kh, st.kw, st.sh, st.sw, st.dh, st.dw, st.pad_t, st.pad_l};
+      static const bool no_col = getenv("BSX_NO_DW_COL") != nullptr;
+      if (!no_col && st.kh == 3 && st.kw == 3 && st.sh == 1 && st.sw == 1 && st.dh == st.dw && st.pad_t == st.dh && st.pad_l == st.dw && st.OH == st.H && st.OW == st.W &&
+          st.H >= 4 * st.dh) {                                   // SAME 3x3, stride 1: the sliding-window column walk
+        const long lanes = (long)n * st.dh * st.W * (st.Cin / 4);
+        dw_col_k<<<blocks_for(lanes), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.out), lanes, st.H, st.W, st.Cin, st.dh, st.act);
+        break;
+      }
       dw_conv_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.out), total, g, st.act);
       break;
     }
