@@ -818,6 +818,7 @@ __device__ __forceinline__ void dw_body(cop_t& op, const FrameCtx& c) {
   const int rows = kFrameThreads / C4, cq = threadIdx.x % C4, r0 = threadIdx.x / C4, ch = cq * 4;
   const int step_y = rows / OW, step_x = rows - step_y * OW, P = total / C4;
   int oy = r0 / OW, ox = r0 - oy * OW;
+  if (c.tl && blockIdx.x == 0 && threadIdx.x == 0) c.tl[265] += 1;      // count of depthwise ops seen by the timeline
   if (r0 < rows)
   for (int p = r0; p < P; p += rows, ox += step_x, oy += step_y) {
     if (ox >= OW) { ox -= OW; oy++; }
@@ -991,6 +992,9 @@ __device__ __forceinline__ void fc_lanes(const Ref& x, int Cin, const glb_f* w2,
   }
 }
 __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
+  const bool dbg = c.tl && blockIdx.x == 0 && threadIdx.x == 0;     // timeline runs: cycles per phase, summed over all SE ops, in tl[260..264]
+  unsigned long long t0 = dbg ? __builtin_readcyclecounter() : 0;
+  auto stamp = [&](int slot) { if (dbg) { const unsigned long long t1 = __builtin_readcyclecounter(); c.tl[slot] += t1 - t0; t0 = t1; } };
   const Ref mean = make_ref(op.in1, c), hid = make_ref(op.in2, c), out = make_ref(op.out, c);
   const int HW = op.H * op.W;
   const glb_f* wts = (const glb_f*)c.weights;
@@ -998,6 +1002,7 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
   const FcPre p1 = fc_preload(op.Cin, wts + op.w2_off, wts + op.b_off, op.C1);
   FcPre p2 = p1;
   if (op.n_fc == 2) p2 = fc_preload(op.C1, wts + op.w3_off, wts + op.b3_off, op.C2);
+  stamp(260);
   if (op.n_cat == 0) gap_one(make_ref(op.in0, c), HW, op.Cin, mean, 0);
   else {
     int coff = 0;
@@ -1006,10 +1011,14 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
       if (!op.gap_sum) coff += op.cat_c[k];
     }
   }
-  if (op.n_fc == 1) { fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, out, p1); return; }
+  stamp(261);
+  if (op.n_fc == 1) { fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, out, p1); stamp(262); return; }
   fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, hid, p1);
+  stamp(262);
   __syncthreads();
+  stamp(263);
   fc_lanes(hid, op.C1, wts + op.w3_off, wts + op.b3_off, op.C2, op.act2, out, p2);
+  stamp(264);
 }
 
 // ---- elementwise -----------------------------------------------------------------------------------------------------------

@@ -40,7 +40,8 @@ METRIC = "composited frames/sec at 640×480 (batch), 1/2/4/8 MI355X + mask IoU v
 NAMES = {"lite": "segm_lite_v681.tflite", "full": "segm_full_v679.tflite",
          "mlkit": "selfiesegmentation_mlkit-256x256-2021_01_19-v1215.f16.tflite", "deeplab": "deeplabv3_257_mv_gpu.tflite"}
 PMC_NAMES = {"frame_program": "frame_program_k", "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
-             "mask_upscale_blur": "mask_tile_k<false>", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k"}
+             "mask_upscale_blur": "mask_tile_k<false>", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k",
+             "seg_head": "seg_head_k", "seg_k2": "seg_k2_k", "seg_k3": "seg_k3_k", "seg_tail": "seg_tail_k", "seg_tail+decode": "seg_tail_k"}
 
 
 def parse():
@@ -159,7 +160,8 @@ def roofline_of(s, pmc, mode_dtype):
     """achieved = ALGORITHMIC bytes (or flops) of the launch / its mean hipEvent duration; traffic = HBM bytes per launch from
     the committed rocprofv3 PMC passes (profiles/pmc_latest.json): (2*FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE doubled per
     MI355X_MICROARCH.md §HBM (gfx950 counts 128-B reads at 64 B)."""
-    k = pmc.get(PMC_NAMES.get(s["name"], ""))
+    want = PMC_NAMES.get(s["name"], "")
+    k = pmc.get(want) or next((v for n_, v in pmc.items() if want and n_.startswith(want)), None)      # template arguments follow the base name
     traffic = int((2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024) if k and "FETCH_SIZE_KiB" in k and "WRITE_SIZE_KiB" in k else None
     peak_tf = F16_PEAK_TFLOPS if mode_dtype == "f16" else FP32_PEAK_TFLOPS
     if s["flops"] > 0 and s["flops"] / max(s["bytes"], 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):

@@ -30,6 +30,9 @@ if "--fine" in sys.argv:
         bodies = [r[2] for r in row]
         busy = sum(1 for b in bodies if b > 500)
         print("  P%-2d wait %6d dma %5d body %6d | body max %6d min %6d busy waves %2d | waitmax %6d" % (i, row[0][0], row[0][1], row[0][2], max(bodies), min(bodies), busy, max(r[0] for r in row)))
+if "--fine" in sys.argv:
+    ph = mg.last_subphase_us
+    print("SE ops, cycles summed over all of them (wave 0): preload %d | pool %d | fc1 %d | barrier %d | fc2 %d" % tuple(int(ph[i] * 100) for i in (4, 5, 6, 7, 8)))
 print("sub-phase accumulators (us):", [round(v, 1) for v in mg.last_subphase_us])
 print("total %.1f us for workgroup 0 (n=%d)" % (tot, n))
 print([l for l in mg.plan().splitlines() if l.startswith("frame program")][0])
