@@ -8,6 +8,6 @@ names, argument meaning and error behaviour.  There is NO CPU fallback: if the H
 is missing or no GPU is visible, calls raise.
 """
 from .api import (  # noqa: F401
-    BsxError, MaskGen, alpha_blend, bs_maskgen_delete, bs_maskgen_new, bs_maskgen_process, bs_tensorflow_version, lib,
-    lib_path, model_describe,
+    Background, BsxError, Live, MaskGen, alpha_blend, bs_maskgen_delete, bs_maskgen_new, bs_maskgen_process, bs_tensorflow_version, lib,
+    lib_path, media_decode, model_describe,
 )

@@ -57,6 +57,18 @@ SYMBOLS = [
     ("bsx_resize_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_bgr_to_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_yuyv_to_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("bsx_background_load", C.c_void_p, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("bsx_background_from_frames", C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
+    ("bsx_background_free", None, [C.c_void_p]),
+    ("bsx_background_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    ("bsx_background_grab", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("bsx_media_decode", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.POINTER(C.c_uint8)), C.c_char_p, C.c_size_t]),
+    ("bsx_media_free", None, [C.POINTER(C.c_uint8)]),
+    ("bsx_live_new", C.c_void_p, [C.c_void_p]),
+    ("bsx_live_delete", None, [C.c_void_p]),
+    ("bsx_live_set_input_frame", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("bsx_live_get_output_mask", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("bsx_live_timings", C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     ("bsx_gaussian_blur_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_flip_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_debug_buffer", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
@@ -306,6 +318,90 @@ def _as_torch(ptr, nbytes, dtype, shape, device):
     torch = _torch()
     typestr = {"uint8": "|u1", "float32": "<f4"}[dtype]
     return torch.as_tensor(_CudaArray(ptr, nbytes, typestr, shape), device="cuda:%d" % device)
+
+
+def media_decode(path: str):
+    """Host-only decode of a background file (GIF / PNG / PPM) → (frames [n,h,w,3] u8 BGR, fps).  BsxError with the decoder's reason."""
+    w, h, fps, ptr = C.c_int(), C.c_int(), C.c_double(), C.POINTER(C.c_uint8)()
+    err = C.create_string_buffer(512)
+    n = lib().bsx_media_decode(os.fsencode(path), C.byref(w), C.byref(h), C.byref(fps), C.byref(ptr), err, len(err))
+    if n <= 0:
+        raise BsxError(err.value.decode(errors="replace") or "media decode failed (%d)" % n)
+    try:
+        frames = np.ctypeslib.as_array(ptr, (n, h.value, w.value, 3)).copy()
+    finally:
+        lib().bsx_media_free(ptr)
+    return frames, fps.value
+
+
+class Background:
+    """load_background / grab_background of app/background.cc on top of a MaskGen's GPU."""
+
+    def __init__(self, mg: MaskGen, path=None, frames=None, fps=0.0, debug=0):
+        self.mg = mg
+        if path is not None:
+            self.h = lib().bsx_background_load(mg.h, os.fsencode(path), debug)
+        else:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            n, hh, ww, _ = frames.shape
+            self.h = lib().bsx_background_from_frames(mg.h, frames.ctypes.data, ww, hh, n, float(fps), debug)
+        if not self.h:
+            raise BsxError("cannot load background")
+        w, h, n, f, v = C.c_int(), C.c_int(), C.c_int(), C.c_double(), C.c_int()
+        lib().bsx_background_info(self.h, C.byref(w), C.byref(h), C.byref(n), C.byref(f), C.byref(v))
+        self.width, self.height, self.n_frames, self.fps, self.video = w.value, h.value, n.value, f.value, bool(v.value)
+
+    def grab(self, width, height, out=None):
+        """→ (frame number, torch u8 cuda [height,width,3])"""
+        torch = _torch()
+        if out is None:
+            out = torch.empty((height, width, 3), dtype=torch.uint8, device="cuda:%d" % self.mg.device)
+        frm = lib().bsx_background_grab(self.h, width, height, C.c_void_p(out.data_ptr()), _stream_ptr())
+        if frm < 0:
+            raise BsxError("bsx_background_grab failed")
+        return frm, out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bsx_background_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Live:
+    """CalcMask (app/deepseg.cc:159-286): set_input_frame / get_output_mask around a worker thread."""
+
+    def __init__(self, mg: MaskGen):
+        self.mg = mg
+        self.h = lib().bsx_live_new(mg.h)
+        if not self.h:
+            raise BsxError("bsx_live_new failed")
+
+    def set_input_frame(self, frame: np.ndarray):
+        frame = np.ascontiguousarray(frame, np.uint8)
+        _check(lib().bsx_live_set_input_frame(self.h, frame.ctypes.data, frame.strides[0]), self.mg.h, "bsx_live_set_input_frame")
+
+    def get_output_mask(self, mask: np.ndarray) -> bool:
+        rc = lib().bsx_live_get_output_mask(self.h, mask.ctypes.data, mask.strides[0])
+        if rc < 0:
+            _check(rc, self.mg.h, "bsx_live_get_output_mask")
+        return rc == 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bsx_live_delete(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def model_describe(path: str) -> str:

@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbsx.so")
-SOURCES = ["tflite_model.cpp", "plan.cpp", "kernels_nn.hip", "kernels_img.hip", "kernels_frame.hip", "kernels_seg.hip", "bsx_api.hip"]
-HEADERS = ["tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", os.path.join("..", "..", "include", "bsx.h")]
+SOURCES = ["tflite_model.cpp", "plan.cpp", "media.cpp", "live.cpp", "kernels_nn.hip", "kernels_img.hip", "kernels_frame.hip", "kernels_seg.hip", "bsx_api.hip"]
+HEADERS = ["media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", os.path.join("..", "..", "include", "bsx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("libbsx build failed")
     if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -23,6 +23,8 @@
  *   bsx_flip_bgr           cv::flip of the output frame   app/deepseg.cc:667-673 (flipHorizontal / flipVertical)
  *   bsx_gaussian_blur_bgr  cv::GaussianBlur of the background app/deepseg.cc:415-431,652-658 (-p bgblur:<n>: blur the camera frame itself
  *                          (or the background image) and composite over it)
+ *   bsx_background_*       load_background / grab_background + reader thread   app/background.cc:29-104,126-194
+ *   bsx_live_*             class CalcMask (worker thread, double buffering)     app/deepseg.cc:159-286
  *   bsx_profile_batch      the per-stage timers           app/deepseg.cc:137-156,701-720 (timinginfo_t)
  *   bsx_get_info           the geometry of backscrub_ctx_t lib/libbackscrub.cc:28-54,234-246
  *
@@ -145,6 +147,32 @@ int bsx_flip_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int 
  * OpenCV's 8-bit fixed-point coefficients; ksize odd, 1 <= ksize <= 31 (the reference's default strength is 25, app/deepseg.cc:429).
  * The "blur my own room" mode of the reference = this on the camera frames, then bsx_step_batch with bg_frame_stride = one frame. */
 int bsx_gaussian_blur_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int ksize, void* stream);
+
+/* ---- background source (app/background.cc) ----
+ * load_background(): a still image or an animation (GIF87a/89a, 8-bit non-interlaced PNG, binary PPM decoded in this library; other
+ * formats through bsx_background_from_frames with frames the caller decoded).  The frames live on the context's GPU; an animation gets
+ * the FPS-paced reader thread of background.cc:29-104 (advances one frame per 1/fps, wraps to 0 at the end).  NULL on error. */
+typedef struct bsx_background bsx_background;
+bsx_background* bsx_background_load(bsx_ctx* ctx, const char* path, int debug);
+bsx_background* bsx_background_from_frames(bsx_ctx* ctx, const uint8_t* h_bgr, int width, int height, int n_frames, double fps, int debug);
+void bsx_background_free(bsx_background* bg);
+int bsx_background_info(const bsx_background* bg, int* width, int* height, int* n_frames, double* fps, int* is_video);
+/* grab_background(): the current frame resized (cv::resize INTER_LINEAR) to width x height into d_bgr_out [height][width][3].
+ * Returns the frame number (1 for a still image; an animation's number can wrap to 0) or -1 on error. */
+int bsx_background_grab(bsx_background* bg, int width, int height, uint8_t* d_bgr_out, void* stream);
+/* host-only decode of the same formats (no GPU): frames → malloc'ed [n][h][w][3] BGR; returns n (> 0) or a negative BSX_E* code */
+int bsx_media_decode(const char* path, int* width, int* height, double* fps, uint8_t** h_bgr, char* errbuf, size_t errcap);
+void bsx_media_free(uint8_t* h_bgr);
+
+/* ---- live single-camera mode: class CalcMask (app/deepseg.cc:159-286) ----
+ * A worker thread runs bs_maskgen_process (bsx_process_host, stream slot 0) on the latest frame handed to set_input_frame; the caller's
+ * loop never blocks on it: get_output_mask copies the newest finished mask if there is one (returns 1) or leaves h_mask untouched (0). */
+typedef struct bsx_live bsx_live;
+bsx_live* bsx_live_new(bsx_ctx* ctx);
+void bsx_live_delete(bsx_live* live);
+int bsx_live_set_input_frame(bsx_live* live, const uint8_t* h_bgr, size_t bgr_stride);
+int bsx_live_get_output_mask(bsx_live* live, uint8_t* h_mask, size_t mask_stride);
+int bsx_live_timings(const bsx_live* live, long* waitns, long* loopns);
 
 /* ---- introspection used by the parity tests and the bench (stage-by-stage checks) ---- */
 /* Device pointer + element count of: 0 = model input tensor [n_streams][in_h][in_w][in_c] f32,
