@@ -39,6 +39,7 @@ struct MicroOp {
                          //     lifetime of [previous op, this op] in the same first-fit allocation as the tensors)
   int ws_off = 0, band_rows = 0;   // dense conv on the matrix cores: LDS workspace (float offset) holding a band of input rows; output rows per band
   int mfma = 0;     // 1: pointwise conv runs on v_mfma_f32_16x16x4_f32 with the weight block staged in LDS
+  int strip = 0;    // depthwise: 1 = register-strip form (dw_strip), 0 = per-pixel form (BSX_NO_DW_STRIP=1)
   int gemv = 0;     // 1: ≤4 output pixels → wave-per-output-channel dot products with [co][ci] weights
   int n_cat = 0;
   int gap_sum = 0;  // pooling ops: the cat[] parts' means are ADDED into the same Cin channels (GAP(a + b)) instead of concatenated

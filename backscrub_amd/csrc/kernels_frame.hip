@@ -854,84 +854,142 @@ __device__ __forceinline__ void dw_body(cop_t& op, const FrameCtx& c) {
     st4(y, p * y.stride + ch, v);
   }
 }
+// ---- depthwise, register-strip form: lane = (channel quad, strip of TX consecutive output columns, output row) ----------------
+// The per-pixel form above reads K*K inputs AND K*K weights from LDS for every output quad: at 6x10x128 (5x5) that is 1.6 MB of
+// ds_read_b128 per op — the op was LDS-bandwidth bound (12.8k of its 13k cycles).  Here a lane loads, per filter row, the
+// (TX-1)*S + K input quads its strip touches and the K weight quads ONCE and forms TX outputs from registers (packed f32 FMAs):
+// (NIN + K) / TX loads per output row-tap instead of 2K.  Channel quad is the fastest lane index: ds_read_b128 / global loads of
+// neighbouring lanes are contiguous.  Per output the FMA order is fy, fx ascending from 0, bias last — bit-identical to dw_body.
+template <int K, int S, int TX, int V, bool XL>     // V = channels per lane (4: b128 accesses; 2: half the registers — the 5x5 forms spill at 4)
+__device__ __forceinline__ void dw_strip(cop_t& op, const FrameCtx& c) {
+  constexpr int NIN = (TX - 1) * S + K;
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  typedef __attribute__((address_space(3))) vec_t lds_vec;
+  typedef __attribute__((address_space(1))) vec_t glb_vec;
+  const Ref x = make_ref(op.in0, c), y = make_ref(op.out, c), res = make_ref(op.res, c);
+  const int C = op.Cin, CV = C / V;
+  const bool staged = op.stage_floats > 0;
+  const lds_f* wl = lds_base() + op.w_lds;
+  const lds_f* bl = wl + (int)(op.b_off - op.w_off);
+  const glb_f* wg = (const glb_f*)(c.weights + op.w_off);
+  const glb_f* bg = (const glb_f*)(c.weights + op.b_off);
+  const int H = op.H, W = op.W, OH = op.OH, OW = op.OW, pt = op.pt, pl = op.pl, act = op.act;
+  const int nstrips = (OW + TX - 1) / TX, total = CV * nstrips * OH;
+  if (c.tl && blockIdx.x == 0 && threadIdx.x == 0) c.tl[265] += 1;
+  for (int item = threadIdx.x; item < total; item += kFrameThreads) {
+    const int t = item / CV, cq = item - t * CV, oy = t / nstrips, sx = t - oy * nstrips;
+    const int ch = cq * V, ox0 = sx * TX, ix0 = ox0 * S - pl;
+    vec_t acc[TX];
+#pragma unroll
+    for (int k = 0; k < TX; k++) acc[k] = (vec_t)(0.f);
+#pragma unroll 1
+    for (int fy = 0; fy < K; fy++) {
+      const int iy = oy * S - pt + fy;
+      const bool vy = iy >= 0 && iy < H;
+      const int rowo = min(max(iy, 0), H - 1) * W * x.stride + ch;
+      vec_t xin[NIN], wv[K];
+#pragma unroll
+      for (int j = 0; j < NIN; j++) {
+        const int ix = ix0 + j, off = rowo + min(max(ix, 0), W - 1) * x.stride;
+        if constexpr (XL) xin[j] = *(const lds_vec*)(x.l + off); else xin[j] = *(const glb_vec*)(x.g + off);
+      }
+#pragma unroll
+      for (int fx = 0; fx < K; fx++) {
+        if (staged) wv[fx] = *(const lds_vec*)(wl + (fy * K + fx) * C + ch); else wv[fx] = *(const glb_vec*)(wg + (fy * K + fx) * C + ch);
+        if (!vy) wv[fx] = (vec_t)(0.f);                       // row outside the image: its taps add 0 (as in dw_body)
+      }
+#pragma unroll
+      for (int j = 0; j < NIN; j++) { const int ix = ix0 + j; if (ix < 0 || ix >= W) xin[j] = (vec_t)(0.f); }
+#pragma unroll
+      for (int k = 0; k < TX; k++) {
+#pragma unroll
+        for (int fx = 0; fx < K; fx++) acc[k] = __builtin_elementwise_fma(xin[k * S + fx], wv[fx], acc[k]);
+      }
+    }
+    vec_t bq;
+    if (staged) bq = *(const lds_vec*)(bl + ch); else bq = *(const glb_vec*)(bg + ch);
+#pragma unroll
+    for (int k = 0; k < TX; k++) {
+      const int ox = ox0 + k;
+      if (ox < OW) {
+        const int pix = oy * OW + ox;
+        vec_t v = acc[k] + bq;
+#pragma unroll
+        for (int e = 0; e < V; e++) v[e] = fp_act(v[e], act);
+        if (res.valid) { vec_t r; if (res.lds) r = *(const lds_vec*)(res.l + pix * res.stride + ch); else r = *(const glb_vec*)(res.g + pix * res.stride + ch); v += r; }
+        if (y.lds) *(lds_vec*)(y.l + pix * y.stride + ch) = v; else *(glb_vec*)(y.g + pix * y.stride + ch) = v;
+      }
+    }
+  }
+}
+template <int K, int S>
+__device__ __forceinline__ void dw_strip_pick(cop_t& op, const FrameCtx& c) {
+  const bool xl = op.in0.space == kLocLds;
+  constexpr int V = K == 5 ? 2 : 4;
+  constexpr int TXA = S == 1 ? 5 : 4;           // input quads per filter row: 9 (5x5) / 7 (3x3) at stride 1, 11 / 9 at stride 2
+  if (S == 1 && op.OW % 5 != 0 && op.OW % 4 == 0) { if (xl) dw_strip<K, S, 4, V, true>(op, c); else dw_strip<K, S, 4, V, false>(op, c); return; }
+  if (xl) dw_strip<K, S, TXA, V, true>(op, c); else dw_strip<K, S, TXA, V, false>(op, c);
+}
 __device__ __forceinline__ void mo_dw(cop_t& op, const FrameCtx& c) {
   const bool xl = op.in0.space == kLocLds;
+  if (op.strip && op.dh == 1 && op.dw == 1 && op.kh == op.kw && op.sh == op.sw && (op.sh == 1 || op.sh == 2)) {
+    if (op.kh == 3) { if (op.sh == 1) dw_strip_pick<3, 1>(op, c); else dw_strip_pick<3, 2>(op, c); return; }
+    if (op.kh == 5) { if (op.sh == 1) dw_strip_pick<5, 1>(op, c); else dw_strip_pick<5, 2>(op, c); return; }
+  }
   if (op.kh == 3) { if (xl) dw_body<3, true>(op, c); else dw_body<3, false>(op, c); }     // planner admits 3x3 and 5x5 only
   else { if (xl) dw_body<5, true>(op, c); else dw_body<5, false>(op, c); }
 }
 
 // ---- global average pool of one input into out[coff .. coff+C) -------------------------------------------------------------
-// Lane layout: CG channel-quads x (64/CG) pixel rows inside a wave, so the row reduction is wave shuffles; the 16 per-wave
-// partials meet in the scratch once.  Two barriers per channel block instead of a multi-level LDS tree.
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// Wave-owned channel quads: wave w pools quads w, w + 16, ... ENTIRELY — lanes = rows (pixels, or per-tile partial sums), one
+// DPP butterfly inside each 16-lane row, the four row totals meet through v_readlane.  No LDS scratch and NO workgroup barrier
+// inside the pooling (the previous form met in the scratch twice per 16 quads: 4-6 barriers of ~1.5k cycles per SE op, 55 % of it).
+__device__ __forceinline__ float dpp_xor16(float v) {          // sum over the lane's row of 16, result in every lane of the row
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float wave_total(float v) {
+  v = dpp_xor16(v);
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16)) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
+}
 template <bool XL>
-__device__ __forceinline__ void gap_body(const Ref& x, int HW, int C, const Ref& out, int coff, bool accumulate) {
-  lds_f* scratch = lds_base();
-  const int C4 = C >> 2;
-  int CG = 1;
-  while (CG * 2 <= C4 && CG * 2 <= 32) CG *= 2;      // 16 waves x CG float4 partials fit kLdsScratchFloats
-  const int rows = kFrameThreads / CG;
-  const int cg = threadIdx.x % CG, row = threadIdx.x / CG;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int base = 0; base < C4; base += CG) {
-    const int cq = base + cg;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-    if (cq < C4) {
-      int p = row;
-      auto ldx = [&](int pp) { if constexpr (XL) return ld_lds4(x.l + pp * x.stride + cq * 4); else return ld_glb4(x.g + pp * x.stride + cq * 4); };
-      for (; p + 3 * rows < HW; p += 4 * rows) {       // four independent loads in flight (address space fixed at compile time:
-        const float4 v0 = ldx(p), v1 = ldx(p + rows);  //  a run-time space test per load would serialise them)
-        const float4 v2 = ldx(p + 2 * rows), v3 = ldx(p + 3 * rows);
-        a0 = add4(a0, v0); a1 = add4(a1, v1); a2 = add4(a2, v2); a3 = add4(a3, v3);
-      }
-      for (; p < HW; p += rows) a0 = add4(a0, ldx(p));
-    }
-    float4 acc = add4(add4(a0, a1), add4(a2, a3));
-    for (int o = CG; o < 64; o <<= 1) {
-      acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
-    }
-    if (lane < CG) st_lds4(scratch + 4 * (wave * CG + lane), acc);
-    __syncthreads();
-    if (threadIdx.x < CG && cq < C4) {
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int w = 0; w < kFrameThreads / 64; w++) t = add4(t, ld_lds4(scratch + 4 * (w * CG + threadIdx.x)));
-      const float inv = (float)HW;
-      t.x /= inv; t.y /= inv; t.z /= inv; t.w /= inv;
-      if (accumulate) t = add4(ld4(out, coff + cq * 4), t);      // GAP(a + b) as GAP(a) + GAP(b): later parts add to the first
+__device__ __forceinline__ void gap_wave(const lds_f* xl, const glb_f* xg, int rows, int stride, int C, float denom, const Ref& out, int coff, bool accumulate) {
+  const int C4 = C >> 2, lane = threadIdx.x & 63;
+  for (int cq = wave_id(); cq < C4; cq += kFrameThreads >> 6) {
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    auto ldx = [&](int r) { if constexpr (XL) return ld_lds4(xl + r * stride + cq * 4); else return ld_glb4(xg + r * stride + cq * 4); };
+    int r = lane;
+    for (; r + 64 < rows; r += 128) { const float4 v0 = ldx(r), v1 = ldx(r + 64); a0 = add4(a0, v0); a1 = add4(a1, v1); }
+    if (r < rows) a0 = add4(a0, ldx(r));
+    a0 = add4(a0, a1);
+    float4 t = make_float4(wave_total(a0.x), wave_total(a0.y), wave_total(a0.z), wave_total(a0.w));
+    if (lane == 0) {
+      t.x /= denom; t.y /= denom; t.z /= denom; t.w /= denom;
+      if (accumulate) t = add4(ld4(out, coff + cq * 4), t);      // GAP(a + b) as GAP(a) + GAP(b): the same lane wrote the first part
       st4(out, coff + cq * 4, t);
     }
-    __syncthreads();
   }
 }
 
 __device__ __forceinline__ void gap_one(const Ref& x, int HW, int C, const Ref& out, int coff, bool accumulate = false) {
-  if (x.lds) gap_body<true>(x, HW, C, out, coff, accumulate); else gap_body<false>(x, HW, C, out, coff, accumulate);
+  if (x.lds) gap_wave<true>(x.l, x.g, HW, x.stride, C, (float)HW, out, coff, accumulate);
+  else gap_wave<false>(x.l, x.g, HW, x.stride, C, (float)HW, out, coff, accumulate);
 }
 
 // one pooled part of a (possibly concatenated / summed) global average pool: a tensor, or per-tile partial sums written by
-// a segment kernel (segments.hpp) — [n][C] floats in the frame's arena slice, mean = sum / hw
+// a segment kernel (segments.hpp) — [n][C] floats in the frame's arena slice, mean = sum / hw.  No barrier inside: the caller
+// publishes the means with one barrier after the last part.
 __device__ __forceinline__ void gap_part(cop_t& op, int k, const FrameCtx& c, const Ref& out, int coff, bool accumulate) {
   const Ref x = make_ref(op.cat[k], c);
   const int C = op.cat_c[k], np = op.cat_parts[k];
   if (np == 0) { gap_one(x, op.cat_hw[k], C, out, coff, accumulate); return; }
-  // slices of the partial sums are added by different lanes (independent loads), then the C channel totals by the first C lanes
-  lds_f* scratch = lds_base();
-  const int S = min(kFrameThreads / C, np), tid = (int)threadIdx.x, ch = tid % C, slice = tid / C;
-  if (slice < S) {
-    float s = 0.f;
-    for (int i = slice; i < np; i += S) s += x.g[i * C + ch];
-    scratch[slice * C + ch] = s;
-  }
-  __syncthreads();
-  if (tid < C) {
-    float s = 0.f;
-    for (int j = 0; j < S; j++) s += scratch[j * C + tid];
-    float m = s / (float)op.cat_hw[k];
-    if (accumulate) m += ld1(out, coff + tid);
-    st1(out, coff + tid, m);
-  }
-  __syncthreads();
+  gap_wave<false>(x.l, x.g, np, C, C, (float)op.cat_hw[k], out, coff, accumulate);
 }
 
 __device__ __forceinline__ void mo_gap(cop_t& op, const FrameCtx& c) {
@@ -1011,6 +1069,7 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
       if (!op.gap_sum) coff += op.cat_c[k];
     }
   }
+  __syncthreads();                 // means complete (the pooling itself is barrier-free)
   stamp(261);
   if (op.n_fc == 1) { fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, out, p1); stamp(262); return; }
   fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, hid, p1);

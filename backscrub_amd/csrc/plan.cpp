@@ -238,6 +238,7 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
     m.cout_pad = st.cout_pad; m.cout_tile = st.cout_tile;
     m.w_off = (long long)st.w_off; m.b_off = (long long)st.b_off; m.w2_off = (long long)st.w2_off;
     m.gemv = gemv_form(st) ? 1 : 0;
+    m.strip = (st.kind == StepKind::DwConv && !getenv("BSX_NO_DW_STRIP")) ? 1 : 0;
     auto L = [&](int t) { return t >= 0 ? loc[t] : Loc(); };
     m.in0 = L(st.in0); m.in1 = L(st.in1); m.in2 = L(st.in2); m.res = L(st.residual); m.scale = L(st.in_scale); m.out = L(st.out);
     if (st.concat_in.size() > 4) return;
