@@ -47,6 +47,8 @@ struct MicroOp {
   // fused squeeze-excite / gate chain (kind == kMicroSe): GAP(in0 | cat[]) → FC1 (w2_off, b_off, act, Cout=C1) → FC2 (w3_off, b3_off, act2, C2)
   long long w3_off = 0, b3_off = 0;
   int C1 = 0, C2 = 0, act2 = 0, n_fc = 0;
+  int fc_stage[2] = {0, 0};   // > 0: [bias | pad | [co][ci] weights] of FC k (fc_stage[k] floats from b_off / b3_off) are DMA'd to LDS offset fc_lds[k]
+  int fc_lds[2] = {0, 0};     //      while the previous micro-op runs, like stage_floats / w_lds (single FC steps use entry 0)
   // fused decoder tail (kind == kMicroTail): z = act(pw(x*s + a)) → t = z + act2(dw3x3(z)) → out = act3(tconv2x2(t)); z lives in an LDS row band
   //   pw: w_off/b_off (Cin → cout_pad), dw: w3_off/b3_off, tconv: w4_off/b4_off (Cout = C2); H,W = tail resolution; ws_off/band_rows = z band
   long long w4_off = 0, b4_off = 0;

@@ -945,18 +945,22 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 // Wave-owned channel quads: wave w pools quads w, w + 16, ... ENTIRELY — lanes = rows (pixels, or per-tile partial sums), one
 // DPP butterfly inside each 16-lane row, the four row totals meet through v_readlane.  No LDS scratch and NO workgroup barrier
 // inside the pooling (the previous form met in the scratch twice per 16 quads: 4-6 barriers of ~1.5k cycles per SE op, 55 % of it).
-__device__ __forceinline__ float dpp_xor16(float v) {          // sum over the lane's row of 16, result in every lane of the row
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppRor4 = 0x124, kDppRor8 = 0x128;   // quad_perm [1,0,3,2] / [2,3,0,1], row_ror:4, row_ror:8
+// float4 per lane → wave total of component (lane & 3) in every lane: a 4x4 reduce-scatter inside each quad (3 DPP exchanges
+// for all four components: lane q of a quad ends with component q), two rotations by whole quads inside the row of 16, two
+// cross-row exchanges — 7 exchanges instead of 4 x 8.
+__device__ __forceinline__ float wave_total_scatter(float4 a, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  const float klo = (b0 ? a.y : a.x) + dpp<kDppQuadXor1>(b0 ? a.x : a.y);
+  const float khi = (b0 ? a.w : a.z) + dpp<kDppQuadXor1>(b0 ? a.z : a.w);
+  float v = (b1 ? khi : klo) + dpp<kDppQuadXor2>(b1 ? klo : khi);        // quad total of component (lane & 3)
+  v += dpp<kDppRor4>(v);                                                 // lanes i, i-4, i-8, i-12 of a row hold the same component
+  v += dpp<kDppRor8>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
   return v;
-}
-__device__ __forceinline__ float wave_total(float v) {
-  v = dpp_xor16(v);
-  const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16)) +
-         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
 }
 template <bool XL>
 __device__ __forceinline__ void gap_wave(const lds_f* xl, const glb_f* xg, int rows, int stride, int C, float denom, const Ref& out, int coff, bool accumulate) {
@@ -968,11 +972,12 @@ __device__ __forceinline__ void gap_wave(const lds_f* xl, const glb_f* xg, int r
     for (; r + 64 < rows; r += 128) { const float4 v0 = ldx(r), v1 = ldx(r + 64); a0 = add4(a0, v0); a1 = add4(a1, v1); }
     if (r < rows) a0 = add4(a0, ldx(r));
     a0 = add4(a0, a1);
-    float4 t = make_float4(wave_total(a0.x), wave_total(a0.y), wave_total(a0.z), wave_total(a0.w));
-    if (lane == 0) {
-      t.x /= denom; t.y /= denom; t.z /= denom; t.w /= denom;
-      if (accumulate) t = add4(ld4(out, coff + cq * 4), t);      // GAP(a + b) as GAP(a) + GAP(b): the same lane wrote the first part
-      st4(out, coff + cq * 4, t);
+    float t = wave_total_scatter(a0, lane);
+    if (lane < 4) {                                                // lane e holds the total of channel 4 cq + e
+      t /= denom;
+      const int e = lane;
+      if (accumulate) t += ld1(out, coff + cq * 4 + e);            // GAP(a + b) as GAP(a) + GAP(b): the same lane wrote the first part
+      st1(out, coff + cq * 4 + e, t);
     }
   }
 }
@@ -1013,7 +1018,7 @@ struct FcPre { float4 w[kFcPre]; float b; };
 __device__ __forceinline__ int fc_group(int Cin) { int L = 8; while (L > 1 && (Cin % (4 * L)) != 0) L >>= 1; return L; }
 __device__ __forceinline__ FcPre fc_preload(int Cin, const glb_f* w2, const glb_f* bias, int Cout) {
   FcPre p;
-  const int L = fc_group(Cin), klen = Cin / L, sub = threadIdx.x % L, co = threadIdx.x / L;
+  const int L = fc_group(Cin), lg = L == 8 ? 3 : (L == 4 ? 2 : (L == 2 ? 1 : 0)), klen = Cin >> lg, sub = threadIdx.x & (L - 1), co = threadIdx.x >> lg;
 #pragma unroll
   for (int q = 0; q < kFcPre; q++) p.w[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   p.b = 0.f;
@@ -1026,9 +1031,9 @@ __device__ __forceinline__ FcPre fc_preload(int Cin, const glb_f* w2, const glb_
   return p;
 }
 __device__ __forceinline__ void fc_lanes(const Ref& x, int Cin, const glb_f* w2, const glb_f* bias, int Cout, int act, const Ref& y, const FcPre& pre) {
-  const int L = fc_group(Cin), klen = Cin / L, sub = threadIdx.x % L, per = kFrameThreads / L;
+  const int L = fc_group(Cin), lg = L == 8 ? 3 : (L == 4 ? 2 : (L == 2 ? 1 : 0)), klen = Cin >> lg, sub = threadIdx.x & (L - 1), per = kFrameThreads >> lg;
   const bool pre_ok = klen <= 4 * kFcPre;
-  for (int co = threadIdx.x / L, it = 0; co < Cout; co += per, it++) {
+  for (int co = threadIdx.x >> lg, it = 0; co < Cout; co += per, it++) {
     const glb_f* wr = w2 + (size_t)co * Cin + sub * klen;
     float acc = 0.f;
     if (it == 0 && pre_ok) {
@@ -1045,8 +1050,27 @@ __device__ __forceinline__ void fc_lanes(const Ref& x, int Cin, const glb_f* w2,
         acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
       }
     }
-    for (int o = L >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (L >= 2) acc += dpp<kDppQuadXor1>(acc);      // the L (<= 8, power of two) lanes of an output are consecutive and aligned
+    if (L >= 4) acc += dpp<kDppQuadXor2>(acc);
+    if (L >= 8) acc += dpp<0x141>(acc);             // row_half_mirror: lane i + lane 7-i = both quad totals of the aligned group of 8
     if (sub == 0) st1(y, co, fp_act(acc + ((it == 0 && pre_ok) ? pre.b : bias[co]), act));
+  }
+}
+// the same layer with its [bias | [co][ci] weights] block staged in LDS by the main loop's DMA (MicroOp::fc_stage)
+__device__ __forceinline__ void fc_lanes_lds(const Ref& x, int Cin, const lds_f* w2, const lds_f* bias, int Cout, int act, const Ref& y) {
+  const int L = fc_group(Cin), lg = L == 8 ? 3 : (L == 4 ? 2 : (L == 2 ? 1 : 0)), klen = Cin >> lg, sub = threadIdx.x & (L - 1), per = kFrameThreads >> lg;
+  for (int co = threadIdx.x >> lg; co < Cout; co += per) {
+    const lds_f* wr = w2 + co * Cin + sub * klen;
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = 0; k < klen; k += 4) {
+      const float4 xv = ld4(x, sub * klen + k), wv = ld_lds4(wr + k);
+      a0 = fmaf(xv.x, wv.x, a0); a1 = fmaf(xv.y, wv.y, a1); a0 = fmaf(xv.z, wv.z, a0); a1 = fmaf(xv.w, wv.w, a1);
+    }
+    float acc = a0 + a1;
+    if (L >= 2) acc += dpp<kDppQuadXor1>(acc);
+    if (L >= 4) acc += dpp<kDppQuadXor2>(acc);
+    if (L >= 8) acc += dpp<0x141>(acc);
+    if (sub == 0) st1(y, co, fp_act(acc + bias[co], act));
   }
 }
 __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
@@ -1057,9 +1081,12 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
   const int HW = op.H * op.W;
   const glb_f* wts = (const glb_f*)c.weights;
   // both FCs' weight slices are requested up front: their HBM/L2 latency hides behind the pooling reductions
-  const FcPre p1 = fc_preload(op.Cin, wts + op.w2_off, wts + op.b_off, op.C1);
-  FcPre p2 = p1;
-  if (op.n_fc == 2) p2 = fc_preload(op.C1, wts + op.w3_off, wts + op.b3_off, op.C2);
+  const bool st1 = op.fc_stage[0] > 0, st2 = op.fc_stage[1] > 0;     // layer's [bias | weights] already in LDS (DMA issued an op ago)
+  const lds_f* l1 = lds_base() + op.fc_lds[0];
+  const lds_f* l2 = lds_base() + op.fc_lds[1];
+  FcPre p1, p2;
+  if (!st1) p1 = fc_preload(op.Cin, wts + op.w2_off, wts + op.b_off, op.C1);
+  if (op.n_fc == 2 && !st2) p2 = fc_preload(op.C1, wts + op.w3_off, wts + op.b3_off, op.C2);
   stamp(260);
   if (op.n_cat == 0) gap_one(make_ref(op.in0, c), HW, op.Cin, mean, 0);
   else {
@@ -1071,12 +1098,15 @@ __device__ __forceinline__ void mo_se(cop_t& op, const FrameCtx& c) {
   }
   __syncthreads();                 // means complete (the pooling itself is barrier-free)
   stamp(261);
-  if (op.n_fc == 1) { fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, out, p1); stamp(262); return; }
-  fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, hid, p1);
+  const Ref& y1 = op.n_fc == 1 ? out : hid;
+  if (st1) fc_lanes_lds(mean, op.Cin, l1 + (int)(op.w2_off - op.b_off), l1, op.C1, op.act, y1);
+  else fc_lanes(mean, op.Cin, wts + op.w2_off, wts + op.b_off, op.C1, op.act, y1, p1);
   stamp(262);
+  if (op.n_fc == 1) return;
   __syncthreads();
   stamp(263);
-  fc_lanes(hid, op.C1, wts + op.w3_off, wts + op.b3_off, op.C2, op.act2, out, p2);
+  if (st2) fc_lanes_lds(hid, op.C1, l2 + (int)(op.w3_off - op.b3_off), l2, op.C2, op.act2, out);
+  else fc_lanes(hid, op.C1, wts + op.w3_off, wts + op.b3_off, op.C2, op.act2, out, p2);
   stamp(264);
 }
 
@@ -1192,9 +1222,25 @@ __device__ __forceinline__ void mo_tconv(cop_t& op, const FrameCtx& c) {
 }
 
 // One wave instruction moves 64 lanes x 16 B = 256 floats: LDS address = M0 (wave-uniform base) + lane * 16.
+// the [bias | weights] blocks of a squeeze-excite op's FC layers (MicroOp::fc_stage)
+__device__ __forceinline__ void stage_fc_async(cop_t& op, const glb_f* gw) {
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef const __attribute__((address_space(1))) void* glb_vp;
+  const int lane4 = (int)(threadIdx.x & 63) * 4;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int sf = op.fc_stage[k];
+    if (sf == 0) continue;
+    const glb_f* src = gw + (k == 0 ? op.b_off : op.b3_off);
+    lds_f* dst = lds_base() + op.fc_lds[k];
+    for (int c0 = wave_id() * 256; c0 < sf; c0 += (kFrameThreads >> 6) * 256)
+      if (c0 + lane4 < sf) __builtin_amdgcn_global_load_lds((glb_vp)(src + c0 + lane4), (lds_vp)(dst + c0), 16, 0, 0);
+  }
+}
+
 __device__ __forceinline__ void stage_weights_async(cop_t& op, const glb_f* gw) {
   const int sf = op.stage_floats;            // multiple of 4; source and slot are 16-byte aligned
-  if (sf == 0) return;
+  if (sf == 0) { stage_fc_async(op, gw); return; }
   typedef __attribute__((address_space(3))) void* lds_vp;
   typedef const __attribute__((address_space(1))) void* glb_vp;
   const int lane4 = (int)(threadIdx.x & 63) * 4;
@@ -1203,7 +1249,6 @@ __device__ __forceinline__ void stage_weights_async(cop_t& op, const glb_f* gw) 
   for (int c0 = wave_id() * 256; c0 < sf; c0 += (kFrameThreads >> 6) * 256)
     if (c0 + lane4 < sf) __builtin_amdgcn_global_load_lds((glb_vp)(src + c0 + lane4), (lds_vp)(dst + c0), 16, 0, 0);
 }
-
 __global__ __launch_bounds__(kFrameThreads) void frame_program_k(const MicroOp* __restrict__ ops, int n_ops, float* arena, long per_frame_floats,
                                                                 float* net_in, float* net_out, const float* __restrict__ weights,
                                                                 unsigned long long* timeline, int repeat) {

@@ -169,6 +169,19 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
     const Step& st = steps[s];
     long nb = st.kind == StepKind::DwConv ? st.Cout : (st.kind == StepKind::TConv ? st.Cout : st.cout_pad);
     long range = ((long)st.b_off - (long)st.w_off) + ((nb + 3) / 4) * 4;
+    // FC layers of a GAP → FC [→ FC] chain (fused into one squeeze-excite micro-op below): [bias | [co][ci] weights] is one contiguous
+    // range of the weight arena; it is staged while the op BEFORE the pool runs, so that the FCs read LDS instead of waiting for L2/HBM
+    if (st.kind == StepKind::PwConv && st.OH * st.OW == 1 && st.w2_off > st.b_off && !getenv("BSX_NO_FC_STAGE")) {
+      auto fc1px = [&](int k) { const Step& f = steps[k]; return f.kind == StepKind::PwConv && f.OH * f.OW == 1; };
+      int q0 = s;
+      while (q0 > 0 && fc1px(q0 - 1)) q0--;
+      const long frange = ((long)st.w2_off - (long)st.b_off) + (long)st.Cout * st.Cin;
+      if (q0 > 0 && s - q0 <= 1 && steps[q0 - 1].kind == StepKind::Gap && frange <= kLdsMaxStageFloats) {
+        stage[s] = (int)((frange + 3) / 4 * 4);
+        slots_from[std::max(q0 - 2, 0)].push_back(s);
+      }
+      continue;
+    }
     bool uses = (st.kind == StepKind::PwConv && !gemv_form(st)) || st.kind == StepKind::Conv || st.kind == StepKind::DwConv || st.kind == StepKind::TConv;
     if (st.kind == StepKind::PwConv && st.cout_pad % 16 != 0) uses = false;     // only the matrix-core form stages
     if (!(uses && st.b_off > st.w_off && range <= kLdsMaxStageFloats)) continue;
@@ -254,6 +267,9 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
     if (st.kind == StepKind::DwConv && !((st.kh == 3 && st.kw == 3) || (st.kh == 5 && st.kw == 5))) return;   // program has 3x3 / 5x5 bodies only
     // weights + bias are contiguous in the arena ([w][pad to 4][b]); the whole range is staged in the slot planned above
     m.stage_floats = stage[s]; m.w_lds = slot[s];
+    if (st.kind == StepKind::PwConv && st.OH * st.OW == 1 && st.w2_off > st.b_off) {     // FC: the staged range is [bias | w2], not [w | bias]
+      m.fc_stage[0] = stage[s]; m.fc_lds[0] = slot[s]; m.stage_floats = 0; m.w_lds = 0;
+    }
     if (st.kind == StepKind::PwConv && !m.gemv) {
       // MFMA form whenever the weight block + bias got an LDS slot and Cout tiles by 16
       m.cout_tile = 16;
@@ -326,14 +342,16 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
         const MicroOp& f1 = prog[i + 1];
         m.kind = kMicroSe; m.in1 = g0.out; m.in2 = f1.out; m.n_fc = 1;
         m.w2_off = (long long)steps[i + 1].w2_off; m.b_off = f1.b_off; m.act = f1.act; m.C1 = f1.Cout; m.out = f1.out;
+        m.fc_stage[0] = f1.fc_stage[0]; m.fc_lds[0] = f1.fc_lds[0]; m.fc_stage[1] = 0;
         size_t used = 2;
         if (is_fc(i + 2, f1.out) && single_use(i + 1)) {
           const MicroOp& f2 = prog[i + 2];
           m.n_fc = 2; m.w3_off = (long long)steps[i + 2].w2_off; m.b3_off = f2.b_off; m.act2 = f2.act; m.C2 = f2.Cout; m.out = f2.out;
+          m.fc_stage[1] = f2.fc_stage[0]; m.fc_lds[1] = f2.fc_lds[0];
           used = 3;
         }
         fusedp.push_back(m);
-        flabels.push_back("se[" + std::to_string(m.n_fc) + "fc] " + labels[i]);
+        flabels.push_back("se[" + std::to_string(m.n_fc) + "fc" + (m.fc_stage[0] ? "+w1" : "") + (m.fc_stage[1] ? "+w2" : "") + "] " + labels[i]);
         i += used - 1;
       } else {
         fusedp.push_back(g0);
