@@ -241,8 +241,21 @@ typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 constexpr int kHSA = kGemmBK + 8;        // halves per LDS row: 80 B → the 16-byte reads of 16 consecutive rows hit distinct bank quads
 // NTW = 16-channel tiles per workgroup (4: a 128 x 64 tile; a 128 x 160 variant for the projection layers measured 25 % slower: registers)
+// XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 and every XCD has its own L2, so "consecutive workgroups
+// share the A tile" only helps if consecutive means consecutive ON ONE XCD.  A 1-D grid is re-indexed so that XCD k walks its own
+// contiguous range of tiles, column tile fastest: the up-to-8 column tiles of a 128-row A block run back to back on the same XCD
+// and the block leaves HBM once instead of once per column tile (bijective for any grid size; speed only, never correctness).
+__device__ __forceinline__ void xcd_tile(unsigned ncol, unsigned* col, long* row) {
+  const unsigned nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, local = orig >> 3, q = nwg >> 3, r = nwg & 7;
+  const unsigned wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  *row = wg / ncol;
+  *col = wg - (unsigned)*row * ncol;
+}
+
+// (min 4 waves per SIMD: left alone the compiler takes 180 registers = 2 workgroups per CU, and the skinny-K expand layers — three K slabs
+//  per tile — then spend their time waiting for the first slab: 128 registers fit without spills)
 template <int TERMS, int NTW>
-__global__ __launch_bounds__(kThreads) void pw_gemm_f16s_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
+__global__ __launch_bounds__(kThreads, 4) void pw_gemm_f16s_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                           const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
                                                           float* __restrict__ y, long M, int HW, int Cin, int Kp, int Cout, int cout_pad, int act,
                                                           const float* __restrict__ fbias) {
@@ -251,8 +264,10 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_f16s_k(const float* __restri
   __shared__ __attribute__((aligned(16))) _Float16 Bh[NTW * 16 * kHSA];
   __shared__ __attribute__((aligned(16))) _Float16 Bl[NTW * 16 * kHSA];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
-  const long m_base = (long)blockIdx.y * kGemmBM;
-  const int n_base = blockIdx.x * (NTW * 16);
+  unsigned tcol; long trow;
+  xcd_tile((unsigned)((cout_pad + NTW * 16 - 1) / (NTW * 16)), &tcol, &trow);
+  const long m_base = trow * kGemmBM;
+  const int n_base = (int)tcol * (NTW * 16);
   const int nt = min(NTW, (cout_pad - n_base) >> 4);
   const _Float16* wh = w16;
   const _Float16* wl = w16 + (size_t)cout_pad * Kp;
@@ -810,10 +825,8 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);
         if (weights16 && st.k16_pad > 0 && f16_terms > 0) {        // split-f16 (3 terms, f32-grade) or plain f16-input (1 term) MFMA
           const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
-          // grid.x = column tile (fastest in dispatch order): the workgroups sharing one 128-row A tile run back to back, so the tile
-          // comes from HBM once and from L2 for the other column tiles (expand layers have up to 8 of them)
-          const dim3 gw(gg.y, gg.x);
-          if (gg.x > 65535) return hipErrorInvalidValue;
+          if ((unsigned long long)gg.x * gg.y >= (1ull << 31)) return hipErrorInvalidValue;
+          const dim3 gw(gg.x * gg.y);                              // 1-D: the kernel derives (column tile, row block) XCD-aware
 #define BSX_F16S(T, N) pw_gemm_f16s_k<T, N><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias))
           if (f16_terms == 3) BSX_F16S(3, 4); else BSX_F16S(1, 4);
 #undef BSX_F16S
