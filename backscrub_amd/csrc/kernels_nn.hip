@@ -27,14 +27,19 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// `act` is uniform across a launch.  Written as a switch, every call compiled into a chain of scalar compares and TAKEN branches around
+// inlined code for all five kinds (incl. the IEEE divide and expf expansions): ~60 instructions and 4-6 pipeline refills per element,
+// 32 elements per lane in a GEMM epilogue.  The three clamp kinds (none / relu / relu6 — everything DeepLab uses) are ONE v_med3_f32 with
+// uniform bounds; only hswish / sigmoid take a (single, uniform) branch.
+__device__ __forceinline__ float act_slow(float v, int act) {
+  if (act == kActHswish) return v * fminf(6.f, fmaxf(0.f, v + 3.f)) / 6.f;
+  return 1.f / (1.f + expf(-v));
+}
+__device__ __noinline__ float act_slow_call(float v, int act) { return act_slow(v, act); }     // out of line: keeps the hot epilogues small
 __device__ __forceinline__ float act_fn(float v, int act) {
-  switch (act) {
-    case kActRelu: return fmaxf(v, 0.f);
-    case kActRelu6: return fminf(fmaxf(v, 0.f), 6.f);
-    case kActHswish: return v * fminf(6.f, fmaxf(0.f, v + 3.f)) / 6.f;
-    case kActSigmoid: return 1.f / (1.f + expf(-v));
-    default: return v;
-  }
+  if (__builtin_expect(act >= kActHswish, 0)) return act_slow_call(v, act);
+  const float lo = act == kActNone ? -__builtin_huge_valf() : 0.f, hi = act == kActRelu6 ? 6.f : __builtin_huge_valf();
+  return __builtin_amdgcn_fmed3f(v, lo, hi);          // med3(v, -inf, +inf) = v for every non-NaN v; max(0, v) / min(max(0, v), 6) otherwise
 }
 
 // -------------------------------------------------------------------------------------
@@ -239,6 +244,7 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_mfma_k(const float* __restri
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int kHSA = kGemmBK + 8;        // halves per LDS row: 80 B → the 16-byte reads of 16 consecutive rows hit distinct bank quads
 // NTW = 16-channel tiles per workgroup (4: a 128 x 64 tile; a 128 x 160 variant for the projection layers measured 25 % slower: registers)
 // XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 and every XCD has its own L2, so "consecutive workgroups
@@ -382,6 +388,148 @@ __global__ __launch_bounds__(kThreads, 4) void pw_gemm_f16s_k(const float* __res
           if (res) o += res[m * Cout + c0 + e];
           y[m * Cout + c0 + e] = o;
         }
+      }
+    }
+  }
+}
+
+// ---- inverted-residual front half: expand 1x1 (+act) → depthwise 3x3 (dilation d, SAME, +act) as ONE kernel -------------------------
+// Workgroup = (frame, chunk of 32 expanded channels).  Phase 1: the chunk of the expanded tensor for the WHOLE frame ([H*W][32] f32,
+// 139 KB at 33x33) is formed in LDS by the split-f16 MFMA product of pw_gemm_f16s_k (same operand split, same term order; A rows come
+// straight from global memory into registers — every A element feeds only the chunk's two column tiles — and the chunk's weights
+// stay in registers).  Phase 2: the depthwise runs from LDS as the sliding-window column walk of dw_col_k (lane = (phase, column,
+// channel quad) stepping d rows at a time, 3 new quads per output) and writes its result.  The expanded tensor — per block of
+// DeepLab the largest write AND the largest read — never reaches HBM: 4 of the block's 6 big tensor passes become 2.
+constexpr int kIrThreads = 512, kIrChunk = 32, kIrSeg = 9;
+template <int TERMS, int SLABS>
+__global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
+                                                            const float* __restrict__ dww, const float* __restrict__ dwb, float* __restrict__ y,
+                                                            int H, int W, int Cin, int Kp, int Cexp, int act1, int act2, int d, int phases) {
+  extern __shared__ __attribute__((aligned(16))) float ir_ex[];          // [H*W][32]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4, q = li & 3;
+  const int HW = H * W, n_base = blockIdx.x * kIrChunk;
+  const float* xf = x + (size_t)blockIdx.y * (size_t)HW * Cin;
+  float* yf = y + (size_t)blockIdx.y * (size_t)HW * Cexp;
+  // ---- phase 1: expand into LDS
+  if (phases & 1) {
+    const _Float16* wh = w16;
+    const _Float16* wl = w16 + (size_t)Cexp * Kp;
+    h8v bh[SLABS][2], bl[SLABS][2];
+#pragma unroll
+    for (int s = 0; s < SLABS; s++)
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++) {
+        bh[s][ni] = *reinterpret_cast<const h8v*>(wh + (size_t)(n_base + 16 * ni + li) * Kp + 32 * s + 8 * g);
+        bl[s][ni] = bh[s][ni];
+        if (TERMS == 3) bl[s][ni] = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + 16 * ni + li) * Kp + 32 * s + 8 * g);
+      }
+    const int c0 = li & ~3;
+    const float4 bv0 = *reinterpret_cast<const float4*>(bias + n_base + c0), bv1 = *reinterpret_cast<const float4*>(bias + n_base + 16 + c0);
+    const int ntile = (HW + 15) >> 4, nw = kIrThreads >> 6;
+    // A operands: straight from global memory (L2: the frame's input is read by all of its chunk workgroups), kIrPf row tiles in
+    // flight per wave — one workgroup owns the CU (139 KB of LDS), so nobody else hides a load that is waited for on the spot.
+    constexpr int kIrPf = 3;
+    float4 ra[kIrPf][SLABS][2];
+    auto fetch = [&](float4 (&dst)[SLABS][2], int rt) {
+      const int pix = min(rt * 16 + li, HW - 1);
+#pragma unroll
+      for (int s = 0; s < SLABS; s++) {
+        const int k = 32 * s + 8 * g;
+        dst[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); dst[s][1] = dst[s][0];
+        if (k < Cin) {                                                   // Cin % 8 == 0: a group of 8 is valid or absent
+          dst[s][0] = *reinterpret_cast<const float4*>(xf + (size_t)pix * Cin + k);
+          dst[s][1] = *reinterpret_cast<const float4*>(xf + (size_t)pix * Cin + k + 4);
+        }
+      }
+    };
+    const int cnt = wave < ntile ? (ntile - wave + nw - 1) / nw : 0;      // this wave's row tiles: wave, wave + nw, ...
+#pragma unroll
+    for (int j = 0; j < kIrPf; j++) if (j < cnt) fetch(ra[j], wave + j * nw);
+    for (int k0 = 0; k0 < cnt; k0 += kIrPf) {
+#pragma unroll
+      for (int j = 0; j < kIrPf; j++) {
+        const int k = k0 + j;
+        if (k >= cnt) break;                                             // wave-uniform
+        const int rt = wave + k * nw;
+        h8v ah[SLABS], al[SLABS];
+#pragma unroll
+        for (int s = 0; s < SLABS; s++) {
+          const float4 v0 = ra[j][s][0], v1 = ra[j][s][1];
+          const h2v a01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y)), a23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w));
+          const h2v a45 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y)), a67 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.z, v1.w));
+          ah[s] = h8v{a01.x, a01.y, a23.x, a23.y, a45.x, a45.y, a67.x, a67.y};
+          al[s] = ah[s];
+          if (TERMS == 3) {
+            const h2v l01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.x - (float)a01.x, v0.y - (float)a01.y));
+            const h2v l23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.z - (float)a23.x, v0.w - (float)a23.y));
+            const h2v l45 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.x - (float)a45.x, v1.y - (float)a45.y));
+            const h2v l67 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.z - (float)a67.x, v1.w - (float)a67.y));
+            al[s] = h8v{l01.x, l01.y, l23.x, l23.y, l45.x, l45.y, l67.x, l67.y};
+          }
+        }
+        if (k + kIrPf < cnt) fetch(ra[j], wave + (k + kIrPf) * nw);       // refill the slot just consumed
+        f4acc acc[2] = {f4acc{0.f, 0.f, 0.f, 0.f}, f4acc{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < SLABS; s++)
+#pragma unroll
+          for (int ni = 0; ni < 2; ni++) {
+            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[s][ni], acc[ni], 0, 0, 0);
+            if (TERMS == 3) {
+              acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], bh[s][ni], acc[ni], 0, 0, 0);
+              acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bl[s][ni], acc[ni], 0, 0, 0);
+            }
+          }
+        const int pix = rt * 16 + 4 * g + q;
+        const float4 v0 = quad_transpose(acc[0], q), v1 = quad_transpose(acc[1], q);     // all four lanes of a quad take part, valid pixel or not
+        if (pix < HW) {
+          *reinterpret_cast<float4*>(ir_ex + (size_t)pix * kIrChunk + c0) =
+              make_float4(act_fn(v0.x + bv0.x, act1), act_fn(v0.y + bv0.y, act1), act_fn(v0.z + bv0.z, act1), act_fn(v0.w + bv0.w, act1));
+          *reinterpret_cast<float4*>(ir_ex + (size_t)pix * kIrChunk + 16 + c0) =
+              make_float4(act_fn(v1.x + bv1.x, act1), act_fn(v1.y + bv1.y, act1), act_fn(v1.z + bv1.z, act1), act_fn(v1.w + bv1.w, act1));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: depthwise 3x3, dilation d, from LDS.  Item = (segment, phase r, column, channel quad); a column is walked d rows at a time
+  // in segments of at most kIrSeg outputs so that every dilation offers ~1000 items to the 512 lanes.
+  if (phases & 2) {
+    const int cq = tid & 7;                                              // kIrThreads % 8 == 0: a lane keeps its channel quad
+    f4v wq[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) wq[t] = *reinterpret_cast<const f4v*>(dww + (size_t)t * Cexp + n_base + 4 * cq);
+    const f4v bq = *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
+    const int L = (H + d - 1) / d, nseg = (L + kIrSeg - 1) / kIrSeg, cols = d * W, total = nseg * cols * 8;
+    const f4v zero = {0.f, 0.f, 0.f, 0.f};
+    for (int item = tid; item < total; item += kIrThreads) {
+      const int t = item >> 3, seg = t / cols, rc = t - seg * cols, r = rc / W, xx = rc - r * W;
+      const bool vl = xx - d >= 0, vr = xx + d < W;
+      const int xl = vl ? xx - d : xx, xr = vr ? xx + d : xx;
+      auto row = [&](int yy, f4v (&o)[3]) {
+        if (yy >= 0 && yy < H) {
+          const float* rp = ir_ex + (size_t)yy * W * kIrChunk + 4 * cq;
+          o[0] = vl ? *reinterpret_cast<const f4v*>(rp + xl * kIrChunk) : zero;
+          o[1] = *reinterpret_cast<const f4v*>(rp + xx * kIrChunk);
+          o[2] = vr ? *reinterpret_cast<const f4v*>(rp + xr * kIrChunk) : zero;
+        } else { o[0] = zero; o[1] = zero; o[2] = zero; }
+      };
+      int yy = r + seg * kIrSeg * d;
+      f4v p[3], c[3], nx[3];
+      row(yy - d, p); row(yy, c);
+      for (int k = 0; k < kIrSeg && yy < H; k++, yy += d) {
+        row(yy + d, nx);
+        f4v acc = zero;
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(p[fx], wq[fx], acc);
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(c[fx], wq[3 + fx], acc);
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(nx[fx], wq[6 + fx], acc);
+        acc += bq;
+        *reinterpret_cast<float4*>(yf + ((size_t)yy * W + xx) * Cexp + n_base + 4 * cq) =
+            make_float4(act_fn(acc.x, act2), act_fn(acc.y, act2), act_fn(acc.z, act2), act_fn(acc.w, act2));
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) { p[fx] = c[fx]; c[fx] = nx[fx]; }
       }
     }
   }
@@ -813,6 +961,20 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       long M = (long)n * st.OH * st.OW;
       dim3 grid(blocks_for(M), st.cout_pad / st.cout_tile);
       int HW = st.OH * st.OW;
+      if (st.fuse_dw >= 0 && weights16 && f16_terms > 0) {          // expand 1x1 + depthwise 3x3 of an inverted-residual block in one kernel
+        const Step& dws = plan.steps[st.fuse_dw];
+        const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
+        const size_t lds = (size_t)HW * kIrChunk * sizeof(float);
+        const dim3 gi(st.Cout / kIrChunk, n);
+        const int slabs = st.k16_pad / 32;
+        static const int ir_phases = getenv("BSX_IR_PHASES") ? atoi(getenv("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
+#define BSX_IR(T, SL) { static bool once = false; if (!once) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(ir_expand_dw_k<T, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return hipErrorInvalidValue; once = true; } \
+          ir_expand_dw_k<T, SL><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.act, dws.act, dws.dh, ir_phases); }
+        if (f16_terms == 3) { if (slabs == 1) BSX_IR(3, 1) else if (slabs == 2) BSX_IR(3, 2) else BSX_IR(3, 3) }
+        else { if (slabs == 1) BSX_IR(1, 1) else if (slabs == 2) BSX_IR(1, 2) else BSX_IR(1, 3) }
+#undef BSX_IR
+        break;
+      }
       if (M <= 4096) {
         long total = M * st.Cout;
         pw_small_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), total, HW, st.Cin, st.Cout, st.cout_pad, st.act, P(st.out_bias));
@@ -849,6 +1011,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       break;
     }
     case StepKind::DwConv: {
+      if (st.fused_away && weights16 && f16_terms > 0) break;       // ran inside the expand convolution before it (ir_expand_dw_k)
       long total = (long)n * st.OH * st.OW * (st.Cin / 4);
       ConvGeom g{st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.cout_pad, st.kh, st.kw, st.sh, st.sw, st.dh, st.dw, st.pad_t, st.pad_l};
       static const bool no_col = getenv("BSX_NO_DW_COL") != nullptr;

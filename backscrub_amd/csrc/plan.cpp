@@ -1002,7 +1002,7 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   plan->weights16.clear();
   for (Step& st : steps) {
     st.w16_off = 0; st.k16_pad = 0;
-    if (st.kind != StepKind::PwConv || st.Cin < 32 || st.cout_pad % 16 != 0 || st.OH * st.OW <= 4) continue;
+    if (st.kind != StepKind::PwConv || st.Cin < 16 || st.Cin % 8 != 0 || st.cout_pad % 16 != 0 || st.OH * st.OW <= 4) continue;
     const int Kp = round_up(st.Cin, 32);
     while (plan->weights16.size() % 8) plan->weights16.push_back(0);          // 16-byte aligned rows
     st.w16_off = plan->weights16.size(); st.k16_pad = Kp;
@@ -1059,6 +1059,22 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   if (!segments || getenv("BSX_NO_SEGMENTS") || !build_segments(g, plan)) {
     plan->seg = SegPlan();
     build_frame_program(g, plan, plan->steps);
+  }
+  // ---- per-launch path (graphs without a frame program: DeepLab): expand 1x1 → depthwise 3x3 pairs of the inverted-residual blocks run as
+  // ONE kernel (kernels_nn.hip: ir_expand_dw_k) — the 6x-expanded tensor, the largest write and read of the block, lives only in LDS.
+  if (plan->program.empty() && !getenv("BSX_NO_IR_FUSE")) {
+    std::vector<Step>& S = plan->steps;
+    auto uses = [&](int t) { int n = 0; for (const Step& q : S) { for (int u : {q.concat_in.empty() ? q.in0 : -1, q.in1, q.in2, q.residual, q.in_scale, q.out_bias}) n += (u == t); for (int u : q.concat_in) n += (u == t); } return n + (t == g.output); };
+    for (size_t i = 0; i + 1 < S.size(); i++) {
+      Step& a = S[i];
+      Step& d = S[i + 1];
+      if (a.kind != StepKind::PwConv || a.k16_pad <= 0 || a.k16_pad > 96 || a.Cout % 32 != 0 || a.cout_pad != a.Cout || a.residual >= 0 || a.in_scale >= 0 || a.in2 >= 0 ||
+          a.out_bias >= 0 || a.OH * a.OW > 1200 || a.OH * a.OW < 64) continue;
+      if (d.kind != StepKind::DwConv || d.in0 != a.out || d.kh != 3 || d.kw != 3 || d.sh != 1 || d.sw != 1 || d.dh != d.dw || d.pad_t != d.dh || d.pad_l != d.dw ||
+          d.OH != d.H || d.OW != d.W || d.residual >= 0 || d.Cin != a.Cout || d.dh < 1 || d.dh > 4 || uses(a.out) != 1) continue;
+      a.fuse_dw = (int)i + 1;
+      d.fused_away = true;
+    }
   }
   return true;
 }

@@ -47,6 +47,8 @@ struct Step {
   bool gap_sum = false;               // Gap over concat_in as a SUM of the parts' means (GAP(a + b) rewritten), not their concatenation
   double macs = 0;                    // per frame
   int last_node = -1;                 // file operator index of the last fused op
+  int fuse_dw = -1;                   // per-launch path, PwConv: index of the depthwise step this expand convolution is fused with (ir_expand_dw_k)
+  bool fused_away = false;            // per-launch path: the step runs inside the previous one
 };
 
 struct Plan {
