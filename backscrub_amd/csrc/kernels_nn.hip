@@ -35,6 +35,9 @@ __device__ __forceinline__ float act_slow(float v, int act) {
   if (act == kActHswish) return v * fminf(6.f, fmaxf(0.f, v + 3.f)) / 6.f;
   return 1.f / (1.f + expf(-v));
 }
+struct ClampK { float lo, hi; };                                     // the three clamp activations as bounds of one v_med3_f32
+__device__ __forceinline__ ClampK clamp_of(int act) { return ClampK{act == kActNone ? -__builtin_huge_valf() : 0.f, act == kActRelu6 ? 6.f : __builtin_huge_valf()}; }
+__device__ __forceinline__ float clampf(float v, const ClampK& c) { return __builtin_amdgcn_fmed3f(v, c.lo, c.hi); }
 __device__ __noinline__ float act_slow_call(float v, int act) { return act_slow(v, act); }     // out of line: keeps the hot epilogues small
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (__builtin_expect(act >= kActHswish, 0)) return act_slow_call(v, act);
@@ -203,31 +206,36 @@ __global__ __launch_bounds__(kThreads) void pw_gemm_mfma_k(const float* __restri
   }
   // epilogue: quad transpose → this lane owns pixel (4g + q) of the m-tile, channels c0 .. c0+3 of the n-tile
   const int q = li & 3;
-#pragma unroll
-  for (int mi = 0; mi < 2; mi++) {
-    const long m = m_base + 32 * wave + 16 * mi + 4 * g + q;
-#pragma unroll
-    for (int ni = 0; ni < 4; ni++) {
-      if (ni >= nt) continue;
-      const int c0 = n_base + 16 * ni + (li & ~3);
-      const float4 v = quad_transpose(acc[mi][ni], q);
-      if (m >= M || c0 >= Cout) continue;
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      if ((Cout & 3) == 0) {
-        float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-        if (fbias) { const float4 fb = *reinterpret_cast<const float4*>(fbias + (m / HW) * (long)Cout + c0); bv.x += fb.x; bv.y += fb.y; bv.z += fb.z; bv.w += fb.w; }
-        float4 o = make_float4(act_fn(vv[0] + bv.x, act), act_fn(vv[1] + bv.y, act), act_fn(vv[2] + bv.z, act), act_fn(vv[3] + bv.w, act));
-        if (res) { const float4 r = *reinterpret_cast<const float4*>(res + m * Cout + c0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-        *reinterpret_cast<float4*>(y + m * Cout + c0) = o;
-      } else {
-        for (int e = 0; e < 4 && c0 + e < Cout; e++) {
-          float o = act_fn(vv[e] + bias[c0 + e] + (fbias ? fbias[(m / HW) * (long)Cout + c0 + e] : 0.f), act);
-          if (res) o += res[m * Cout + c0 + e];
-          y[m * Cout + c0 + e] = o;
+  // the epilogue is instantiated twice and the (uniform) activation kind tested ONCE: a test per element is a taken branch per element
+  auto epilogue = [&](auto actf) {
+  #pragma unroll
+    for (int mi = 0; mi < 2; mi++) {
+      const long m = m_base + 32 * wave + 16 * mi + 4 * g + q;
+  #pragma unroll
+      for (int ni = 0; ni < 4; ni++) {
+        if (ni >= nt) continue;
+        const int c0 = n_base + 16 * ni + (li & ~3);
+        const float4 v = quad_transpose(acc[mi][ni], q);
+        if (m >= M || c0 >= Cout) continue;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        if ((Cout & 3) == 0) {
+          float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+          if (fbias) { const float4 fb = *reinterpret_cast<const float4*>(fbias + (m / HW) * (long)Cout + c0); bv.x += fb.x; bv.y += fb.y; bv.z += fb.z; bv.w += fb.w; }
+          float4 o = make_float4(actf(vv[0] + bv.x), actf(vv[1] + bv.y), actf(vv[2] + bv.z), actf(vv[3] + bv.w));
+          if (res) { const float4 r = *reinterpret_cast<const float4*>(res + m * Cout + c0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+          *reinterpret_cast<float4*>(y + m * Cout + c0) = o;
+        } else {
+          for (int e = 0; e < 4 && c0 + e < Cout; e++) {
+            float o = actf(vv[e] + bias[c0 + e] + (fbias ? fbias[(m / HW) * (long)Cout + c0 + e] : 0.f));
+            if (res) o += res[m * Cout + c0 + e];
+            y[m * Cout + c0 + e] = o;
+          }
         }
       }
     }
-  }
+  };
+  if (act >= kActHswish) epilogue([&](float v) { return act_slow(v, act); });
+  else { const ClampK ck = clamp_of(act); epilogue([&](float v) { return clampf(v, ck); }); }
 }
 
 // -------------------------------------------------------------------------------------
@@ -366,31 +374,36 @@ __global__ __launch_bounds__(kThreads, 4) void pw_gemm_f16s_k(const float* __res
     __syncthreads();
   }
   const int q = li & 3;
-#pragma unroll
-  for (int mi = 0; mi < 2; mi++) {
-    const long m = m_base + 32 * wave + 16 * mi + 4 * g + q;
-#pragma unroll
-    for (int ni = 0; ni < NTW; ni++) {
-      if (ni >= nt) continue;
-      const int c0 = n_base + 16 * ni + (li & ~3);
-      const float4 v = quad_transpose(acc[mi][ni], q);
-      if (m >= M || c0 >= Cout) continue;
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      if ((Cout & 3) == 0) {
-        float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-        if (fbias) { const float4 fb = *reinterpret_cast<const float4*>(fbias + (m / HW) * (long)Cout + c0); bv.x += fb.x; bv.y += fb.y; bv.z += fb.z; bv.w += fb.w; }
-        float4 o = make_float4(act_fn(vv[0] + bv.x, act), act_fn(vv[1] + bv.y, act), act_fn(vv[2] + bv.z, act), act_fn(vv[3] + bv.w, act));
-        if (res) { const float4 r = *reinterpret_cast<const float4*>(res + m * Cout + c0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-        *reinterpret_cast<float4*>(y + m * Cout + c0) = o;
-      } else {
-        for (int e = 0; e < 4 && c0 + e < Cout; e++) {
-          float o = act_fn(vv[e] + bias[c0 + e] + (fbias ? fbias[(m / HW) * (long)Cout + c0 + e] : 0.f), act);
-          if (res) o += res[m * Cout + c0 + e];
-          y[m * Cout + c0 + e] = o;
+  // the epilogue is instantiated twice and the (uniform) activation kind tested ONCE: a test per element is a taken branch per element
+  auto epilogue = [&](auto actf) {
+  #pragma unroll
+    for (int mi = 0; mi < 2; mi++) {
+      const long m = m_base + 32 * wave + 16 * mi + 4 * g + q;
+  #pragma unroll
+      for (int ni = 0; ni < NTW; ni++) {
+        if (ni >= nt) continue;
+        const int c0 = n_base + 16 * ni + (li & ~3);
+        const float4 v = quad_transpose(acc[mi][ni], q);
+        if (m >= M || c0 >= Cout) continue;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        if ((Cout & 3) == 0) {
+          float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+          if (fbias) { const float4 fb = *reinterpret_cast<const float4*>(fbias + (m / HW) * (long)Cout + c0); bv.x += fb.x; bv.y += fb.y; bv.z += fb.z; bv.w += fb.w; }
+          float4 o = make_float4(actf(vv[0] + bv.x), actf(vv[1] + bv.y), actf(vv[2] + bv.z), actf(vv[3] + bv.w));
+          if (res) { const float4 r = *reinterpret_cast<const float4*>(res + m * Cout + c0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+          *reinterpret_cast<float4*>(y + m * Cout + c0) = o;
+        } else {
+          for (int e = 0; e < 4 && c0 + e < Cout; e++) {
+            float o = actf(vv[e] + bias[c0 + e] + (fbias ? fbias[(m / HW) * (long)Cout + c0 + e] : 0.f));
+            if (res) o += res[m * Cout + c0 + e];
+            y[m * Cout + c0 + e] = o;
+          }
         }
       }
     }
-  }
+  };
+  if (act >= kActHswish) epilogue([&](float v) { return act_slow(v, act); });
+  else { const ClampK ck = clamp_of(act); epilogue([&](float v) { return clampf(v, ck); }); }
 }
 
 // ---- inverted-residual front half: expand 1x1 (+act) → depthwise 3x3 (dilation d, SAME, +act) as ONE kernel -------------------------
@@ -407,9 +420,14 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
                                                             int H, int W, int Cin, int Kp, int Cexp, int act1, int act2, int d, int phases) {
   extern __shared__ __attribute__((aligned(16))) float ir_ex[];          // [H*W][32]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4, q = li & 3;
-  const int HW = H * W, n_base = blockIdx.x * kIrChunk;
-  const float* xf = x + (size_t)blockIdx.y * (size_t)HW * Cin;
-  float* yf = y + (size_t)blockIdx.y * (size_t)HW * Cexp;
+  // XCD-aware order: all chunk workgroups of a frame run back to back on ONE XCD, so the frame's input is fetched into that XCD's L2 once
+  // (in dispatch order they would spread over all eight L2s: the input crossed the fabric eight times — that, not arithmetic, bound phase 1)
+  unsigned chunk; long frame;
+  xcd_tile((unsigned)(Cexp / kIrChunk), &chunk, &frame);
+  const int HW = H * W, n_base = (int)chunk * kIrChunk;
+  const ClampK k1 = clamp_of(act1), k2 = clamp_of(act2);                   // the planner fuses clamp activations only (none / relu / relu6)
+  const float* xf = x + (size_t)frame * (size_t)HW * Cin;
+  float* yf = y + (size_t)frame * (size_t)HW * Cexp;
   // ---- phase 1: expand into LDS
   if (phases & 1) {
     const _Float16* wh = w16;
@@ -483,9 +501,9 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
         const float4 v0 = quad_transpose(acc[0], q), v1 = quad_transpose(acc[1], q);     // all four lanes of a quad take part, valid pixel or not
         if (pix < HW) {
           *reinterpret_cast<float4*>(ir_ex + (size_t)pix * kIrChunk + c0) =
-              make_float4(act_fn(v0.x + bv0.x, act1), act_fn(v0.y + bv0.y, act1), act_fn(v0.z + bv0.z, act1), act_fn(v0.w + bv0.w, act1));
+              make_float4(clampf(v0.x + bv0.x, k1), clampf(v0.y + bv0.y, k1), clampf(v0.z + bv0.z, k1), clampf(v0.w + bv0.w, k1));
           *reinterpret_cast<float4*>(ir_ex + (size_t)pix * kIrChunk + 16 + c0) =
-              make_float4(act_fn(v1.x + bv1.x, act1), act_fn(v1.y + bv1.y, act1), act_fn(v1.z + bv1.z, act1), act_fn(v1.w + bv1.w, act1));
+              make_float4(clampf(v1.x + bv1.x, k1), clampf(v1.y + bv1.y, k1), clampf(v1.z + bv1.z, k1), clampf(v1.w + bv1.w, k1));
         }
       }
     }
@@ -527,7 +545,7 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
         for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(nx[fx], wq[6 + fx], acc);
         acc += bq;
         *reinterpret_cast<float4*>(yf + ((size_t)yy * W + xx) * Cexp + n_base + 4 * cq) =
-            make_float4(act_fn(acc.x, act2), act_fn(acc.y, act2), act_fn(acc.z, act2), act_fn(acc.w, act2));
+            make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
 #pragma unroll
         for (int fx = 0; fx < 3; fx++) { p[fx] = c[fx]; c[fx] = nx[fx]; }
       }
@@ -961,11 +979,12 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       long M = (long)n * st.OH * st.OW;
       dim3 grid(blocks_for(M), st.cout_pad / st.cout_tile);
       int HW = st.OH * st.OW;
+      static const bool no_gemm = getenv("BSX_NO_PW_GEMM") != nullptr;
       if (st.fuse_dw >= 0 && weights16 && f16_terms > 0) {          // expand 1x1 + depthwise 3x3 of an inverted-residual block in one kernel
         const Step& dws = plan.steps[st.fuse_dw];
         const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
         const size_t lds = (size_t)HW * kIrChunk * sizeof(float);
-        const dim3 gi(st.Cout / kIrChunk, n);
+        const dim3 gi((unsigned)(st.Cout / kIrChunk) * (unsigned)n);
         const int slabs = st.k16_pad / 32;
         static const int ir_phases = getenv("BSX_IR_PHASES") ? atoi(getenv("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
 #define BSX_IR(T, SL) { static bool once = false; if (!once) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(ir_expand_dw_k<T, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return hipErrorInvalidValue; once = true; } \
@@ -981,7 +1000,6 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         break;
       }
       // enough rows and channels to fill 128 x 64 MFMA tiles → the GEMM form (BSX_NO_PW_GEMM=1 keeps the lane-per-pixel form)
-      static const bool no_gemm = getenv("BSX_NO_PW_GEMM") != nullptr;
       // (even K = 8 / N = 16 layers: the tiles are mostly padding, but A is read once and coalesced — measured faster than the lane-per-pixel form)
       if (!no_gemm && M >= 8192 && (st.Cin & 3) == 0 && st.Cin >= 8 && st.cout_pad % 16 == 0 && st.cout_pad >= 16) {
         dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);

@@ -1069,9 +1069,9 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
       Step& a = S[i];
       Step& d = S[i + 1];
       if (a.kind != StepKind::PwConv || a.k16_pad <= 0 || a.k16_pad > 96 || a.Cout % 32 != 0 || a.cout_pad != a.Cout || a.residual >= 0 || a.in_scale >= 0 || a.in2 >= 0 ||
-          a.out_bias >= 0 || a.OH * a.OW > 1200 || a.OH * a.OW < 64) continue;
+          a.out_bias >= 0 || a.OH * a.OW > 1200 || a.OH * a.OW < 64 || a.act >= kActHswish) continue;
       if (d.kind != StepKind::DwConv || d.in0 != a.out || d.kh != 3 || d.kw != 3 || d.sh != 1 || d.sw != 1 || d.dh != d.dw || d.pad_t != d.dh || d.pad_l != d.dw ||
-          d.OH != d.H || d.OW != d.W || d.residual >= 0 || d.Cin != a.Cout || d.dh < 1 || d.dh > 4 || uses(a.out) != 1) continue;
+          d.OH != d.H || d.OW != d.W || d.residual >= 0 || d.Cin != a.Cout || d.dh < 1 || d.dh > 4 || d.act >= kActHswish || uses(a.out) != 1) continue;
       a.fuse_dw = (int)i + 1;
       d.fused_away = true;
     }
