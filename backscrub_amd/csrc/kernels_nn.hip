@@ -406,58 +406,67 @@ __global__ __launch_bounds__(kThreads, 4) void pw_gemm_f16s_k(const float* __res
   else { const ClampK ck = clamp_of(act); epilogue([&](float v) { return clampf(v, ck); }); }
 }
 
-// ---- inverted-residual front half: expand 1x1 (+act) → depthwise 3x3 (dilation d, SAME, +act) as ONE kernel -------------------------
-// Workgroup = (frame, chunk of 32 expanded channels).  Phase 1: the chunk of the expanded tensor for the WHOLE frame ([H*W][32] f32,
-// 139 KB at 33x33) is formed in LDS by the split-f16 MFMA product of pw_gemm_f16s_k (same operand split, same term order; A rows come
-// straight from global memory into registers — every A element feeds only the chunk's two column tiles — and the chunk's weights
-// stay in registers).  Phase 2: the depthwise runs from LDS as the sliding-window column walk of dw_col_k (lane = (phase, column,
-// channel quad) stepping d rows at a time, 3 new quads per output) and writes its result.  The expanded tensor — per block of
-// DeepLab the largest write AND the largest read — never reaches HBM: 4 of the block's 6 big tensor passes become 2.
-constexpr int kIrThreads = 512, kIrChunk = 32, kIrSeg = 9;
-template <int TERMS, int SLABS>
+// ---- inverted-residual front half: expand 1x1 (+act) → depthwise 3x3 (+act) as ONE kernel ----------------------------------------------
+// Workgroup = (frame, row band, chunk of CH expanded channels).  Phase 1: the chunk of the expanded tensor for the band's rows (+ the rows
+// the 3x3 window reaches: [rows][W][CH] f32, 139 KB for a whole 33x33 frame at CH = 32) is formed in LDS by the split-f16 MFMA product of
+// pw_gemm_f16s_k (same operand split, same term order; A rows come straight from global memory into registers — every A element feeds
+// only the chunk's column tiles — and the chunk's weights stay in registers).  Phase 2: the depthwise runs from LDS — stride 1 (any
+// dilation d) as the sliding-window column walk of dw_col_k (lane = (phase, column, channel quad) stepping d rows at a time, 3 new quads
+// per output), stride 2 as nine taps per output — and writes its result.  The expanded tensor — per inverted-residual block the largest
+// write AND the largest read — never reaches HBM: 4 of the block's 6 big tensor passes become 2.
+constexpr int kIrThreads = 512, kIrSeg = 9;
+template <int TERMS, int SLABS, int CH>
 __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                             const float* __restrict__ dww, const float* __restrict__ dwb, float* __restrict__ y,
-                                                            int H, int W, int Cin, int Kp, int Cexp, int act1, int act2, int d, int phases) {
-  extern __shared__ __attribute__((aligned(16))) float ir_ex[];          // [H*W][32]
+                                                            int H, int W, int Cin, int Kp, int Cexp, int cout_pad, int act1, int act2, int d, int S, int pt, int pl,
+                                                            int OH, int OW, int BH, int nbands, int phases) {
+  extern __shared__ __attribute__((aligned(16))) float ir_ex[];          // [rows of the band][W][CH]
+  constexpr int NT = (CH + 15) / 16, CQ = CH / 4;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4, q = li & 3;
-  // XCD-aware order: all chunk workgroups of a frame run back to back on ONE XCD, so the frame's input is fetched into that XCD's L2 once
-  // (in dispatch order they would spread over all eight L2s: the input crossed the fabric eight times — that, not arithmetic, bound phase 1)
-  unsigned chunk; long frame;
-  xcd_tile((unsigned)(Cexp / kIrChunk), &chunk, &frame);
-  const int HW = H * W, n_base = (int)chunk * kIrChunk;
+  // XCD-aware order: all chunk workgroups of a (frame, band) run back to back on ONE XCD, so the band's input is fetched into that XCD's L2
+  // once (in dispatch order they would spread over all eight L2s: the input crossed the fabric eight times — that, not arithmetic, bound phase 1)
+  unsigned chunk; long rest;
+  xcd_tile((unsigned)(Cexp / CH), &chunk, &rest);
+  const long frame = rest / nbands;
+  const int band = (int)(rest - frame * nbands);
+  const int oy0 = band * BH, oy1 = min(oy0 + BH, OH);
+  const int e0 = max(S * oy0 - pt, 0), e1 = min(S * (oy1 - 1) - pt + 2 * d + 1, H);      // expanded rows [e0, e1) of this band
+  const int HWb = (e1 - e0) * W, n_base = (int)chunk * CH;
   const ClampK k1 = clamp_of(act1), k2 = clamp_of(act2);                   // the planner fuses clamp activations only (none / relu / relu6)
-  const float* xf = x + (size_t)frame * (size_t)HW * Cin;
-  float* yf = y + (size_t)frame * (size_t)HW * Cexp;
+  const float* xf = x + ((size_t)frame * (size_t)H + (size_t)e0) * (size_t)W * Cin;
+  float* yf = y + (size_t)frame * (size_t)OH * OW * Cexp;
   // ---- phase 1: expand into LDS
   if (phases & 1) {
     const _Float16* wh = w16;
-    const _Float16* wl = w16 + (size_t)Cexp * Kp;
-    h8v bh[SLABS][2], bl[SLABS][2];
+    const _Float16* wl = w16 + (size_t)cout_pad * Kp;
+    h8v bh[SLABS][NT], bl[SLABS][NT];
 #pragma unroll
     for (int s = 0; s < SLABS; s++)
 #pragma unroll
-      for (int ni = 0; ni < 2; ni++) {
-        bh[s][ni] = *reinterpret_cast<const h8v*>(wh + (size_t)(n_base + 16 * ni + li) * Kp + 32 * s + 8 * g);
-        bl[s][ni] = bh[s][ni];
-        if (TERMS == 3) bl[s][ni] = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + 16 * ni + li) * Kp + 32 * s + 8 * g);
+      for (int ni = 0; ni < NT; ni++) {
+        bh[s][ni] = h8v{0, 0, 0, 0, 0, 0, 0, 0}; bl[s][ni] = bh[s][ni];
+        if (16 * ni + li < CH) {                                           // CH = 24: the second column tile is half empty
+          bh[s][ni] = *reinterpret_cast<const h8v*>(wh + (size_t)(n_base + 16 * ni + li) * Kp + 32 * s + 8 * g);
+          if (TERMS == 3) bl[s][ni] = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + 16 * ni + li) * Kp + 32 * s + 8 * g);
+        }
       }
     const int c0 = li & ~3;
-    const float4 bv0 = *reinterpret_cast<const float4*>(bias + n_base + c0), bv1 = *reinterpret_cast<const float4*>(bias + n_base + 16 + c0);
-    const int ntile = (HW + 15) >> 4, nw = kIrThreads >> 6;
-    // A operands: straight from global memory (L2: the frame's input is read by all of its chunk workgroups), kIrPf row tiles in
-    // flight per wave — one workgroup owns the CU (139 KB of LDS), so nobody else hides a load that is waited for on the spot.
+    float4 bv[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ni++) bv[ni] = 16 * ni + c0 < CH ? *reinterpret_cast<const float4*>(bias + n_base + 16 * ni + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ntile = (HWb + 15) >> 4, nw = kIrThreads >> 6;
+    // A operands: straight from global memory (L2: the band's input is read by all of its chunk workgroups), kIrPf row tiles in
+    // flight per wave — one workgroup owns the CU (its LDS), so nobody else hides a load that is waited for on the spot.
     constexpr int kIrPf = 3;
     float4 ra[kIrPf][SLABS][2];
     auto fetch = [&](float4 (&dst)[SLABS][2], int rt) {
-      const int pix = min(rt * 16 + li, HW - 1);
+      const int pix = min(rt * 16 + li, HWb - 1);
 #pragma unroll
       for (int s = 0; s < SLABS; s++) {
-        const int k = 32 * s + 8 * g;
+        const int k = 32 * s + 8 * g;                                      // Cin % 4 == 0: each float4 is valid or absent
         dst[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); dst[s][1] = dst[s][0];
-        if (k < Cin) {                                                   // Cin % 8 == 0: a group of 8 is valid or absent
-          dst[s][0] = *reinterpret_cast<const float4*>(xf + (size_t)pix * Cin + k);
-          dst[s][1] = *reinterpret_cast<const float4*>(xf + (size_t)pix * Cin + k + 4);
-        }
+        if (k < Cin) dst[s][0] = *reinterpret_cast<const float4*>(xf + (size_t)pix * Cin + k);
+        if (k + 4 < Cin) dst[s][1] = *reinterpret_cast<const float4*>(xf + (size_t)pix * Cin + k + 4);
       }
     };
     const int cnt = wave < ntile ? (ntile - wave + nw - 1) / nw : 0;      // this wave's row tiles: wave, wave + nw, ...
@@ -486,11 +495,13 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
           }
         }
         if (k + kIrPf < cnt) fetch(ra[j], wave + (k + kIrPf) * nw);       // refill the slot just consumed
-        f4acc acc[2] = {f4acc{0.f, 0.f, 0.f, 0.f}, f4acc{0.f, 0.f, 0.f, 0.f}};
+        f4acc acc[NT];
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) acc[ni] = f4acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < SLABS; s++)
 #pragma unroll
-          for (int ni = 0; ni < 2; ni++) {
+          for (int ni = 0; ni < NT; ni++) {
             acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[s][ni], acc[ni], 0, 0, 0);
             if (TERMS == 3) {
               acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], bh[s][ni], acc[ni], 0, 0, 0);
@@ -498,43 +509,43 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
             }
           }
         const int pix = rt * 16 + 4 * g + q;
-        const float4 v0 = quad_transpose(acc[0], q), v1 = quad_transpose(acc[1], q);     // all four lanes of a quad take part, valid pixel or not
-        if (pix < HW) {
-          *reinterpret_cast<float4*>(ir_ex + (size_t)pix * kIrChunk + c0) =
-              make_float4(clampf(v0.x + bv0.x, k1), clampf(v0.y + bv0.y, k1), clampf(v0.z + bv0.z, k1), clampf(v0.w + bv0.w, k1));
-          *reinterpret_cast<float4*>(ir_ex + (size_t)pix * kIrChunk + 16 + c0) =
-              make_float4(clampf(v1.x + bv1.x, k1), clampf(v1.y + bv1.y, k1), clampf(v1.z + bv1.z, k1), clampf(v1.w + bv1.w, k1));
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) {
+          const float4 v = quad_transpose(acc[ni], q);                   // all four lanes of a quad take part, valid pixel or not
+          if (pix < HWb && 16 * ni + c0 < CH)
+            *reinterpret_cast<float4*>(ir_ex + (size_t)pix * CH + 16 * ni + c0) =
+                make_float4(clampf(v.x + bv[ni].x, k1), clampf(v.y + bv[ni].y, k1), clampf(v.z + bv[ni].z, k1), clampf(v.w + bv[ni].w, k1));
         }
       }
     }
   }
   __syncthreads();
-  // ---- phase 2: depthwise 3x3, dilation d, from LDS.  Item = (segment, phase r, column, channel quad); a column is walked d rows at a time
-  // in segments of at most kIrSeg outputs so that every dilation offers ~1000 items to the 512 lanes.
-  if (phases & 2) {
-    const int cq = tid & 7;                                              // kIrThreads % 8 == 0: a lane keeps its channel quad
-    f4v wq[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) wq[t] = *reinterpret_cast<const f4v*>(dww + (size_t)t * Cexp + n_base + 4 * cq);
-    const f4v bq = *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
-    const int L = (H + d - 1) / d, nseg = (L + kIrSeg - 1) / kIrSeg, cols = d * W, total = nseg * cols * 8;
-    const f4v zero = {0.f, 0.f, 0.f, 0.f};
+  if (!(phases & 2)) return;
+  const f4v zero = {0.f, 0.f, 0.f, 0.f};
+  if (S == 1) {
+    // ---- phase 2, stride 1 (SAME, dilation d).  Item = (segment, phase r, column, channel quad); a column is walked d rows at a time in
+    // segments of at most kIrSeg outputs so that every dilation offers ~1000 items to the 512 lanes.
+    const int L = (oy1 - oy0 + d - 1) / d, nseg = (L + kIrSeg - 1) / kIrSeg, cols = d * W, total = nseg * cols * CQ;
     for (int item = tid; item < total; item += kIrThreads) {
-      const int t = item >> 3, seg = t / cols, rc = t - seg * cols, r = rc / W, xx = rc - r * W;
+      const int t = item / CQ, cq = item - t * CQ, seg = t / cols, rc = t - seg * cols, r = rc / W, xx = rc - r * W;
+      f4v wq[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) wq[k] = *reinterpret_cast<const f4v*>(dww + (size_t)k * Cexp + n_base + 4 * cq);
+      const f4v bq = *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
       const bool vl = xx - d >= 0, vr = xx + d < W;
       const int xl = vl ? xx - d : xx, xr = vr ? xx + d : xx;
       auto row = [&](int yy, f4v (&o)[3]) {
         if (yy >= 0 && yy < H) {
-          const float* rp = ir_ex + (size_t)yy * W * kIrChunk + 4 * cq;
-          o[0] = vl ? *reinterpret_cast<const f4v*>(rp + xl * kIrChunk) : zero;
-          o[1] = *reinterpret_cast<const f4v*>(rp + xx * kIrChunk);
-          o[2] = vr ? *reinterpret_cast<const f4v*>(rp + xr * kIrChunk) : zero;
+          const float* rp = ir_ex + (size_t)(yy - e0) * W * CH + 4 * cq;
+          o[0] = vl ? *reinterpret_cast<const f4v*>(rp + xl * CH) : zero;
+          o[1] = *reinterpret_cast<const f4v*>(rp + xx * CH);
+          o[2] = vr ? *reinterpret_cast<const f4v*>(rp + xr * CH) : zero;
         } else { o[0] = zero; o[1] = zero; o[2] = zero; }
       };
-      int yy = r + seg * kIrSeg * d;
+      int yy = oy0 + r + seg * kIrSeg * d;
       f4v p[3], c[3], nx[3];
       row(yy - d, p); row(yy, c);
-      for (int k = 0; k < kIrSeg && yy < H; k++, yy += d) {
+      for (int k = 0; k < kIrSeg && yy < oy1; k++, yy += d) {
         row(yy + d, nx);
         f4v acc = zero;
 #pragma unroll
@@ -544,11 +555,34 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
 #pragma unroll
         for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(nx[fx], wq[6 + fx], acc);
         acc += bq;
-        *reinterpret_cast<float4*>(yf + ((size_t)yy * W + xx) * Cexp + n_base + 4 * cq) =
+        *reinterpret_cast<float4*>(yf + ((size_t)yy * OW + xx) * Cexp + n_base + 4 * cq) =
             make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
 #pragma unroll
         for (int fx = 0; fx < 3; fx++) { p[fx] = c[fx]; c[fx] = nx[fx]; }
       }
+    }
+  } else {
+    // ---- phase 2, stride 2 (dilation 1): item = (output pixel of the band, channel quad), nine taps from LDS, (fy, fx) ascending
+    const int total = (oy1 - oy0) * OW * CQ;
+    for (int item = tid; item < total; item += kIrThreads) {
+      const int t = item / CQ, cq = item - t * CQ, oyl = t / OW, ox = t - oyl * OW, oy = oy0 + oyl;
+      f4v acc = zero;
+#pragma unroll
+      for (int fy = 0; fy < 3; fy++) {
+        const int iy = S * oy - pt + fy;
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) {
+          const int ix = S * ox - pl + fx;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const f4v xv = *reinterpret_cast<const f4v*>(ir_ex + ((size_t)(iy - e0) * W + ix) * CH + 4 * cq);
+            const f4v wv = *reinterpret_cast<const f4v*>(dww + (size_t)(fy * 3 + fx) * Cexp + n_base + 4 * cq);
+            acc = __builtin_elementwise_fma(xv, wv, acc);
+          }
+        }
+      }
+      acc += *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
+      *reinterpret_cast<float4*>(yf + ((size_t)oy * OW + ox) * Cexp + n_base + 4 * cq) =
+          make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
     }
   }
 }
@@ -982,15 +1016,19 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       static const bool no_gemm = getenv("BSX_NO_PW_GEMM") != nullptr;
       if (st.fuse_dw >= 0 && weights16 && f16_terms > 0) {          // expand 1x1 + depthwise 3x3 of an inverted-residual block in one kernel
         const Step& dws = plan.steps[st.fuse_dw];
+        const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dws.OH, dws.sh, dws.dh);
+        if (ig.CH == 0) return hipErrorInvalidValue;                 // the planner checked the same function
         const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
-        const size_t lds = (size_t)HW * kIrChunk * sizeof(float);
-        const dim3 gi((unsigned)(st.Cout / kIrChunk) * (unsigned)n);
+        const size_t lds = (size_t)ig.rows * st.OW * ig.CH * sizeof(float);
+        const dim3 gi((unsigned)(st.Cout / ig.CH) * (unsigned)ig.nbands * (unsigned)n);
         const int slabs = st.k16_pad / 32;
         static const int ir_phases = getenv("BSX_IR_PHASES") ? atoi(getenv("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
-#define BSX_IR(T, SL) { static bool once = false; if (!once) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(ir_expand_dw_k<T, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return hipErrorInvalidValue; once = true; } \
-          ir_expand_dw_k<T, SL><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.act, dws.act, dws.dh, ir_phases); }
-        if (f16_terms == 3) { if (slabs == 1) BSX_IR(3, 1) else if (slabs == 2) BSX_IR(3, 2) else BSX_IR(3, 3) }
-        else { if (slabs == 1) BSX_IR(1, 1) else if (slabs == 2) BSX_IR(1, 2) else BSX_IR(1, 3) }
+#define BSX_IR(T, SL, C) { static bool once = false; if (!once) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(ir_expand_dw_k<T, SL, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return hipErrorInvalidValue; once = true; } \
+          ir_expand_dw_k<T, SL, C><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases); }
+#define BSX_IR_C(T, SL) { if (ig.CH == 32) BSX_IR(T, SL, 32) else if (ig.CH == 24) BSX_IR(T, SL, 24) else BSX_IR(T, SL, 16) }
+        if (f16_terms == 3) { if (slabs == 1) BSX_IR_C(3, 1) else if (slabs == 2) BSX_IR_C(3, 2) else BSX_IR_C(3, 3) }
+        else { if (slabs == 1) BSX_IR_C(1, 1) else if (slabs == 2) BSX_IR_C(1, 2) else BSX_IR_C(1, 3) }
+#undef BSX_IR_C
 #undef BSX_IR
         break;
       }

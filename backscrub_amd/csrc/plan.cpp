@@ -82,6 +82,13 @@ std::string Plan::describe() const {
              kn[(int)st.kind], st.label.c_str(), st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.kh, st.kw, st.sh, st.dh, act_name(st.act),
              st.residual, st.in_scale, st.macs);
     s += line;
+    if (st.fuse_dw >= 0) {
+      const Step& dd = steps[st.fuse_dw];
+      const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dd.OH, dd.sh, dd.dh);
+      snprintf(line, sizeof line, "      ^ fused with step %d (expand + depthwise in one kernel: %d channels x %d rows per workgroup, %d band(s))\n", st.fuse_dw, ig.CH, ig.BH, ig.nbands);
+      s.insert(s.size() - 1, "");
+      s += line;
+    }
   }
   return s;
 }
@@ -1002,7 +1009,7 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   plan->weights16.clear();
   for (Step& st : steps) {
     st.w16_off = 0; st.k16_pad = 0;
-    if (st.kind != StepKind::PwConv || st.Cin < 16 || st.Cin % 8 != 0 || st.cout_pad % 16 != 0 || st.OH * st.OW <= 4) continue;
+    if (st.kind != StepKind::PwConv || st.Cin < 8 || st.Cin % 4 != 0 || st.cout_pad % 16 != 0 || st.OH * st.OW <= 4) continue;
     const int Kp = round_up(st.Cin, 32);
     while (plan->weights16.size() % 8) plan->weights16.push_back(0);          // 16-byte aligned rows
     st.w16_off = plan->weights16.size(); st.k16_pad = Kp;
@@ -1068,10 +1075,13 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
     for (size_t i = 0; i + 1 < S.size(); i++) {
       Step& a = S[i];
       Step& d = S[i + 1];
-      if (a.kind != StepKind::PwConv || a.k16_pad <= 0 || a.k16_pad > 96 || a.Cout % 32 != 0 || a.cout_pad != a.Cout || a.residual >= 0 || a.in_scale >= 0 || a.in2 >= 0 ||
-          a.out_bias >= 0 || a.OH * a.OW > 1200 || a.OH * a.OW < 64 || a.act >= kActHswish) continue;
-      if (d.kind != StepKind::DwConv || d.in0 != a.out || d.kh != 3 || d.kw != 3 || d.sh != 1 || d.sw != 1 || d.dh != d.dw || d.pad_t != d.dh || d.pad_l != d.dw ||
-          d.OH != d.H || d.OW != d.W || d.residual >= 0 || d.Cin != a.Cout || d.dh < 1 || d.dh > 4 || d.act >= kActHswish || uses(a.out) != 1) continue;
+      if (a.kind != StepKind::PwConv || a.k16_pad <= 0 || a.k16_pad > 96 || a.residual >= 0 || a.in_scale >= 0 || a.in2 >= 0 || a.out_bias >= 0 ||
+          a.OH * a.OW < 64 || a.act >= kActHswish) continue;
+      if (d.kind != StepKind::DwConv || d.in0 != a.out || d.kh != 3 || d.kw != 3 || d.sh != d.sw || d.dh != d.dw || d.residual >= 0 || d.Cin != a.Cout ||
+          d.dh < 1 || d.dh > 4 || d.act >= kActHswish || uses(a.out) != 1) continue;
+      if (d.sh == 1) { if (d.pad_t != d.dh || d.pad_l != d.dw || d.OH != d.H || d.OW != d.W) continue; }      // SAME, any dilation: sliding-window column walk
+      else if (d.sh != 2 || d.dh != 1 || d.pad_t < 0 || d.pad_t > 1 || d.pad_l < 0 || d.pad_l > 1) continue;   // stride 2: plain 3x3
+      if (ir_geometry(a.OH, a.OW, a.Cout, d.OH, d.sh, d.dh).CH == 0) continue;
       a.fuse_dw = (int)i + 1;
       d.fused_away = true;
     }

@@ -51,6 +51,26 @@ struct Step {
   bool fused_away = false;            // per-launch path: the step runs inside the previous one
 };
 
+// Geometry of the fused expand + depthwise kernel (kernels_nn.hip: ir_expand_dw_k), shared by the planner (is the pair fusable?) and the
+// launcher: CH expanded channels per workgroup, BH depthwise output rows per row band; the band's expanded rows live in LDS.
+struct IrGeom { int CH = 0, BH = 0, nbands = 0, rows = 0; };
+inline IrGeom ir_geometry(int H, int W, int Cexp, int OH, int S, int d) {
+  const long budget = 150 * 1024;                      // bytes of LDS for the expanded band
+  for (int CH : {32, 24, 16}) {
+    if (Cexp % CH) continue;
+    auto rows_for = [&](int bh) { const int r = S * (bh - 1) + 2 * d + 1; return r < H ? r : H; };
+    int BH = OH;
+    while (BH > 1 && (long)rows_for(BH) * W * CH * 4 > budget) BH--;
+    if ((long)rows_for(BH) * W * CH * 4 > budget) continue;
+    const int nb = (OH + BH - 1) / BH;
+    BH = (OH + nb - 1) / nb;                             // even bands
+    if (nb > 1 && BH < 4 * d) continue;                  // halo rows would dominate
+    IrGeom g; g.CH = CH; g.BH = BH; g.nbands = nb; g.rows = rows_for(BH);
+    return g;
+  }
+  return IrGeom();
+}
+
 struct Plan {
   std::vector<Step> steps;
   std::vector<float> weights;         // packed weight arena (host copy)
