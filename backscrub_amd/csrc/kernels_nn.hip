@@ -532,21 +532,28 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
 #pragma unroll
       for (int k = 0; k < 9; k++) wq[k] = *reinterpret_cast<const f4v*>(dww + (size_t)k * Cexp + n_base + 4 * cq);
       const f4v bq = *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
+      // columns outside the image: their taps get ZERO WEIGHTS (the expanded values are finite, clamp-bounded) and a clamped address,
+      // instead of a select per loaded quad in every step
       const bool vl = xx - d >= 0, vr = xx + d < W;
-      const int xl = vl ? xx - d : xx, xr = vr ? xx + d : xx;
-      auto row = [&](int yy, f4v (&o)[3]) {
+      if (!vl) { wq[0] = zero; wq[3] = zero; wq[6] = zero; }
+      if (!vr) { wq[2] = zero; wq[5] = zero; wq[8] = zero; }
+      const float* col = ir_ex + (size_t)xx * CH + 4 * cq;
+      const int dl = vl ? -d * CH : 0, dr = vr ? d * CH : 0, rstep = d * W * CH;
+      auto row = [&](int yy, int off, f4v (&o)[3]) {                   // off = (yy - e0) * W * CH
         if (yy >= 0 && yy < H) {
-          const float* rp = ir_ex + (size_t)(yy - e0) * W * CH + 4 * cq;
-          o[0] = vl ? *reinterpret_cast<const f4v*>(rp + xl * CH) : zero;
-          o[1] = *reinterpret_cast<const f4v*>(rp + xx * CH);
-          o[2] = vr ? *reinterpret_cast<const f4v*>(rp + xr * CH) : zero;
+          o[0] = *reinterpret_cast<const f4v*>(col + off + dl);
+          o[1] = *reinterpret_cast<const f4v*>(col + off);
+          o[2] = *reinterpret_cast<const f4v*>(col + off + dr);
         } else { o[0] = zero; o[1] = zero; o[2] = zero; }
       };
       int yy = oy0 + r + seg * kIrSeg * d;
+      int off = (yy - e0) * W * CH;
+      float* yp = yf + ((size_t)yy * OW + xx) * Cexp + n_base + 4 * cq;
+      const size_t ystep = (size_t)d * OW * Cexp;
       f4v p[3], c[3], nx[3];
-      row(yy - d, p); row(yy, c);
-      for (int k = 0; k < kIrSeg && yy < oy1; k++, yy += d) {
-        row(yy + d, nx);
+      row(yy - d, off - rstep, p); row(yy, off, c);
+      for (int k = 0; k < kIrSeg && yy < oy1; k++, yy += d, off += rstep, yp += ystep) {
+        row(yy + d, off + rstep, nx);
         f4v acc = zero;
 #pragma unroll
         for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(p[fx], wq[fx], acc);
@@ -555,8 +562,7 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
 #pragma unroll
         for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(nx[fx], wq[6 + fx], acc);
         acc += bq;
-        *reinterpret_cast<float4*>(yf + ((size_t)yy * OW + xx) * Cexp + n_base + 4 * cq) =
-            make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
+        *reinterpret_cast<float4*>(yp) = make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
 #pragma unroll
         for (int fx = 0; fx < 3; fx++) { p[fx] = c[fx]; c[fx] = nx[fx]; }
       }
@@ -660,6 +666,16 @@ __global__ __launch_bounds__(kThreads) void conv_k(const float* __restrict__ x, 
   }
   float* yp = y + p * g.Cout + co0;
   const float* rp = res ? res + p * g.Cout + co0 : nullptr;
+  if ((g.Cout & 3) == 0 && co0 + CT <= g.Cout) {                 // 16-byte stores: a lane's CT outputs are contiguous (scalar stores touched 64 lines per instruction)
+#pragma unroll
+    for (int t = 0; t < CT; t += 4) {
+      float4 v = make_float4(act_fn(acc[t] + bias[co0 + t], act), act_fn(acc[t + 1] + bias[co0 + t + 1], act), act_fn(acc[t + 2] + bias[co0 + t + 2], act),
+                             act_fn(acc[t + 3] + bias[co0 + t + 3], act));
+      if (rp) { const float4 r = *reinterpret_cast<const float4*>(rp + t); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      *reinterpret_cast<float4*>(yp + t) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < CT; t++) {
     if (co0 + t < g.Cout) {
