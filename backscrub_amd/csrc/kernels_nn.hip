@@ -269,7 +269,7 @@ __device__ __forceinline__ void xcd_tile(unsigned ncol, unsigned* col, long* row
 // (min 4 waves per SIMD: left alone the compiler takes 180 registers = 2 workgroups per CU, and the skinny-K expand layers — three K slabs
 //  per tile — then spend their time waiting for the first slab: 128 registers fit without spills)
 template <int TERMS, int NTW>
-__global__ __launch_bounds__(kThreads, 4) void pw_gemm_f16s_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
+__global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                           const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
                                                           float* __restrict__ y, long M, int HW, int Cin, int Kp, int Cout, int cout_pad, int act,
                                                           const float* __restrict__ fbias) {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kThreads, 4) void pw_gemm_f16s_k(const float* __res
   __shared__ __attribute__((aligned(16))) _Float16 Bl[NTW * 16 * kHSA];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
   unsigned tcol; long trow;
-  xcd_tile((unsigned)((cout_pad + NTW * 16 - 1) / (NTW * 16)), &tcol, &trow);
+  xcd_tile((unsigned)((Cout + NTW * 16 - 1) / (NTW * 16)), &tcol, &trow);      // columns >= Cout are padding: no tile for them
   const long m_base = trow * kGemmBM;
   const int n_base = (int)tcol * (NTW * 16);
   const int nt = min(NTW, (cout_pad - n_base) >> 4);
@@ -1059,10 +1059,16 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);
         if (weights16 && st.k16_pad > 0 && f16_terms > 0) {        // split-f16 (3 terms, f32-grade) or plain f16-input (1 term) MFMA
           const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
-          if ((unsigned long long)gg.x * gg.y >= (1ull << 31)) return hipErrorInvalidValue;
-          const dim3 gw(gg.x * gg.y);                              // 1-D: the kernel derives (column tile, row block) XCD-aware
+          // column tiles: 64 channels (NTW = 4), or 80 / 48 in ONE tile where that covers the whole layer (NTW = 5 / 3: the A block is
+          // staged and split once instead of once per column tile — the 480 -> 80 and 288 -> 48 project layers)
+          static const bool wide_ok = getenv("BSX_NO_GEMM_NTW") == nullptr;
+          const int ntw = (wide_ok && st.Cout == 80) ? 5 : ((wide_ok && st.Cout == 48) ? 3 : 4);
+          const unsigned ncol = (unsigned)((st.Cout + ntw * 16 - 1) / (ntw * 16));
+          if ((unsigned long long)gg.x * ncol >= (1ull << 31)) return hipErrorInvalidValue;
+          const dim3 gw(gg.x * ncol);                              // 1-D: the kernel derives (column tile, row block) XCD-aware
 #define BSX_F16S(T, N) pw_gemm_f16s_k<T, N><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias))
-          if (f16_terms == 3) BSX_F16S(3, 4); else BSX_F16S(1, 4);
+          if (f16_terms == 3) { if (ntw == 5) BSX_F16S(3, 5); else if (ntw == 3) BSX_F16S(3, 3); else BSX_F16S(3, 4); }
+          else { if (ntw == 5) BSX_F16S(1, 5); else if (ntw == 3) BSX_F16S(1, 3); else BSX_F16S(1, 4); }
 #undef BSX_F16S
           break;
         }
