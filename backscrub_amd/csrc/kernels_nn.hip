@@ -1062,7 +1062,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
           // column tiles: 64 channels (NTW = 4), or 80 / 48 in ONE tile where that covers the whole layer (NTW = 5 / 3: the A block is
           // staged and split once instead of once per column tile — the 480 -> 80 and 288 -> 48 project layers)
           static const bool wide_ok = getenv("BSX_NO_GEMM_NTW") == nullptr;
-          const int ntw = (wide_ok && st.Cout == 80) ? 5 : ((wide_ok && st.Cout == 48) ? 3 : 4);
+          const int ntw = (wide_ok && st.Cout % 80 == 0) ? 5 : ((wide_ok && st.Cout == 48) ? 3 : 4);
           const unsigned ncol = (unsigned)((st.Cout + ntw * 16 - 1) / (ntw * 16));
           if ((unsigned long long)gg.x * ncol >= (1ull << 31)) return hipErrorInvalidValue;
           const dim3 gw(gg.x * ncol);                              // 1-D: the kernel derives (column tile, row block) XCD-aware
