@@ -656,6 +656,13 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       default: b = in + o + (st.residual >= 0 ? o : 0) + (st.in_scale >= 0 ? st.Cin : 0); break;
     }
     const bool is_tail = atail && &st == &c->plan.steps.back();
+    const bool ir_on = c->d_weights16 && c->f16_terms > 0;
+    if (st.fused_away && ir_on) { put(j++, st.label + " (inside the launch before)", 0, 0); continue; }      // the no-op slot of a fused pair
+    if (st.fuse_dw >= 0 && ir_on) {                              // expand + depthwise in one launch: reads the expand's input, writes the depthwise's output
+      const Step& dd = c->plan.steps[st.fuse_dw];
+      put(j++, st.label + "+" + dd.label, N * 4.0 * (in + (double)dd.OH * dd.OW * dd.Cout), N * 2.0 * (st.macs + dd.macs));
+      continue;
+    }
     put(j++, is_tail ? st.label + "+argmax" : st.label, is_tail ? N * (4.0 * in + 2.0 * st.OH * st.OW) : N * b * 4.0, N * 2.0 * st.macs);
   }
   if (!fused_decode) put(j++, "decode_iir", N * ((double)c->outW * c->outH * c->outC * 4.0 + 2.0 * c->outW * c->outH), 0);

@@ -253,7 +253,7 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
         for s in stats:
             s["GBps"] = s["bytes"] / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
         extra = [s for s in stats if s["name"].endswith("(standalone)")]   # measured for its roofline line, not part of the step
-        stats = [s for s in stats if not s["name"].endswith("(standalone)")]
+        stats = [s for s in stats if not s["name"].endswith("(standalone)") and "(inside the launch before)" not in s["name"]]   # fused-away steps launch nothing
         if dump_launches:
             with open(dump_launches, "w") as f:
                 f.write(mg.plan())
