@@ -657,7 +657,16 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     }
     const bool is_tail = atail && &st == &c->plan.steps.back();
     const bool ir_on = c->d_weights16 && c->f16_terms > 0;
-    if (st.fused_away && ir_on) { put(j++, st.label + " (inside the launch before)", 0, 0); continue; }      // the no-op slot of a fused pair
+    static const bool head0_on = getenv("BSX_NO_HEAD0") == nullptr;
+    const bool h0 = head0_on && c->plan.steps[0].fuse_head0;
+    const bool h0_member = h0 && (&st == &c->plan.steps[1] || &st == &c->plan.steps[2]);
+    if (h0_member || (st.fused_away && !(h0 && &st <= &c->plan.steps[2]) && ir_on)) { put(j++, st.label + " (inside the launch before)", 0, 0); continue; }   // no-op slot of a fused group
+    if (st.fuse_head0 && h0) {                                   // stem + depthwise + 1x1: reads the network input, writes the 1x1's output
+      const Step& d1 = c->plan.steps[1];
+      const Step& p2 = c->plan.steps[2];
+      put(j++, st.label + "+" + d1.label + "+" + p2.label, N * 4.0 * (in + (double)p2.OH * p2.OW * p2.Cout), N * 2.0 * (st.macs + d1.macs + p2.macs));
+      continue;
+    }
     if (st.fuse_dw >= 0 && ir_on) {                              // expand + depthwise in one launch: reads the expand's input, writes the depthwise's output
       const Step& dd = c->plan.steps[st.fuse_dw];
       put(j++, st.label + "+" + dd.label, N * 4.0 * (in + (double)dd.OH * dd.OW * dd.Cout), N * 2.0 * (st.macs + dd.macs));

@@ -593,6 +593,165 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
   }
 }
 
+// ---- DeepLab's first three layers in one kernel: stem conv 3x3/s2 (3 → 16) → depthwise 3x3 → 1x1 (16 → C2 <= 16) ------------------------
+// Workgroup = (frame, band of BH output rows).  The input rows the band needs, the stem's band (+1 halo row each side: SAME padding of the
+// depthwise = zero rows outside the image) and the depthwise's band live in LDS; only the C2-channel result is written.  Unfused, the two
+// 16-channel tensors at stem resolution (1 MB per frame each at 129x129) were written and read back: 5.6 MB of traffic per frame for 0.8 MB
+// of input and 0.5 MB of output.  Plain f32 FMAs (3 / 16 input channels: an MFMA slab would be mostly padding), (fy, fx, ci) ascending, bias last.
+constexpr int kH0Threads = 512;
+__global__ __launch_bounds__(kH0Threads) void dl_head0_k(const float* __restrict__ x, const float* __restrict__ ws, const float* __restrict__ bs,
+                                                        const float* __restrict__ wd, const float* __restrict__ bd, const float* __restrict__ wp,
+                                                        const float* __restrict__ bp, float* __restrict__ y, int H0, int W0, int H1, int W1, int pt, int pl,
+                                                        int C2, int pw_cout_pad, int act_s, int act_d, int act_p, int BH, int nbands, int phases) {
+  extern __shared__ __attribute__((aligned(16))) float h0_lds[];
+  const int tid = threadIdx.x;
+  const long frame = blockIdx.x / nbands;
+  const int band = (int)(blockIdx.x - frame * nbands);
+  const int oy0 = band * BH, oy1 = min(oy0 + BH, H1), SR = oy1 - oy0 + 2, sy0 = oy0 - 1;      // stem rows [sy0, sy0 + SR)
+  const int IR = 2 * SR + 1, iy0 = 2 * sy0 - pt, rowf = (W0 + 2) * 3;                          // input rows [iy0, iy0 + IR), one zero pixel left and right
+  float* in_t = h0_lds;                                         // [IR][W0 + 2][3]
+  float* S = in_t + (((2 * (BH + 2) + 1) * rowf + 3) & ~3);      // [SR][W1][16]
+  float* D = S + (BH + 2) * W1 * 16;                             // [BH][W1][16]
+  float* wl = D + BH * W1 * 16;                                  // stem [27][16] + bias 16 | dw [9][16] + bias 16 | pw [16][16] + bias 16
+  const ClampK ks = clamp_of(act_s), kd = clamp_of(act_d), kp = clamp_of(act_p);
+  // ---- weights and the input rows
+  for (int i = tid; i < 27 * 16 + 16 + 9 * 16 + 16 + 16 * 16 + 16; i += kH0Threads) {
+    float v;
+    if (i < 432) v = ws[i];
+    else if (i < 448) v = bs[i - 432];
+    else if (i < 592) v = wd[i - 448];
+    else if (i < 608) v = bd[i - 592];
+    else if (i < 864) { const int k = (i - 608) >> 4, co = (i - 608) & 15; v = co < pw_cout_pad ? wp[k * pw_cout_pad + co] : 0.f; }
+    else v = (i - 864) < pw_cout_pad ? bp[i - 864] : 0.f;
+    wl[i] = v;
+  }
+  const float* xf = x + (size_t)frame * (size_t)H0 * W0 * 3;
+  if (phases & 1) {
+    // row by row (no per-element division), ALL of the lane's loads requested before the first LDS store (one workgroup owns the CU: nobody
+    // else would hide a load waited for on the spot); in_t pixel j = image column j - 1
+    const int e0 = tid, e1 = tid + kH0Threads;                  // rowf <= 2 * kH0Threads (checked by the planner)
+    constexpr int kMaxIR = 21;                                   // BH <= 8
+    float v[kMaxIR][2];
+#pragma unroll
+    for (int r = 0; r < kMaxIR; r++) {
+      const int gy = iy0 + r;
+      const bool rowok = r < IR && gy >= 0 && gy < H0;
+      const float* rp = xf + (size_t)(rowok ? gy : 0) * W0 * 3 - 3;
+      v[r][0] = (rowok && e0 >= 3 && e0 < W0 * 3 + 3) ? rp[e0] : 0.f;
+      v[r][1] = (rowok && e1 >= 3 && e1 < W0 * 3 + 3) ? rp[e1] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < kMaxIR; r++) {
+      if (r < IR) {
+        in_t[r * rowf + e0] = v[r][0];
+        if (e1 < rowf) in_t[r * rowf + e1] = v[r][1];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- stem on the matrix cores: v_mfma_f32_16x16x4_f32 over the im2col axis k = (fy, fx, ci) (27 of 28 slots used), wave = one tile of 16
+  // pixels of a row x 16 channels; A comes from the LDS input rows through a per-lane offset table, B (the weights) stays in registers.
+  // (The VALU form — lane = (column, channel quad), rows in registers — ran at 20 % of the vector peak: 270 LDS reads per lane.)
+  if (phases & 2) {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4, q = li & 3, c0 = li & ~3;
+    int koff[7];
+    float wsr[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+      const int k = 4 * t + g;
+      const bool valid = k < 27;
+      const int fy = k / 9, r9 = k - 9 * fy, fx = r9 / 3, ci = r9 - 3 * fx;
+      koff[t] = valid ? fy * rowf + fx * 3 + ci : 0;
+      wsr[t] = valid ? wl[k * 16 + li] : 0.f;
+    }
+    const float4 bias4 = *reinterpret_cast<const float4*>(wl + 432 + c0);
+    const int ctiles = (W1 + 15) >> 4, ntile = SR * ctiles;
+    for (int t = wave; t < ntile; t += 2 * (kH0Threads >> 6)) {          // two tiles per iteration: their dependent MFMA chains interleave
+      const int t1 = t + (kH0Threads >> 6);
+      const bool two = t1 < ntile;
+      const int ra = t / ctiles, ca = t - ra * ctiles, rb = two ? t1 / ctiles : ra, cb = two ? t1 - rb * ctiles : ca;
+      const float* ba = in_t + (2 * ra) * rowf + (2 * min(16 * ca + li, W1 - 1) - pl + 1) * 3;
+      const float* bb = in_t + (2 * rb) * rowf + (2 * min(16 * cb + li, W1 - 1) - pl + 1) * 3;
+      float va[7], vb[7];
+#pragma unroll
+      for (int u = 0; u < 7; u++) { va[u] = ba[koff[u]]; vb[u] = bb[koff[u]]; }
+      f4acc acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 7; u++) {
+        acca = __builtin_amdgcn_mfma_f32_16x16x4f32(va[u], wsr[u], acca, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[u], wsr[u], accb, 0, 0, 0);
+      }
+      auto put = [&](const f4acc acc, int row, int ct) {
+        const float4 v = quad_transpose(acc, q);
+        const int px = 16 * ct + 4 * g + q, sy = sy0 + row;
+        if (px < W1) {
+          float4 o = make_float4(clampf(v.x + bias4.x, ks), clampf(v.y + bias4.y, ks), clampf(v.z + bias4.z, ks), clampf(v.w + bias4.w, ks));
+          if (sy < 0 || sy >= H1) o = make_float4(0.f, 0.f, 0.f, 0.f);     // rows outside the image are the depthwise's zero padding
+          *reinterpret_cast<float4*>(S + ((size_t)row * W1 + px) * 16 + c0) = o;
+        }
+      };
+      put(acca, ra, ca);
+      if (two) put(accb, rb, cb);
+    }
+  }
+  __syncthreads();
+  // ---- depthwise 3x3 (SAME): lane = (column, channel quad) walks the band's rows with a 3-row window
+  if (phases & 4) {
+    const float* wdw = wl + 448;
+    for (int item = tid; item < W1 * 4; item += kH0Threads) {
+      const int xx = item >> 2, cq = item & 3;
+      f4v wq[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) wq[k] = *reinterpret_cast<const f4v*>(wdw + k * 16 + 4 * cq);
+      const f4v bq = *reinterpret_cast<const f4v*>(wdw + 144 + 4 * cq);
+      const f4v zero = {0.f, 0.f, 0.f, 0.f};
+      const bool vl = xx >= 1, vr = xx + 1 < W1;
+      if (!vl) { wq[0] = zero; wq[3] = zero; wq[6] = zero; }
+      if (!vr) { wq[2] = zero; wq[5] = zero; wq[8] = zero; }
+      const float* col = S + (size_t)xx * 16 + 4 * cq;
+      const int dl = vl ? -16 : 0, dr = vr ? 16 : 0, rs = W1 * 16;
+      auto row = [&](int r, f4v (&o)[3]) { o[0] = *reinterpret_cast<const f4v*>(col + r * rs + dl); o[1] = *reinterpret_cast<const f4v*>(col + r * rs); o[2] = *reinterpret_cast<const f4v*>(col + r * rs + dr); };
+      f4v p[3], c[3], nx[3];
+      row(0, p); row(1, c);
+      for (int r = 0; r < oy1 - oy0; r++) {
+        row(r + 2, nx);
+        f4v acc = zero;
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(p[fx], wq[fx], acc);
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(c[fx], wq[3 + fx], acc);
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(nx[fx], wq[6 + fx], acc);
+        acc += bq;
+        *reinterpret_cast<float4*>(D + ((size_t)r * W1 + xx) * 16 + 4 * cq) = make_float4(clampf(acc.x, kd), clampf(acc.y, kd), clampf(acc.z, kd), clampf(acc.w, kd));
+#pragma unroll
+        for (int fx = 0; fx < 3; fx++) { p[fx] = c[fx]; c[fx] = nx[fx]; }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 1x1 (16 → C2): lane = (pixel of the band, output quad), ci ascending, bias last
+  if (phases & 8) {
+    const float* wpw = wl + 608;
+    const int CQ2 = C2 >> 2, total = (oy1 - oy0) * W1 * CQ2;
+    float* yf = y + ((size_t)frame * H1 + oy0) * (size_t)W1 * C2;
+    for (int item = tid; item < total; item += kH0Threads) {
+      const int pix = item / CQ2, cq = item - pix * CQ2;
+      f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; k4++) {
+        const f4v dv = *reinterpret_cast<const f4v*>(D + (size_t)pix * 16 + 4 * k4);
+        acc = __builtin_elementwise_fma((f4v)(dv.x), *reinterpret_cast<const f4v*>(wpw + (4 * k4) * 16 + 4 * cq), acc);
+        acc = __builtin_elementwise_fma((f4v)(dv.y), *reinterpret_cast<const f4v*>(wpw + (4 * k4 + 1) * 16 + 4 * cq), acc);
+        acc = __builtin_elementwise_fma((f4v)(dv.z), *reinterpret_cast<const f4v*>(wpw + (4 * k4 + 2) * 16 + 4 * cq), acc);
+        acc = __builtin_elementwise_fma((f4v)(dv.w), *reinterpret_cast<const f4v*>(wpw + (4 * k4 + 3) * 16 + 4 * cq), acc);
+      }
+      acc += *reinterpret_cast<const f4v*>(wpw + 256 + 4 * cq);
+      *reinterpret_cast<float4*>(yf + (size_t)pix * C2 + 4 * cq) = make_float4(clampf(acc.x, kp), clampf(acc.y, kp), clampf(acc.z, kp), clampf(acc.w, kp));
+    }
+  }
+}
+
 // Few pixels (squeeze-excite / gate FCs: one "pixel" per stream): lane = one output value, so a
 // 256-stream batch still fills thousands of lanes instead of one workgroup.
 __global__ __launch_bounds__(kThreads) void pw_small_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -1029,6 +1188,8 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       long M = (long)n * st.OH * st.OW;
       dim3 grid(blocks_for(M), st.cout_pad / st.cout_tile);
       int HW = st.OH * st.OW;
+      static const bool no_head0 = getenv("BSX_NO_HEAD0") != nullptr;
+      if (st.fused_away && plan.steps[0].fuse_head0 && !no_head0) break;      // ran inside dl_head0_k
       static const bool no_gemm = getenv("BSX_NO_PW_GEMM") != nullptr;
       if (st.fuse_dw >= 0 && weights16 && f16_terms > 0) {          // expand 1x1 + depthwise 3x3 of an inverted-residual block in one kernel
         const Step& dws = plan.steps[st.fuse_dw];
@@ -1082,6 +1243,20 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       break;
     }
     case StepKind::Conv: {
+      static const bool no_head0 = getenv("BSX_NO_HEAD0") != nullptr;
+      if (st.fuse_head0 && !no_head0) {             // stem + depthwise + 1x1 (plan.steps[1], [2]) in one tiled kernel
+        const Step& d1 = plan.steps[1];
+        const Step& p2 = plan.steps[2];
+        const int BH = head0_band_rows(st.W, st.OW), nb = (st.OH + BH - 1) / BH;
+        const size_t fl = (size_t)((((2 * (BH + 2) + 1) * (st.W + 2) * 3 + 3) & ~3)) + (size_t)(BH + 2) * st.OW * 16 + (size_t)BH * st.OW * 16 + 1024;
+        static const int h0_phases = getenv("BSX_H0_PHASES") ? atoi(getenv("BSX_H0_PHASES")) : 15;   // timing experiments
+        static bool once = false;
+        if (!once) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(dl_head0_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return hipErrorInvalidValue; once = true; }
+        dl_head0_k<<<(unsigned)nb * (unsigned)n, kH0Threads, fl * sizeof(float), s>>>(P(st.in0), w, b, weights + d1.w_off, weights + d1.b_off, weights + p2.w_off,
+                                                                                    weights + p2.b_off, P(p2.out), st.H, st.W, st.OH, st.OW, st.pad_t, st.pad_l, p2.Cout,
+                                                                                    p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases);
+        break;
+      }
       long M = (long)n * st.OH * st.OW;
       ConvGeom g{st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.cout_pad, st.kh, st.kw, st.sh, st.sw, st.dh, st.dw, st.pad_t, st.pad_l};
       dim3 grid(blocks_for(M), st.cout_pad / 16);
@@ -1089,7 +1264,9 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       break;
     }
     case StepKind::DwConv: {
-      if (st.fused_away && weights16 && f16_terms > 0) break;       // ran inside the expand convolution before it (ir_expand_dw_k)
+      static const bool no_head0 = getenv("BSX_NO_HEAD0") != nullptr;
+      if (st.fused_away && &st == &plan.steps[1] && plan.steps[0].fuse_head0) { if (!no_head0) break; }      // ran inside dl_head0_k
+      else if (st.fused_away && weights16 && f16_terms > 0) break;       // ran inside the expand convolution before it (ir_expand_dw_k)
       long total = (long)n * st.OH * st.OW * (st.Cin / 4);
       ConvGeom g{st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.cout_pad, st.kh, st.kw, st.sh, st.sw, st.dh, st.dw, st.pad_t, st.pad_l};
       static const bool no_col = getenv("BSX_NO_DW_COL") != nullptr;

@@ -82,6 +82,7 @@ std::string Plan::describe() const {
              kn[(int)st.kind], st.label.c_str(), st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.kh, st.kw, st.sh, st.dh, act_name(st.act),
              st.residual, st.in_scale, st.macs);
     s += line;
+    if (st.fuse_head0) { s += "      ^ fused with steps 1 and 2 (stem + depthwise + 1x1 in one tiled kernel)\n"; }
     if (st.fuse_dw >= 0) {
       const Step& dd = steps[st.fuse_dw];
       const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dd.OH, dd.sh, dd.dh);
@@ -1072,6 +1073,18 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   if (plan->program.empty() && !getenv("BSX_NO_IR_FUSE")) {
     std::vector<Step>& S = plan->steps;
     auto uses = [&](int t) { int n = 0; for (const Step& q : S) { for (int u : {q.concat_in.empty() ? q.in0 : -1, q.in1, q.in2, q.residual, q.in_scale, q.out_bias}) n += (u == t); for (int u : q.concat_in) n += (u == t); } return n + (t == g.output); };
+    // stem conv 3x3/s2 (3 → 16) → depthwise 3x3 → 1x1 (16 → ≤16): one tiled kernel, the two 16-channel full-resolution tensors only in LDS
+    if (S.size() > 3 && !getenv("BSX_NO_HEAD0")) {
+      Step& c0 = S[0]; Step& d1 = S[1]; Step& p2 = S[2];
+      const bool ok = c0.kind == StepKind::Conv && c0.kh == 3 && c0.kw == 3 && c0.sh == 2 && c0.sw == 2 && c0.dh == 1 && c0.dw == 1 && c0.Cin == 3 && c0.Cout == 16 &&
+                      c0.cout_pad == 16 && c0.residual < 0 && c0.act < kActHswish && c0.in0 == g.input && uses(c0.out) == 1 &&
+                      d1.kind == StepKind::DwConv && d1.in0 == c0.out && d1.kh == 3 && d1.kw == 3 && d1.sh == 1 && d1.sw == 1 && d1.dh == 1 && d1.dw == 1 &&
+                      d1.pad_t == 1 && d1.pad_l == 1 && d1.OH == d1.H && d1.OW == d1.W && d1.Cin == 16 && d1.residual < 0 && d1.act < kActHswish && uses(d1.out) == 1 &&
+                      p2.kind == StepKind::PwConv && p2.in0 == d1.out && p2.Cin == 16 && p2.Cout % 4 == 0 && p2.Cout <= 16 && p2.residual < 0 && p2.in_scale < 0 &&
+                      p2.in2 < 0 && p2.out_bias < 0 && p2.act < kActHswish && p2.OH == d1.OH && p2.OW == d1.OW && p2.out != g.output &&
+                      2 * (c0.OW - 1) - c0.pad_l + 2 <= c0.W && c0.pad_l >= 0 && c0.pad_l <= 1 && (c0.W + 2) * 3 <= 1024 && head0_band_rows(c0.W, c0.OW) >= 2;
+      if (ok) { c0.fuse_head0 = true; d1.fused_away = true; p2.fused_away = true; }
+    }
     for (size_t i = 0; i + 1 < S.size(); i++) {
       Step& a = S[i];
       Step& d = S[i + 1];

@@ -48,7 +48,8 @@ struct Step {
   double macs = 0;                    // per frame
   int last_node = -1;                 // file operator index of the last fused op
   int fuse_dw = -1;                   // per-launch path, PwConv: index of the depthwise step this expand convolution is fused with (ir_expand_dw_k)
-  bool fused_away = false;            // per-launch path: the step runs inside the previous one
+  bool fused_away = false;            // per-launch path: the step runs inside an earlier one
+  bool fuse_head0 = false;            // per-launch path, stem Conv: runs together with the depthwise and the 1x1 after it (dl_head0_k)
 };
 
 // Geometry of the fused expand + depthwise kernel (kernels_nn.hip: ir_expand_dw_k), shared by the planner (is the pair fusable?) and the
@@ -69,6 +70,15 @@ inline IrGeom ir_geometry(int H, int W, int Cexp, int OH, int S, int d) {
     return g;
   }
   return IrGeom();
+}
+
+// rows of the stem's output one workgroup of dl_head0_k owns (its LDS holds the input rows, the stem band and the depthwise band)
+inline int head0_band_rows(int W0, int W1) {
+  for (int bh = 8; bh >= 2; bh--) {
+    const long fl = (long)(2 * (bh + 2) + 1) * (W0 + 2) * 3 + (long)(bh + 2) * W1 * 16 + (long)bh * W1 * 16 + 1024;
+    if (fl * 4 <= 156 * 1024) return bh;
+  }
+  return 0;
 }
 
 struct Plan {
