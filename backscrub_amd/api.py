@@ -54,6 +54,7 @@ SYMBOLS = [
     ("bsx_masks_device", C.c_void_p, [C.c_void_p]),
     ("bsx_composite_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_step_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    ("bsx_step_batch_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_resize_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_bgr_to_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_yuyv_to_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -161,6 +162,14 @@ class MaskGen:
         _check(lib().bsx_step_batch(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride,
                                     C.c_void_p(out.data_ptr()), n, _stream_ptr()), self.h, "bsx_step_batch")
         return out
+
+    def step_yuyv(self, frames, bg, out_yuyv):
+        """one main-loop iteration with the composite written as YUYV 4:2:2 [n,H,W,2] (convert_rgb_to_yuyv fused into the blend)"""
+        n = self._n(frames)
+        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        _check(lib().bsx_step_batch_yuyv(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride,
+                                         C.c_void_p(out_yuyv.data_ptr()), n, _stream_ptr()), self.h, "bsx_step_batch_yuyv")
+        return out_yuyv
 
     def profile(self, frames, bg, out, iters=5):
         """per-launch hipEvent timings of the whole per-batch sequence → list of dicts"""

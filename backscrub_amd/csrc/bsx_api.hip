@@ -102,6 +102,7 @@ struct bsx_ctx {
   uint8_t* d_ofinal = nullptr;
   uint8_t* d_masks = nullptr;
   uint8_t* d_host_frame = nullptr;  // staging for bsx_process_host
+  uint8_t* d_bgr_scratch = nullptr; // BGR composite of bsx_step_batch_yuyv when the fused YUYV epilogue does not apply (lazy)
   float* d_color_lut = nullptr;
   MicroOp* d_program = nullptr;     // per-frame network program (kernels_frame.hip)
   bool use_program = false;
@@ -395,7 +396,7 @@ void bsx_delete(bsx_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
+  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -464,15 +465,24 @@ int bsx_composite_batch(bsx_ctx* c, const uint8_t* d_bg, size_t bg_frame_stride,
   return BSX_OK;
 }
 
-int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream) {
+namespace {
+// yuyv: the composite leaves as YUYV 4:2:2 (2 B/px) — convert_rgb_to_yuyv (deepseg.cc:87-106) applied in the blend's epilogue
+int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, int yuyv) {
   if (!c || !d_frames || !d_bg || !d_out || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  if (yuyv && (c->width & 1)) return BSX_EINVAL;                // 4:2:2 pairs pixels horizontally
   DeviceGuard guard(c->device);
-  const bool fuse = !c->onmask && !c->no_mask_blend_fusion &&
-                    mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, d_out);
+  const bool fuse = !c->onmask && !c->no_mask_blend_fusion && (!yuyv || ((uintptr_t)d_out & 3) == 0) &&
+                    mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, yuyv ? d_frames : d_out);
   if (!fuse) {
     int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
     if (rc) return rc;
-    return bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, d_out, n, stream);
+    if (!yuyv) return bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, d_out, n, stream);
+    // unfused geometry: composite into a context-owned BGR scratch, then pack
+    const size_t need = (size_t)c->n_streams * c->width * c->height * 3;
+    if (!c->d_bgr_scratch) BSX_HIP(c, hipMalloc(&c->d_bgr_scratch, need));
+    rc = bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, c->d_bgr_scratch, n, stream);
+    if (rc) return rc;
+    return bsx_bgr_to_yuyv(c, c->d_bgr_scratch, d_out, c->width, c->height, n, stream);
   }
   // process (prep → network → decode), then mask-upscale+blur and alpha blend of each tile in ONE launch
   hipStream_t s = pick(c, stream);
@@ -484,8 +494,16 @@ int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, siz
   if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); }
   if (!fused_decode && (rc = run_decode(c, n, s))) return rc;
   BSX_HIP(c, launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg,
-                               bg_frame_stride, d_frames, d_out, n, s));
+                               bg_frame_stride, d_frames, d_out, n, s, yuyv));
   return BSX_OK;
+}
+}  // namespace
+
+int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream) {
+  return step_impl(c, d_frames, d_bg, bg_frame_stride, d_out, n, stream, 0);
+}
+int bsx_step_batch_yuyv(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out_yuyv, int n, void* stream) {
+  return step_impl(c, d_frames, d_bg, bg_frame_stride, d_out_yuyv, n, stream, 1);
 }
 
 int bsx_resize_bgr(bsx_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream) {

@@ -272,6 +272,22 @@ __device__ __forceinline__ void blend_quad(const uint32_t a[3], const uint32_t b
   o[2] = blend_word(a[2], b[2], m23, m33);
 }
 
+// ---- BGR → YUYV (cv::cvtColor(COLOR_RGB2YUV) on BGR-ordered bytes, then 4:2:2 pack Y0 V Y1 U) -----
+__device__ __forceinline__ void rgb2yuv(int R, int G, int B, int* Y, int* U, int* V) {
+  const int shift = 14, half = 1 << 13, delta = 128 << 14;
+  int y = (R * 4899 + G * 9617 + B * 1868 + half) >> shift;
+  int u = ((B - y) * 8061 + delta + half) >> shift;
+  int v = ((R - y) * 14369 + delta + half) >> shift;
+  *Y = min(max(y, 0), 255); *U = min(max(u, 0), 255); *V = min(max(v, 0), 255);
+}
+// two neighbouring pixels (bytes as stored: channel 0 is taken as "R", deepseg.cc:90) → one YUYV word Y0 | V<<8 | Y1<<16 | U<<24
+__device__ __forceinline__ uint32_t yuyv_pair(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2) {
+  int y0, u0, v0, y1, u1, v1;
+  rgb2yuv((int)a0, (int)a1, (int)a2, &y0, &u0, &v0);
+  rgb2yuv((int)b0, (int)b1, (int)b2, &y1, &u1, &v1);
+  return (uint32_t)y0 | ((uint32_t)((v0 + v1) / 2) << 8) | ((uint32_t)y1 << 16) | ((uint32_t)((u0 + u1) / 2) << 24);
+}
+
 // ---- pieces shared by the two mask tile kernels ------------------------------------------------------------------------------
 // Composite operands of a lane's kTileItems 4-pixel groups (12 B of background + 12 B of frame each), requested at the very
 // top of the kernel so that their HBM latency hides behind the LDS phases.
@@ -335,11 +351,12 @@ __device__ __forceinline__ void tile_hsum5(const uint8_t* up, uint16_t* hs, int 
 // 4 pixels (W, roi.x and roi.w multiples of 4, checked by the launcher: 12 bytes = 3 aligned words per image).
 template <bool BLEND>
 __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __restrict__ mask, uint8_t* __restrict__ outp, const TileBlendOperands& o,
-                                                 int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid) {
+                                                 int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int yuyv) {
   const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
   const int gx = tx0 + lx;
+  const int obpp = yuyv ? 2 : 3;                                 // composite written as packed BGR or as YUYV 4:2:2 (convert_rgb_to_yuyv fused in)
   uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx;
-  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx) * 3 : nullptr;
+  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx) * obpp : nullptr;
 #pragma unroll
   for (int i = 0; i < kTileItems; i++) {
     const int ly = ly0 + 8 * i, gy = ty0 + ly;
@@ -358,10 +375,15 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
     if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
     else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
     if constexpr (BLEND) {
-      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * 3);
+      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * obpp);
       uint32_t o3[3];
       blend_quad(o.a[i], o.b[i], packed, o3);
-      __builtin_nontemporal_store(o3[0], op); __builtin_nontemporal_store(o3[1], op + 1); __builtin_nontemporal_store(o3[2], op + 2);
+      if (yuyv) {                                                  // deepseg.cc:87-106 on the four composited pixels: 8 bytes instead of 12
+        __builtin_nontemporal_store(yuyv_pair(o3[0] & 255u, (o3[0] >> 8) & 255u, (o3[0] >> 16) & 255u, o3[0] >> 24, o3[1] & 255u, (o3[1] >> 8) & 255u), op);
+        __builtin_nontemporal_store(yuyv_pair((o3[1] >> 16) & 255u, o3[1] >> 24, o3[2] & 255u, (o3[2] >> 8) & 255u, (o3[2] >> 16) & 255u, o3[2] >> 24), op + 1);
+      } else {
+        __builtin_nontemporal_store(o3[0], op); __builtin_nontemporal_store(o3[1], op + 1); __builtin_nontemporal_store(o3[2], op + 2);
+      }
     }
   }
 }
@@ -370,7 +392,7 @@ template <bool BLEND>
 __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                                uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                                const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
-                                                               uint8_t* __restrict__ outp) {
+                                                               uint8_t* __restrict__ outp, int yuyv) {
   // coefficients are 0..2048: kept as 16-bit so that every product below is a full-rate 24-bit multiply
   __shared__ int col_sx[kHW], col_sx1[kHW], row_s0[kHH], row_s1[kHH];
   __shared__ short col_a0[kHW], col_a1[kHW], row_b0[kHH], row_b1[kHH];
@@ -447,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
   __syncthreads();
   tile_hsum5(up, hs, tid);                                                                       // 4.
   __syncthreads();
-  tile_vsum5_store<BLEND>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid);                     // 5.
+  tile_vsum5_store<BLEND>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv);               // 5.
 }
 
 // ---- mask tile, single-round-trip form ---------------------------------------------------------------------------------
@@ -462,7 +484,7 @@ template <bool BLEND>
 __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                        uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                        const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
-                                                       uint8_t* __restrict__ outp) {
+                                                       uint8_t* __restrict__ outp, int yuyv) {
   __shared__ short col_c0[kHW], col_c1[kHW], col_a0[kHW], col_a1[kHW];     // block-relative tap columns, coefficients
   __shared__ short row_r0[kHH], row_r1[kHH], row_b0[kHH], row_b1[kHH];     // block-relative tap rows, coefficients
   __shared__ __attribute__((aligned(16))) uint16_t hq_hs[kMaxSrcRows * kHW > kHH * kTW ? kMaxSrcRows * kHW : kHH * kTW];
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   __syncthreads();
   tile_hsum5(up, hs, tid);                                                                       // 4.
   __syncthreads();
-  tile_vsum5_store<BLEND>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid);                     // 5.
+  tile_vsum5_store<BLEND>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv);               // 5.
 }
 
 // ---- alpha blend: 16 pixels (16 mask bytes, 48+48 source bytes, 48 output bytes) per lane (helpers: see blend_quad above) -----
@@ -601,23 +623,21 @@ __global__ __launch_bounds__(kThreads) void resize_bgr_k(const uint8_t* __restri
   o[0] = (uint8_t)v[0]; o[1] = (uint8_t)v[1]; o[2] = (uint8_t)v[2];
 }
 
-// ---- BGR → YUYV (cv::cvtColor(COLOR_RGB2YUV) on BGR-ordered bytes, then 4:2:2 pack Y0 V Y1 U) -----
-__device__ __forceinline__ void rgb2yuv(int R, int G, int B, int* Y, int* U, int* V) {
-  const int shift = 14, half = 1 << 13, delta = 128 << 14;
-  int y = (R * 4899 + G * 9617 + B * 1868 + half) >> shift;
-  int u = ((B - y) * 8061 + delta + half) >> shift;
-  int v = ((R - y) * 14369 + delta + half) >> shift;
-  *Y = min(max(y, 0), 255); *U = min(max(u, 0), 255); *V = min(max(v, 0), 255);
-}
 __global__ __launch_bounds__(kThreads) void yuyv_k(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, long pairs) {
   long i = (long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= pairs) return;
   const uint8_t* p = in + i * 6;
-  int y0, u0, v0, y1, u1, v1;
-  rgb2yuv(p[0], p[1], p[2], &y0, &u0, &v0);
-  rgb2yuv(p[3], p[4], p[5], &y1, &u1, &v1);
-  uint32_t u = (uint32_t)((u0 + u1) / 2), v = (uint32_t)((v0 + v1) / 2);
-  out[i] = (uint32_t)y0 | (v << 8) | ((uint32_t)y1 << 16) | (u << 24);
+  out[i] = yuyv_pair(p[0], p[1], p[2], p[3], p[4], p[5]);
+}
+// composite outside the ROI in YUYV form = the background converted: lane = one pixel pair of the frame, pairs inside the ROI belong to the tiles
+__global__ __launch_bounds__(kThreads) void outside_roi_yuyv_k(const uint8_t* __restrict__ bg, long bg_stride, uint32_t* __restrict__ out, int W, int H, Rect4 roi) {
+  const unsigned i = blockIdx.x * kThreads + threadIdx.x, ppr = (unsigned)W / 2;
+  if (i >= ppr * (unsigned)H) return;
+  const unsigned row = i / ppr, x = (i - row * ppr) * 2;
+  if ((int)row >= roi.y && (int)row < roi.y + roi.h && (int)x >= roi.x && (int)x < roi.x + roi.w) return;
+  const long n = blockIdx.y;
+  const uint8_t* p = bg + (bg_stride ? n * bg_stride : 0) + ((long)row * W + x) * 3;
+  out[n * (long)(W / 2) * H + i] = yuyv_pair(p[0], p[1], p[2], p[3], p[4], p[5]);
 }
 
 // ---- YUYV → BGR ingest (cv::COLOR_YUV2BGR_YUYV, BT.601 limited range, 20-bit fixed point) --------------------------------
@@ -714,8 +734,8 @@ static bool mask_tile_usable(const ResizeTab& tab) { return tab.mode == 0 && tab
 hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                                     int n, hipStream_t s) {
   dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
-  if (mask_tile_usable(tab)) mask_tile_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr);
-  else mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr);
+  if (mask_tile_usable(tab)) mask_tile_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0);
+  else mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0);
   return hipGetLastError();
 }
 
@@ -725,15 +745,17 @@ bool mask_blend_fusable(int W, int H, Rect4 roi, const uint8_t* bg, size_t bg_st
 }
 
 hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
-                             const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s) {
+                             const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s, int yuyv) {
   // outside the ROI the persistent mask is 255 forever (libbackscrub.cc:248-249), i.e. the composite there IS the background
   // ((a*255 + b*0)/255 == a): those strips are copied, the ROI is composited by the mask tiles
-  if (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H)
+  if (yuyv && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
+    outside_roi_yuyv_k<<<dim3(blocks_for((long)(W / 2) * H), n), kThreads, 0, s>>>(bg, (long)bg_stride, reinterpret_cast<uint32_t*>(out), W, H, roi);
+  else if (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H)
     outside_roi_copy_k<<<dim3(blocks_for((long)(H - roi.h) * (W * 3 / 4) + (long)roi.h * ((W - roi.w) * 3 / 4)), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H,
                                                                                                                                  roi);
   dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
-  if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
-  else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out);
+  if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv);
+  else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv);
   return hipGetLastError();
 }
 

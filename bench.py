@@ -420,6 +420,27 @@ def main():
                                      "compute, double-buffered); %.1f GB/s each way" % (B, B, B * W * H * 3 / (dt / io_steps) / 1e9)}
         del bufs, h_in, h_out
 
+    # the same step with the composite leaving as YUYV 4:2:2 (convert_rgb_to_yuyv fused into the blend epilogue): reported
+    # next to `value`, never as `value`; checked bit for bit against the two-call form on the last step
+    if rank == 0 and world == 1 and W % 2 == 0 and not args.no_extra_configs:
+        mg, d_frames, d_bg, d_out = res["mg"], res["d_frames"], res["d_bg"], res["d_out"]
+        d_yuyv = torch.empty((B, H, W, 2), dtype=torch.uint8, device="cuda")
+        mg.reset(); mg.step(d_frames, d_bg, d_out); a = mg.bgr_to_yuyv(d_out)          # both forms from the same (fresh) temporal state
+        mg.reset(); mg.step_yuyv(d_frames, d_bg, d_yuyv)
+        same = bool(torch.equal(a, d_yuyv))
+        for _ in range(args.warmup):
+            mg.step_yuyv(d_frames, d_bg, d_yuyv)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            mg.step_yuyv(d_frames, d_bg, d_yuyv)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        result["yuyv_out"] = {"value": round(B * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
+                              "bit_identical_to_step_then_bgr_to_yuyv": same,
+                              "note": "bsx_step_batch_yuyv: composite written as YUYV (2 B/px instead of 3), no separate packing pass"}
+        del d_yuyv, a
+
     main_samples = None
     if rank == 0:
         main_samples = (res["model_path"], res["host"][:4].copy(), res["bg_host"], res["masks_k"], res["out_k"], res["photo"])

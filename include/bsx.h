@@ -16,6 +16,7 @@
  *   bsx_process_batch      the same function for n_streams device-resident frames at once
  *   bsx_composite_batch    alpha_blend()                  app/deepseg.cc:108-134 (file-static)
  *   bsx_step_batch         one main-loop iteration        app/deepseg.cc:634-661
+ *   bsx_step_batch_yuyv    … with convert_rgb_to_yuyv fused app/deepseg.cc:634-681
  *                          (set_input_frame → mask → alpha_blend), batched
  *   bsx_resize_bgr         grab_background() cv::resize   app/background.cc:178-194
  *   bsx_bgr_to_yuyv        convert_rgb_to_yuyv()          app/deepseg.cc:87-106
@@ -128,6 +129,12 @@ int bsx_composite_batch(bsx_ctx* ctx, const uint8_t* d_bg, size_t bg_frame_strid
 /* bsx_process_batch followed by bsx_composite_batch on the same stream. */
 int bsx_step_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                    uint8_t* d_out, int n, void* stream);
+
+/* The same main-loop iteration with the composite leaving as YUYV 4:2:2 [n][height][width][2] (bytes Y0 V Y1 U): convert_rgb_to_yuyv
+ * (app/deepseg.cc:87-106, applied at :681 right after alpha_blend) runs in the blend's epilogue — 2 B/px written instead of 3, and no separate
+ * pass over the composite — for callers that feed a V4L2 YUYV sink.  Bit-identical to bsx_step_batch followed by bsx_bgr_to_yuyv.  width even. */
+int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
+                        uint8_t* d_out_yuyv, int n, void* stream);
 
 /* cv::resize(src, dst, Size(dw,dh)) with INTER_LINEAR on packed BGR u8 (device pointers, n images). */
 int bsx_resize_bgr(bsx_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream);

@@ -445,6 +445,38 @@ def test_yuyv_matches_oracle(bs, oracle):
     mg.close()
 
 
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA), ("full", (1280, 720)), ("lite", (322, 242))])
+def test_step_with_fused_yuyv_output(bs, oracle, key, res):
+    """bsx_step_batch_yuyv = alpha_blend then convert_rgb_to_yuyv (app/deepseg.cc:661,681) in one pass: bit-identical to the two-call
+    form and to the oracle's packer on the composite — full-frame ROI (lite/VGA), ROI with background strips outside (mlkit/VGA), HD,
+    and a geometry the fused tile kernel does not take (322x242: scratch + packer fallback)."""
+    import torch
+    from backscrub_amd import synth
+    W, H = res
+    n = 3
+    mg_a = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    mg_b = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    bg = _dev(synth.random_u8((n, H, W, 3), 77))
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    yuyv = torch.empty((n, H, W, 2), dtype=torch.uint8, device="cuda")
+    for t in range(3):
+        frames = _dev(np.stack([synth.frame(W, H, i, t) for i in range(n)]))
+        mg_a.step(frames, bg, out)
+        mg_b.step_yuyv(frames, bg, yuyv)
+        want = mg_a.bgr_to_yuyv(out).cpu().numpy()
+        got = yuyv.cpu().numpy()
+        assert np.array_equal(got, want), "t=%d: %d bytes differ" % (t, (got != want).sum())
+        comp = out.cpu().numpy()
+        assert np.array_equal(got[0], oracle.bgr_to_yuyv(comp[0]))
+        assert np.array_equal(mg_a.masks().cpu().numpy(), mg_b.masks().cpu().numpy())
+    bg1 = bg[0].contiguous()                                             # one shared background image
+    mg_a.step(frames, bg1, out)
+    mg_b.step_yuyv(frames, bg1, yuyv)
+    assert np.array_equal(yuyv.cpu().numpy(), mg_a.bgr_to_yuyv(out).cpu().numpy())
+    mg_a.close()
+    mg_b.close()
+
+
 def test_yuyv_to_bgr_matches_oracle(bs, oracle):
     from backscrub_amd import synth
     img = synth.random_u8((2, 480, 640, 2), 13)
