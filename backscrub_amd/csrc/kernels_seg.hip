@@ -128,18 +128,22 @@ __device__ __forceinline__ void seg_gate(const SegGate& gt, const float* __restr
     s_mean[tid] = m;
   }
   __syncthreads();
-  if (tid < f1.Cout) {
+  // FC layers: lane = (output, slice of the inputs) — 8 consecutive lanes share an output and meet through DPP.  (One lane per output walked
+  // its whole weight row with a stride of Cin floats: every lane on the same two LDS banks, a 16-way conflict per step, 2 us per layer.)
+  auto fc = [&](const SegFc& f, const float* x, const float* wl, const float* bl, float* y) {
+    const int out = tid >> 3, ks = tid & 7, kper = f.Cin >> 3;               // Cin is 16 or 32 (checked by the planner)
     float acc = 0.f;
-    for (int k = 0; k < f1.Cin; k++) acc = fmaf(s_mean[k], w1[tid * f1.Cin + k], acc);
-    (gt.n_fc == 1 ? s_gate : s_hid)[tid] = sg_act(acc + b1[tid], f1.act);
-  }
+    if (out < f.Cout)
+      for (int j = 0; j < kper; j++) acc = fmaf(x[ks * kper + j], wl[out * f.Cin + ks * kper + j], acc);
+    acc += dpp_quad(acc, 1);
+    acc += dpp_quad(acc, 2);
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x141, 0xf, 0xf, true));   // row_half_mirror: both quads of the 8
+    if (out < f.Cout && ks == 0) y[out] = sg_act(acc + bl[out], f.act);
+  };
+  fc(f1, s_mean, w1, b1, gt.n_fc == 1 ? s_gate : s_hid);
   __syncthreads();
   if (gt.n_fc == 2) {
-    if (tid < f2.Cout) {
-      float acc = 0.f;
-      for (int k = 0; k < f2.Cin; k++) acc = fmaf(s_hid[k], w2[tid * f2.Cin + k], acc);
-      s_gate[tid] = sg_act(acc + b2[tid], f2.act);
-    }
+    fc(f2, s_hid, w2, b2, s_gate);
     __syncthreads();
   }
 }

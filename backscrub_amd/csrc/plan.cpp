@@ -424,7 +424,7 @@ SegDwW dw_w(const Step& st) { SegDwW c; c.w_off = (long long)st.w_off; c.b_off =
 SegFc fc_w(const Step& st) { SegFc c; c.w_off = (long long)st.w2_off; c.b_off = (long long)st.b_off; c.Cin = st.Cin; c.Cout = st.Cout; c.act = st.act; return c; }
 
 bool is_pw16(const Step& st) { return st.kind == StepKind::PwConv && st.Cin == 16 && st.Cout == 16 && st.cout_pad == 16 && st.OH * st.OW > 4; }
-bool is_fc_step(const Step& st) { return st.kind == StepKind::PwConv && st.OH * st.OW == 1 && st.w2_off != 0 && st.residual < 0 && st.in_scale < 0 && st.in2 < 0 && st.Cin <= 32 && st.Cout <= 32; }
+bool is_fc_step(const Step& st) { return st.kind == StepKind::PwConv && st.OH * st.OW == 1 && st.w2_off != 0 && st.residual < 0 && st.in_scale < 0 && st.in2 < 0 && st.Cin <= 32 && st.Cin % 8 == 0 && st.Cout <= 32; }
 bool is_dw3(const Step& st, int stride) {
   return st.kind == StepKind::DwConv && st.kh == 3 && st.kw == 3 && st.sh == stride && st.sw == stride && st.dh == 1 && st.dw == 1;
 }

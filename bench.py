@@ -441,6 +441,28 @@ def main():
                               "note": "bsx_step_batch_yuyv: composite written as YUYV (2 B/px instead of 3), no separate packing pass"}
         del d_yuyv, a
 
+    # the blend kernel with ONE BACKGROUND PER STREAM (animated backgrounds): nothing of its 10 B/px comes out of L2, unlike the shared
+    # 0.9 MB picture of the default job whose roofline_blend line is flattered by cache hits (its PMC traffic is below the algorithmic bytes)
+    if rank == 0 and world == 1 and not args.no_extra_configs and not args.per_stream_bg:
+        mg, d_frames, d_out = res["mg"], res["d_frames"], res["d_out"]
+        d_bg_ps = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            mg.composite(d_bg_ps, d_frames, None, d_out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 10
+        e0.record()
+        for _ in range(iters):
+            mg.composite(d_bg_ps, d_frames, None, d_out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        by = 10.0 * W * H * B
+        result["roofline_blend_per_stream_bg"] = {"kernel": "blend", "bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                                                  "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None, "avg_ms": round(ms, 4),
+                                                  "algorithmic_bytes_per_launch": int(by),
+                                                  "note": "bsx_composite_batch with a separate background image per stream: every byte of the 10 B/px is HBM traffic"}
+        del d_bg_ps
+
     main_samples = None
     if rank == 0:
         main_samples = (res["model_path"], res["host"][:4].copy(), res["bg_host"], res["masks_k"], res["out_k"], res["photo"])
