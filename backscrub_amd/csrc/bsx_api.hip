@@ -675,8 +675,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     }
     const bool is_tail = atail && &st == &c->plan.steps.back();
     const bool ir_on = c->d_weights16 && c->f16_terms > 0;
-    static const bool head0_on = getenv("BSX_NO_HEAD0") == nullptr;
-    const bool h0 = head0_on && c->plan.steps[0].fuse_head0;
+    const bool h0 = c->plan.steps[0].fuse_head0;
     const bool h0_member = h0 && (&st == &c->plan.steps[1] || &st == &c->plan.steps[2]);
     if (h0_member || (st.fused_away && !(h0 && &st <= &c->plan.steps[2]) && ir_on)) { put(j++, st.label + " (inside the launch before)", 0, 0); continue; }   // no-op slot of a fused group
     if (st.fuse_head0 && h0) {                                   // stem + depthwise + 1x1: reads the network input, writes the 1x1's output

@@ -1188,8 +1188,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       long M = (long)n * st.OH * st.OW;
       dim3 grid(blocks_for(M), st.cout_pad / st.cout_tile);
       int HW = st.OH * st.OW;
-      static const bool no_head0 = getenv("BSX_NO_HEAD0") != nullptr;
-      if (st.fused_away && plan.steps[0].fuse_head0 && !no_head0) break;      // ran inside dl_head0_k
+      if (st.fused_away && plan.steps[0].fuse_head0) break;          // ran inside dl_head0_k (the planner decides: BSX_NO_HEAD0 is read there)
       static const bool no_gemm = getenv("BSX_NO_PW_GEMM") != nullptr;
       if (st.fuse_dw >= 0 && weights16 && f16_terms > 0) {          // expand 1x1 + depthwise 3x3 of an inverted-residual block in one kernel
         const Step& dws = plan.steps[st.fuse_dw];
@@ -1243,8 +1242,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       break;
     }
     case StepKind::Conv: {
-      static const bool no_head0 = getenv("BSX_NO_HEAD0") != nullptr;
-      if (st.fuse_head0 && !no_head0) {             // stem + depthwise + 1x1 (plan.steps[1], [2]) in one tiled kernel
+      if (st.fuse_head0) {             // stem + depthwise + 1x1 (plan.steps[1], [2]) in one tiled kernel
         const Step& d1 = plan.steps[1];
         const Step& p2 = plan.steps[2];
         const int BH = head0_band_rows(st.W, st.OW), nb = (st.OH + BH - 1) / BH;
@@ -1264,9 +1262,8 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       break;
     }
     case StepKind::DwConv: {
-      static const bool no_head0 = getenv("BSX_NO_HEAD0") != nullptr;
-      if (st.fused_away && &st == &plan.steps[1] && plan.steps[0].fuse_head0) { if (!no_head0) break; }      // ran inside dl_head0_k
-      else if (st.fused_away && weights16 && f16_terms > 0) break;       // ran inside the expand convolution before it (ir_expand_dw_k)
+      if (st.fused_away && &st == &plan.steps[1] && plan.steps[0].fuse_head0) break;      // ran inside dl_head0_k
+      if (st.fused_away && weights16 && f16_terms > 0) break;       // ran inside the expand convolution before it (ir_expand_dw_k)
       long total = (long)n * st.OH * st.OW * (st.Cin / 4);
       ConvGeom g{st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.cout_pad, st.kh, st.kw, st.sh, st.sw, st.dh, st.dw, st.pad_t, st.pad_l};
       static const bool no_col = getenv("BSX_NO_DW_COL") != nullptr;

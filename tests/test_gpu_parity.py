@@ -226,8 +226,9 @@ NETWORK_PATHS = {
     "mlkit": [("segments + middle program", {}, "segment head"), ("whole-network program", {"BSX_NO_SEGMENTS": "1"}, "frame program: ON"),
               ("one launch per step", {"BSX_NO_FRAME_PROGRAM": "1"}, "frame program: off")],
     # DeepLab runs per launch: the split-f16 MFMA GEMM (default) and the f32 MFMA GEMM, with and without the planner's rewrites
-    "deeplab": [("split-f16 MFMA GEMM", {}, "conv#66-pool"), ("f32 MFMA GEMM", {"BSX_F16_GEMM": "off"}, "conv#66-pool"),
-                ("no graph rewrites", {"BSX_NO_REWRITES": "1"}, "concat#65")],
+    "deeplab": [("split-f16 MFMA GEMM, fused head and expand+depthwise kernels", {}, "fused with step"), ("f32 MFMA GEMM", {"BSX_F16_GEMM": "off"}, "conv#66-pool"),
+                ("no graph rewrites", {"BSX_NO_REWRITES": "1"}, "concat#65"),
+                ("one launch per layer (no fused head, no fused expand+depthwise)", {"BSX_NO_IR_FUSE": "1", "BSX_NO_HEAD0": "1"}, "conv#66-pool")],
 }
 
 
@@ -242,7 +243,7 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc = oracle.Ctx(path, W, H)
     oc.prep(f)
     want = oc.infer()
-    knobs = ("BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM")
+    knobs = ("BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
     for name, env, marker in NETWORK_PATHS[key]:
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
@@ -260,6 +261,28 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     for k in knobs:
         monkeypatch.delenv(k, raising=False)
     oc.close()
+
+
+def test_deeplab_batch_of_eight_uses_the_gemm_kernels_on_every_level(bs, oracle):
+    """With 8 streams even the 33x33 layers have M >= 8192 rows, i.e. every pointwise convolution runs as the split-f16 MFMA GEMM (64-, 80- and
+    48-column tiles) next to the fused kernels: logits of all eight streams within 1e-4 of the oracle's."""
+    from backscrub_amd import synth
+    path = model_path("deeplab")
+    W, H = VGA
+    n = 8
+    frames = np.stack([synth.frame(W, H, i % 3, i) for i in range(n)])
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    mg.run_stage(0, _dev(frames))
+    mg.run_stage(1, n=n)
+    got = mg.output_tensor().cpu().numpy()
+    oc = oracle.Ctx(path, W, H)
+    for i in (0, 3, 7):
+        oc.prep(frames[i])
+        want = oc.infer()
+        err = float(np.abs(got[i] - want).max()) / max(1.0, float(np.abs(want).max()))
+        assert err < 1e-4, "stream %d: rel err %g" % (i, err)
+    oc.close()
+    mg.close()
 
 
 def test_deeplab_fast_f16_mode_is_close_but_not_parity_grade(bs, oracle, monkeypatch):
