@@ -519,6 +519,14 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
       }
     }
   }
+  // the depthwise weights + bias of the chunk: [9][CH] + [CH] behind the tile (a lane's channel quad changes from item to item when CH / 4 does not
+  // divide the workgroup size, so registers cannot hold them; nine global loads per item were most of the stride-2 phase)
+  float* dwl = ir_ex + (size_t)(e1 - e0) * W * CH;
+  for (int i = tid; i < 10 * CQ; i += kIrThreads) {
+    const int k = i / CQ, cq = i - k * CQ;
+    *reinterpret_cast<f4v*>(dwl + k * CH + 4 * cq) = k < 9 ? *reinterpret_cast<const f4v*>(dww + (size_t)k * Cexp + n_base + 4 * cq)
+                                                           : *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
+  }
   __syncthreads();
   if (!(phases & 2)) return;
   const f4v zero = {0.f, 0.f, 0.f, 0.f};
@@ -530,8 +538,8 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
       const int t = item / CQ, cq = item - t * CQ, seg = t / cols, rc = t - seg * cols, r = rc / W, xx = rc - r * W;
       f4v wq[9];
 #pragma unroll
-      for (int k = 0; k < 9; k++) wq[k] = *reinterpret_cast<const f4v*>(dww + (size_t)k * Cexp + n_base + 4 * cq);
-      const f4v bq = *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
+      for (int k = 0; k < 9; k++) wq[k] = *reinterpret_cast<const f4v*>(dwl + k * CH + 4 * cq);
+      const f4v bq = *reinterpret_cast<const f4v*>(dwl + 9 * CH + 4 * cq);
       // columns outside the image: their taps get ZERO WEIGHTS (the expanded values are finite, clamp-bounded) and a clamped address,
       // instead of a select per loaded quad in every step
       const bool vl = xx - d >= 0, vr = xx + d < W;
@@ -581,12 +589,12 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
           const int ix = S * ox - pl + fx;
           if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
             const f4v xv = *reinterpret_cast<const f4v*>(ir_ex + ((size_t)(iy - e0) * W + ix) * CH + 4 * cq);
-            const f4v wv = *reinterpret_cast<const f4v*>(dww + (size_t)(fy * 3 + fx) * Cexp + n_base + 4 * cq);
+            const f4v wv = *reinterpret_cast<const f4v*>(dwl + (fy * 3 + fx) * CH + 4 * cq);
             acc = __builtin_elementwise_fma(xv, wv, acc);
           }
         }
       }
-      acc += *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
+      acc += *reinterpret_cast<const f4v*>(dwl + 9 * CH + 4 * cq);
       *reinterpret_cast<float4*>(yf + ((size_t)oy * OW + ox) * Cexp + n_base + 4 * cq) =
           make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
     }
@@ -1195,7 +1203,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dws.OH, dws.sh, dws.dh);
         if (ig.CH == 0) return hipErrorInvalidValue;                 // the planner checked the same function
         const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
-        const size_t lds = (size_t)ig.rows * st.OW * ig.CH * sizeof(float);
+        const size_t lds = ((size_t)ig.rows * st.OW * ig.CH + 10 * (size_t)ig.CH) * sizeof(float);
         const dim3 gi((unsigned)(st.Cout / ig.CH) * (unsigned)ig.nbands * (unsigned)n);
         const int slabs = st.k16_pad / 32;
         static const int ir_phases = getenv("BSX_IR_PHASES") ? atoi(getenv("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
