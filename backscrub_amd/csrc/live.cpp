@@ -12,8 +12,11 @@
 // Plain C++ threads over the C ABI of bsx.h; nothing here touches a kernel directly.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -30,7 +33,7 @@ struct bsx_background {
   bsx_ctx* ctx = nullptr;
   int debug = 0;
   bool video = false;
-  volatile bool run = false;
+  std::atomic<bool> run{false};
   int width = 0, height = 0, n_frames = 0;
   double fps = 0;
   uint8_t* d_frames = nullptr;          // [n_frames][height][width][3] BGR on the context's GPU
@@ -42,15 +45,16 @@ struct bsx_background {
 struct bsx_live {
   bsx_ctx* ctx = nullptr;
   int width = 0, height = 0;
-  volatile bool running = false;
+  std::atomic<bool> running{false};
   std::vector<uint8_t> frame1, frame2, mask1, mask2;
   std::vector<uint8_t>*frame_current, *frame_next, *mask_current, *mask_out;
   std::mutex lock_frame, lock_mask;
   std::condition_variable condition_new_frame;
-  bool new_frame = false, new_mask = false;
-  int failed = 0;
+  bool new_frame = false;                 // guarded by lock_frame
+  std::atomic<bool> new_mask{false};      // set under lock_mask, polled without it by get_output_mask (as the reference does, deepseg.cc:280)
+  std::atomic<int> failed{0};
   std::thread thread;
-  long waitns = 0, loopns = 0;
+  std::atomic<long> waitns{0}, loopns{0};
 };
 
 namespace {

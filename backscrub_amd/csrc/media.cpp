@@ -143,7 +143,7 @@ bool decode_gif(const std::vector<uint8_t>& file, Media* m, std::string* err) {
     if (disposal == 2) fill(fx, fy, fw, fh, transparent >= 0 ? black : bgc);
     else if (disposal == 3) canvas = restore;
     transparent = -1; disposal = 0; delay_cs = 0;
-    if (m->frames.size() > 4096) break;
+    if (m->frames.size() > 4096 || m->frames.size() * (size_t)W * H * 3 > (size_t)1 << 30) { *err = "GIF: animation larger than 1 GiB decoded"; return false; }
   }
   if (m->frames.empty()) { *err = "GIF: no image"; return false; }
   m->fps = m->frames.size() > 1 ? 100.0 * (double)m->frames.size() / (double)total_delay : 0.0;
