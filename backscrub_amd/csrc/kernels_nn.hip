@@ -618,9 +618,10 @@ __global__ __launch_bounds__(kH0Threads) void dl_head0_k(const float* __restrict
   const int oy0 = band * BH, oy1 = min(oy0 + BH, H1), SR = oy1 - oy0 + 2, sy0 = oy0 - 1;      // stem rows [sy0, sy0 + SR)
   const int IR = 2 * SR + 1, iy0 = 2 * sy0 - pt, rowf = (W0 + 2) * 3;                          // input rows [iy0, iy0 + IR), one zero pixel left and right
   float* in_t = h0_lds;                                         // [IR][W0 + 2][3]
-  float* S = in_t + (((2 * (BH + 2) + 1) * rowf + 3) & ~3);      // [SR][W1][16]
-  float* D = S + (BH + 2) * W1 * 16;                             // [BH][W1][16]
-  float* wl = D + BH * W1 * 16;                                  // stem [27][16] + bias 16 | dw [9][16] + bias 16 | pw [16][16] + bias 16
+  float* D = h0_lds;                                             // [BH][W1][16]: over the input rows, which are dead once the stem has run
+  const int r0f = ((2 * (BH + 2) + 1) * rowf + 3) & ~3, r0d = BH * W1 * 16;
+  float* S = h0_lds + (r0f > r0d ? r0f : r0d);                   // [SR][W1][16]
+  float* wl = S + (BH + 2) * W1 * 16;                            // stem [27][16] + bias 16 | dw [9][16] + bias 16 | pw [16][16] + bias 16
   const ClampK ks = clamp_of(act_s), kd = clamp_of(act_d), kp = clamp_of(act_p);
   // ---- weights and the input rows
   for (int i = tid; i < 27 * 16 + 16 + 9 * 16 + 16 + 16 * 16 + 16; i += kH0Threads) {
@@ -1254,7 +1255,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const Step& d1 = plan.steps[1];
         const Step& p2 = plan.steps[2];
         const int BH = head0_band_rows(st.W, st.OW), nb = (st.OH + BH - 1) / BH;
-        const size_t fl = (size_t)((((2 * (BH + 2) + 1) * (st.W + 2) * 3 + 3) & ~3)) + (size_t)(BH + 2) * st.OW * 16 + (size_t)BH * st.OW * 16 + 1024;
+        const size_t fl = (size_t)head0_lds_floats(st.W, st.OW, BH);
         static const int h0_phases = getenv("BSX_H0_PHASES") ? atoi(getenv("BSX_H0_PHASES")) : 15;   // timing experiments
         static bool once = false;
         if (!once) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(dl_head0_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return hipErrorInvalidValue; once = true; }

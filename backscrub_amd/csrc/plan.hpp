@@ -91,11 +91,16 @@ inline IrGeom ir_geometry(int H, int W, int Cexp, int OH, int S, int d) {
 }
 
 // rows of the stem's output one workgroup of dl_head0_k owns (its LDS holds the input rows, the stem band and the depthwise band)
+inline long head0_lds_floats(int W0, int W1, int bh) {            // the depthwise band aliases the input rows (dead after the stem)
+  const long in_t = (((2l * (bh + 2) + 1) * (W0 + 2) * 3 + 3) & ~3l), dband = (long)bh * W1 * 16;
+  return (in_t > dband ? in_t : dband) + (long)(bh + 2) * W1 * 16 + 1024;
+}
 inline int head0_band_rows(int W0, int W1) {
-  for (int bh = 8; bh >= 2; bh--) {
-    const long fl = (long)(2 * (bh + 2) + 1) * (W0 + 2) * 3 + (long)(bh + 2) * W1 * 16 + (long)bh * W1 * 16 + 1024;
-    if (fl * 4 <= 156 * 1024) return bh;
-  }
+  if (const char* e = getenv("BSX_H0_BH")) { const int bh = atoi(e); if (bh >= 1 && bh <= 8 && head0_lds_floats(W0, W1, bh) * 4 <= 156 * 1024) return bh; }   // timing experiments
+  for (int bh = 8; bh >= 2; bh--)                                // two workgroups per CU (their phases overlap) if a band of >= 2 rows allows it
+    if (head0_lds_floats(W0, W1, bh) * 4 <= 80 * 1024) return bh;
+  for (int bh = 8; bh >= 2; bh--)
+    if (head0_lds_floats(W0, W1, bh) * 4 <= 156 * 1024) return bh;
   return 0;
 }
 
