@@ -501,6 +501,26 @@ def main():
                     result["configs"].append(frag)
                 except Exception as e:
                     result["configs"].append({"baseline_config": tag, "workload": desc, "error": repr(e)})
+            # g1: the reduced-precision GEMM modes of the per-launch (DeepLab) path next to the default, each with its own parity sample — the
+            # default (split-f16 MFMA, f32-grade) is the one `configs[3]` reports; "fast" (plain f16 operands) is opt-in and IoU-gated
+            result["gemm_modes"] = []
+            for mode, what in (("fast", "plain f16 MFMA operands (1 term), f32 accumulate — what SetAllowFp16PrecisionForFp32 permits (lib/libbackscrub.cc:225)"),
+                               ("off", "f32 MFMA (v_mfma_f32_16x16x4_f32), no fused expand+depthwise kernels")):
+                try:
+                    os.environ["BSX_F16_GEMM"] = mode
+                    r = measure(steps=3, warmup=1, rank=0, world=1, local_rank=local_rank, profile_iters=1, model_key="deeplab", W=640, H=480, B=1024, bg_ring=True)
+                    frag = {"BSX_F16_GEMM": mode, "what": what, "workload": "configs[3] geometry", "value": round(r["fps"], 1), "unit": "frames/s",
+                            "ms_per_step": round(r["ms_per_step"], 4)}
+                    samples = (r["model_path"], r["host"][:2].copy(), r["bg_host"], r["masks_k"], r["out_k"], r["photo"])
+                    release(r)
+                    if not args.no_cpu_baseline:
+                        mp_, fr_, bg_, mk_, out_, photo_ = samples
+                        frag["parity_sample"] = parity_sample(mp_, 640, 480, fr_, bg_, mk_, out_, need_person=photo_)
+                    result["gemm_modes"].append(frag)
+                except Exception as e:
+                    result["gemm_modes"].append({"BSX_F16_GEMM": mode, "error": repr(e)})
+                finally:
+                    os.environ.pop("BSX_F16_GEMM", None)
             try:
                 result["single_stream"] = {"what": "bsx_process_host per call (= bs_maskgen_process through the C++ shim): H2D frame, whole mask pipeline, D2H mask, synchronous",
                                            "runs": [single_stream_latency("lite", 640, 480, 200), single_stream_latency("deeplab", 640, 480, 60)],
