@@ -200,6 +200,8 @@ int init_device_state(bsx_ctx* c) {
     BSX_HIP(c, hipMemcpy(c->d_program, c->plan.program.data(), c->plan.program.size() * sizeof(MicroOp), hipMemcpyHostToDevice));
     BSX_HIP(c, frame_program_prepare(c->plan.program_lds_floats));
     if (c->plan.seg.on) BSX_HIP(c, seg_prepare());
+  } else {
+    BSX_HIP(c, nn_prepare());                 // per-launch path: the fused kernels' dynamic-LDS limits on this device
   }
   BSX_HIP(c, hipMalloc(&c->d_canvas, N * canvas_elems(c->inW, c->inH) * sizeof(uint32_t)));
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));

@@ -1182,6 +1182,20 @@ hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofi
   return hipGetLastError();
 }
 
+// Dynamic-LDS limits of the fused kernels.  Function attributes belong to the (device, kernel) pair: set for the CURRENT device, once per context
+// (bsx_new, under its device guard) — a process-wide "done" flag would leave a second GPU's copies at the 64 KB default.
+hipError_t nn_prepare() {
+  const int full = 160 * 1024;
+  hipError_t e;
+#define BSX_ATTR(K) if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, full)) != hipSuccess) return e
+#define BSX_ATTR_IR(T, SL) BSX_ATTR((ir_expand_dw_k<T, SL, 32>)); BSX_ATTR((ir_expand_dw_k<T, SL, 24>)); BSX_ATTR((ir_expand_dw_k<T, SL, 16>))
+  BSX_ATTR_IR(3, 1); BSX_ATTR_IR(3, 2); BSX_ATTR_IR(3, 3); BSX_ATTR_IR(1, 1); BSX_ATTR_IR(1, 2); BSX_ATTR_IR(1, 3);
+  BSX_ATTR(dl_head0_k);
+#undef BSX_ATTR_IR
+#undef BSX_ATTR
+  return hipSuccess;
+}
+
 hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
                        hipStream_t s, const uint16_t* weights16, int f16_terms) {
   auto P = [&](int t) -> float* {
@@ -1208,7 +1222,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const dim3 gi((unsigned)(st.Cout / ig.CH) * (unsigned)ig.nbands * (unsigned)n);
         const int slabs = st.k16_pad / 32;
         static const int ir_phases = getenv("BSX_IR_PHASES") ? atoi(getenv("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
-#define BSX_IR(T, SL, C) { static bool once = false; if (!once) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(ir_expand_dw_k<T, SL, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return hipErrorInvalidValue; once = true; } \
+#define BSX_IR(T, SL, C) { \
           ir_expand_dw_k<T, SL, C><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases); }
 #define BSX_IR_C(T, SL) { if (ig.CH == 32) BSX_IR(T, SL, 32) else if (ig.CH == 24) BSX_IR(T, SL, 24) else BSX_IR(T, SL, 16) }
         if (f16_terms == 3) { if (slabs == 1) BSX_IR_C(3, 1) else if (slabs == 2) BSX_IR_C(3, 2) else BSX_IR_C(3, 3) }
@@ -1257,8 +1271,6 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const int BH = head0_band_rows(st.W, st.OW), nb = (st.OH + BH - 1) / BH;
         const size_t fl = (size_t)head0_lds_floats(st.W, st.OW, BH);
         static const int h0_phases = getenv("BSX_H0_PHASES") ? atoi(getenv("BSX_H0_PHASES")) : 15;   // timing experiments
-        static bool once = false;
-        if (!once) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(dl_head0_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return hipErrorInvalidValue; once = true; }
         dl_head0_k<<<(unsigned)nb * (unsigned)n, kH0Threads, fl * sizeof(float), s>>>(P(st.in0), w, b, weights + d1.w_off, weights + d1.b_off, weights + p2.w_off,
                                                                                     weights + p2.b_off, P(p2.out), st.H, st.W, st.OH, st.OW, st.pad_t, st.pad_l, p2.Cout,
                                                                                     p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases);
