@@ -17,6 +17,8 @@ namespace bsx {
 // The network input / output tensors live in their own batch-major buffers (net_in / net_out).
 // weights16 / f16_terms: the split-f16 MFMA form of the large pointwise convolutions (Step::w16_off, plan.weights16):
 // 3 = hi/lo split of both operands (f32-grade results, the default), 1 = plain f16 inputs (IoU-gated fast mode), 0 = f32 MFMA
+// f16_terms: low nibble = MFMA terms (0: f32 MFMA kernels, 1: plain f16 operands, 3: split f16); bit 4 (with 1 term only) = the fused expand+depthwise
+// kernels store their output as f16 and the project GEMM that consumes it reads f16 (opt-in reduced-precision storage, BSX_F16_GEMM=fast16)
 hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
                        hipStream_t s, const uint16_t* weights16 = nullptr, int f16_terms = 0);
 

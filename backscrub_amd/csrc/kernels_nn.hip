@@ -268,7 +268,7 @@ __device__ __forceinline__ void xcd_tile(unsigned ncol, unsigned* col, long* row
 
 // (min 4 waves per SIMD: left alone the compiler takes 180 registers = 2 workgroups per CU, and the skinny-K expand layers — three K slabs
 //  per tile — then spend their time waiting for the first slab: 128 registers fit without spills)
-template <int TERMS, int NTW>
+template <int TERMS, int NTW, bool IN16 = false>      // IN16: x holds f16 values (written by ir_expand_dw_k<.., OUT16>), TERMS == 1 only
 __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                           const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
                                                           float* __restrict__ y, long M, int HW, int Cin, int Kp, int Cout, int cout_pad, int act,
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
       const long m = m_base + row;
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M && k0 + kq < Cin) {
-        float4 v = *reinterpret_cast<const float4*>(x + m * Cin + k0 + kq);
+        float4 v;
+        if (IN16) { const h4v hv = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(x) + m * Cin + k0 + kq); v = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w); }
+        else v = *reinterpret_cast<const float4*>(x + m * Cin + k0 + kq);
         if (scale) {
           const float4 sv = *reinterpret_cast<const float4*>(scale + (m / HW) * (long)Cin + k0 + kq);
           v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w);
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
 // per output), stride 2 as nine taps per output — and writes its result.  The expanded tensor — per inverted-residual block the largest
 // write AND the largest read — never reaches HBM: 4 of the block's 6 big tensor passes become 2.
 constexpr int kIrThreads = 512, kIrSeg = 9;
-template <int TERMS, int SLABS, int CH>
+template <int TERMS, int SLABS, int CH, bool OUT16 = false>      // OUT16: the depthwise result is stored as f16 (reduced-precision storage mode)
 __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                             const float* __restrict__ dww, const float* __restrict__ dwb, float* __restrict__ y,
                                                             int H, int W, int Cin, int Kp, int Cexp, int cout_pad, int act1, int act2, int d, int S, int pt, int pl,
@@ -435,6 +437,7 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
   const ClampK k1 = clamp_of(act1), k2 = clamp_of(act2);                   // the planner fuses clamp activations only (none / relu / relu6)
   const float* xf = x + ((size_t)frame * (size_t)H + (size_t)e0) * (size_t)W * Cin;
   float* yf = y + (size_t)frame * (size_t)OH * OW * Cexp;
+  _Float16* yh = reinterpret_cast<_Float16*>(y) + (size_t)frame * (size_t)OH * OW * Cexp;      // (OUT16) the same tensor as packed halves: [n][OH*OW][Cexp]
   // ---- phase 1: expand into LDS
   if (phases & 1) {
     const _Float16* wh = w16;
@@ -570,7 +573,8 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
 #pragma unroll
         for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(nx[fx], wq[6 + fx], acc);
         acc += bq;
-        *reinterpret_cast<float4*>(yp) = make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
+        if (OUT16) *reinterpret_cast<h4v*>(yh + (yp - yf)) = h4v{(_Float16)clampf(acc.x, k2), (_Float16)clampf(acc.y, k2), (_Float16)clampf(acc.z, k2), (_Float16)clampf(acc.w, k2)};
+        else *reinterpret_cast<float4*>(yp) = make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
 #pragma unroll
         for (int fx = 0; fx < 3; fx++) { p[fx] = c[fx]; c[fx] = nx[fx]; }
       }
@@ -595,8 +599,9 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
         }
       }
       acc += *reinterpret_cast<const f4v*>(dwl + 9 * CH + 4 * cq);
-      *reinterpret_cast<float4*>(yf + ((size_t)oy * OW + ox) * Cexp + n_base + 4 * cq) =
-          make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
+      const size_t oo = ((size_t)oy * OW + ox) * Cexp + n_base + 4 * cq;
+      if (OUT16) *reinterpret_cast<h4v*>(yh + oo) = h4v{(_Float16)clampf(acc.x, k2), (_Float16)clampf(acc.y, k2), (_Float16)clampf(acc.z, k2), (_Float16)clampf(acc.w, k2)};
+      else *reinterpret_cast<float4*>(yf + oo) = make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
     }
   }
 }
@@ -1190,6 +1195,9 @@ hipError_t nn_prepare() {
 #define BSX_ATTR(K) if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, full)) != hipSuccess) return e
 #define BSX_ATTR_IR(T, SL) BSX_ATTR((ir_expand_dw_k<T, SL, 32>)); BSX_ATTR((ir_expand_dw_k<T, SL, 24>)); BSX_ATTR((ir_expand_dw_k<T, SL, 16>))
   BSX_ATTR_IR(3, 1); BSX_ATTR_IR(3, 2); BSX_ATTR_IR(3, 3); BSX_ATTR_IR(1, 1); BSX_ATTR_IR(1, 2); BSX_ATTR_IR(1, 3);
+#define BSX_ATTR_IR16(T, SL) BSX_ATTR((ir_expand_dw_k<T, SL, 32, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 24, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 16, true>))
+  BSX_ATTR_IR16(1, 1); BSX_ATTR_IR16(1, 2); BSX_ATTR_IR16(1, 3); BSX_ATTR_IR16(3, 1); BSX_ATTR_IR16(3, 2); BSX_ATTR_IR16(3, 3);
+#undef BSX_ATTR_IR16
   BSX_ATTR(dl_head0_k);
 #undef BSX_ATTR_IR
 #undef BSX_ATTR
@@ -1222,10 +1230,13 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const dim3 gi((unsigned)(st.Cout / ig.CH) * (unsigned)ig.nbands * (unsigned)n);
         const int slabs = st.k16_pad / 32;
         static const int ir_phases = getenv("BSX_IR_PHASES") ? atoi(getenv("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
-#define BSX_IR(T, SL, C) { \
-          ir_expand_dw_k<T, SL, C><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases); }
+        // reduced-precision storage (f16_terms bit 4): only when the depthwise output's single reader is a GEMM that will take the f16 form (same M rule)
+        const bool out16 = (f16_terms & 16) && (size_t)st.fuse_dw + 1 < plan.steps.size() && plan.steps[st.fuse_dw + 1].in_from_fused_dw &&
+                           plan.steps[st.fuse_dw + 1].in0 == dws.out && (long)n * dws.OH * dws.OW >= 8192 && !no_gemm;
+#define BSX_IR(T, SL, C) { if (out16) ir_expand_dw_k<T, SL, C, true><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases); \
+          else ir_expand_dw_k<T, SL, C, false><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases); }
 #define BSX_IR_C(T, SL) { if (ig.CH == 32) BSX_IR(T, SL, 32) else if (ig.CH == 24) BSX_IR(T, SL, 24) else BSX_IR(T, SL, 16) }
-        if (f16_terms == 3) { if (slabs == 1) BSX_IR_C(3, 1) else if (slabs == 2) BSX_IR_C(3, 2) else BSX_IR_C(3, 3) }
+        if ((f16_terms & 15) == 3) { if (slabs == 1) BSX_IR_C(3, 1) else if (slabs == 2) BSX_IR_C(3, 2) else BSX_IR_C(3, 3) }
         else { if (slabs == 1) BSX_IR_C(1, 1) else if (slabs == 2) BSX_IR_C(1, 2) else BSX_IR_C(1, 3) }
 #undef BSX_IR_C
 #undef BSX_IR
@@ -1240,7 +1251,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       // (even K = 8 / N = 16 layers: the tiles are mostly padding, but A is read once and coalesced — measured faster than the lane-per-pixel form)
       if (!no_gemm && M >= 8192 && (st.Cin & 3) == 0 && st.Cin >= 8 && st.cout_pad % 16 == 0 && st.cout_pad >= 16) {
         dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);
-        if (weights16 && st.k16_pad > 0 && f16_terms > 0) {        // split-f16 (3 terms, f32-grade) or plain f16-input (1 term) MFMA
+        if (weights16 && st.k16_pad > 0 && (f16_terms & 15) > 0) {        // split-f16 (3 terms, f32-grade) or plain f16-input (1 term) MFMA
           const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
           // column tiles: 64 channels (NTW = 4), or 80 / 48 in ONE tile where that covers the whole layer (NTW = 5 / 3: the A block is
           // staged and split once instead of once per column tile — the 480 -> 80 and 288 -> 48 project layers)
@@ -1250,7 +1261,12 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
           if ((unsigned long long)gg.x * ncol >= (1ull << 31)) return hipErrorInvalidValue;
           const dim3 gw(gg.x * ncol);                              // 1-D: the kernel derives (column tile, row block) XCD-aware
 #define BSX_F16S(T, N) pw_gemm_f16s_k<T, N><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias))
-          if (f16_terms == 3) { if (ntw == 5) BSX_F16S(3, 5); else if (ntw == 3) BSX_F16S(3, 3); else BSX_F16S(3, 4); }
+          if ((f16_terms & 15) == 3) { if (ntw == 5) BSX_F16S(3, 5); else if (ntw == 3) BSX_F16S(3, 3); else BSX_F16S(3, 4); }
+          else if ((f16_terms & 16) && st.in_from_fused_dw) {        // its input was stored as f16 by the fused kernel before it (same M rule on both sides)
+#define BSX_F16S16(N) pw_gemm_f16s_k<1, N, true><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias))
+            if (ntw == 5) BSX_F16S16(5); else if (ntw == 3) BSX_F16S16(3); else BSX_F16S16(4);
+#undef BSX_F16S16
+          }
           else { if (ntw == 5) BSX_F16S(1, 5); else if (ntw == 3) BSX_F16S(1, 3); else BSX_F16S(1, 4); }
 #undef BSX_F16S
           break;

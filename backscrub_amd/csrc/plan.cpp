@@ -1097,6 +1097,13 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
       if (ir_geometry(a.OH, a.OW, a.Cout, d.OH, d.sh, d.dh).CH == 0) continue;
       a.fuse_dw = (int)i + 1;
       d.fused_away = true;
+      // the depthwise output's only reader, when it is a GEMM-capable 1x1: lets the reduced-precision storage mode keep that tensor in f16
+      if (i + 2 < S.size()) {
+        Step& pj = S[i + 2];
+        if (pj.kind == StepKind::PwConv && pj.in0 == d.out && uses(d.out) == 1 && pj.k16_pad > 0 && pj.in_scale < 0 && pj.in2 < 0 && (pj.Cin & 3) == 0 &&
+            pj.cout_pad % 16 == 0 && pj.OH == d.OH && pj.OW == d.OW)
+          pj.in_from_fused_dw = true;
+      }
     }
   }
   return true;

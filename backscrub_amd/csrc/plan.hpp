@@ -50,6 +50,7 @@ struct Step {
   double macs = 0;                    // per frame
   int last_node = -1;                 // file operator index of the last fused op
   int fuse_dw = -1;                   // per-launch path, PwConv: index of the depthwise step this expand convolution is fused with (ir_expand_dw_k)
+  bool in_from_fused_dw = false;      // per-launch path, PwConv: in0 is the output of a fused expand+depthwise pair and has no other reader (may be stored as f16)
   bool fused_away = false;            // per-launch path: the step runs inside an earlier one
   bool fuse_head0 = false;            // per-launch path, stem Conv: runs together with the depthwise and the 1x1 after it (dl_head0_k)
 };

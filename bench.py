@@ -504,7 +504,8 @@ def main():
             # g1: the reduced-precision GEMM modes of the per-launch (DeepLab) path next to the default, each with its own parity sample — the
             # default (split-f16 MFMA, f32-grade) is the one `configs[3]` reports; "fast" (plain f16 operands) is opt-in and IoU-gated
             result["gemm_modes"] = []
-            for mode, what in (("fast", "plain f16 MFMA operands (1 term), f32 accumulate — what SetAllowFp16PrecisionForFp32 permits (lib/libbackscrub.cc:225)"),
+            for mode, what in (("fast16", "fast + the depthwise outputs of the fused inverted-residual blocks stored as f16 (16-bit activation storage for the largest tensors that reach HBM)"),
+                               ("fast", "plain f16 MFMA operands (1 term), f32 accumulate — what SetAllowFp16PrecisionForFp32 permits (lib/libbackscrub.cc:225)"),
                                ("off", "f32 MFMA (v_mfma_f32_16x16x4_f32), no fused expand+depthwise kernels")):
                 try:
                     os.environ["BSX_F16_GEMM"] = mode

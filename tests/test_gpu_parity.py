@@ -285,6 +285,34 @@ def test_deeplab_batch_of_eight_uses_the_gemm_kernels_on_every_level(bs, oracle)
     mg.close()
 
 
+def test_deeplab_f16_storage_mode_is_gated_by_iou(bs, oracle, monkeypatch):
+    """BSX_F16_GEMM=fast16: plain f16 MFMA operands AND the depthwise outputs of the fused blocks stored as f16 (half the traffic of the largest
+    tensors that still reach HBM).  Opt-in, IoU-gated like `fast`: the mask of the photo fixture stays within IoU 0.995 of the oracle's and the
+    logits within 2e-2, and the mode must not be the default."""
+    from backscrub_amd import synth
+    path = model_path("deeplab")
+    W, H = VGA
+    n = 8                                                             # >= 8 streams: every layer takes the GEMM / f16-input form
+    frames = np.stack([synth.frame(W, H, i % 3, i) for i in range(n)])
+    monkeypatch.setenv("BSX_F16_GEMM", "fast16")
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    monkeypatch.delenv("BSX_F16_GEMM")
+    mg.run_stage(0, _dev(frames))
+    mg.run_stage(1, n=n)
+    got = mg.output_tensor().cpu().numpy()
+    oc = oracle.Ctx(path, W, H)
+    errs = []
+    for i in (0, 5):
+        oc.prep(frames[i])
+        want = oc.infer()
+        errs.append(float(np.abs(got[i] - want).max()) / max(1.0, float(np.abs(want).max())))
+        agree = (got[i].argmax(-1) == want.argmax(-1)).mean()
+        assert agree >= 0.995, "stream %d: argmax agreement %.5f" % (i, agree)
+    assert max(errs) < 2e-2 and max(errs) > 1e-5, errs                # close, and visibly NOT the f32-grade default
+    oc.close()
+    mg.close()
+
+
 def test_deeplab_fast_f16_mode_is_close_but_not_parity_grade(bs, oracle, monkeypatch):
     """BSX_F16_GEMM=fast (plain f16 MFMA inputs, f32 accumulate — what SetAllowFp16PrecisionForFp32 permits, lib/libbackscrub.cc:225)
     is an opt-in mode: its logits are close (1e-2) but it is NOT held to the 1e-4 parity bar; the default split-f16 mode is."""
