@@ -94,6 +94,39 @@ def test_frame_program_lds_reservations_do_not_collide(key, real):
     assert int(fields["lds_floats"]) <= 160 * 256
 
 
+@pytest.mark.parametrize("real", [True, False])
+def test_deeplab_plan_fuses_the_head_and_every_expand_depthwise_pair(real, monkeypatch):
+    """Host-only check of the per-launch planner (plan.cpp): DeepLab's first three layers form the tiled head kernel, all 16 expand 1x1 → depthwise 3x3
+    pairs fuse, every fused pair's LDS geometry (plan.hpp ir_geometry) fits — whole frame at 33x33, row bands of <= 78 KB (two workgroups per CU) above —
+    and the switches that turn the fusions off produce the plain per-layer plan."""
+    import re
+
+    import backscrub_amd
+    path = model_path("deeplab", prefer_real=real)
+    if real and "synthetic" in os.path.basename(path):
+        pytest.skip("reference model not staged on this box")
+    for k in ("BSX_NO_IR_FUSE", "BSX_NO_HEAD0", "BSX_IR_GEOM", "BSX_H0_BH"):
+        monkeypatch.delenv(k, raising=False)
+    text = backscrub_amd.model_describe(path)
+    assert "fused with steps 1 and 2 (stem + depthwise + 1x1 in one tiled kernel)" in text
+    pairs = re.findall(r"\^ fused with step (\d+) \(expand \+ depthwise in one kernel: (\d+) channels x (\d+) rows per workgroup, (\d+) band", text)
+    assert len(pairs) == 16, text
+    steps = {int(m.group(1)): m for m in re.finditer(r"^ *(\d+) (\w+) +\S+ +in (\d+)x(\d+)x(\d+) -> out (\d+)x(\d+)x(\d+) k\dx\d s(\d) d(\d)", text, re.M)}
+    for dw_step, ch, bh, nb in pairs:
+        m = steps[int(dw_step)]
+        H, W, C, OH, S, d = int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6)), int(m.group(9)), int(m.group(10))
+        ch, bh, nb = int(ch), int(bh), int(nb)
+        assert m.group(2) == "dwconv" and C % ch == 0 and ch in (16, 24, 32)
+        assert nb * bh >= OH and (nb - 1) * bh < OH                       # the bands cover the output rows exactly once
+        rows = min(H, S * (bh - 1) + 2 * d + 1)
+        lds = rows * W * ch * 4
+        assert lds <= (150 if nb == 1 else 78) * 1024, (dw_step, lds)
+    monkeypatch.setenv("BSX_NO_IR_FUSE", "1")
+    monkeypatch.setenv("BSX_NO_HEAD0", "1")
+    plain = backscrub_amd.model_describe(path)
+    assert "fused with" not in plain and len(plain.splitlines()) < len(text.splitlines())
+
+
 # ---- hostile / unsupported files: an error string, never a crash, an exception across the C ABI or a wrong network ----
 def _describe_bytes(tmp_path, data, name="segm_hostile.tflite"):
     import ctypes
