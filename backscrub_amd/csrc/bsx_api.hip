@@ -192,6 +192,7 @@ int init_device_state(bsx_ctx* c) {
   BSX_HIP(c, hipMemcpy(c->d_weights16, c->plan.weights16.data(), c->plan.weights16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   // off = f32 MFMA; fast = plain f16 operands (1 term); fast16 = fast + the depthwise outputs of the fused blocks STORED as f16 (bit 4: kernels.hpp)
   if (const char* m = getenv("BSX_F16_GEMM")) c->f16_terms = !strcmp(m, "off") ? 0 : (!strcmp(m, "fast") ? 1 : (!strcmp(m, "fast16") ? 17 : 3));
+  if (const char* m = getenv("BSX_GEMM_RING")) { if (atoi(m) != 0 && c->f16_terms > 0) c->f16_terms |= 32; }       // LDS-DMA ring GEMM (experiment switch)
   // The per-frame program pays off when most tensors stay in LDS (Meet / MLKit families); graphs whose tensors mostly
   // spill (DeepLab: 33x33x480) run faster as one batch-wide launch per step.  BSX_FORCE_FRAME_PROGRAM / BSX_NO_FRAME_PROGRAM override.
   c->use_program = !c->plan.program.empty() && getenv("BSX_NO_FRAME_PROGRAM") == nullptr &&

@@ -18,6 +18,7 @@
 //  * Accumulation is ci-ascending FMA with the bias added last, the same association as
 //    the TFLite reference kernels the CPU oracle restates (differences are FMA rounding).
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.hpp"
 #include "mfma_tile.hpp"
@@ -254,6 +255,10 @@ typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int kHSA = kGemmBK + 8;        // halves per LDS row: 80 B → the 16-byte reads of 16 consecutive rows hit distinct bank quads
+// (An unpadded 64-byte row with the chunk XOR-swizzled by (0, 3, 2, 1)[row / 4] is conflict-free for the real ds_read_b128 lane groups — the padded
+//  rows leave SQ_LDS_BANK_CONFLICT at 50 % of SQ_LDS_IDX_ACTIVE — but measured 1-3 % SLOWER: the kernel is not LDS-bound and the swizzle costs VALU
+//  in the staging stores.  The ring kernel below, whose layout is produced by the DMA for free, uses it: hsw.)
+__device__ __forceinline__ int hsw(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 // NTW = 16-channel tiles per workgroup (4: a 128 x 64 tile; a 128 x 160 variant for the projection layers measured 25 % slower: registers)
 // XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 and every XCD has its own L2, so "consecutive workgroups
 // share the A tile" only helps if consecutive means consecutive ON ONE XCD.  A 1-D grid is re-indexed so that XCD k walks its own
@@ -266,13 +271,90 @@ __device__ __forceinline__ void xcd_tile(unsigned ncol, unsigned* col, long* row
   *col = wg - (unsigned)*row * ncol;
 }
 
+// Epilogue of the 16x16-tile GEMM kernels: quad transpose → this lane owns pixel (4g + q) of each m-tile and channels c0 .. c0+3 of each n-tile.
+// Instantiated twice and the (uniform) activation kind tested ONCE: a test per element is a taken branch per element.
+// ALL of the lane's bias / per-frame bias / residual quads are requested up front from clamped (always valid) addresses: written as
+// "skip the tile if it is outside" every (m-tile, n-tile) was its own basic block — load, wait, store, ten times in a row, each a full trip to
+// L2 / HBM under load — and timing the kernel without its epilogue showed a third of its time there (480 -> 80 project layer: 690 -> 446 us).
+template <int NTW>
+__device__ __forceinline__ void gemm_store_tile(f4acc (&acc)[2][NTW], long m_wave, int li, int g, int nt, int n_base, long M, int HW, int Cout,
+                                                const float* __restrict__ bias, const float* __restrict__ fbias, const float* __restrict__ res,
+                                                float* __restrict__ y, int act) {
+  const int q = li & 3;
+  if ((Cout & 3) == 0) {
+    auto epilogue = [&](auto actf) {
+      float4 bv[NTW], ex[2][NTW];                                         // ex: the per-frame bias (added before the activation) OR the residual (after): launch_step never passes both
+      int c0s[NTW];
+      long ms[2];
+      const bool fb_on = fbias != nullptr, res_on = res != nullptr;      // (uniform)
+#pragma unroll
+      for (int ni = 0; ni < NTW; ni++) {
+        c0s[ni] = n_base + 16 * ni + (li & ~3);
+        bv[ni] = *reinterpret_cast<const float4*>(bias + min(c0s[ni], Cout - 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; mi++) {
+        ms[mi] = m_wave + 16 * mi + 4 * g + q;
+#pragma unroll
+        for (int ni = 0; ni < NTW; ni++) ex[mi][ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (fb_on || res_on) {                                              // one uniform branch around all of the loads
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+          const long mc = min(ms[mi], M - 1);
+          const float* ep = fb_on ? fbias + (mc / HW) * (long)Cout : res + mc * Cout;
+#pragma unroll
+          for (int ni = 0; ni < NTW; ni++) ex[mi][ni] = *reinterpret_cast<const float4*>(ep + min(c0s[ni], Cout - 4));
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; mi++) {
+#pragma unroll
+        for (int ni = 0; ni < NTW; ni++) {
+          const float4 v = quad_transpose(acc[mi][ni], q);
+          float4 b4 = bv[ni];
+          const float4 e4 = ex[mi][ni];
+          if (fb_on) { b4.x += e4.x; b4.y += e4.y; b4.z += e4.z; b4.w += e4.w; }
+          float4 o = make_float4(actf(v.x + b4.x), actf(v.y + b4.y), actf(v.z + b4.z), actf(v.w + b4.w));
+          if (!fb_on && res_on) { o.x += e4.x; o.y += e4.y; o.z += e4.z; o.w += e4.w; }
+          if (ni < nt && ms[mi] < M && c0s[ni] < Cout) *reinterpret_cast<float4*>(y + ms[mi] * Cout + c0s[ni]) = o;
+        }
+      }
+    };
+    if (act >= kActHswish) epilogue([&](float v) { return act_slow(v, act); });
+    else { const ClampK ck = clamp_of(act); epilogue([&](float v) { return clampf(v, ck); }); }
+    return;
+  }
+  auto epilogue = [&](auto actf) {
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++) {
+      const long m = m_wave + 16 * mi + 4 * g + q;
+#pragma unroll
+      for (int ni = 0; ni < NTW; ni++) {
+        if (ni >= nt) continue;
+        const int c0 = n_base + 16 * ni + (li & ~3);
+        const float4 v = quad_transpose(acc[mi][ni], q);
+        if (m >= M || c0 >= Cout) continue;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < 4 && c0 + e < Cout; e++) {
+          float o = actf(vv[e] + bias[c0 + e] + (fbias ? fbias[(m / HW) * (long)Cout + c0 + e] : 0.f));
+          if (res) o += res[m * Cout + c0 + e];
+          y[m * Cout + c0 + e] = o;
+        }
+      }
+    }
+  };
+  if (act >= kActHswish) epilogue([&](float v) { return act_slow(v, act); });
+  else { const ClampK ck = clamp_of(act); epilogue([&](float v) { return clampf(v, ck); }); }
+}
+
 // (min 4 waves per SIMD: left alone the compiler takes 180 registers = 2 workgroups per CU, and the skinny-K expand layers — three K slabs
 //  per tile — then spend their time waiting for the first slab: 128 registers fit without spills)
 template <int TERMS, int NTW, bool IN16 = false>      // IN16: x holds f16 values (written by ir_expand_dw_k<.., OUT16>), TERMS == 1 only
 __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                           const float* __restrict__ res, const float* __restrict__ scale, const float* __restrict__ addx,
                                                           float* __restrict__ y, long M, int HW, int Cin, int Kp, int Cout, int cout_pad, int act,
-                                                          const float* __restrict__ fbias) {
+                                                          const float* __restrict__ fbias, int dbg = 0) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[kGemmBM * kHSA];
   __shared__ __attribute__((aligned(16))) _Float16 Al[kGemmBM * kHSA];
   __shared__ __attribute__((aligned(16))) _Float16 Bh[NTW * 16 * kHSA];
@@ -293,7 +375,7 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int f = tid + i * kThreads, row = f >> 3, kq = (f & 7) * 4;
-      const long m = m_base + row;
+      const long m = (dbg & 1) ? row : m_base + row;
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M && k0 + kq < Cin) {
         float4 v;
@@ -325,6 +407,7 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
   for (int mi = 0; mi < 2; mi++)
 #pragma unroll
     for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = f4acc{0.f, 0.f, 0.f, 0.f};
+  const int gs = 8 * g;
   fetch(0);
   for (int k0 = 0; k0 < Kp; k0 += kGemmBK) {
 #pragma unroll
@@ -354,15 +437,15 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
     h8v ah[2], al[2];
 #pragma unroll
     for (int mi = 0; mi < 2; mi++) {
-      ah[mi] = *reinterpret_cast<const h8v*>(&Ah[(32 * wave + 16 * mi + li) * kHSA + 8 * g]);
-      if (TERMS == 3) al[mi] = *reinterpret_cast<const h8v*>(&Al[(32 * wave + 16 * mi + li) * kHSA + 8 * g]);
+      ah[mi] = *reinterpret_cast<const h8v*>(&Ah[(32 * wave + 16 * mi + li) * kHSA + gs]);
+      if (TERMS == 3) al[mi] = *reinterpret_cast<const h8v*>(&Al[(32 * wave + 16 * mi + li) * kHSA + gs]);
     }
 #pragma unroll
     for (int ni = 0; ni < NTW; ni++) {
       if (ni < nt) {
-        const h8v bh = *reinterpret_cast<const h8v*>(&Bh[(16 * ni + li) * kHSA + 8 * g]);
+        const h8v bh = *reinterpret_cast<const h8v*>(&Bh[(16 * ni + li) * kHSA + gs]);
         h8v bl = bh;
-        if (TERMS == 3) bl = *reinterpret_cast<const h8v*>(&Bl[(16 * ni + li) * kHSA + 8 * g]);
+        if (TERMS == 3) bl = *reinterpret_cast<const h8v*>(&Bl[(16 * ni + li) * kHSA + gs]);
 #pragma unroll
         for (int mi = 0; mi < 2; mi++) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
@@ -375,37 +458,150 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
     }
     __syncthreads();
   }
-  const int q = li & 3;
-  // the epilogue is instantiated twice and the (uniform) activation kind tested ONCE: a test per element is a taken branch per element
-  auto epilogue = [&](auto actf) {
-  #pragma unroll
-    for (int mi = 0; mi < 2; mi++) {
-      const long m = m_base + 32 * wave + 16 * mi + 4 * g + q;
-  #pragma unroll
-      for (int ni = 0; ni < NTW; ni++) {
-        if (ni >= nt) continue;
-        const int c0 = n_base + 16 * ni + (li & ~3);
-        const float4 v = quad_transpose(acc[mi][ni], q);
-        if (m >= M || c0 >= Cout) continue;
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        if ((Cout & 3) == 0) {
-          float4 bv = *reinterpret_cast<const float4*>(bias + c0);
-          if (fbias) { const float4 fb = *reinterpret_cast<const float4*>(fbias + (m / HW) * (long)Cout + c0); bv.x += fb.x; bv.y += fb.y; bv.z += fb.z; bv.w += fb.w; }
-          float4 o = make_float4(actf(vv[0] + bv.x), actf(vv[1] + bv.y), actf(vv[2] + bv.z), actf(vv[3] + bv.w));
-          if (res) { const float4 r = *reinterpret_cast<const float4*>(res + m * Cout + c0); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-          *reinterpret_cast<float4*>(y + m * Cout + c0) = o;
-        } else {
-          for (int e = 0; e < 4 && c0 + e < Cout; e++) {
-            float o = actf(vv[e] + bias[c0 + e] + (fbias ? fbias[(m / HW) * (long)Cout + c0 + e] : 0.f));
-            if (res) o += res[m * Cout + c0 + e];
-            y[m * Cout + c0 + e] = o;
+  if (dbg & 2) { if (acc[0][0][0] != 12345.678f) return; }
+  gemm_store_tile<NTW>(acc, m_base + 32 * wave, li, g, nt, n_base, M, HW, Cout, bias, fbias, res, y, act);
+}
+
+// ---- the same split-f16 GEMM with BOTH operands delivered by LDS-DMA rings (f32 activations, no prologue ops) ----------------------------------
+// pw_gemm_f16s_k keeps at most ONE K slab per workgroup in flight, in registers (16 floats per lane: two slabs ahead cost the fourth workgroup per
+// CU and lost), and PMC shows its waves waiting on memory for 71-79 % of their cycles at ~4.1 TB/s: too few bytes in flight, not too few MFMAs
+// (MFMA pipe 10-18 % busy).  Here nothing in flight occupies a register: every wave moves ITS OWN 32 rows x 32 floats of A (4 pieces of 1 KB) and its
+// share of the weight slab with global_load_lds_dwordx4 into a ring of kRingD stages, kRingD - 1 slabs ahead of the one being multiplied — 2 workgroups
+// per CU x 2 stages x 16 KB = 64 KB per CU continuously outstanding.  A stays f32 in LDS and is split into halves by the wave that multiplies it
+// (a wave owns its rows: every element is converted exactly once, as before); A needs no barrier at all (own rows, own vmcnt), the weights one per slab.
+// Ring reads are inline-asm ds_read_b128: the compiler orders any LDS read it can see behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which
+// would collapse the ring to depth 1; the waits below are explicit (vmcnt counts in order: stage k is complete when at most the pieces of the newer
+// stages remain).  Layouts are XOR-swizzled ON THE GLOBAL SIDE (the DMA writes lane l at base + 16 l): A row r holds float4 chunk c at position
+// c ^ asw(r), weights chunk c of channel row r at c ^ hsw(r) — both conflict-free for the b128 lane groups (see hsw above).
+constexpr int kRingD = 3;
+typedef __attribute__((address_space(3))) void* lds_vp_t;
+typedef const __attribute__((address_space(1))) void* glb_vp_t;
+__device__ __forceinline__ int asw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
+template <int OFF> __device__ __forceinline__ f4v lds_rd_f4(unsigned addr) { f4v v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); return v; }
+template <int OFF> __device__ __forceinline__ h8v lds_rd_h8(unsigned addr) { h8v v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); return v; }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TERMS, int NTW>
+__global__ __launch_bounds__(kThreads, 2) void pw_gemm_ring_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
+                                                              const float* __restrict__ res, float* __restrict__ y, long M, int HW, int Cin, int Kp, int Cout,
+                                                              int cout_pad, int act, const float* __restrict__ fbias, int dbg = 0) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];
+  constexpr int PL = TERMS == 3 ? 2 : 1;                    // weight planes (hi | lo)
+  constexpr int NPB = PL * NTW;                             // 1 KB weight pieces per slab (16 channels x 32 halves each)
+  constexpr int NBW = (NPB + 3) / 4;                        // ... per wave (the last ones may repeat a piece: same bytes to the same place)
+  constexpr int NP = 4 + NBW;                               // DMA instructions per wave and stage
+  constexpr int kAStage = kGemmBM * kGemmBK * 4, kBStage = NPB * 1024;       // bytes
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  unsigned tcol; long trow;
+  xcd_tile((unsigned)((Cout + NTW * 16 - 1) / (NTW * 16)), &tcol, &trow);
+  const long m_base = trow * kGemmBM;
+  const int n_base = (int)tcol * (NTW * 16);
+  const int nt = min(NTW, (cout_pad - n_base) >> 4);
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_vp_t)ring;             // A stages first, then the weight stages
+  char* ringb = reinterpret_cast<char*>(ring);
+  // ---- DMA sources.  A piece p = rows 8p .. 8p+7 of the wave's 32; lane = (row l >> 3, chunk position l & 7)
+  const float* pa[4];
+  int ca[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int r = 8 * p + (lane >> 3);
+    const long m = min(((dbg & 1) ? 0 : m_base) + 32 * wave + r, M - 1);                      // rows past the end: a valid row, results dropped
+    ca[p] = 4 * ((lane & 7) ^ asw(r & 15));
+    pa[p] = x + m * Cin + ca[p];
+  }
+  const _Float16* pb[NBW];
+  int qb[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; j++) {
+    const int qq = (wave + 4 * j) % NPB, plane = qq / NTW, tile = qq - plane * NTW, r = lane >> 2;
+    const int ch = min(n_base + 16 * tile + r, cout_pad - 1);
+    qb[j] = qq;
+    pb[j] = w16 + ((size_t)plane * cout_pad + ch) * Kp + 8 * ((lane & 3) ^ hsw(r));
+  }
+  auto issue = [&](int slab, int stage) {
+    const int k0 = slab * kGemmBK;
+    char* as = ringb + stage * kAStage + wave * 4096;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const float* src = pa[p] + k0;
+      if (k0 + ca[p] >= Cin) src -= ca[p];                                  // K tail: any finite value (chunk 0 of the slab); its weights are zero
+      __builtin_amdgcn_global_load_lds((glb_vp_t)src, (lds_vp_t)(as + p * 1024), 16, 0, 0);
+    }
+    char* bs = ringb + kRingD * kAStage + stage * kBStage;
+#pragma unroll
+    for (int j = 0; j < NBW; j++) __builtin_amdgcn_global_load_lds((glb_vp_t)(pb[j] + k0), (lds_vp_t)(bs + qb[j] * 1024), 16, 0, 0);
+  };
+  f4acc acc[2][NTW];
+#pragma unroll
+  for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = f4acc{0.f, 0.f, 0.f, 0.f};
+  // fragment addresses inside a stage: A row li (+16 for the second m-tile = offset 2048), chunks 2g and 2g + 1 (positions differ in bit 0: ^ 16 bytes)
+  const unsigned a_lane = lds0 + wave * 4096 + li * 128 + (((2 * g) ^ asw(li)) << 4);
+  const unsigned b_lane = lds0 + kRingD * kAStage + li * 64 + ((g ^ hsw(li)) << 4);
+  const int nslab = Kp / kGemmBK;
+#pragma unroll
+  for (int sl = 0; sl < kRingD - 1; sl++) if (sl < nslab) issue(sl, sl);
+  int stage = 0;
+  for (int k = 0; k < nslab; k++) {
+    // stage k complete for THIS wave (newer stages may still be in flight), then for everyone (the weights are shared)
+    if (k + kRingD - 2 < nslab) wait_vm<(kRingD - 2) * NP>();
+    else wait_vm<0>();                                                      // (kRingD = 3: the last slab has nothing newer behind it)
+    asm volatile("s_barrier" ::: "memory");           // (as a builtin the compiler puts s_waitcnt vmcnt(0) in front of it on gfx9: every stage would drain)
+    if (k + kRingD - 1 < nslab) issue(k + kRingD - 1, stage == 0 ? kRingD - 1 : stage - 1);      // the stage everybody finished before the barrier
+    const unsigned av = a_lane + stage * kAStage, bv = b_lane + stage * kBStage;
+    f4v a00 = lds_rd_f4<0>(av), a01 = lds_rd_f4<0>(av ^ 16u), a10 = lds_rd_f4<2048>(av), a11 = lds_rd_f4<2048>(av ^ 16u);
+    h8v bh = lds_rd_h8<0>(bv), bl = bh;
+    if (TERMS == 3) bl = lds_rd_h8<NTW * 1024>(bv);
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11) : "n"(TERMS == 3 ? 2 : 1) : "memory");   // A landed; the weights may still be on their way
+    h8v ah[2], al[2];
+    auto split = [&](const f4v v0, const f4v v1, h8v& hi, h8v& lo) {
+      const h2v a01h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y)), a23h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w));
+      const h2v a45h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y)), a67h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.z, v1.w));
+      hi = h8v{a01h.x, a01h.y, a23h.x, a23h.y, a45h.x, a45h.y, a67h.x, a67h.y};
+      lo = hi;
+      if (TERMS == 3) {
+        const h2v l01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.x - (float)a01h.x, v0.y - (float)a01h.y));
+        const h2v l23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.z - (float)a23h.x, v0.w - (float)a23h.y));
+        const h2v l45 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.x - (float)a45h.x, v1.y - (float)a45h.y));
+        const h2v l67 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.z - (float)a67h.x, v1.w - (float)a67h.y));
+        lo = h8v{l01.x, l01.y, l23.x, l23.y, l45.x, l45.y, l67.x, l67.y};
+      }
+    };
+    split(a00, a01, ah[0], al[0]);
+    split(a10, a11, ah[1], al[1]);
+    auto mul = [&](auto NI, h8v& wh_, h8v& wl_) {
+      constexpr int ni = decltype(NI)::value;
+      h8v nh = wh_, nl = wl_;
+      if (ni + 1 < NTW) {                                                  // next tile's weights requested before this tile's MFMAs
+        nh = lds_rd_h8<(ni + 1) * 1024>(bv);
+        nl = nh;
+        if (TERMS == 3) nl = lds_rd_h8<(NTW + ni + 1) * 1024>(bv);
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(wh_), "+v"(wl_) : "n"(TERMS == 3 ? 2 : 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh_), "+v"(wl_)::"memory");
+      }
+      if (ni < nt) {
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], wh_, acc[mi][ni], 0, 0, 0);
+          if (TERMS == 3) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], wh_, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], wl_, acc[mi][ni], 0, 0, 0);
           }
         }
       }
-    }
-  };
-  if (act >= kActHswish) epilogue([&](float v) { return act_slow(v, act); });
-  else { const ClampK ck = clamp_of(act); epilogue([&](float v) { return clampf(v, ck); }); }
+      wh_ = nh; wl_ = nl;
+    };
+    mul(std::integral_constant<int, 0>{}, bh, bl);
+    if constexpr (NTW > 1) mul(std::integral_constant<int, 1>{}, bh, bl);
+    if constexpr (NTW > 2) mul(std::integral_constant<int, 2>{}, bh, bl);
+    if constexpr (NTW > 3) mul(std::integral_constant<int, 3>{}, bh, bl);
+    if constexpr (NTW > 4) mul(std::integral_constant<int, 4>{}, bh, bl);
+    stage = stage + 1 == kRingD ? 0 : stage + 1;
+  }
+  if (dbg & 2) { if (acc[0][0][0] != 12345.678f) return; }
+  gemm_store_tile<NTW>(acc, m_base + 32 * wave, li, g, nt, n_base, M, HW, Cout, bias, fbias, res, y, act);
 }
 
 // ---- inverted-residual front half: expand 1x1 (+act) → depthwise 3x3 (+act) as ONE kernel ----------------------------------------------
@@ -418,7 +614,8 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
 // write AND the largest read — never reaches HBM: 4 of the block's 6 big tensor passes become 2.
 constexpr int kIrThreads = 512, kIrSeg = 9;
 template <int TERMS, int SLABS, int CH, bool OUT16 = false>      // OUT16: the depthwise result is stored as f16 (reduced-precision storage mode)
-__global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
+// (row-banded layers run TWO workgroups per CU = 4 waves per SIMD, i.e. within 128 registers: the 24-channel variant fits by itself, the 16-channel one is held to it)
+__global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void ir_expand_dw_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                             const float* __restrict__ dww, const float* __restrict__ dwb, float* __restrict__ y,
                                                             int H, int W, int Cin, int Kp, int Cexp, int cout_pad, int act1, int act2, int d, int S, int pt, int pl,
                                                             int OH, int OW, int BH, int nbands, int phases) {
@@ -525,6 +722,7 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
   // the depthwise weights + bias of the chunk: [9][CH] + [CH] behind the tile (a lane's channel quad changes from item to item when CH / 4 does not
   // divide the workgroup size, so registers cannot hold them; nine global loads per item were most of the stride-2 phase)
   float* dwl = ir_ex + (size_t)(e1 - e0) * W * CH;
+  if (tid < 4) dwl[10 * CH + tid] = 0.f;                                 // the quad every row outside the image is read from (phase 2, stride 1)
   for (int i = tid; i < 10 * CQ; i += kIrThreads) {
     const int k = i / CQ, cq = i - k * CQ;
     *reinterpret_cast<f4v*>(dwl + k * CH + 4 * cq) = k < 9 ? *reinterpret_cast<const f4v*>(dww + (size_t)k * Cexp + n_base + 4 * cq)
@@ -535,10 +733,16 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
   const f4v zero = {0.f, 0.f, 0.f, 0.f};
   if (S == 1) {
     // ---- phase 2, stride 1 (SAME, dilation d).  Item = (segment, phase r, column, channel quad); a column is walked d rows at a time in
-    // segments of at most kIrSeg outputs so that every dilation offers ~1000 items to the 512 lanes.
+    // segments of at most kIrSeg outputs so that every dilation offers ~1000 items to the 512 lanes.  The phase is VALU-issue bound (PMC: 0.3
+    // VALU instructions per wave quad-cycle, MFMA pipe 11 %), so the walk is written for instruction count: the 3-row window ROTATES BY NAME
+    // (three steps per loop trip: no register moves — they were 12 of ~60 instructions per output), rows outside the image are read from a quad of
+    // zeros in LDS through an address select (no branch, no zero-fill of the window), and the item's two divisions are multiplications.
     const int L = (oy1 - oy0 + d - 1) / d, nseg = (L + kIrSeg - 1) / kIrSeg, cols = d * W, total = nseg * cols * CQ;
+    const unsigned mcols = 0xFFFFFFFFu / (unsigned)cols + 1u, mw = 0xFFFFFFFFu / (unsigned)W + 1u;      // t / cols, rc / W: exact below 2^16 (checked at launch)
+    const float* zq = dwl + 10 * CH;
     for (int item = tid; item < total; item += kIrThreads) {
-      const int t = item / CQ, cq = item - t * CQ, seg = t / cols, rc = t - seg * cols, r = rc / W, xx = rc - r * W;
+      const int t = item / CQ, cq = item - t * CQ, seg = (int)__umulhi((unsigned)t, mcols), rc = t - seg * cols,
+                r = (int)__umulhi((unsigned)rc, mw), xx = rc - r * W;
       f4v wq[9];
 #pragma unroll
       for (int k = 0; k < 9; k++) wq[k] = *reinterpret_cast<const f4v*>(dwl + k * CH + 4 * cq);
@@ -548,22 +752,21 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
       const bool vl = xx - d >= 0, vr = xx + d < W;
       if (!vl) { wq[0] = zero; wq[3] = zero; wq[6] = zero; }
       if (!vr) { wq[2] = zero; wq[5] = zero; wq[8] = zero; }
+      const int xl = vl ? xx - d : xx, xr = vr ? xx + d : xx, rstep = d * W * CH;
       const float* col = ir_ex + (size_t)xx * CH + 4 * cq;
-      const int dl = vl ? -d * CH : 0, dr = vr ? d * CH : 0, rstep = d * W * CH;
+      const float* coll = ir_ex + (size_t)xl * CH + 4 * cq;
+      const float* colr = ir_ex + (size_t)xr * CH + 4 * cq;
       auto row = [&](int yy, int off, f4v (&o)[3]) {                   // off = (yy - e0) * W * CH
-        if (yy >= 0 && yy < H) {
-          o[0] = *reinterpret_cast<const f4v*>(col + off + dl);
-          o[1] = *reinterpret_cast<const f4v*>(col + off);
-          o[2] = *reinterpret_cast<const f4v*>(col + off + dr);
-        } else { o[0] = zero; o[1] = zero; o[2] = zero; }
+        const bool in = yy >= 0 && yy < H;
+        o[0] = *reinterpret_cast<const f4v*>(in ? coll + off : zq);
+        o[1] = *reinterpret_cast<const f4v*>(in ? col + off : zq);
+        o[2] = *reinterpret_cast<const f4v*>(in ? colr + off : zq);
       };
       int yy = oy0 + r + seg * kIrSeg * d;
       int off = (yy - e0) * W * CH;
       float* yp = yf + ((size_t)yy * OW + xx) * Cexp + n_base + 4 * cq;
       const size_t ystep = (size_t)d * OW * Cexp;
-      f4v p[3], c[3], nx[3];
-      row(yy - d, off - rstep, p); row(yy, off, c);
-      for (int k = 0; k < kIrSeg && yy < oy1; k++, yy += d, off += rstep, yp += ystep) {
+      auto step = [&](const f4v (&p)[3], const f4v (&c)[3], f4v (&nx)[3]) {
         row(yy + d, off + rstep, nx);
         f4v acc = zero;
 #pragma unroll
@@ -575,8 +778,18 @@ __global__ __launch_bounds__(kIrThreads) void ir_expand_dw_k(const float* __rest
         acc += bq;
         if (OUT16) *reinterpret_cast<h4v*>(yh + (yp - yf)) = h4v{(_Float16)clampf(acc.x, k2), (_Float16)clampf(acc.y, k2), (_Float16)clampf(acc.z, k2), (_Float16)clampf(acc.w, k2)};
         else *reinterpret_cast<float4*>(yp) = make_float4(clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2));
-#pragma unroll
-        for (int fx = 0; fx < 3; fx++) { p[fx] = c[fx]; c[fx] = nx[fx]; }
+        yy += d; off += rstep; yp += ystep;
+      };
+      f4v ra[3], rb[3], rc3[3];
+      row(yy - d, off - rstep, ra); row(yy, off, rb);
+      static_assert(kIrSeg % 3 == 0, "the window rotates by name in groups of three steps");
+      for (int k = 0; k < kIrSeg / 3; k++) {
+        if (yy >= oy1) break;
+        step(ra, rb, rc3);
+        if (yy >= oy1) break;
+        step(rb, rc3, ra);
+        if (yy >= oy1) break;
+        step(rc3, ra, rb);
       }
     }
   } else {
@@ -725,9 +938,10 @@ __global__ __launch_bounds__(kH0Threads) void dl_head0_k(const float* __restrict
       const float* col = S + (size_t)xx * 16 + 4 * cq;
       const int dl = vl ? -16 : 0, dr = vr ? 16 : 0, rs = W1 * 16;
       auto row = [&](int r, f4v (&o)[3]) { o[0] = *reinterpret_cast<const f4v*>(col + r * rs + dl); o[1] = *reinterpret_cast<const f4v*>(col + r * rs); o[2] = *reinterpret_cast<const f4v*>(col + r * rs + dr); };
-      f4v p[3], c[3], nx[3];
-      row(0, p); row(1, c);
-      for (int r = 0; r < oy1 - oy0; r++) {
+      // (the 3-row window rotates by name, three steps per loop trip: no register moves)
+      const int nr = oy1 - oy0;
+      int r = 0;
+      auto step = [&](const f4v (&p)[3], const f4v (&c)[3], f4v (&nx)[3]) {
         row(r + 2, nx);
         f4v acc = zero;
 #pragma unroll
@@ -738,8 +952,16 @@ __global__ __launch_bounds__(kH0Threads) void dl_head0_k(const float* __restrict
         for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(nx[fx], wq[6 + fx], acc);
         acc += bq;
         *reinterpret_cast<float4*>(D + ((size_t)r * W1 + xx) * 16 + 4 * cq) = make_float4(clampf(acc.x, kd), clampf(acc.y, kd), clampf(acc.z, kd), clampf(acc.w, kd));
-#pragma unroll
-        for (int fx = 0; fx < 3; fx++) { p[fx] = c[fx]; c[fx] = nx[fx]; }
+        r++;
+      };
+      f4v ra[3], rb[3], rc[3];
+      row(0, ra); row(1, rb);
+      while (r < nr) {
+        step(ra, rb, rc);
+        if (r >= nr) break;
+        step(rb, rc, ra);
+        if (r >= nr) break;
+        step(rc, ra, rb);
       }
     }
   }
@@ -1199,6 +1421,8 @@ hipError_t nn_prepare() {
   BSX_ATTR_IR16(1, 1); BSX_ATTR_IR16(1, 2); BSX_ATTR_IR16(1, 3); BSX_ATTR_IR16(3, 1); BSX_ATTR_IR16(3, 2); BSX_ATTR_IR16(3, 3);
 #undef BSX_ATTR_IR16
   BSX_ATTR(dl_head0_k);
+  BSX_ATTR((pw_gemm_ring_k<3, 3>)); BSX_ATTR((pw_gemm_ring_k<3, 4>)); BSX_ATTR((pw_gemm_ring_k<3, 5>));
+  BSX_ATTR((pw_gemm_ring_k<1, 3>)); BSX_ATTR((pw_gemm_ring_k<1, 4>)); BSX_ATTR((pw_gemm_ring_k<1, 5>));
 #undef BSX_ATTR_IR
 #undef BSX_ATTR
   return hipSuccess;
@@ -1226,7 +1450,8 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dws.OH, dws.sh, dws.dh);
         if (ig.CH == 0) return hipErrorInvalidValue;                 // the planner checked the same function
         const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
-        const size_t lds = ((size_t)ig.rows * st.OW * ig.CH + 10 * (size_t)ig.CH) * sizeof(float);
+        const size_t lds = ((size_t)ig.rows * st.OW * ig.CH + 10 * (size_t)ig.CH + 4) * sizeof(float);      // band + depthwise weights and bias + a quad of zeros
+        if ((long)ig.rows * st.OW * dws.dh >= 65536) return hipErrorInvalidValue;   // the kernel divides item indices by multiplication
         const dim3 gi((unsigned)(st.Cout / ig.CH) * (unsigned)ig.nbands * (unsigned)n);
         const int slabs = st.k16_pad / 32;
         static const int ir_phases = getenv("BSX_IR_PHASES") ? atoi(getenv("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
@@ -1252,15 +1477,27 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       if (!no_gemm && M >= 8192 && (st.Cin & 3) == 0 && st.Cin >= 8 && st.cout_pad % 16 == 0 && st.cout_pad >= 16) {
         dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);
         if (weights16 && st.k16_pad > 0 && (f16_terms & 15) > 0) {        // split-f16 (3 terms, f32-grade) or plain f16-input (1 term) MFMA
+          if (st.out_bias >= 0 && st.residual >= 0) return hipErrorInvalidValue;      // the epilogue carries ONE extra operand per tile (see gemm_store_tile)
           const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
           // column tiles: 64 channels (NTW = 4), or 80 / 48 in ONE tile where that covers the whole layer (NTW = 5 / 3: the A block is
           // staged and split once instead of once per column tile — the 480 -> 80 and 288 -> 48 project layers)
           static const bool wide_ok = getenv("BSX_NO_GEMM_NTW") == nullptr;
+          static const int gemm_dbg = getenv("BSX_GEMM_DBG") ? atoi(getenv("BSX_GEMM_DBG")) : 0;      // timing experiments: 1 = A from one L2-resident block, 2 = no stores
           const int ntw = (wide_ok && st.Cout % 80 == 0) ? 5 : ((wide_ok && st.Cout == 48) ? 3 : 4);
           const unsigned ncol = (unsigned)((st.Cout + ntw * 16 - 1) / (ntw * 16));
           if ((unsigned long long)gg.x * ncol >= (1ull << 31)) return hipErrorInvalidValue;
           const dim3 gw(gg.x * ncol);                              // 1-D: the kernel derives (column tile, row block) XCD-aware
-#define BSX_F16S(T, N) pw_gemm_f16s_k<T, N><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias))
+          // f32 activations, no prologue ops: both operands through the LDS-DMA rings (bit 5 of f16_terms; BSX_GEMM_RING=0 clears it)
+          if ((f16_terms & 32) && st.in_scale < 0 && st.in2 < 0 && !((f16_terms & 16) && st.in_from_fused_dw)) {
+            const int terms = f16_terms & 15;
+            const size_t lds = (size_t)kRingD * (kGemmBM * kGemmBK * 4 + (terms == 3 ? 2 : 1) * ntw * 1024);
+#define BSX_RING(T, N) pw_gemm_ring_k<T, N><<<gw, kThreads, lds, s>>>(P(st.in0), w16, b, P(st.residual), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias), gemm_dbg)
+            if (terms == 3) { if (ntw == 5) BSX_RING(3, 5); else if (ntw == 3) BSX_RING(3, 3); else BSX_RING(3, 4); }
+            else { if (ntw == 5) BSX_RING(1, 5); else if (ntw == 3) BSX_RING(1, 3); else BSX_RING(1, 4); }
+#undef BSX_RING
+            break;
+          }
+#define BSX_F16S(T, N) pw_gemm_f16s_k<T, N><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias), gemm_dbg)
           if ((f16_terms & 15) == 3) { if (ntw == 5) BSX_F16S(3, 5); else if (ntw == 3) BSX_F16S(3, 3); else BSX_F16S(3, 4); }
           else if ((f16_terms & 16) && st.in_from_fused_dw) {        // its input was stored as f16 by the fused kernel before it (same M rule on both sides)
 #define BSX_F16S16(N) pw_gemm_f16s_k<1, N, true><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias))

@@ -263,15 +263,19 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc.close()
 
 
-def test_deeplab_batch_of_eight_uses_the_gemm_kernels_on_every_level(bs, oracle):
+@pytest.mark.parametrize("ring", ["0", "1"])
+def test_deeplab_batch_of_eight_uses_the_gemm_kernels_on_every_level(bs, oracle, monkeypatch, ring):
     """With 8 streams even the 33x33 layers have M >= 8192 rows, i.e. every pointwise convolution runs as the split-f16 MFMA GEMM (64-, 80- and
-    48-column tiles) next to the fused kernels: logits of all eight streams within 1e-4 of the oracle's."""
+    48-column tiles) next to the fused kernels: logits of all eight streams within 1e-4 of the oracle's.  Both GEMM kernels: operands staged
+    through registers (ring = 0) and delivered by the LDS-DMA rings (ring = 1); 8 x 1089 rows = 68 full 128-row blocks + a block of 8 rows."""
     from backscrub_amd import synth
     path = model_path("deeplab")
     W, H = VGA
     n = 8
     frames = np.stack([synth.frame(W, H, i % 3, i) for i in range(n)])
+    monkeypatch.setenv("BSX_GEMM_RING", ring)
     mg = bs.MaskGen(path, W, H, n_streams=n)
+    monkeypatch.delenv("BSX_GEMM_RING")
     mg.run_stage(0, _dev(frames))
     mg.run_stage(1, n=n)
     got = mg.output_tensor().cpu().numpy()
