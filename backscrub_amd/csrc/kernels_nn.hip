@@ -254,6 +254,33 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+// x = hi + lo for two floats: hi = the f16 below |x| (round toward zero: never overflows to inf), lo = f16(x - hi).  The residual is ONE mixed-precision
+// FMA per element (v_fma_mix{lo,hi}_f16: f16 x f32 + f32 → f16, x - hi is exact in f32) instead of convert-back + subtract + pack: 3 instructions per
+// pair, not 5 — the split is most of the VALU work of every kernel that multiplies f32 activations on the f16 matrix cores.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+}
+template <int TERMS, typename Q>                    // Q: float4 or f4v
+__device__ __forceinline__ void split8(const Q v0, const Q v1, h8v& hi, h8v& lo) {
+  u4v h, l;
+  if (TERMS == 3) {
+    unsigned a, b;
+    split_pair(v0.x, v0.y, a, b); h.x = a; l.x = b;
+    split_pair(v0.z, v0.w, a, b); h.y = a; l.y = b;
+    split_pair(v1.x, v1.y, a, b); h.z = a; l.z = b;
+    split_pair(v1.z, v1.w, a, b); h.w = a; l.w = b;
+  } else {
+    h.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y)); h.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w));
+    h.z = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y)); h.w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.z, v1.w));
+    l = h;
+  }
+  hi = __builtin_bit_cast(h8v, h);
+  lo = __builtin_bit_cast(h8v, l);
+}
 constexpr int kHSA = kGemmBK + 8;        // halves per LDS row: 80 B → the 16-byte reads of 16 consecutive rows hit distinct bank quads
 // (An unpadded 64-byte row with the chunk XOR-swizzled by (0, 3, 2, 1)[row / 4] is conflict-free for the real ds_read_b128 lane groups — the padded
 //  rows leave SQ_LDS_BANK_CONFLICT at 50 % of SQ_LDS_IDX_ACTIVE — but measured 1-3 % SLOWER: the kernel is not LDS-bound and the swizzle costs VALU
@@ -371,26 +398,26 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
   constexpr int kBP = (NTW * 64 + kThreads - 1) / kThreads;       // 16-byte weight pieces per lane and K step
   float4 ra[4];
   h8v rbh[kBP], rbl[kBP];
+  // Every A load is unconditional: rows past M read row M - 1 (their results are dropped), quads past Cin read the slab's first quad (any finite
+  // value: their weights are zero) — as predicated loads each came with a zero fill, a select and a divergent branch.
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int f = tid + i * kThreads, row = f >> 3, kq = (f & 7) * 4;
-      const long m = (dbg & 1) ? row : m_base + row;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M && k0 + kq < Cin) {
-        float4 v;
-        if (IN16) { const h4v hv = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(x) + m * Cin + k0 + kq); v = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w); }
-        else v = *reinterpret_cast<const float4*>(x + m * Cin + k0 + kq);
-        if (scale) {
-          const float4 sv = *reinterpret_cast<const float4*>(scale + (m / HW) * (long)Cin + k0 + kq);
-          v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w);
-        }
-        if (addx) {
-          const float4 av = *reinterpret_cast<const float4*>(addx + m * Cin + k0 + kq);
-          v.x = __fadd_rn(v.x, av.x); v.y = __fadd_rn(v.y, av.y); v.z = __fadd_rn(v.z, av.z); v.w = __fadd_rn(v.w, av.w);
-        }
-        ra[i] = v;
+      const long m = min((dbg & 1) ? (long)row : m_base + row, M - 1);
+      const int k = k0 + kq < Cin ? k0 + kq : k0;
+      float4 v;
+      if (IN16) { const h4v hv = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(x) + m * Cin + k); v = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w); }
+      else v = *reinterpret_cast<const float4*>(x + m * Cin + k);
+      if (scale) {                                                         // (uniform)
+        const float4 sv = *reinterpret_cast<const float4*>(scale + (m / HW) * (long)Cin + k);
+        v.x = __fmul_rn(v.x, sv.x); v.y = __fmul_rn(v.y, sv.y); v.z = __fmul_rn(v.z, sv.z); v.w = __fmul_rn(v.w, sv.w);
       }
+      if (addx) {
+        const float4 av = *reinterpret_cast<const float4*>(addx + m * Cin + k);
+        v.x = __fadd_rn(v.x, av.x); v.y = __fadd_rn(v.y, av.y); v.z = __fadd_rn(v.z, av.z); v.w = __fadd_rn(v.w, av.w);
+      }
+      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < kBP; i++) {
@@ -414,15 +441,16 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
     for (int i = 0; i < 4; i++) {
       const int f = tid + i * kThreads, row = f >> 3, kq = (f & 7) * 4;
       const float4 v = ra[i];
-      const h2v h01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)), h23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
-      const h4v hi = {h01.x, h01.y, h23.x, h23.y};
-      *reinterpret_cast<h4v*>(&Ah[row * kHSA + kq]) = hi;
+      u2v hi, lo;
       if (TERMS == 3) {
-        const h2v l01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01.x, v.y - (float)h01.y));
-        const h2v l23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23.x, v.w - (float)h23.y));
-        const h4v lo = {l01.x, l01.y, l23.x, l23.y};
-        *reinterpret_cast<h4v*>(&Al[row * kHSA + kq]) = lo;
+        unsigned a, b;
+        split_pair(v.x, v.y, a, b); hi.x = a; lo.x = b;
+        split_pair(v.z, v.w, a, b); hi.y = a; lo.y = b;
+        *reinterpret_cast<u2v*>(&Al[row * kHSA + kq]) = lo;
+      } else {
+        hi.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)); hi.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
       }
+      *reinterpret_cast<u2v*>(&Ah[row * kHSA + kq]) = hi;
     }
 #pragma unroll
     for (int i = 0; i < kBP; i++) {
@@ -556,17 +584,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_gemm_ring_k(const float* __res
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11) : "n"(TERMS == 3 ? 2 : 1) : "memory");   // A landed; the weights may still be on their way
     h8v ah[2], al[2];
     auto split = [&](const f4v v0, const f4v v1, h8v& hi, h8v& lo) {
-      const h2v a01h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y)), a23h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w));
-      const h2v a45h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y)), a67h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.z, v1.w));
-      hi = h8v{a01h.x, a01h.y, a23h.x, a23h.y, a45h.x, a45h.y, a67h.x, a67h.y};
-      lo = hi;
-      if (TERMS == 3) {
-        const h2v l01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.x - (float)a01h.x, v0.y - (float)a01h.y));
-        const h2v l23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.z - (float)a23h.x, v0.w - (float)a23h.y));
-        const h2v l45 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.x - (float)a45h.x, v1.y - (float)a45h.y));
-        const h2v l67 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.z - (float)a67h.x, v1.w - (float)a67h.y));
-        lo = h8v{l01.x, l01.y, l23.x, l23.y, l45.x, l45.y, l67.x, l67.y};
-      }
+      split8<TERMS>(v0, v1, hi, lo);
     };
     split(a00, a01, ah[0], al[0]);
     split(a10, a11, ah[1], al[1]);
@@ -657,18 +675,50 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
     const int ntile = (HWb + 15) >> 4, nw = kIrThreads >> 6;
     // A operands: straight from global memory (L2: the band's input is read by all of its chunk workgroups), kIrPf row tiles in
     // flight per wave — one workgroup owns the CU (its LDS), so nobody else hides a load that is waited for on the spot.
-    constexpr int kIrPf = 3;
-    float4 ra[kIrPf][SLABS][2];
-    auto fetch = [&](float4 (&dst)[SLABS][2], int rt) {
-      const int pix = min(rt * 16 + li, HWb - 1);
+    constexpr int kIrPf = 3;                                              // (5 / 6 tiles in flight, which the registers of a CU-owning workgroup allow, measured 3-6 % SLOWER)
+    f4v ra[kIrPf][SLABS][2];
+    // K tail (Cin % 32 != 0): the quads past Cin are read from the row's first quad instead — any finite value does, their weights are zero (the
+    // planner pads w16 with zeros) — so that every load is unconditional: predicated, each tile carried 24 selects, the zero fill of its 24
+    // registers and 11 divergent branches, a third of the phase's instructions.
+    //
+    // STAGE (32-channel chunks): the MFMA A layout wants lane (li, g) to hold 32 bytes of ROW li — sixteen different rows in sixteen consecutive
+    // lanes, i.e. one cache-line lookup per lane: the phase ran at ~64 cycles per 1 KB load instruction (measured: time = 7k + 64 x instructions
+    // cycles per workgroup for K = 32 / 64 / 96).  Instead eight consecutive lanes read one row's 128 bytes (8 lines per instruction, not 64),
+    // each wave re-orders the tile through its own 2 KB of LDS (written at lane x 16 B, the chunk order XOR-swizzled on the GLOBAL side exactly
+    // as in pw_gemm_ring_k, fragments read back with two conflict-free ds_read_b128) — no barrier: the LDS serves one wave's operations in order.
+    constexpr bool STAGE = CH == 32;
+    const int lr = lane >> 3, lp = lane & 7;
+    int koff[SLABS][2];
 #pragma unroll
-      for (int s = 0; s < SLABS; s++) {
-        const int k = 32 * s + 8 * g;                                      // Cin % 4 == 0: each float4 is valid or absent
-        dst[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); dst[s][1] = dst[s][0];
-        if (k < Cin) dst[s][0] = *reinterpret_cast<const float4*>(xf + (size_t)pix * Cin + k);
-        if (k + 4 < Cin) dst[s][1] = *reinterpret_cast<const float4*>(xf + (size_t)pix * Cin + k + 4);
+    for (int s = 0; s < SLABS; s++) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int k = STAGE ? 32 * s + 4 * (lp ^ asw(8 * h + lr)) : 32 * s + 8 * g + 4 * h;      // Cin % 4 == 0: each float4 is valid or absent
+        koff[s][h] = k < Cin ? k : 0;
+      }
+    }
+    auto fetch = [&](f4v (&dst)[SLABS][2], int rt) {
+      if (STAGE) {                                                       // dst[s][h]: rows 8h .. 8h+7 of the tile, this lane's 16 bytes of row 8h + lr
+        const float* r0 = xf + (size_t)min(rt * 16 + lr, HWb - 1) * Cin;
+        const float* r1 = xf + (size_t)min(rt * 16 + 8 + lr, HWb - 1) * Cin;
+#pragma unroll
+        for (int s = 0; s < SLABS; s++) {
+          dst[s][0] = *reinterpret_cast<const f4v*>(r0 + koff[s][0]);
+          dst[s][1] = *reinterpret_cast<const f4v*>(r1 + koff[s][1]);
+        }
+      } else {
+        const float* rp = xf + (size_t)min(rt * 16 + li, HWb - 1) * Cin;
+#pragma unroll
+        for (int s = 0; s < SLABS; s++) {
+          dst[s][0] = *reinterpret_cast<const f4v*>(rp + koff[s][0]);
+          dst[s][1] = *reinterpret_cast<const f4v*>(rp + koff[s][1]);
+        }
       }
     };
+    float* stg = ir_ex + (size_t)(e1 - e0) * W * CH + 10 * CH + 4 + wave * 512;      // this wave's [16 rows][8 quads] buffer (STAGE)
+    const int st_w = lane * 4, st_r = li * 32 + (((2 * g) ^ asw(li)) << 2);           // written at lane x 16 B (+ 1 KB for the second row group); fragment quads 2g, 2g + 1
+    // (Measured and dropped: an "L2 warm-up" — each chunk workgroup first requests its 1 / nchunk share of the band's input so that the tile loop
+    //  runs on L2 hits — 3-5 % slower; 5 or 6 tiles in flight per wave instead of 3 — 3-6 % slower.  The phase is not waiting for memory.)
     const int cnt = wave < ntile ? (ntile - wave + nw - 1) / nw : 0;      // this wave's row tiles: wave, wave + nw, ...
 #pragma unroll
     for (int j = 0; j < kIrPf; j++) if (j < cnt) fetch(ra[j], wave + j * nw);
@@ -681,18 +731,12 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
         h8v ah[SLABS], al[SLABS];
 #pragma unroll
         for (int s = 0; s < SLABS; s++) {
-          const float4 v0 = ra[j][s][0], v1 = ra[j][s][1];
-          const h2v a01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y)), a23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.z, v0.w));
-          const h2v a45 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y)), a67 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.z, v1.w));
-          ah[s] = h8v{a01.x, a01.y, a23.x, a23.y, a45.x, a45.y, a67.x, a67.y};
-          al[s] = ah[s];
-          if (TERMS == 3) {
-            const h2v l01 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.x - (float)a01.x, v0.y - (float)a01.y));
-            const h2v l23 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v0.z - (float)a23.x, v0.w - (float)a23.y));
-            const h2v l45 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.x - (float)a45.x, v1.y - (float)a45.y));
-            const h2v l67 = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v1.z - (float)a67.x, v1.w - (float)a67.y));
-            al[s] = h8v{l01.x, l01.y, l23.x, l23.y, l45.x, l45.y, l67.x, l67.y};
-          }
+          if (STAGE) {
+            *reinterpret_cast<f4v*>(stg + st_w) = ra[j][s][0];
+            *reinterpret_cast<f4v*>(stg + 256 + st_w) = ra[j][s][1];
+            const f4v v0 = *reinterpret_cast<const f4v*>(stg + st_r), v1 = *reinterpret_cast<const f4v*>(stg + (st_r ^ 4));
+            split8<TERMS>(v0, v1, ah[s], al[s]);
+          } else split8<TERMS>(ra[j][s][0], ra[j][s][1], ah[s], al[s]);
         }
         if (k + kIrPf < cnt) fetch(ra[j], wave + (k + kIrPf) * nw);       // refill the slot just consumed
         f4acc acc[NT];
@@ -1450,7 +1494,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dws.OH, dws.sh, dws.dh);
         if (ig.CH == 0) return hipErrorInvalidValue;                 // the planner checked the same function
         const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
-        const size_t lds = ((size_t)ig.rows * st.OW * ig.CH + 10 * (size_t)ig.CH + 4) * sizeof(float);      // band + depthwise weights and bias + a quad of zeros
+        const size_t lds = (size_t)ir_lds_bytes(ig.rows, st.OW, ig.CH);
         if ((long)ig.rows * st.OW * dws.dh >= 65536) return hipErrorInvalidValue;   // the kernel divides item indices by multiplication
         const dim3 gi((unsigned)(st.Cout / ig.CH) * (unsigned)ig.nbands * (unsigned)n);
         const int slabs = st.k16_pad / 32;

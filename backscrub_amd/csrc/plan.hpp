@@ -58,22 +58,26 @@ struct Step {
 // Geometry of the fused expand + depthwise kernel (kernels_nn.hip: ir_expand_dw_k), shared by the planner (is the pair fusable?) and the
 // launcher: CH expanded channels per workgroup, BH depthwise output rows per row band; the band's expanded rows live in LDS.
 struct IrGeom { int CH = 0, BH = 0, nbands = 0, rows = 0; };
+// LDS of one workgroup: the band of the expanded chunk + depthwise weights, bias and a quad of zeros + (32-channel chunks only) the eight
+// per-wave 2 KB buffers the input tiles are re-ordered through (coalesced loads → MFMA fragments)
+inline long ir_stage_floats(int CH) { return CH == 32 ? 8 * 512 : 0; }
+inline long ir_lds_bytes(int rows, int W, int CH) { return ((long)rows * W * CH + 10 * CH + 4 + ir_stage_floats(CH)) * 4; }
 inline IrGeom ir_geometry(int H, int W, int Cexp, int OH, int S, int d) {
   if (const char* e = getenv("BSX_IR_GEOM")) {                     // timing experiments: "W:CH,BH" overrides the choice for layers W pixels wide
     int w = 0, ch = 0, bh = 0;
     if (sscanf(e, "%d:%d,%d", &w, &ch, &bh) == 3 && w == W && ch > 0 && Cexp % ch == 0 && bh > 0) {
       IrGeom g; g.CH = ch; g.BH = bh < OH ? bh : OH; g.nbands = (OH + g.BH - 1) / g.BH;
       const int r = S * (g.BH - 1) + 2 * d + 1; g.rows = r < H ? r : H;
-      if ((long)g.rows * W * ch * 4 <= 150 * 1024) return g;
+      if (ir_lds_bytes(g.rows, W, ch) <= 160 * 1024) return g;
     }
   }
   auto rows_for = [&](int bh) { const int r = S * (bh - 1) + 2 * d + 1; return r < H ? r : H; };
   // 1. the whole frame in one band (no halo rows, every input row read once per chunk): one workgroup per CU
   for (int CH : {32, 24, 16}) {
     if (Cexp % CH) continue;
-    if ((long)rows_for(OH) * W * CH * 4 <= 150 * 1024) { IrGeom g; g.CH = CH; g.BH = OH; g.nbands = 1; g.rows = rows_for(OH); return g; }
+    if (ir_lds_bytes(rows_for(OH), W, CH) <= 160 * 1024) { IrGeom g; g.CH = CH; g.BH = OH; g.nbands = 1; g.rows = rows_for(OH); return g; }
   }
-  // 2. row bands: small enough for TWO workgroups per CU (<= 78 KB) — one workgroup's MFMA/global phase then overlaps the other's LDS/VALU phase
+  // 2. row bands: small enough for TWO workgroups per CU (<= 80 KB each, everything included) — one workgroup's MFMA/global phase then overlaps the other's LDS/VALU phase
   //    (measured on the 129x129 and 65x65 layers: 1.16 -> 0.91 ms, 0.41 -> 0.33 ms against the largest band that fits one workgroup per CU).
   //    Score = useful rows per band row x MFMA column-tile occupancy.
   IrGeom best;
@@ -81,8 +85,8 @@ inline IrGeom ir_geometry(int H, int W, int Cexp, int OH, int S, int d) {
   for (int CH : {32, 24, 16}) {
     if (Cexp % CH) continue;
     int BH = OH;
-    while (BH > 1 && (long)rows_for(BH) * W * CH * 4 > 78 * 1024) BH--;
-    if ((long)rows_for(BH) * W * CH * 4 > 78 * 1024 || BH < 2) continue;
+    while (BH > 1 && ir_lds_bytes(rows_for(BH), W, CH) > 80 * 1024) BH--;
+    if (ir_lds_bytes(rows_for(BH), W, CH) > 80 * 1024 || BH < 2) continue;
     const int nb = (OH + BH - 1) / BH;
     BH = (OH + nb - 1) / nb;                             // even bands
     const double score = (double)(S * BH) / rows_for(BH) * CH / ((CH + 15) / 16 * 16);
