@@ -254,6 +254,7 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 // x = hi + lo for two floats: hi = the f16 below |x| (round toward zero: never overflows to inf), lo = f16(x - hi).  The residual is ONE mixed-precision
@@ -1356,7 +1357,8 @@ __global__ __launch_bounds__(kThreads) void resize_px_k(const float* __restrict_
 // pixels its 64 x 4 output pixels interpolate from in LDS and every lane scans the 21 classes of its pixel from there.
 // Same interpolation arithmetic (interp / bilerp) and the same first-maximum-wins scan as the unfused kernels.
 // -------------------------------------------------------------------------------------
-constexpr int kFusedTW = 64, kFusedTH = 4, kFusedMaxSrc = 160;    // source pixels per tile (rows x cols), C <= kResizePxMaxC
+constexpr int kFusedTW = 64, kFusedTH = 16, kFusedMaxSrc = 160;    // source pixels per tile (rows x cols), C <= kResizePxMaxC
+template <bool PERSON_ONLY>      // true: only "is the first maximum the person class?" is formed (two running maxima), not the argmax itself
 __global__ __launch_bounds__(kThreads) void resize_argmax_iir_k(const float* __restrict__ x, uint8_t* __restrict__ ofinal, int H, int W, int C, int OH, int OW,
                                                                float hs, float ws, int half_pixel, int person) {
   __shared__ float src[kFusedMaxSrc * kResizePxMaxC];
@@ -1371,23 +1373,76 @@ __global__ __launch_bounds__(kThreads) void resize_argmax_iir_k(const float* __r
   interp(min(ox0 + kFusedTW - 1, OW - 1), ws, half_pixel, W, &fr, &a0, &sx1);
   const int SR = sy1 - sy0 + 1, SC = sx1 - sx0 + 1;
   const float* b = x + n * (long)H * W * C;
+  // Every lane owns kFusedTH / 4 pixels of one column (rows ty, ty + 4, ...).  Their previous mask bytes are requested FIRST: the kernel is a chain
+  // of memory latencies (source window → barrier → arithmetic → old byte → store), not of arithmetic, and this takes one link out of it.
+  constexpr int PPL = kFusedTH / 4;
+  const int ox = ox0 + tx;
+  uint8_t* obase = ofinal + n * (long)OH * OW + ox;
+  uint8_t old[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; k++) { const int oy = oy0 + ty + 4 * k; old[k] = (ox < OW && oy < OH) ? obase[(long)oy * OW] : (uint8_t)0; }
+  // LDS pixels are padded to CP floats — 24 for the 21 classes: 16-byte aligned, so that a lane reads a corner's classes as six ds_read_b128 instead of
+  // 21 ds_read_b32
+  const int CP = C <= 24 ? 24 : kResizePxMaxC;
+  const unsigned cmagic = 0xFFFFFFFFu / (unsigned)C + 1u;                // i / C for i < 2^16
   for (int r = 0; r < SR; r++) {
     const float* row = b + ((long)(sy0 + r) * W + sx0) * C;
-    for (int i = threadIdx.x; i < SC * C; i += kThreads) src[r * SC * C + i] = row[i];
+    for (int i = threadIdx.x; i < SC * C; i += kThreads) {
+      const int px = (int)__umulhi((unsigned)i, cmagic);
+      src[(r * SC + px) * CP + (i - px * C)] = row[i];
+    }
   }
   __syncthreads();
-  const int ox = ox0 + tx, oy = oy0 + ty;
-  if (ox >= OW || oy >= OH) return;
-  float dy, dx; int y0, y1, x0, x1;
-  interp(oy, hs, half_pixel, H, &dy, &y0, &y1);
+  if (ox >= OW) return;
+  float dx; int x0, x1;
   interp(ox, ws, half_pixel, W, &dx, &x0, &x1);
-  const float* p00 = src + ((y0 - sy0) * SC + (x0 - sx0)) * C; const float* p10 = src + ((y1 - sy0) * SC + (x0 - sx0)) * C;
-  const float* p01 = src + ((y0 - sy0) * SC + (x1 - sx0)) * C; const float* p11 = src + ((y1 - sy0) * SC + (x1 - sx0)) * C;
-  float maxval = -10000.f; int maxpos = 0;                         // first maximum wins, as the reference loop
-  for (int c = 0; c < C; c++) { const float v = bilerp(p00[c], p10[c], p01[c], p11[c], dy, dx); if (v > maxval) { maxval = v; maxpos = c; } }
-  const uint8_t val = maxpos == person ? 0 : 255;
-  uint8_t* o = ofinal + n * (long)OH * OW + (long)oy * OW + ox;
-  *o = (uint8_t)((val & 0xE0) | (*o >> 3));
+#pragma unroll
+  for (int k = 0; k < PPL; k++) {
+    const int oy = oy0 + ty + 4 * k;
+    if (oy >= OH) break;
+    float dy; int y0, y1;
+    interp(oy, hs, half_pixel, H, &dy, &y0, &y1);
+    const float* p00 = src + ((y0 - sy0) * SC + (x0 - sx0)) * CP; const float* p10 = src + ((y1 - sy0) * SC + (x0 - sx0)) * CP;
+    const float* p01 = src + ((y0 - sy0) * SC + (x1 - sx0)) * CP; const float* p11 = src + ((y1 - sy0) * SC + (x1 - sx0)) * CP;
+    float maxval = -10000.f; int maxpos = 0;                         // first maximum wins, as the reference loop
+    // PERSON_ONLY: the scan "v > maxval → take it" ends on the person class iff v[person] > max(-10000, v[c < person]) and v[person] >= max(v[c > person])
+    float mbefore = -10000.f, mafter = -__builtin_inff(), vperson = 0.f;
+    if (CP == 24) {
+      // four classes at a time; the arithmetic of bilerp() exactly — ((x * wy) * wx) per corner, summed left to right, nothing contracted
+      // (-ffp-contract=off) — on two-wide vectors (v_pk_mul_f32 / v_pk_add_f32)
+      const float omdy = 1.f - dy, omdx = 1.f - dx;
+      const f2v wy0 = {omdy, omdy}, wy1 = {dy, dy}, wx0 = {omdx, omdx}, wx1 = {dx, dx};
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const f4v v00 = *reinterpret_cast<const f4v*>(p00 + 4 * q), v10 = *reinterpret_cast<const f4v*>(p10 + 4 * q);
+        const f4v v01 = *reinterpret_cast<const f4v*>(p01 + 4 * q), v11 = *reinterpret_cast<const f4v*>(p11 + 4 * q);
+        float r4[4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const f2v a = (f2v{v00[2 * h], v00[2 * h + 1]} * wy0) * wx0, bb = (f2v{v10[2 * h], v10[2 * h + 1]} * wy1) * wx0;
+          const f2v c2 = (f2v{v01[2 * h], v01[2 * h + 1]} * wy0) * wx1, d = (f2v{v11[2 * h], v11[2 * h + 1]} * wy1) * wx1;
+          const f2v sum = ((a + bb) + c2) + d;
+          r4[2 * h] = sum.x; r4[2 * h + 1] = sum.y;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int c = 4 * q + e;
+          if (PERSON_ONLY) {
+            if (c < C) {                                                 // (uniform conditions)
+              if (c < person) mbefore = fmaxf(mbefore, r4[e]);
+              else if (c > person) mafter = fmaxf(mafter, r4[e]);
+              else vperson = r4[e];
+            }
+          } else if (c < C && r4[e] > maxval) { maxval = r4[e]; maxpos = c; }
+        }
+      }
+      if (PERSON_ONLY) maxpos = (vperson > mbefore && vperson >= mafter) ? person : person + 1;
+    } else {
+      for (int c = 0; c < C; c++) { const float v = bilerp(p00[c], p10[c], p01[c], p11[c], dy, dx); if (v > maxval) { maxval = v; maxpos = c; } }
+    }
+    const uint8_t val = maxpos == person ? 0 : 255;
+    obase[(long)oy * OW] = (uint8_t)((val & 0xE0) | (old[k] >> 3));
+  }
 }
 
 // -------------------------------------------------------------------------------------
@@ -1449,7 +1504,9 @@ hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofi
   if (st.align_corners && st.OH > 1) hs = (float)(st.H - 1) / (float)(st.OH - 1);
   if (st.align_corners && st.OW > 1) ws = (float)(st.W - 1) / (float)(st.OW - 1);
   dim3 grid((st.OW + kFusedTW - 1) / kFusedTW, (st.OH + kFusedTH - 1) / kFusedTH, n);
-  resize_argmax_iir_k<<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, 15);
+  const int person = 15;                                           // lib/libbackscrub.cc:330 (pascal VOC class 15)
+  if (st.Cin <= 24 && person < st.Cin) resize_argmax_iir_k<true><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person);
+  else resize_argmax_iir_k<false><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person);
   return hipGetLastError();
 }
 
