@@ -311,41 +311,48 @@ __device__ __forceinline__ void gemm_store_tile(f4acc (&acc)[2][NTW], long m_wav
   const int q = li & 3;
   if ((Cout & 3) == 0) {
     auto epilogue = [&](auto actf) {
-      float4 bv[NTW], ex[2][NTW];                                         // ex: the per-frame bias (added before the activation) OR the residual (after): launch_step never passes both
+      float4 bv[NTW];
       int c0s[NTW];
-      long ms[2];
       const bool fb_on = fbias != nullptr, res_on = res != nullptr;      // (uniform)
 #pragma unroll
       for (int ni = 0; ni < NTW; ni++) {
         c0s[ni] = n_base + 16 * ni + (li & ~3);
         bv[ni] = *reinterpret_cast<const float4*>(bias + min(c0s[ni], Cout - 4));
       }
+      // ex: the per-frame bias (added before the activation) OR the residual (after): launch_step never passes both.  One m-tile at a time when the
+      // column tile is wide (NTW > 5: 2 x NTW quads would not fit the registers), both at once otherwise.
+      constexpr int MB = NTW > 5 ? 1 : 2;
 #pragma unroll
-      for (int mi = 0; mi < 2; mi++) {
-        ms[mi] = m_wave + 16 * mi + 4 * g + q;
+      for (int m0 = 0; m0 < 2; m0 += MB) {
+        float4 ex[MB][NTW];
+        long ms[MB];
 #pragma unroll
-        for (int ni = 0; ni < NTW; ni++) ex[mi][ni] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      if (fb_on || res_on) {                                              // one uniform branch around all of the loads
+        for (int mi = 0; mi < MB; mi++) {
+          ms[mi] = m_wave + 16 * (m0 + mi) + 4 * g + q;
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++) {
-          const long mc = min(ms[mi], M - 1);
-          const float* ep = fb_on ? fbias + (mc / HW) * (long)Cout : res + mc * Cout;
-#pragma unroll
-          for (int ni = 0; ni < NTW; ni++) ex[mi][ni] = *reinterpret_cast<const float4*>(ep + min(c0s[ni], Cout - 4));
+          for (int ni = 0; ni < NTW; ni++) ex[mi][ni] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-      }
+        if (fb_on || res_on) {                                            // one uniform branch around all of the loads
 #pragma unroll
-      for (int mi = 0; mi < 2; mi++) {
+          for (int mi = 0; mi < MB; mi++) {
+            const long mc = min(ms[mi], M - 1);
+            const float* ep = fb_on ? fbias + (mc / HW) * (long)Cout : res + mc * Cout;
 #pragma unroll
-        for (int ni = 0; ni < NTW; ni++) {
-          const float4 v = quad_transpose(acc[mi][ni], q);
-          float4 b4 = bv[ni];
-          const float4 e4 = ex[mi][ni];
-          if (fb_on) { b4.x += e4.x; b4.y += e4.y; b4.z += e4.z; b4.w += e4.w; }
-          float4 o = make_float4(actf(v.x + b4.x), actf(v.y + b4.y), actf(v.z + b4.z), actf(v.w + b4.w));
-          if (!fb_on && res_on) { o.x += e4.x; o.y += e4.y; o.z += e4.z; o.w += e4.w; }
-          if (ni < nt && ms[mi] < M && c0s[ni] < Cout) *reinterpret_cast<float4*>(y + ms[mi] * Cout + c0s[ni]) = o;
+            for (int ni = 0; ni < NTW; ni++) ex[mi][ni] = *reinterpret_cast<const float4*>(ep + min(c0s[ni], Cout - 4));
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MB; mi++) {
+#pragma unroll
+          for (int ni = 0; ni < NTW; ni++) {
+            const float4 v = quad_transpose(acc[m0 + mi][ni], q);
+            float4 b4 = bv[ni];
+            const float4 e4 = ex[mi][ni];
+            if (fb_on) { b4.x += e4.x; b4.y += e4.y; b4.z += e4.z; b4.w += e4.w; }
+            float4 o = make_float4(actf(v.x + b4.x), actf(v.y + b4.y), actf(v.z + b4.z), actf(v.w + b4.w));
+            if (!fb_on && res_on) { o.x += e4.x; o.y += e4.y; o.z += e4.z; o.w += e4.w; }
+            if (ni < nt && ms[mi] < M && c0s[ni] < Cout) *reinterpret_cast<float4*>(y + ms[mi] * Cout + c0s[ni]) = o;
+          }
         }
       }
     };
@@ -1584,6 +1591,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
           // staged and split once instead of once per column tile — the 480 -> 80 and 288 -> 48 project layers)
           static const bool wide_ok = getenv("BSX_NO_GEMM_NTW") == nullptr;
           static const int gemm_dbg = getenv("BSX_GEMM_DBG") ? atoi(getenv("BSX_GEMM_DBG")) : 0;      // timing experiments: 1 = A from one L2-resident block, 2 = no stores
+          // (128-column tiles for the 256-channel ASPP layers — A staged twice instead of four times — measured 35-43 % SLOWER: 168 registers, 3 workgroups per CU)
           const int ntw = (wide_ok && st.Cout % 80 == 0) ? 5 : ((wide_ok && st.Cout == 48) ? 3 : 4);
           const unsigned ncol = (unsigned)((st.Cout + ntw * 16 - 1) / (ntw * 16));
           if ((unsigned long long)gg.x * ncol >= (1ull << 31)) return hipErrorInvalidValue;
