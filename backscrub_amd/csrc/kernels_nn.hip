@@ -906,26 +906,44 @@ __global__ __launch_bounds__(kH0Threads) void dl_head0_k(const float* __restrict
   }
   const float* xf = x + (size_t)frame * (size_t)H0 * W0 * 3;
   if (phases & 1) {
-    // row by row (no per-element division), ALL of the lane's loads requested before the first LDS store (one workgroup owns the CU: nobody
-    // else would hide a load waited for on the spot); in_t pixel j = image column j - 1
-    const int e0 = tid, e1 = tid + kH0Threads;                  // rowf <= 2 * kH0Threads (checked by the planner)
-    constexpr int kMaxIR = 21;                                   // BH <= 8
-    float v[kMaxIR][2];
+    // The band's input rows are ONE contiguous piece of the frame (rows iy0 .. iy0 + IR - 1, clipped to the image: up to 21 x 771 floats): read it as
+    // a flat stream of 16-byte quads — all of a lane's quads requested before the first LDS store — and scatter the floats to their (row, column)
+    // in LDS.  (Row by row with one float per lane it took 22 dword loads per lane: 477 us of the kernel's 1024 just to bring the input in.)
+    // in_t pixel j = image column j - 1: a row's floats land at r * rowf + 3 + e; the pad pixels and the rows outside the image are zero-filled.
+    const int rowg = W0 * 3;
+    const int gy_lo = max(iy0, 0), gy_hi = min(iy0 + IR, H0);              // valid image rows [gy_lo, gy_hi)
+    const int r_off = gy_lo - iy0, nf = max(gy_hi - gy_lo, 0) * rowg, nq = nf >> 2;
+    const float* src = xf + (size_t)gy_lo * rowg;                         // (4-byte aligned only: the hardware takes dword-aligned dwordx4 loads)
+    constexpr int kMaxQ = 8;                                              // 21 rows x 771 floats / 4 / 512 lanes
+    f4v v[kMaxQ];
 #pragma unroll
-    for (int r = 0; r < kMaxIR; r++) {
-      const int gy = iy0 + r;
-      const bool rowok = r < IR && gy >= 0 && gy < H0;
-      const float* rp = xf + (size_t)(rowok ? gy : 0) * W0 * 3 - 3;
-      v[r][0] = (rowok && e0 >= 3 && e0 < W0 * 3 + 3) ? rp[e0] : 0.f;
-      v[r][1] = (rowok && e1 >= 3 && e1 < W0 * 3 + 3) ? rp[e1] : 0.f;
+    for (int k = 0; k < kMaxQ; k++) {
+      const int i = tid + k * kH0Threads;
+      v[k] = *reinterpret_cast<const f4v*>(src + 4 * (size_t)min(i, max(nq - 1, 0)));
     }
+    float tailv = 0.f;
+    if (tid < (nf & 3)) tailv = src[4 * nq + tid];
+    // zero fill: pad pixels of every row, whole rows outside the image
+    for (int i = tid; i < IR * 6; i += kH0Threads) { const int r = i / 6, e = i - 6 * r; in_t[r * rowf + (e < 3 ? e : rowf - 6 + e)] = 0.f; }
+    for (int r = 0; r < IR; r++) {
+      if (r >= r_off && r < r_off + (gy_hi - gy_lo)) continue;          // (uniform)
+      for (int e = tid; e < rowg; e += kH0Threads) in_t[r * rowf + 3 + e] = 0.f;
+    }
+    const unsigned gmagic = 0xFFFFFFFFu / (unsigned)rowg + 1u;            // f / rowg for f < 2^16
 #pragma unroll
-    for (int r = 0; r < kMaxIR; r++) {
-      if (r < IR) {
-        in_t[r * rowf + e0] = v[r][0];
-        if (e1 < rowf) in_t[r * rowf + e1] = v[r][1];
+    for (int k = 0; k < kMaxQ; k++) {
+      const int i = tid + k * kH0Threads;
+      if (i < nq) {
+        const int f = 4 * i;
+        int r = (int)__umulhi((unsigned)f, gmagic), e = f - r * rowg;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          in_t[(r_off + r) * rowf + 3 + e] = v[k][c];
+          if (++e == rowg) { e = 0; r++; }
+        }
       }
     }
+    if (tid < (nf & 3)) { const int f = 4 * nq + tid, r = (int)__umulhi((unsigned)f, gmagic), e = f - r * rowg; in_t[(r_off + r) * rowf + 3 + e] = tailv; }
   }
   __syncthreads();
   // ---- stem on the matrix cores: v_mfma_f32_16x16x4_f32 over the im2col axis k = (fy, fx, ci) (27 of 28 slots used), wave = one tile of 16
