@@ -676,10 +676,9 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
           if (TERMS == 3) bl[s][ni] = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + 16 * ni + li) * Kp + 32 * s + 8 * g);
         }
       }
-    const int c0 = li & ~3;
-    float4 bv[NT];
+    float bch[NT];                                                        // bias of this lane's channel (16 ni + li) of each column tile
 #pragma unroll
-    for (int ni = 0; ni < NT; ni++) bv[ni] = 16 * ni + c0 < CH ? *reinterpret_cast<const float4*>(bias + n_base + 16 * ni + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ni = 0; ni < NT; ni++) bch[ni] = 16 * ni + li < CH ? bias[n_base + 16 * ni + li] : 0.f;
     const int ntile = (HWb + 15) >> 4, nw = kIrThreads >> 6;
     // A operands: straight from global memory (L2: the band's input is read by all of its chunk workgroups), kIrPf row tiles in
     // flight per wave — one workgroup owns the CU (its LDS), so nobody else hides a load that is waited for on the spot.
@@ -730,44 +729,62 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
     const int cnt = wave < ntile ? (ntile - wave + nw - 1) / nw : 0;      // this wave's row tiles: wave, wave + nw, ...
 #pragma unroll
     for (int j = 0; j < kIrPf; j++) if (j < cnt) fetch(ra[j], wave + j * nw);
+    // One tile: re-order (STAGE) and split the A rows, refill the prefetch slot, multiply, store.  (FAST = no branch anywhere in the tile, so that a
+    // group of kIrPf tiles is ONE basic block and the scheduler may run tile j + 1's LDS round trip and split under tile j's MFMA chain: measured,
+    // no gain where it fit the registers — 1- and 2-slab variants — and 240 bytes of spill, 1.09 -> 1.68 ms, in the 3-slab one.  Not used.)
+    auto tile = [&](auto FASTC, int j, int k) {
+      constexpr bool FAST = decltype(FASTC)::value;
+      const int rt = wave + k * nw;
+      h8v ah[SLABS], al[SLABS];
+#pragma unroll
+      for (int s = 0; s < SLABS; s++) {
+        if (STAGE) {
+          *reinterpret_cast<f4v*>(stg + st_w) = ra[j][s][0];
+          *reinterpret_cast<f4v*>(stg + 256 + st_w) = ra[j][s][1];
+          const f4v v0 = *reinterpret_cast<const f4v*>(stg + st_r), v1 = *reinterpret_cast<const f4v*>(stg + (st_r ^ 4));
+          split8<TERMS>(v0, v1, ah[s], al[s]);
+        } else split8<TERMS>(ra[j][s][0], ra[j][s][1], ah[s], al[s]);
+      }
+      if (FAST || k + kIrPf < cnt) fetch(ra[j], wave + (k + kIrPf) * nw);       // refill the slot just consumed
+      f4acc acc[NT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ni++) acc[ni] = f4acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < SLABS; s++)
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) {
+          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[s][ni], acc[ni], 0, 0, 0);
+          if (TERMS == 3) {
+            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], bh[s][ni], acc[ni], 0, 0, 0);
+            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bl[s][ni], acc[ni], 0, 0, 0);
+          }
+        }
+      // MFMA C layout as it is — lane (li, g) holds channel 16 ni + li of pixels 4g .. 4g + 3 — stored as four 4-byte LDS writes per column tile
+      // (16 lanes = 64 contiguous bytes of one pixel; the two pixels of a 32-lane store group are 2-way on the banks, which a 4-byte store
+      // hides).  Transposed to one 16-byte write per pixel it was 32 more vector instructions per tile (DPP + selects) in an issue-bound
+      // phase (PMC: the two waves of a SIMD keep its issue port 72 % busy) and a 4-way bank conflict on every store.
+      const int pb = rt * 16 + 4 * g;
+      const bool whole = FAST || rt * 16 + 16 <= HWb;                      // (uniform: only the band's last tile can be short)
+#pragma unroll
+      for (int ni = 0; ni < NT; ni++) {
+        if (CH % 16 != 0 && 16 * ni + li >= CH) continue;                 // CH = 24: the second column tile is half empty
+        float* dst = ir_ex + (size_t)pb * CH + 16 * ni + li;
+        const float o0 = clampf(acc[ni][0] + bch[ni], k1), o1 = clampf(acc[ni][1] + bch[ni], k1), o2 = clampf(acc[ni][2] + bch[ni], k1),
+                    o3 = clampf(acc[ni][3] + bch[ni], k1);
+        if (whole) { dst[0] = o0; dst[CH] = o1; dst[2 * CH] = o2; dst[3 * CH] = o3; }
+        else {
+          if (pb < HWb) dst[0] = o0;
+          if (pb + 1 < HWb) dst[CH] = o1;
+          if (pb + 2 < HWb) dst[2 * CH] = o2;
+          if (pb + 3 < HWb) dst[3 * CH] = o3;
+        }
+      }
+    };
     for (int k0 = 0; k0 < cnt; k0 += kIrPf) {
 #pragma unroll
       for (int j = 0; j < kIrPf; j++) {
-        const int k = k0 + j;
-        if (k >= cnt) break;                                             // wave-uniform
-        const int rt = wave + k * nw;
-        h8v ah[SLABS], al[SLABS];
-#pragma unroll
-        for (int s = 0; s < SLABS; s++) {
-          if (STAGE) {
-            *reinterpret_cast<f4v*>(stg + st_w) = ra[j][s][0];
-            *reinterpret_cast<f4v*>(stg + 256 + st_w) = ra[j][s][1];
-            const f4v v0 = *reinterpret_cast<const f4v*>(stg + st_r), v1 = *reinterpret_cast<const f4v*>(stg + (st_r ^ 4));
-            split8<TERMS>(v0, v1, ah[s], al[s]);
-          } else split8<TERMS>(ra[j][s][0], ra[j][s][1], ah[s], al[s]);
-        }
-        if (k + kIrPf < cnt) fetch(ra[j], wave + (k + kIrPf) * nw);       // refill the slot just consumed
-        f4acc acc[NT];
-#pragma unroll
-        for (int ni = 0; ni < NT; ni++) acc[ni] = f4acc{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < SLABS; s++)
-#pragma unroll
-          for (int ni = 0; ni < NT; ni++) {
-            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[s][ni], acc[ni], 0, 0, 0);
-            if (TERMS == 3) {
-              acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], bh[s][ni], acc[ni], 0, 0, 0);
-              acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bl[s][ni], acc[ni], 0, 0, 0);
-            }
-          }
-        const int pix = rt * 16 + 4 * g + q;
-#pragma unroll
-        for (int ni = 0; ni < NT; ni++) {
-          const float4 v = quad_transpose(acc[ni], q);                   // all four lanes of a quad take part, valid pixel or not
-          if (pix < HWb && 16 * ni + c0 < CH)
-            *reinterpret_cast<float4*>(ir_ex + (size_t)pix * CH + 16 * ni + c0) =
-                make_float4(clampf(v.x + bv[ni].x, k1), clampf(v.y + bv[ni].y, k1), clampf(v.z + bv[ni].z, k1), clampf(v.w + bv[ni].w, k1));
-        }
+        if (k0 + j >= cnt) break;                                         // wave-uniform
+        tile(std::false_type{}, j, k0 + j);
       }
     }
   }
