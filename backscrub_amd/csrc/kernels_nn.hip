@@ -1425,7 +1425,9 @@ __global__ __launch_bounds__(kThreads) void resize_argmax_iir_k(const float* __r
   for (int k = 0; k < PPL; k++) { const int oy = oy0 + ty + 4 * k; old[k] = (ox < OW && oy < OH) ? obase[(long)oy * OW] : (uint8_t)0; }
   // LDS pixels are padded to CP floats — 24 for the 21 classes: 16-byte aligned, so that a lane reads a corner's classes as six ds_read_b128 instead of
   // 21 ds_read_b32
-  const int CP = C <= 24 ? 24 : kResizePxMaxC;
+  const bool generic = person < 0;                                       // (BSX_TAIL_GENERIC: person arrives as -1 - person)
+  if (generic) person = -1 - person;
+  const int CP = (C <= 24 && !generic) ? 24 : kResizePxMaxC;
   const unsigned cmagic = 0xFFFFFFFFu / (unsigned)C + 1u;                // i / C for i < 2^16
   for (int r = 0; r < SR; r++) {
     const float* row = b + ((long)(sy0 + r) * W + sx0) * C;
@@ -1547,8 +1549,9 @@ hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofi
   if (st.align_corners && st.OW > 1) ws = (float)(st.W - 1) / (float)(st.OW - 1);
   dim3 grid((st.OW + kFusedTW - 1) / kFusedTW, (st.OH + kFusedTH - 1) / kFusedTH, n);
   const int person = 15;                                           // lib/libbackscrub.cc:330 (pascal VOC class 15)
-  if (st.Cin <= 24 && person < st.Cin) resize_argmax_iir_k<true><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person);
-  else resize_argmax_iir_k<false><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person);
+  const bool generic = getenv("BSX_TAIL_GENERIC") != nullptr;             // (read per launch) tests: the scalar argmax scan over 32-float LDS pixels (what more than 24 classes take)
+  if (!generic && st.Cin <= 24 && person < st.Cin) resize_argmax_iir_k<true><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person);
+  else resize_argmax_iir_k<false><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, generic ? -1 - person : person);
   return hipGetLastError();
 }
 

@@ -426,6 +426,33 @@ def test_deeplab_argmax_agreement(bs, oracle):
     mg.close()
 
 
+def test_deeplab_tail_forms_agree(bs, monkeypatch):
+    """The fused resize + argmax + IIR tail has two forms: 24-float LDS pixels read as quads with the person test from two running maxima (21
+    classes), and the scalar first-maximum scan over 32-float pixels (what more than 24 classes would take, BSX_TAIL_GENERIC=1).  Same
+    interpolation arithmetic, same decision: on the photo fixture (a real person: both byte values occur) the decoded `ofinal` bytes after three
+    steps (the IIR carries over) must be identical."""
+    from tools import make_photo_fixture as P
+    path = model_path("deeplab")
+    if "synthetic" in os.path.basename(path):
+        pytest.skip("reference model not staged on this box")
+    W, H = VGA
+    frames = P.load_frames()
+    n = frames.shape[0]
+    outs = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("BSX_TAIL_GENERIC", "1")
+        mg = bs.MaskGen(path, W, H, n_streams=n)
+        for t in range(3):
+            mg.process_batch(_dev(frames if t != 1 else frames[::-1].copy()))
+        outs.append(mg.ofinal().cpu().numpy().copy())
+        mg.close()
+    monkeypatch.delenv("BSX_TAIL_GENERIC")
+    assert outs[0].shape == outs[1].shape and outs[0].size > 0
+    assert np.array_equal(outs[0], outs[1])
+    assert len(np.unique(outs[0])) > 2            # person and background pixels at several IIR levels
+
+
 # --------------------------------------------------------------------------------------------
 # the drop-in single-frame host path and its reference-style error behaviour
 # --------------------------------------------------------------------------------------------
