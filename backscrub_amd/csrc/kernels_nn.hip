@@ -809,7 +809,8 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
     const int L = (oy1 - oy0 + d - 1) / d, nseg = (L + kIrSeg - 1) / kIrSeg, cols = d * W, total = nseg * cols * CQ;
     const unsigned mcols = 0xFFFFFFFFu / (unsigned)cols + 1u, mw = 0xFFFFFFFFu / (unsigned)W + 1u;      // t / cols, rc / W: exact below 2^16 (checked at launch)
     const float* zq = dwl + 10 * CH;
-    for (int item = tid; item < total; item += kIrThreads) {
+    // one unit of work: `nsteps` consecutive outputs of item `item` starting at its step `k0`
+    auto walk = [&](int item, int k0, int nsteps) {
       const int t = item / CQ, cq = item - t * CQ, seg = (int)__umulhi((unsigned)t, mcols), rc = t - seg * cols,
                 r = (int)__umulhi((unsigned)rc, mw), xx = rc - r * W;
       f4v wq[9];
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
         o[1] = *reinterpret_cast<const f4v*>(in ? col + off : zq);
         o[2] = *reinterpret_cast<const f4v*>(in ? colr + off : zq);
       };
-      int yy = oy0 + r + seg * kIrSeg * d;
+      int yy = oy0 + r + (seg * kIrSeg + k0) * d;
       int off = (yy - e0) * W * CH;
       float* yp = yf + ((size_t)yy * OW + xx) * Cexp + n_base + 4 * cq;
       const size_t ystep = (size_t)d * OW * Cexp;
@@ -852,15 +853,22 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
       f4v ra[3], rb[3], rc3[3];
       row(yy - d, off - rstep, ra); row(yy, off, rb);
       static_assert(kIrSeg % 3 == 0, "the window rotates by name in groups of three steps");
-      for (int k = 0; k < kIrSeg / 3; k++) {
-        if (yy >= oy1) break;
+      for (int left = nsteps; left > 0 && yy < oy1;) {
         step(ra, rb, rc3);
-        if (yy >= oy1) break;
+        if (--left == 0 || yy >= oy1) break;
         step(rb, rc3, ra);
-        if (yy >= oy1) break;
+        if (--left == 0 || yy >= oy1) break;
         step(rc3, ra, rb);
+        --left;
       }
-    }
+    };
+    // Full rounds of 512 items walk their whole segment.  The items left over (always 32 x CQ / 8 of them at 33 x 33: 1056 = 2 x 512 + 32) would keep
+    // ONE wave busy for a third round while seven idle — a third of the phase — so they are cut into single outputs, one per lane (9 quads loaded
+    // for one output instead of 3: a round and a half of work instead of a whole one).
+    // (Only a SMALL remainder is cut up: at a quarter of a round or more the whole walks are cheaper — the 65 x 65 bands measured +16 % cut up.)
+    const int rem = total % kIrThreads, main_total = rem * 4 <= kIrThreads ? total - rem : total;
+    for (int item = tid; item < main_total; item += kIrThreads) walk(item, 0, kIrSeg);
+    for (int u = tid; u < (total - main_total) * kIrSeg; u += kIrThreads) { const int li2 = u / kIrSeg; walk(main_total + li2, u - li2 * kIrSeg, 1); }
   } else {
     // ---- phase 2, stride 2 (dilation 1): item = (output pixel of the band, channel quad), nine taps from LDS, (fy, fx) ascending
     const int total = (oy1 - oy0) * OW * CQ;
