@@ -1082,7 +1082,8 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
                       d1.pad_t == 1 && d1.pad_l == 1 && d1.OH == d1.H && d1.OW == d1.W && d1.Cin == 16 && d1.residual < 0 && d1.act < kActHswish && uses(d1.out) == 1 &&
                       p2.kind == StepKind::PwConv && p2.in0 == d1.out && p2.Cin == 16 && p2.Cout % 4 == 0 && p2.Cout <= 16 && p2.residual < 0 && p2.in_scale < 0 &&
                       p2.in2 < 0 && p2.out_bias < 0 && p2.act < kActHswish && p2.OH == d1.OH && p2.OW == d1.OW && p2.out != g.output &&
-                      2 * (c0.OW - 1) - c0.pad_l + 2 <= c0.W && c0.pad_l >= 0 && c0.pad_l <= 1 && (c0.W + 2) * 3 <= 1024 && head0_band_rows(c0.W, c0.OW) >= 2;
+                      2 * (c0.OW - 1) - c0.pad_l + 2 <= c0.W && c0.pad_l >= 0 && c0.pad_l <= 1 && (c0.W + 2) * 3 <= 1024 && head0_band_rows(c0.W, c0.OW) >= 2 &&
+                      (2 * (head0_band_rows(c0.W, c0.OW) + 2) + 1) * c0.W * 3 <= 4 * 8 * 512;      // the band's input rows: at most 8 quads per lane (dl_head0_k)
       if (ok) { c0.fuse_head0 = true; d1.fused_away = true; p2.fused_away = true; }
     }
     for (size_t i = 0; i + 1 < S.size(); i++) {
