@@ -639,9 +639,9 @@ __global__ __launch_bounds__(kThreads, 2) void pw_gemm_ring_k(const float* __res
 // per output), stride 2 as nine taps per output — and writes its result.  The expanded tensor — per inverted-residual block the largest
 // write AND the largest read — never reaches HBM: 4 of the block's 6 big tensor passes become 2.
 constexpr int kIrThreads = 512, kIrSeg = 9;
-template <int TERMS, int SLABS, int CH, bool OUT16 = false>      // OUT16: the depthwise result is stored as f16 (reduced-precision storage mode)
+template <int TERMS, int SLABS, int CH, bool OUT16 = false, int THREADS = kIrThreads>      // OUT16: the depthwise result is stored as f16 (reduced-precision storage mode); THREADS: 512, or 1024 (four waves per SIMD at <= 128 registers)
 // (row-banded layers run TWO workgroups per CU = 4 waves per SIMD, i.e. within 128 registers: the 24-channel variant fits by itself, the 16-channel one is held to it)
-__global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void ir_expand_dw_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 || (SLABS == 1 && CH == 16)) ? 4 : 2) void ir_expand_dw_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
                                                             const float* __restrict__ dww, const float* __restrict__ dwb, float* __restrict__ y,
                                                             int H, int W, int Cin, int Kp, int Cexp, int cout_pad, int act1, int act2, int d, int S, int pt, int pl,
                                                             int OH, int OW, int BH, int nbands, int phases) {
@@ -679,10 +679,10 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
     float bch[NT];                                                        // bias of this lane's channel (16 ni + li) of each column tile
 #pragma unroll
     for (int ni = 0; ni < NT; ni++) bch[ni] = 16 * ni + li < CH ? bias[n_base + 16 * ni + li] : 0.f;
-    const int ntile = (HWb + 15) >> 4, nw = kIrThreads >> 6;
+    const int ntile = (HWb + 15) >> 4, nw = THREADS >> 6;
     // A operands: straight from global memory (L2: the band's input is read by all of its chunk workgroups), kIrPf row tiles in
     // flight per wave — one workgroup owns the CU (its LDS), so nobody else hides a load that is waited for on the spot.
-    constexpr int kIrPf = 3;                                              // (5 / 6 tiles in flight, which the registers of a CU-owning workgroup allow, measured 3-6 % SLOWER)
+    constexpr int kIrPf = THREADS == 1024 ? 2 : 3;                                              // (5 / 6 tiles in flight, which the registers of a CU-owning workgroup allow, measured 3-6 % SLOWER)
     f4v ra[kIrPf][SLABS][2];
     // K tail (Cin % 32 != 0): the quads past Cin are read from the row's first quad instead — any finite value does, their weights are zero (the
     // planner pads w16 with zeros) — so that every load is unconditional: predicated, each tile carried 24 selects, the zero fill of its 24
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
     // cycles per workgroup for K = 32 / 64 / 96).  Instead eight consecutive lanes read one row's 128 bytes (8 lines per instruction, not 64),
     // each wave re-orders the tile through its own 2 KB of LDS (written at lane x 16 B, the chunk order XOR-swizzled on the GLOBAL side exactly
     // as in pw_gemm_ring_k, fragments read back with two conflict-free ds_read_b128) — no barrier: the LDS serves one wave's operations in order.
-    constexpr bool STAGE = CH == 32;
+    constexpr bool STAGE = CH == 32 && THREADS == 512;              // (the 1024-lane form has no LDS left for sixteen 2 KB buffers)
     const int lr = lane >> 3, lp = lane & 7;
     int koff[SLABS][2];
 #pragma unroll
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
   // divide the workgroup size, so registers cannot hold them; nine global loads per item were most of the stride-2 phase)
   float* dwl = ir_ex + (size_t)(e1 - e0) * W * CH;
   if (tid < 4) dwl[10 * CH + tid] = 0.f;                                 // the quad every row outside the image is read from (phase 2, stride 1)
-  for (int i = tid; i < 10 * CQ; i += kIrThreads) {
+  for (int i = tid; i < 10 * CQ; i += THREADS) {
     const int k = i / CQ, cq = i - k * CQ;
     *reinterpret_cast<f4v*>(dwl + k * CH + 4 * cq) = k < 9 ? *reinterpret_cast<const f4v*>(dww + (size_t)k * Cexp + n_base + 4 * cq)
                                                            : *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
@@ -866,13 +866,13 @@ __global__ __launch_bounds__(kIrThreads, (SLABS == 1 && CH == 16) ? 4 : 2) void 
     // ONE wave busy for a third round while seven idle — a third of the phase — so they are cut into single outputs, one per lane (9 quads loaded
     // for one output instead of 3: a round and a half of work instead of a whole one).
     // (Only a SMALL remainder is cut up: at a quarter of a round or more the whole walks are cheaper — the 65 x 65 bands measured +16 % cut up.)
-    const int rem = total % kIrThreads, main_total = rem * 4 <= kIrThreads ? total - rem : total;
-    for (int item = tid; item < main_total; item += kIrThreads) walk(item, 0, kIrSeg);
-    for (int u = tid; u < (total - main_total) * kIrSeg; u += kIrThreads) { const int li2 = u / kIrSeg; walk(main_total + li2, u - li2 * kIrSeg, 1); }
+    const int rem = total % THREADS, main_total = rem * 4 <= THREADS ? total - rem : total;
+    for (int item = tid; item < main_total; item += THREADS) walk(item, 0, kIrSeg);
+    for (int u = tid; u < (total - main_total) * kIrSeg; u += THREADS) { const int li2 = u / kIrSeg; walk(main_total + li2, u - li2 * kIrSeg, 1); }
   } else {
     // ---- phase 2, stride 2 (dilation 1): item = (output pixel of the band, channel quad), nine taps from LDS, (fy, fx) ascending
     const int total = (oy1 - oy0) * OW * CQ;
-    for (int item = tid; item < total; item += kIrThreads) {
+    for (int item = tid; item < total; item += THREADS) {
       const int t = item / CQ, cq = item - t * CQ, oyl = t / OW, ox = t - oyl * OW, oy = oy0 + oyl;
       f4v acc = zero;
 #pragma unroll
@@ -1575,6 +1575,7 @@ hipError_t nn_prepare() {
   BSX_ATTR_IR16(1, 1); BSX_ATTR_IR16(1, 2); BSX_ATTR_IR16(1, 3); BSX_ATTR_IR16(3, 1); BSX_ATTR_IR16(3, 2); BSX_ATTR_IR16(3, 3);
 #undef BSX_ATTR_IR16
   BSX_ATTR(dl_head0_k);
+  BSX_ATTR((ir_expand_dw_k<3, 1, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 2, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 3, 32, false, 1024>));
   BSX_ATTR((pw_gemm_ring_k<3, 3>)); BSX_ATTR((pw_gemm_ring_k<3, 4>)); BSX_ATTR((pw_gemm_ring_k<3, 5>));
   BSX_ATTR((pw_gemm_ring_k<1, 3>)); BSX_ATTR((pw_gemm_ring_k<1, 4>)); BSX_ATTR((pw_gemm_ring_k<1, 5>));
 #undef BSX_ATTR_IR
@@ -1612,6 +1613,18 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         // reduced-precision storage (f16_terms bit 4): only when the depthwise output's single reader is a GEMM that will take the f16 form (same M rule)
         const bool out16 = (f16_terms & 16) && (size_t)st.fuse_dw + 1 < plan.steps.size() && plan.steps[st.fuse_dw + 1].in_from_fused_dw &&
                            plan.steps[st.fuse_dw + 1].in0 == dws.out && (long)n * dws.OH * dws.OW >= 8192 && !no_gemm;
+        // 1024-lane workgroups (four waves per SIMD, <= 128 registers, input rows straight into the MFMA layout: no LDS left for sixteen re-order
+        // buffers) for the whole-frame 32-channel layers.  Measured per K: 16 input channels (64-byte rows: nothing to coalesce) 149 -> 134 us;
+        // 32 channels equal; 48 (two slabs) +5 %; 80 (three slabs) spills at 128 registers, 1.06 -> 1.72 ms.  Default: the 16-channel layers only
+        // (BSX_IR_WAVES16 = bit mask over the slab count, for experiments; 0 = never).
+        static const int w16_mask = getenv("BSX_IR_WAVES16") ? atoi(getenv("BSX_IR_WAVES16")) : -1;
+        const bool w16_on = w16_mask < 0 ? (slabs == 1 && st.Cin <= 16) : ((w16_mask >> (slabs - 1)) & 1) != 0;
+        if ((f16_terms & 15) == 3 && !out16 && ig.CH == 32 && ig.nbands == 1 && slabs >= 1 && slabs <= 3 && w16_on) {
+#define BSX_IR16(SL) ir_expand_dw_k<3, SL, 32, false, 1024><<<gi, 1024, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases)
+          if (slabs == 1) BSX_IR16(1); else if (slabs == 2) BSX_IR16(2); else BSX_IR16(3);
+#undef BSX_IR16
+          break;
+        }
 #define BSX_IR(T, SL, C) { if (out16) ir_expand_dw_k<T, SL, C, true><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases); \
           else ir_expand_dw_k<T, SL, C, false><<<gi, kIrThreads, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases); }
 #define BSX_IR_C(T, SL) { if (ig.CH == 32) BSX_IR(T, SL, 32) else if (ig.CH == 24) BSX_IR(T, SL, 24) else BSX_IR(T, SL, 16) }
