@@ -1,0 +1,71 @@
+"""LDS layouts of the LDS-DMA ring GEMM and of the fused kernel's re-order buffers (csrc/kernels_nn.hip: hsw / asw), checked against the bank
+model of MI355X_MICROARCH.md (ds_read_b128: four groups of 16 lanes over a 256-byte window of 16-byte slots) — no GPU needed.
+
+The DMA writes lane l's 16 bytes at piece_base + 16 l, so the swizzle is applied on the GLOBAL side: LDS position p of row r holds global chunk
+p ^ sw(r); the reader, who wants chunk c, looks at position c ^ sw(r).  These tests pin (1) that the two sides agree, (2) that every fragment
+read of the kernels is conflict-free, (3) that the un-swizzled layouts are not (i.e. the test would notice a regression)."""
+import itertools
+
+G128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+G128 = G128 + [[l + 32 for l in g] for g in G128]
+
+
+def extra_cycles(addr_of_lane):
+    """LDS cycles beyond the conflict-free four of one ds_read_b128 (byte address per lane)."""
+    tot = 0
+    for grp in G128:
+        slots = {}
+        for l in grp:
+            a = addr_of_lane(l)
+            assert a % 16 == 0
+            slots.setdefault((a // 16) % 16, set()).add(a)
+        tot += sum(len(v) - 1 for v in slots.values())
+    return tot
+
+
+def hsw(row):      # f16 operand rows of 64 bytes (4 chunks of 8 halves)
+    return (4 - ((row >> 2) & 3)) & 3
+
+
+def asw(row):      # f32 activation rows of 128 bytes (8 chunks of 4 floats)
+    return ((row >> 1) & 1) | (((row >> 3) & 1) << 2)
+
+
+def test_weight_rows_are_conflict_free_with_hsw_and_not_without():
+    read = lambda sw: extra_cycles(lambda l: (l & 15) * 64 + (((l >> 4) ^ sw(l & 15)) << 4))
+    assert read(hsw) == 0
+    assert read(lambda r: 0) > 0
+    assert extra_cycles(lambda l: (l & 15) * 80 + (l >> 4) * 16) > 0      # the padded 80-byte rows of pw_gemm_f16s_k: free for 16 CONSECUTIVE lanes only
+
+
+def test_activation_rows_are_conflict_free_with_asw_and_not_without():
+    for h in (0, 1):          # the two quads of a lane's 8 floats: chunks 2g and 2g + 1
+        read = lambda sw: extra_cycles(lambda l: (l & 15) * 128 + (((2 * (l >> 4) + h) ^ sw(l & 15)) << 4))
+        assert read(asw) == 0
+        assert read(lambda r: 0) > 0
+
+
+def test_dma_side_and_reader_side_agree():
+    # A piece: 8 rows x 8 chunk positions, lane = (row l >> 3, position l & 7) loads global chunk position ^ asw(row)
+    for piece in range(4):
+        lds = {}
+        for l in range(64):
+            row = 8 * piece + (l >> 3)
+            lds[(row, l & 7)] = (l & 7) ^ asw(row & 15)
+        for row, c in itertools.product(range(8 * piece, 8 * piece + 8), range(8)):
+            assert lds[(row, c ^ asw(row & 15))] == c
+    # weight piece: 16 channel rows x 4 chunk positions
+    lds = {}
+    for l in range(64):
+        row = l >> 2
+        lds[(row, l & 3)] = (l & 3) ^ hsw(row)
+    for row, c in itertools.product(range(16), range(4)):
+        assert lds[(row, c ^ hsw(row))] == c
+
+
+def test_fragment_reads_use_xor_16_for_the_second_quad():
+    # kernels read the second quad of a lane's 8 floats at (address ^ 16): positions (2g) ^ s and (2g + 1) ^ s differ in bit 0 only
+    for li, g in itertools.product(range(16), range(4)):
+        a0 = li * 128 + (((2 * g) ^ asw(li)) << 4)
+        a1 = li * 128 + (((2 * g + 1) ^ asw(li)) << 4)
+        assert a1 == a0 ^ 16
