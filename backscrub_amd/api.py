@@ -166,6 +166,9 @@ class MaskGen:
     def step_yuyv(self, frames, bg, out_yuyv):
         """one main-loop iteration with the composite written as YUYV 4:2:2 [n,H,W,2] (convert_rgb_to_yuyv fused into the blend)"""
         n = self._n(frames)
+        if (out_yuyv.dim() != 4 or tuple(out_yuyv.shape[1:]) != (self.height, self.width, 2) or out_yuyv.shape[0] < n or not out_yuyv.is_contiguous()
+                or not out_yuyv.is_cuda or out_yuyv.dtype != _torch().uint8):
+            raise BsxError("out_yuyv must be a contiguous cuda uint8 tensor [>=%d,%d,%d,2]" % (n, self.height, self.width))
         stride = 0 if bg.dim() == 3 else bg.stride(0)
         _check(lib().bsx_step_batch_yuyv(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride,
                                          C.c_void_p(out_yuyv.data_ptr()), n, _stream_ptr()), self.h, "bsx_step_batch_yuyv")
@@ -392,10 +395,17 @@ class Live:
             raise BsxError("bsx_live_new failed")
 
     def set_input_frame(self, frame: np.ndarray):
-        frame = np.ascontiguousarray(frame, np.uint8)
+        if not isinstance(frame, np.ndarray) or frame.dtype != np.uint8 or frame.shape != (self.mg.height, self.mg.width, 3):
+            raise BsxError("frame must be uint8 [%d,%d,3]" % (self.mg.height, self.mg.width))
+        if frame.strides[2] != 1 or frame.strides[1] != 3:
+            frame = np.ascontiguousarray(frame)
         _check(lib().bsx_live_set_input_frame(self.h, frame.ctypes.data, frame.strides[0]), self.mg.h, "bsx_live_set_input_frame")
 
     def get_output_mask(self, mask: np.ndarray) -> bool:
+        if (not isinstance(mask, np.ndarray) or mask.dtype != np.uint8 or mask.shape != (self.mg.height, self.mg.width) or mask.strides[1] != 1
+                or mask.strides[0] < self.mg.width or not mask.flags.writeable):
+            # the C side writes height rows of width bytes (as process_host does)
+            raise BsxError("mask must be a writable uint8 [%d,%d] array with unit inner stride" % (self.mg.height, self.mg.width))
         rc = lib().bsx_live_get_output_mask(self.h, mask.ctypes.data, mask.strides[0])
         if rc < 0:
             _check(rc, self.mg.h, "bsx_live_get_output_mask")

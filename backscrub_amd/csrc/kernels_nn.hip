@@ -1634,14 +1634,17 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
 #undef BSX_IR
         break;
       }
-      if (M <= 4096) {
+      const bool gemm_ok = !no_gemm && M >= 8192 && (st.Cin & 3) == 0 && st.Cin >= 8 && st.cout_pad % 16 == 0 && st.cout_pad >= 16;
+      // a step that carries a per-frame out_bias (the folded ASPP pool branch) has two forms only — this one and the GEMMs: between their M ranges
+      // (DeepLab at 4-7 streams) and with BSX_NO_PW_GEMM it stays on the lane-per-output form
+      if (M <= 4096 || (st.out_bias >= 0 && !gemm_ok)) {
         long total = M * st.Cout;
         pw_small_k<<<blocks_for(total), kThreads, 0, s>>>(P(st.in0), w, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), total, HW, st.Cin, st.Cout, st.cout_pad, st.act, P(st.out_bias));
         break;
       }
       // enough rows and channels to fill 128 x 64 MFMA tiles → the GEMM form (BSX_NO_PW_GEMM=1 keeps the lane-per-pixel form)
       // (even K = 8 / N = 16 layers: the tiles are mostly padding, but A is read once and coalesced — measured faster than the lane-per-pixel form)
-      if (!no_gemm && M >= 8192 && (st.Cin & 3) == 0 && st.Cin >= 8 && st.cout_pad % 16 == 0 && st.cout_pad >= 16) {
+      if (gemm_ok) {
         dim3 gg((unsigned)((M + kGemmBM - 1) / kGemmBM), (st.cout_pad + kGemmBN - 1) / kGemmBN);
         if (weights16 && st.k16_pad > 0 && (f16_terms & 15) > 0) {        // split-f16 (3 terms, f32-grade) or plain f16-input (1 term) MFMA
           if (st.out_bias >= 0 && st.residual >= 0) return hipErrorInvalidValue;      // the epilogue carries ONE extra operand per tile (see gemm_store_tile)

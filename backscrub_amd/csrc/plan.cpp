@@ -494,7 +494,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   if (uses_of(c0) != 1) return seg_fail(23);
   // activations the kernels implement: a clamp (none / relu / relu6) everywhere, hard-swish also on the stem, the logistic also on the output
   auto clampish = [](int a) { return a == kActNone || a == kActRelu || a == kActRelu6; };
-  if (!(clampish(stem.act) || stem.act == kActHswish) || !(clampish(ttc.act) || ttc.act == kActSigmoid) || (ttc.act == kActSigmoid && ttc.Cout != 1)) return seg_fail(34);
+  if (!(clampish(stem.act) || stem.act == kActHswish) || !(ttc.act == kActNone || ttc.act == kActSigmoid) || (ttc.act == kActSigmoid && ttc.Cout != 1)) return seg_fail(34);
   for (const Step* q : {&hpw, &hdw, &pwa, &pwb, &kdw, &kp1, &kd, &kp2, &tpw, &tdw}) if (!clampish(q->act)) return seg_fail(35);
 
   // ---- dedicated, never-reused arena space for everything that crosses a kernel boundary (a segment kernel reads and writes
@@ -1064,7 +1064,16 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   for (const Step& st : steps) plan->macs_per_frame += st.macs;
   plan->steps = std::move(steps);
   plan->seg = SegPlan();
-  if (!segments || getenv("BSX_NO_SEGMENTS") || !build_segments(g, plan)) {
+  bool seg_ok = false;
+  if (segments && !getenv("BSX_NO_SEGMENTS")) {
+    // build_segments re-points tensor offsets, grows the arena and appends synthetic tensors BEFORE its last checks (an unsupported middle):
+    // a failed attempt must leave the plan exactly as the unsegmented paths expect it
+    const std::vector<long> off0 = plan->tensor_off;
+    const size_t arena0 = plan->arena_floats_per_stream, nt0 = g.tensors.size();
+    seg_ok = build_segments(g, plan);
+    if (!seg_ok) { plan->tensor_off = off0; plan->arena_floats_per_stream = arena0; g.tensors.resize(nt0); }
+  }
+  if (!seg_ok) {
     plan->seg = SegPlan();
     build_frame_program(g, plan, plan->steps);
   }

@@ -69,7 +69,7 @@ def parse():
 
 def resolve_model(key):
     if key in NAMES:
-        real = os.path.join(ROOT, "oracle", "_ref", "models", NAMES[key])    # model DATA staged from the reference checkout
+        real = os.path.join(ROOT, "models", NAMES[key])    # model DATA the user supplies; tools/stage_models.py copies the reference's files here
         if os.path.exists(real):
             return real, NAMES[key], "reference weights"
         from tools import make_synthetic_model

@@ -14,7 +14,7 @@ def pytest_configure(config):
 
 
 def _real_models():
-    return sorted(glob.glob(os.path.join(ROOT, "oracle", "_ref", "models", "*.tflite")))
+    return sorted(glob.glob(os.path.join(ROOT, "models", "*.tflite")))
 
 
 MODEL_KEYS = {
@@ -27,9 +27,9 @@ MODEL_KEYS = {
 
 def model_path(key, prefer_real=True):
     """Path of a model for tests: the reference's real .tflite when it was staged into
-    oracle/_ref/models (git-ignored, travels to the GPU box), else the synthetic
+    models/ (tools/stage_models.py; git-ignored, travels to the GPU box), else the synthetic
     same-architecture model with seeded random weights under tests/golden/models."""
-    real = os.path.join(ROOT, "oracle", "_ref", "models", MODEL_KEYS[key])
+    real = os.path.join(ROOT, "models", MODEL_KEYS[key])
     if prefer_real and os.path.exists(real):
         return real
     return synthetic_model_path(key)

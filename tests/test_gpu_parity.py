@@ -369,9 +369,12 @@ def test_end_to_end_iou_and_composite(bs, oracle, key, res, real):
             assert iou >= 0.999, "t=%d stream %d IoU %.5f" % (t, i, iou)
             if np.array_equal(got_mask[i], want_mask):
                 assert np.array_equal(got_out[i], want_out)
-            # composite: <= 1 LSB except where a decision pixel flipped (bounded by the IoU bar)
+            # composite: the blend is bit-exact, so the composite can only differ where the full-resolution masks differ (a flipped decision
+            # pixel of the model-resolution mask, bounded by the IoU bar) — everywhere else the difference is 0, not just <= 1 LSB
             diff = np.abs(got_out[i].astype(np.int16) - want_out.astype(np.int16)).max(-1)
-            assert (diff > 1).mean() <= 1e-3, "t=%d stream %d: %.5f of pixels differ by > 1 LSB" % (t, i, (diff > 1).mean())
+            same = got_mask[i] == want_mask
+            assert int(diff[same].max(initial=0)) == 0, "t=%d stream %d: composite differs where the masks agree" % (t, i)
+            assert (~same).mean() <= 1e-3, "t=%d stream %d: %.5f of mask pixels differ" % (t, i, (~same).mean())
     for c in oc:
         c.close()
     mg.close()
@@ -402,8 +405,9 @@ def test_end_to_end_on_the_photo_fixture(bs, oracle, key):
             iou = _iou_fg(got_mask[i], want_mask, need_person=(t == 2))
             assert iou >= 0.999, "%s t=%d frame %d IoU %.5f" % (key, t, i, iou)
             want_out = oracle.alpha_blend(bg, frames[i], want_mask)
+            # the north star's bar, as stated: max-abs <= 1 LSB over the whole composited frame (default, parity-grade path, real weights)
             diff = np.abs(got_out[i].astype(np.int16) - want_out.astype(np.int16)).max(-1)
-            assert (diff > 1).mean() <= 1e-3, "%s t=%d frame %d: %.5f of pixels differ by > 1 LSB" % (key, t, i, (diff > 1).mean())
+            assert int(diff.max()) <= 1, "%s t=%d frame %d: composite max-abs %d (%d pixels > 1 LSB)" % (key, t, i, int(diff.max()), int((diff > 1).sum()))
     for c in oc:
         c.close()
     mg.close()

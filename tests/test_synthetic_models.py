@@ -24,7 +24,7 @@ def _signature(m):
 
 @pytest.mark.parametrize("key", list(MODEL_KEYS))
 def test_synthetic_matches_reference_architecture(key):
-    real = os.path.join(ROOT, "oracle", "_ref", "models", MODEL_KEYS[key])
+    real = os.path.join(ROOT, "models", MODEL_KEYS[key])
     if not os.path.exists(real):
         pytest.skip("reference model not staged (only available where /root/reference exists)")
     a, b = _signature(T.load(real)), _signature(T.loads(T.dumps(S.build(key))))
