@@ -76,6 +76,9 @@ SYMBOLS = [
     ("bsx_debug_run_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_plan_describe", C.c_char_p, [C.c_void_p]),
     ("bsx_debug_tensor", C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_long]),
+    ("bsx_model_precompile", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("bsx_model_kernel_source", C.c_long, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("bsx_debug_tensor_of", C.c_long, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_long]),
     ("bsx_debug_program_timeline", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p]),
     ("bsx_model_describe", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("bsx_profile_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.c_void_p]),
@@ -284,7 +287,14 @@ class MaskGen:
     def plan(self) -> str:
         return lib().bsx_plan_describe(self.h).decode()
 
-    def graph_tensor(self, idx) -> np.ndarray:
+    def graph_tensor(self, idx, stream=None) -> np.ndarray:
+        if stream is not None:
+            n = lib().bsx_debug_tensor_of(self.h, idx, stream, None, 0)
+            if n < 0:
+                raise BsxError("tensor %d not materialised" % idx)
+            a = np.empty(n, np.float32)
+            lib().bsx_debug_tensor_of(self.h, idx, stream, a.ctypes.data_as(C.POINTER(C.c_float)), n)
+            return a
         n = lib().bsx_debug_tensor(self.h, idx, None, 0)
         if n < 0:
             raise BsxError("tensor %d not materialised" % idx)
@@ -421,6 +431,24 @@ class Live:
             self.close()
         except Exception:
             pass
+
+
+def model_precompile(path: str, arch: str | None = None) -> str:
+    """Host only: emit + compile (hipRTC) the kernel specialised to this model's graph into the code-object cache; returns the note."""
+    buf = C.create_string_buffer(1 << 14)
+    rc = lib().bsx_model_precompile(os.fsencode(path), arch.encode() if arch else None, buf, len(buf))
+    if rc != 0:
+        raise BsxError(buf.value.decode(errors="replace"))
+    return buf.value.decode()
+
+
+def model_kernel_source(path: str) -> str:
+    """The generated HIP source of the specialised per-frame program ('' when the graph has none)."""
+    buf = C.create_string_buffer(1 << 20)
+    n = lib().bsx_model_kernel_source(os.fsencode(path), buf, len(buf))
+    if n < 0:
+        raise BsxError(buf.value.decode(errors="replace"))
+    return buf.value.decode() if n > 0 else ""
 
 
 def model_describe(path: str) -> str:

@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbsx.so")
-SOURCES = ["tflite_model.cpp", "plan.cpp", "media.cpp", "live.cpp", "kernels_nn.hip", "kernels_img.hip", "kernels_frame.hip", "kernels_seg.hip", "bsx_api.hip"]
-HEADERS = ["media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", os.path.join("..", "..", "include", "bsx.h")]
+SOURCES = ["tflite_model.cpp", "plan.cpp", "gen_mid.cpp", "rtc.cpp", "media.cpp", "live.cpp", "kernels_nn.hip", "kernels_img.hip", "kernels_frame.hip", "kernels_seg.hip", "bsx_api.hip"]
+HEADERS = ["mid_prelude.hip", "gen_mid.hpp", "rtc.hpp", "media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", os.path.join("..", "..", "include", "bsx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]
@@ -29,8 +29,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def embed_prelude():
+    """csrc/mid_prelude.hip → csrc/build/mid_prelude_str.inc: the device templates as a C++ raw string literal that gen_mid.cpp includes
+    (the specialised kernels are compiled from it by hipRTC when a context is created)."""
+    src = os.path.join(CSRC, "mid_prelude.hip")
+    dst = os.path.join(OBJ, "mid_prelude_str.inc")
+    text = open(src).read()
+    assert ')BSXRTC"' not in text
+    body = 'R"BSXRTC(' + text + ')BSXRTC"\n'
+    if not os.path.exists(dst) or open(dst).read() != body:
+        with open(dst, "w") as f:
+            f.write(body)
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
+    embed_prelude()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     procs = []
@@ -54,7 +68,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("libbsx build failed")
     if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz", "-lpthread"]
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz", "-lpthread", "-lhiprtc", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -16,7 +16,9 @@
 #include <vector>
 
 #include "../../include/bsx.h"
+#include "gen_mid.hpp"
 #include "kernels.hpp"
+#include "rtc.hpp"
 #include "plan.hpp"
 #include "tflite_model.hpp"
 
@@ -106,6 +108,8 @@ struct bsx_ctx {
   float* d_color_lut = nullptr;
   MicroOp* d_program = nullptr;     // per-frame network program (kernels_frame.hip)
   bool use_program = false;
+  RtcKernel mid;                    // the same program as ONE graph-specialised kernel, compiled by hipRTC when the context is created
+  std::string mid_note;             //   (gen_mid.cpp, mid_prelude.hip); mid.fn == nullptr: the interpreter runs (BSX_NO_RTC=1, or why in mid_note)
   BilateralParams bilateral{};
   DevResizeTab tab_down, tab_up;
   std::map<std::pair<std::pair<int, int>, std::pair<int, int>>, DevResizeTab> bg_tabs;
@@ -202,6 +206,23 @@ int init_device_state(bsx_ctx* c) {
     BSX_HIP(c, hipMemcpy(c->d_program, c->plan.program.data(), c->plan.program.size() * sizeof(MicroOp), hipMemcpyHostToDevice));
     BSX_HIP(c, frame_program_prepare(c->plan.program_lds_floats));
     if (c->plan.seg.on) BSX_HIP(c, seg_prepare());
+    // Specialise the program to this graph: straight-line code with compile-time geometry instead of the interpreted micro-op table.
+    // Compiled by hipRTC for this device's architecture (cached on disk; bsx_model_precompile fills the cache without a GPU).
+    // Anything the generator does not cover, or a failed compilation, leaves the interpreter in charge — never an error.
+    if (!getenv("BSX_NO_RTC")) {
+      std::string why, log;
+      const std::string src = generate_mid_source(c->plan, &why);
+      if (src.empty()) c->mid_note = "interpreted (" + why + ")";
+      else {
+        hipDeviceProp_t prop;
+        std::vector<char> code;
+        bool cached = false;
+        if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) c->mid_note = "interpreted (no device properties)";
+        else if (!rtc_build(src, prop.gcnArchName, &code, &log, &cached)) { c->mid_note = "interpreted (hipRTC: " + log.substr(0, 400) + ")"; if (getenv("BSX_RTC_DEBUG")) fprintf(stderr, "%s\n", log.c_str()); }
+        else if (rtc_load(code, "bsx_mid", &c->mid) != hipSuccess) { c->mid_note = "interpreted (code object did not load)"; (void)hipGetLastError(); }
+        else c->mid_note = std::string("specialised kernel (hipRTC") + (cached ? ", from the cache)" : ", compiled now)");
+      }
+    } else c->mid_note = "interpreted (BSX_NO_RTC)";
   } else {
     BSX_HIP(c, nn_prepare());                 // per-launch path: the fused kernels' dynamic-LDS limits on this device
   }
@@ -256,6 +277,18 @@ bool argmax_tail(const bsx_ctx* c) {
   return !c->use_program && !c->keep_logits && c->model_type == BSX_MODEL_DEEPLAB && !c->plan.steps.empty() && c->plan.steps.back().out == c->plan.output &&
          resize_argmax_fusable(c->plan.steps.back());
 }
+// the middle of a segmented plan / the whole-network program: the specialised kernel when one was built, else the interpreter
+hipError_t launch_program(bsx_ctx* c, int n, hipStream_t s, unsigned long long* timeline = nullptr) {
+  long pf = (long)c->plan.arena_floats_per_stream;
+  if (c->mid.fn) {
+    float* arena = c->d_arena;
+    const float* weights = c->d_weights;
+    void* args[] = {&arena, &pf, &weights, &timeline};
+    return hipModuleLaunchKernel(c->mid.fn, (unsigned)n, 1, 1, kFrameThreads, 1, 1, 0, s, args, nullptr);
+  }
+  return launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out, c->d_weights, n, s,
+                              timeline);
+}
 bool infer_decodes(const bsx_ctx* c) { return (c->use_program && c->plan.seg.on && !c->keep_logits) || argmax_tail(c); }
 int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0) {
   if (c->use_program && c->plan.seg.on) {
@@ -263,15 +296,13 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
     const long pf = (long)c->plan.arena_floats_per_stream;
     BSX_HIP(c, launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s));
     BSX_HIP(c, launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s));
-    BSX_HIP(c, launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out,
-                                    c->d_weights, n, s));
+    BSX_HIP(c, launch_program(c, n, s));
     BSX_HIP(c, launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s));
     BSX_HIP(c, launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal + (size_t)slot * c->outW * c->outH, c->d_weights, logits, n, s));
     return BSX_OK;
   }
   if (c->use_program) {
-    BSX_HIP(c, launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena,
-                                    (long)c->plan.arena_floats_per_stream, c->d_net_in, c->d_net_out, c->d_weights, n, s));
+    BSX_HIP(c, launch_program(c, n, s));
     return BSX_OK;
   }
   const bool fused_tail = !logits && argmax_tail(c);
@@ -383,6 +414,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
              c->use_program ? "ON" : "off", c->plan.program.size(), c->plan.program_lds_floats, c->plan.program_lds_floats / 256.0,
              c->plan.program_lds_tensors, c->plan.program_global_tensors);
     c->plan_text += line;
+    if (c->use_program) c->plan_text += "program execution: " + c->mid_note + "\n";
     if (c->use_program && c->plan.seg.on) c->plan_text += c->plan.seg_text;
     for (size_t i = 0; i < c->plan.program_labels.size(); i++) { c->plan_text += "P" + std::to_string(i) + " " + c->plan.program_labels[i] + "\n"; }
   }
@@ -400,6 +432,7 @@ void bsx_delete(bsx_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  rtc_unload(&c->mid);
   void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
@@ -612,13 +645,11 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       const SegPlan& sp = c->plan.seg;
       BSX_TIMED(launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s));
       BSX_TIMED(launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s));
-      BSX_TIMED(launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out,
-                                     c->d_weights, n, s));
+      BSX_TIMED(launch_program(c, n, s));
       BSX_TIMED(launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s));
       BSX_TIMED(launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal, c->d_weights, !fused_decode, n, s));
     } else if (c->use_program)
-      BSX_TIMED(launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out,
-                                     c->d_weights, n, s));
+      BSX_TIMED(launch_program(c, n, s));
     else {
       for (size_t si = 0; si + (atail ? 1 : 0) < c->plan.steps.size(); si++)
         BSX_TIMED(launch_step(c->plan.steps[si], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms));
@@ -718,8 +749,7 @@ int bsx_debug_program_timeline(bsx_ctx* c, int n, unsigned long long* ticks, int
   BSX_HIP(c, hipMalloc(&d, kTl * sizeof(unsigned long long)));
   BSX_HIP(c, hipMemset(d, 0, kTl * sizeof(unsigned long long)));
   hipStream_t s = pick(c, stream);
-  BSX_HIP(c, launch_frame_program(c->d_program, L, c->plan.program_lds_floats, c->d_arena, (long)c->plan.arena_floats_per_stream, c->d_net_in,
-                                  c->d_net_out, c->d_weights, n, s, d));
+  BSX_HIP(c, launch_program(c, n, s, d));
   BSX_HIP(c, hipStreamSynchronize(s));
   BSX_HIP(c, hipMemcpy(ticks, d, std::min((size_t)cap, kTl) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   (void)hipFree(d);
@@ -749,7 +779,49 @@ int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
   return rc;
 }
 
+long bsx_model_kernel_source(const char* model_path, char* buf, size_t cap) {
+  if (!model_path || !buf || !cap) return BSX_EINVAL;
+  try {
+    Graph g; Plan p;
+    std::string err, why;
+    if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { snprintf(buf, cap, "%s", err.c_str()); return BSX_EMODEL; }
+    const std::string src = generate_mid_source(p, &why);
+    if (src.empty()) { snprintf(buf, cap, "%s", why.c_str()); return 0; }
+    snprintf(buf, cap, "%s", src.c_str());
+    return (long)src.size();
+  } catch (...) { snprintf(buf, cap, "exception while reading the model"); return BSX_EMODEL; }
+}
+
+int bsx_model_precompile(const char* model_path, const char* arch, char* msg, size_t cap) {
+  if (!model_path || !msg || !cap) return BSX_EINVAL;
+  try {
+    Graph g; Plan p;
+    std::string err, why, log;
+    if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { snprintf(msg, cap, "%s", err.c_str()); return BSX_EMODEL; }
+    const std::string src = generate_mid_source(p, &why);
+    if (src.empty()) { snprintf(msg, cap, "interpreted (%s)", why.c_str()); return BSX_OK; }
+    std::vector<char> code;
+    bool cached = false;
+    if (!rtc_build(src, arch ? arch : "gfx950", &code, &log, &cached)) { snprintf(msg, cap, "hipRTC failed: %s", log.c_str()); return BSX_EMODEL; }
+    snprintf(msg, cap, "%s (%zu bytes of source, %zu bytes of code object, cache %s)", cached ? "cached" : "compiled", src.size(), code.size(), rtc_cache_dir().c_str());
+    return BSX_OK;
+  } catch (...) { snprintf(msg, cap, "exception while reading the model"); return BSX_EMODEL; }
+}
+
 const char* bsx_plan_describe(bsx_ctx* c) { return c ? c->plan_text.c_str() : ""; }
+
+long bsx_debug_tensor_of(bsx_ctx* c, int t, int stream_idx, float* h_out, long cap) {
+  if (!c || t < 0 || t >= (int)c->graph.tensors.size() || c->plan.tensor_off[t] < 0 || stream_idx < 0 || stream_idx >= c->n_streams) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
+  const long n = (long)c->graph.tensors[t].elems();
+  if (!h_out) return n;
+  // network input / output and the per-launch arena are batch-major (stream i at + i * elems); the per-frame program's arena is frame-major
+  const float* p = (t == c->plan.input || t == c->plan.output || !c->use_program) ? c->tensor_ptr(t) + (size_t)stream_idx * (size_t)n
+                                                                                 : c->tensor_ptr(t) + (size_t)stream_idx * c->plan.arena_floats_per_stream;
+  if (hipDeviceSynchronize() != hipSuccess) return BSX_EDEVICE;
+  if (hipMemcpy(h_out, p, sizeof(float) * (size_t)std::min(n, cap), hipMemcpyDeviceToHost) != hipSuccess) return BSX_EDEVICE;
+  return n;
+}
 
 long bsx_debug_tensor(bsx_ctx* c, int t, float* h_out, long cap) {
   if (!c || t < 0 || t >= (int)c->graph.tensors.size() || c->plan.tensor_off[t] < 0) return BSX_EINVAL;

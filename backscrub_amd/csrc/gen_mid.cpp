@@ -1,0 +1,139 @@
+// gen_mid.cpp — emits the graph-specialised source of the per-frame network program (see mid_prelude.hip, rtc.hpp).
+//
+// Input: the planner's micro-op list (Plan::program — geometry, LDS offsets, weight slots, operand address spaces; plan.cpp).
+// Output: one HIP translation unit = the device templates of mid_prelude.hip + one traits struct per op + a kernel that calls the
+// op bodies in program order with one barrier between them.  Nothing in the kernel is read from a table at run time.
+// Graphs with micro-ops the templates do not cover return an empty string: the interpreter (kernels_frame.hip) runs them.
+#include "gen_mid.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+
+namespace bsx {
+namespace {
+
+const char kPrelude[] =
+#include "build/mid_prelude_str.inc"
+    ;
+
+struct Out {
+  std::string s;
+  void f(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+    char buf[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    s += buf;
+  }
+};
+
+int sp_of(const Loc& l) { return l.space == kLocNone ? 0 : (l.space == kLocLds ? 1 : 2); }      // SP_NONE / SP_LDS / SP_GLB
+bool plain(const Loc& l) { return l.space == kLocNone || l.space == kLocLds || l.space == kLocGlobal; }   // no network input / output buffers in a middle program
+
+void loc(Out& o, const char* p, const Loc& l) { o.f("  static constexpr int %s_SP = %d, %s_OFF = %d, %s_ST = %d;\n", p, sp_of(l), p, l.off, p, l.stride); }
+
+}  // namespace
+
+std::string generate_mid_source(const Plan& plan, std::string* why) {
+  auto fail = [&](const std::string& m) { if (why) *why = m; return std::string(); };
+  const std::vector<MicroOp>& P = plan.program;
+  if (P.empty()) return fail("no program");
+  Out o;
+  o.s.reserve(sizeof kPrelude + 64 * 1024);
+  o.s += kPrelude;
+  o.f("\nnamespace bsxm {\n");
+  std::string body;
+  Out k;
+  const int n = (int)P.size();
+  // weight staging of op i (issued while op i-1 runs; op 0's before the first barrier)
+  auto stage_of = [&](int i, Out& dst) {
+    const MicroOp& m = P[i];
+    if (m.stage_floats > 0) dst.f("  stage<%d>(W + %lld, L + %d);\n", m.stage_floats, m.w_off, m.w_lds);
+    else {
+      if (m.fc_stage[0] > 0) dst.f("  stage<%d>(W + %lld, L + %d);\n", m.fc_stage[0], m.b_off, m.fc_lds[0]);
+      if (m.fc_stage[1] > 0) dst.f("  stage<%d>(W + %lld, L + %d);\n", m.fc_stage[1], m.b3_off, m.fc_lds[1]);
+    }
+  };
+  stage_of(0, k);
+  for (int i = 0; i < n; i++) {
+    const MicroOp& m = P[i];
+    for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.scale, &m.out}) if (!plain(*l)) return fail("operand in the network input / output buffer");
+    k.f("  // ---- P%d %s\n  op_barrier();\n  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[%d] = __builtin_amdgcn_s_memrealtime();\n", i,
+        i < (int)plan.program_labels.size() ? plan.program_labels[i].c_str() : "", i);
+    if (i + 1 < n) stage_of(i + 1, k);
+    if (m.kind == (int)StepKind::PwConv && m.mfma && !m.gemv) {
+      if (m.Cin % 4 || m.cout_pad % 16 || m.stage_floats <= 0) return fail("pw: channel counts / unstaged weights");
+      if (m.scale.space != kLocNone && m.scale.space != kLocLds) return fail("pw: scale vector outside LDS");
+      o.f("struct Op%d {\n  static constexpr int P = %d, CIN = %d, COUT = %d, CPAD = %d, ACT = %d;\n", i, m.OH * m.OW, m.Cin, m.Cout, m.cout_pad, m.act);
+      loc(o, "X", m.in0); loc(o, "Y", m.out); loc(o, "R", m.res); loc(o, "D", m.in2);
+      o.f("  static constexpr int S_OFF = %d, W_LDS = %d, B_LDS = %d;\n};\n", m.scale.space == kLocLds ? m.scale.off : -1, m.w_lds, m.w_lds + (int)(m.b_off - m.w_off));
+      k.f("  op_pw<Op%d>(L, A);\n", i);
+    } else if (m.kind == (int)StepKind::DwConv) {
+      const bool ok = m.strip && m.dh == 1 && m.dw == 1 && m.kh == m.kw && (m.kh == 3 || m.kh == 5) && m.sh == m.sw && (m.sh == 1 || m.sh == 2) && m.Cin % 4 == 0;
+      if (!ok) return fail("dw: geometry outside the strip form");
+      const int K = m.kh, S = m.sh, V = K == 5 ? 2 : 4;
+      int TX = S == 1 ? 5 : 4;
+      if (S == 1 && m.OW % 5 != 0 && m.OW % 4 == 0) TX = 4;
+      const bool staged = m.stage_floats > 0;
+      o.f("struct Op%d {\n  static constexpr int K = %d, S = %d, H = %d, W = %d, OH = %d, OW = %d, PT = %d, PL = %d, C = %d, ACT = %d, V = %d, TX = %d;\n", i, K, S, m.H, m.W,
+          m.OH, m.OW, m.pt, m.pl, m.Cin, m.act, V, TX);
+      loc(o, "X", m.in0); loc(o, "Y", m.out); loc(o, "R", m.res);
+      if (staged) o.f("  static constexpr int W_SP = SP_LDS, W_OFF = %d, B_OFF = %d;\n};\n", m.w_lds, m.w_lds + (int)(m.b_off - m.w_off));
+      else {
+        if (m.w_off > 0x7fffffffll || m.b_off > 0x7fffffffll) return fail("dw: weight offset");
+        o.f("  static constexpr int W_SP = SP_GLB, W_OFF = %lld, B_OFF = %lld;\n};\n", m.w_off, m.b_off);
+      }
+      k.f("  op_dw<Op%d>(L, A, W);\n", i);
+    } else if (m.kind == kMicroSe) {
+      if (m.in1.space != kLocLds || (m.n_fc == 2 && m.in2.space != kLocLds) || m.Cin % 4 || m.C1 % 1) return fail("se: mean / hidden vectors outside LDS");
+      // pooling parts → mean vector (LDS, at in1)
+      const int mean = m.in1.off;
+      auto part = [&](const Loc& l, int rows, int C, int hw, int coff, bool accum, bool partials) {
+        const int st = partials ? C : l.stride;
+        k.f("  gap_part<%d, %d, %d, %d, %d, %d, %d, %s, %d>(L, A);\n", partials ? 2 : sp_of(l), l.off, st, rows, C, hw, coff, accum ? "true" : "false", mean);
+      };
+      if (m.n_cat == 0) part(m.in0, m.H * m.W, m.Cin, m.H * m.W, 0, false, false);
+      else {
+        int coff = 0;
+        for (int c = 0; c < m.n_cat; c++) {
+          if (!plain(m.cat[c]) || m.cat_c[c] % 4) return fail("se: pooled part");
+          const bool partials = m.cat_parts[c] > 0;
+          if (partials && m.cat[c].space != kLocGlobal) return fail("se: partial sums outside the arena");
+          part(m.cat[c], partials ? m.cat_parts[c] : m.cat_hw[c], m.cat_c[c], m.cat_hw[c], coff, m.gap_sum && c > 0, partials);
+          if (!m.gap_sum) coff += m.cat_c[c];
+        }
+      }
+      k.f("  __syncthreads();\n");
+      const Loc& y1 = m.n_fc == 1 ? m.out : m.in2;
+      auto fc = [&](int cin, int cout, int act, int stage, int lds, long long w2, long long b, int x_off, const Loc& y) {
+        if (stage > 0) k.f("  fc_layer<%d, %d, %d, SP_LDS, %d, %d, %d, %d, %d>(L, A, W);\n", cin, cout, act, lds + (int)(w2 - b), lds, x_off, sp_of(y), y.off);
+        else k.f("  fc_layer<%d, %d, %d, SP_GLB, %lld, %lld, %d, %d, %d>(L, A, W);\n", cin, cout, act, w2, b, x_off, sp_of(y), y.off);
+      };
+      if (m.w2_off > 0x7fffffffll || m.w3_off > 0x7fffffffll) return fail("se: weight offset");
+      fc(m.Cin, m.C1, m.act, m.fc_stage[0], m.fc_lds[0], m.w2_off, m.b_off, mean, y1);
+      if (m.n_fc == 2) {
+        k.f("  __syncthreads();\n");
+        fc(m.C1, m.C2, m.act2, m.fc_stage[1], m.fc_lds[1], m.w3_off, m.b3_off, m.in2.off, m.out);
+      }
+    } else if (m.kind == (int)StepKind::Resize) {
+      if (m.Cin % 4) return fail("resize: channels");
+      o.f("struct Op%d {\n  static constexpr int H = %d, W = %d, OH = %d, OW = %d, C = %d;\n  static constexpr bool HALF_PIXEL = %s, ALIGN = %s;\n", i, m.H, m.W, m.OH, m.OW, m.Cin,
+          m.half_pixel ? "true" : "false", m.align_corners ? "true" : "false");
+      loc(o, "X", m.in0); loc(o, "Y", m.out);
+      o.f("};\n");
+      k.f("  op_resize<Op%d>(L, A);\n", i);
+    } else {
+      return fail("micro-op kind " + std::to_string(m.kind) + " has no specialised body");
+    }
+  }
+  o.f("}  // namespace bsxm\n\nusing namespace bsxm;\n");
+  o.f("extern \"C\" __global__ void __launch_bounds__(1024) bsx_mid(float* __restrict__ arena, long per_frame, const float* __restrict__ weights, unsigned long long* tl) {\n");
+  o.f("  __shared__ __attribute__((aligned(16))) float smem[%d];\n", plan.program_lds_floats);
+  o.f("  lds_f* L = (lds_f*)smem;\n  glb_f* A = (glb_f*)(arena + (size_t)blockIdx.x * (size_t)per_frame);\n  const glb_f* W = (const glb_f*)weights;\n");
+  o.s += k.s;
+  o.f("  op_barrier();\n  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[%d] = __builtin_amdgcn_s_memrealtime();\n}\n", n);
+  return o.s;
+}
+
+}  // namespace bsx

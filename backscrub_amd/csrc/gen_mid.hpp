@@ -1,0 +1,13 @@
+// gen_mid.hpp — source generator of the graph-specialised per-frame program (gen_mid.cpp).
+#pragma once
+#include <string>
+
+#include "plan.hpp"
+
+namespace bsx {
+
+// HIP source of the kernel `bsx_mid(float* arena, long per_frame, const float* weights, unsigned long long* timeline)` specialised to
+// plan.program (one 1024-lane workgroup per frame, static LDS of plan.program_lds_floats floats), or "" with the reason in *why.
+std::string generate_mid_source(const Plan& plan, std::string* why);
+
+}  // namespace bsx

@@ -1,0 +1,367 @@
+// mid_prelude.hip — device templates of the SPECIALISED per-frame network program (gfx950).
+//
+// The interpreter of kernels_frame.hip walks a micro-op table: every op pays a descriptor fetch, a dispatch chain, run-time
+// index arithmetic (integer division by tensor widths, address-space tests) and loops whose trip counts the compiler cannot
+// see — measured 2-3k cycles per op before the first useful instruction, and bodies 3-6x longer than their arithmetic.
+// Here every op of ONE planned graph becomes a call of one of these templates with ALL geometry, LDS offsets, strides,
+// activations and operand address spaces as compile-time constants of a traits struct the generator (gen_mid.cpp) emits;
+// the kernel is compiled with hipRTC when the context is created (rtc.cpp; cached on disk) and is straight-line code:
+// no descriptors, no dispatch, only the bodies this graph uses.  (tools/microbench_icache.hip: cold straight-line code
+// costs < 10 % over warm code on gfx950 — code size is not the constraint, dependent latency is.)
+//
+// Reference: what this executes is the middle of Interpreter::Invoke() (/root/reference/lib/libbackscrub.cc:307) for the
+// Meet / MLKit graphs — CONV_2D 1x1, DEPTHWISE_CONV_2D, the squeeze-excite / gate chains (AVERAGE_POOL_2D, FULLY_CONNECTED /
+// 1x1 CONV_2D, RELU, LOGISTIC, MUL), RESIZE_BILINEAR — with TFLite's f32 semantics (bias added last, fused activations).
+//
+// This file is embedded into libbsx.so as a string (build.py) and is ALSO a valid stand-alone HIP translation unit, so that
+// `hipcc -fsyntax-only` and the tests can check it without a GPU.
+#if !defined(__HIPCC_RTC__)
+#include <hip/hip_runtime.h>
+#endif
+
+namespace bsxm {
+
+enum { SP_NONE = 0, SP_LDS = 1, SP_GLB = 2 };                                   // operand address spaces (frame_program.hpp: LocSpace)
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 3, ACT_HSWISH = 100, ACT_SIGMOID = 101 };   // tflite_model.hpp: Activation
+constexpr int kThreads = 1024, kWaves = 16;
+
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(1))) float glb_f;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f4v lds_v4;
+typedef __attribute__((address_space(1))) f4v glb_v4;
+typedef __attribute__((address_space(3))) f2v lds_v2;
+typedef __attribute__((address_space(1))) f2v glb_v2;
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// compile-time address-space loads / stores: one ds_* or global_* instruction, never a flat access and never a branch
+template <int SP> __device__ __forceinline__ f4v ld4(const lds_f* l, const glb_f* g, int off) {
+  if constexpr (SP == SP_LDS) return *(const lds_v4*)(l + off); else return *(const glb_v4*)(g + off);
+}
+template <int SP> __device__ __forceinline__ void st4(lds_f* l, glb_f* g, int off, f4v v) {
+  if constexpr (SP == SP_LDS) *(lds_v4*)(l + off) = v; else *(glb_v4*)(g + off) = v;
+}
+template <int SP> __device__ __forceinline__ f2v ld2(const lds_f* l, const glb_f* g, int off) {
+  if constexpr (SP == SP_LDS) return *(const lds_v2*)(l + off); else return *(const glb_v2*)(g + off);
+}
+template <int SP> __device__ __forceinline__ void st2(lds_f* l, glb_f* g, int off, f2v v) {
+  if constexpr (SP == SP_LDS) *(lds_v2*)(l + off) = v; else *(glb_v2*)(g + off) = v;
+}
+template <int SP> __device__ __forceinline__ float ld1(const lds_f* l, const glb_f* g, int off) {
+  if constexpr (SP == SP_LDS) return l[off]; else return g[off];
+}
+template <int SP> __device__ __forceinline__ void st1(lds_f* l, glb_f* g, int off, float v) {
+  if constexpr (SP == SP_LDS) l[off] = v; else g[off] = v;
+}
+
+// activations: hardware exp2 / rcp (≈1 ulp), the same forms as the interpreter (kernels_frame.hip: fp_act)
+template <int ACT> __device__ __forceinline__ float act1(float v) {
+  if constexpr (ACT == ACT_NONE) return v;
+  else if constexpr (ACT == ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+  else if constexpr (ACT == ACT_HSWISH) return v * __builtin_fminf(6.f, __builtin_fmaxf(0.f, v + 3.f)) * 0.16666667163372040f;
+  else if constexpr (ACT == ACT_RELU) return __builtin_fmaxf(v, 0.f);
+  else return __builtin_fminf(__builtin_fmaxf(v, 0.f), 6.f);
+}
+template <int ACT> __device__ __forceinline__ f4v act4(f4v v) { f4v r = {act1<ACT>(v.x), act1<ACT>(v.y), act1<ACT>(v.z), act1<ACT>(v.w)}; return r; }
+template <int ACT> __device__ __forceinline__ f2v act2(f2v v) { f2v r = {act1<ACT>(v.x), act1<ACT>(v.y)}; return r; }
+
+// ---- DPP helpers ---------------------------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRor4 = 0x124, kRor8 = 0x128, kHalfMirror = 0x141;
+__device__ __forceinline__ float dpp_self(float v, bool x2) {      // lane ^ 1 / lane ^ 2 inside a quad, old value = own
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, x2 ? __builtin_amdgcn_update_dpp(i, i, kQuadXor2, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(i, i, kQuadXor1, 0xf, 0xf, true));
+}
+// 4x4 transpose inside each quad of adjacent lanes (mfma_tile.hpp): lane (g, li) ends with row 4g + (li & 3), columns 4 (li >> 2) .. +3
+__device__ __forceinline__ f4v quad_transpose(const f4v acc, int q) {
+  const bool odd = q & 1, hi = q & 2;
+  const float rx = dpp_self(odd ? acc[0] : acc[1], false), ry = dpp_self(odd ? acc[2] : acc[3], false);
+  const float t0 = odd ? rx : acc[0], t1 = odd ? acc[1] : rx, t2 = odd ? ry : acc[2], t3 = odd ? acc[3] : ry;
+  const float r0 = dpp_self(hi ? t0 : t2, true), r1 = dpp_self(hi ? t1 : t3, true);
+  f4v r;
+  if (hi) { r[0] = r0; r[1] = r1; r[2] = t2; r[3] = t3; } else { r[0] = t0; r[1] = t1; r[2] = r0; r[3] = r1; }
+  return r;
+}
+// float4 per lane → wave total of component (lane & 3) in every lane (kernels_frame.hip: wave_total_scatter)
+__device__ __forceinline__ float wave_total_scatter(f4v a, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  const float klo = (b0 ? a.y : a.x) + dpp<kQuadXor1>(b0 ? a.x : a.y);
+  const float khi = (b0 ? a.w : a.z) + dpp<kQuadXor1>(b0 ? a.z : a.w);
+  float v = (b1 ? khi : klo) + dpp<kQuadXor2>(b1 ? klo : khi);
+  v += dpp<kRor4>(v);
+  v += dpp<kRor8>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// ---- weight staging: asynchronous global → LDS DMA (global_load_lds_dwordx4, tracked by vmcnt) ---------------------------------
+// One wave instruction moves 64 lanes x 16 B; LDS address = M0 (wave-uniform) + lane * 16.  FLOATS and both addresses are compile-time.
+template <int FLOATS> __device__ __forceinline__ void stage(const glb_f* src, lds_f* dst) {
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef const __attribute__((address_space(1))) void* glb_vp;
+  if constexpr (FLOATS > 0) {
+    const int lane4 = (int)(threadIdx.x & 63) * 4, w = wave_id();
+    constexpr int CH = (FLOATS + 255) / 256;                      // 1 KiB chunks
+#pragma unroll
+    for (int i = 0; i < (CH + kWaves - 1) / kWaves; i++) {
+      const int c0 = (w + i * kWaves) * 256;
+      if (c0 < FLOATS && c0 + lane4 < FLOATS) __builtin_amdgcn_global_load_lds((glb_vp)(src + c0 + lane4), (lds_vp)(dst + c0), 16, 0, 0);
+    }
+  }
+}
+// every op starts here: the previous op's LDS writes and this op's staged weights (DMA issued an op earlier) are visible
+__device__ __forceinline__ void op_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// ---- 1x1 convolution on v_mfma_f32_16x16x4_f32 (exact f32) ----------------------------------------------------------------------
+// Wave = 16-pixel x 16-channel tile.  Operand maps: A lane (li, g) holds x[pixel m0 + li][16 j + 4 g .. +3] (one 16-byte load per
+// 16 input channels, its four components feed four successive MFMAs); B lane holds w[16 j + 4 g + r][n0 + li]; D lane holds pixels
+// m0 + 4 g + r of channel n0 + li.  A K tail of 8 (K = 24, 72, 88 …) runs as TWO MFMAs with lane g holding k = base + 2 g + r instead
+// of four half-empty ones.  All operands of a tile are requested before the first MFMA; two accumulator chains alternate (a
+// dependent f32 MFMA has 40 cycles of latency against 32 of issue).
+// Traits: P CIN COUT CPAD ACT | X_SP X_OFF X_ST | Y_SP Y_OFF Y_ST | R_SP R_OFF R_ST | S_OFF (LDS, -1: none) | D_SP D_OFF D_ST | W_LDS B_LDS
+template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
+  constexpr int P = T::P, CIN = T::CIN, CPAD = T::CPAD, MT = (P + 15) / 16, NT = CPAD / 16, TILES = MT * NT;
+  constexpr int NJ = CIN / 16, TAIL = CIN % 16, TM = TAIL / 4;      // TM = MFMAs of the tail (0..3)
+  static_assert(CIN % 4 == 0 && CPAD % 16 == 0, "op_pw: channel counts");
+  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, wave = wave_id();
+  const lds_f* wl = L + T::W_LDS;
+  const lds_f* bl = L + T::B_LDS;
+#pragma unroll
+  for (int it = 0; it < (TILES + kWaves - 1) / kWaves; it++) {
+    const int wi = wave + it * kWaves;
+    if (wi >= TILES) break;
+    const int tn = wi / MT, tm = wi - tn * MT, m0 = tm << 4, n0 = tn << 4;
+    const int arow = (P % 16 == 0) ? m0 + li : min(m0 + li, P - 1);      // rows past the end read a valid pixel; results are dropped
+    const int xo = arow * T::X_ST + 4 * g;
+    const lds_f* bp = wl + (4 * g) * CPAD + n0 + li;
+    f4v a[NJ > 0 ? NJ : 1];
+    float b[NJ > 0 ? NJ : 1][4];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      a[j] = ld4<T::X_SP>(L + T::X_OFF, A + T::X_OFF, xo + 16 * j);
+      const lds_f* br = bp + (16 * j) * CPAD;
+      b[j][0] = br[0]; b[j][1] = br[CPAD]; b[j][2] = br[2 * CPAD]; b[j][3] = br[3 * CPAD];
+    }
+    // K tail: lane g holds k = 16 NJ + TM g + r, r < TM
+    float ta[3] = {0.f, 0.f, 0.f}, tb[3] = {0.f, 0.f, 0.f};
+    if constexpr (TM > 0) {
+      const int k0 = 16 * NJ + TM * g;
+#pragma unroll
+      for (int r = 0; r < TM; r++) { ta[r] = ld1<T::X_SP>(L + T::X_OFF, A + T::X_OFF, arow * T::X_ST + k0 + r); tb[r] = wl[(k0 + r) * CPAD + n0 + li]; }
+    }
+    if constexpr (T::S_OFF >= 0) {                                   // squeeze-excite scale on the input channels (always an LDS vector)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) { const f4v sv = *(const lds_v4*)(L + T::S_OFF + 16 * j + 4 * g); a[j].x = __fmul_rn(a[j].x, sv.x); a[j].y = __fmul_rn(a[j].y, sv.y); a[j].z = __fmul_rn(a[j].z, sv.z); a[j].w = __fmul_rn(a[j].w, sv.w); }
+      if constexpr (TM > 0) {
+#pragma unroll
+        for (int r = 0; r < TM; r++) ta[r] = __fmul_rn(ta[r], L[T::S_OFF + 16 * NJ + TM * g + r]);
+      }
+    }
+    if constexpr (T::D_SP != SP_NONE) {                              // x * s + d  (gate * skip + up-sampled tensor)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) { const f4v dv = ld4<T::D_SP>(L + T::D_OFF, A + T::D_OFF, arow * T::D_ST + 16 * j + 4 * g); a[j].x = __fadd_rn(a[j].x, dv.x); a[j].y = __fadd_rn(a[j].y, dv.y); a[j].z = __fadd_rn(a[j].z, dv.z); a[j].w = __fadd_rn(a[j].w, dv.w); }
+      if constexpr (TM > 0) {
+#pragma unroll
+        for (int r = 0; r < TM; r++) ta[r] = __fadd_rn(ta[r], ld1<T::D_SP>(L + T::D_OFF, A + T::D_OFF, arow * T::D_ST + 16 * NJ + TM * g + r));
+      }
+    }
+    f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; j += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j][0], acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1 < NJ ? j + 1 : j].x, b[j + 1 < NJ ? j + 1 : j][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j][1], acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1 < NJ ? j + 1 : j].y, b[j + 1 < NJ ? j + 1 : j][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j][2], acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1 < NJ ? j + 1 : j].z, b[j + 1 < NJ ? j + 1 : j][2], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j][3], acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1 < NJ ? j + 1 : j].w, b[j + 1 < NJ ? j + 1 : j][3], acc1, 0, 0, 0);
+    }
+    if constexpr (TM > 0) {
+#pragma unroll
+      for (int r = 0; r < TM; r++) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[r], tb[r], acc1, 0, 0, 0);
+    }
+    const f4v acc = acc0 + acc1;
+    // epilogue: lane owns pixel m0 + 4 g + (li & 3), channels n0 + 4 (li >> 2) .. +3 → one 16-byte bias load, residual load, store
+    const int q = li & 3, c0 = n0 + (li & ~3), pix = m0 + 4 * g + q;
+    f4v v = quad_transpose(acc, q);
+    if ((T::COUT % 16 == 0 || c0 < T::COUT) && (P % 16 == 0 || pix < P)) {
+      v = act4<T::ACT>(v + *(const lds_v4*)(bl + c0));
+      if constexpr (T::R_SP != SP_NONE) v += ld4<T::R_SP>(L + T::R_OFF, A + T::R_OFF, pix * T::R_ST + c0);
+      st4<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + c0, v);
+    }
+  }
+}
+
+// ---- depthwise k x k, register-strip form -----------------------------------------------------------------------------------------
+// lane = (channel pair / quad, strip of TX consecutive output columns, output row): per filter row the lane loads the (TX-1) S + K
+// inputs its strip touches and the K weights once and forms TX outputs from registers (kernels_frame.hip: dw_strip).  Everything
+// — the item decomposition included — is compile-time here; rows and columns outside the image contribute exact zeros.
+// FMA order per output: fy, fx ascending, bias last (TFLite reference order).
+// Traits: K S H W OH OW PT PL C ACT | X_SP X_OFF X_ST | Y_SP Y_OFF Y_ST | R_SP R_OFF R_ST | W_SP (LDS staged / GLB) W_OFF B_OFF | V TX
+template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, const glb_f* Wg) {
+  constexpr int K = T::K, S = T::S, TX = T::TX, V = T::V, C = T::C, CV = C / V, NIN = (TX - 1) * S + K;
+  constexpr int NSTRIPS = (T::OW + TX - 1) / TX, TOTAL = CV * NSTRIPS * T::OH;
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  auto ldx = [&](int off) -> vec_t { if constexpr (V == 4) return ld4<T::X_SP>(L + T::X_OFF, A + T::X_OFF, off); else return ld2<T::X_SP>(L + T::X_OFF, A + T::X_OFF, off); };
+  auto ldw = [&](int off) -> vec_t { if constexpr (V == 4) return ld4<T::W_SP>(L, Wg, off); else return ld2<T::W_SP>(L, Wg, off); };
+#pragma unroll
+  for (int it = 0; it < (TOTAL + kThreads - 1) / kThreads; it++) {
+    const int item = (int)threadIdx.x + it * kThreads;
+    if (item >= TOTAL) break;
+    const int t = item / CV, cq = item - t * CV, oy = t / NSTRIPS, sx = t - oy * NSTRIPS;
+    const int ch = cq * V, ox0 = sx * TX, ix0 = ox0 * S - T::PL;
+    vec_t acc[TX];
+#pragma unroll
+    for (int k = 0; k < TX; k++) acc[k] = (vec_t)(0.f);
+    // one filter row: the (TX-1) S + K inputs of the strip (clamped addresses, zeroed outside the image) and the K weights (zeroed when the row is outside)
+    auto load_row = [&](int fy, vec_t (&xin)[NIN], vec_t (&wv)[K]) {
+      const int iy = oy * S - T::PT + fy;
+      const bool vy = iy >= 0 && iy < T::H;
+      const int rowo = min(max(iy, 0), T::H - 1) * T::W * T::X_ST + ch;
+#pragma unroll
+      for (int j = 0; j < NIN; j++) xin[j] = ldx(rowo + min(max(ix0 + j, 0), T::W - 1) * T::X_ST);
+#pragma unroll
+      for (int fx = 0; fx < K; fx++) { wv[fx] = ldw(T::W_OFF + (fy * K + fx) * C + ch); if (!vy) wv[fx] = (vec_t)(0.f); }
+    };
+    auto fma_row = [&](vec_t (&xin)[NIN], const vec_t (&wv)[K]) {
+#pragma unroll
+      for (int j = 0; j < NIN; j++) { const int ix = ix0 + j; if (ix < 0 || ix >= T::W) xin[j] = (vec_t)(0.f); }
+#pragma unroll
+      for (int k = 0; k < TX; k++) {
+#pragma unroll
+        for (int fx = 0; fx < K; fx++) acc[k] = __builtin_elementwise_fma(xin[k * S + fx], wv[fx], acc[k]);
+      }
+    };
+    if constexpr (T::X_SP == SP_LDS) {
+      // LDS input: fully unrolled — the scheduler overlaps the next rows' ds_reads with this row's FMAs
+#pragma unroll
+      for (int fy = 0; fy < K; fy++) { vec_t xin[NIN], wv[K]; load_row(fy, xin, wv); fma_row(xin, wv); }
+    } else {
+      // global input: exactly ONE row ahead in flight (all K rows at once — what full unrolling turns into — needs K (NIN + K) V registers: spills)
+      vec_t xa[NIN], wa[K];
+      load_row(0, xa, wa);
+#pragma unroll 1
+      for (int fy = 0; fy < K; fy++) {
+        vec_t xb[NIN], wb[K];
+        load_row(fy + 1 < K ? fy + 1 : fy, xb, wb);               // the last trip re-requests its own row (cached) instead of branching
+        fma_row(xa, wa);
+#pragma unroll
+        for (int j = 0; j < NIN; j++) xa[j] = xb[j];
+#pragma unroll
+        for (int fx = 0; fx < K; fx++) wa[fx] = wb[fx];
+      }
+    }
+    const vec_t bq = ldw(T::B_OFF + ch);
+#pragma unroll
+    for (int k = 0; k < TX; k++) {
+      const int ox = ox0 + k;
+      if (T::OW % TX == 0 || ox < T::OW) {
+        const int pix = oy * T::OW + ox;
+        vec_t v = acc[k] + bq;
+        if constexpr (V == 4) v = act4<T::ACT>(v); else v = act2<T::ACT>(v);
+        if constexpr (T::R_SP != SP_NONE) { if constexpr (V == 4) v += ld4<T::R_SP>(L + T::R_OFF, A + T::R_OFF, pix * T::R_ST + ch); else v += ld2<T::R_SP>(L + T::R_OFF, A + T::R_OFF, pix * T::R_ST + ch); }
+        if constexpr (V == 4) st4<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + ch, v); else st2<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + ch, v);
+      }
+    }
+  }
+}
+
+// ---- global average pool of one part into mean[COFF .. COFF + C): wave-owned channel quads, no LDS scratch, no barrier inside ------
+// rows = pixels of a tensor, or per-tile partial sums written by a segment kernel ([ROWS][C] floats, mean = sum / HW)
+template <int SP, int OFF, int ST, int ROWS, int C, int HW, int COFF, bool ACCUM, int MEAN_OFF>
+__device__ __forceinline__ void gap_part(lds_f* L, glb_f* A) {
+  constexpr int C4 = C / 4;
+  const int lane = threadIdx.x & 63, wave = wave_id();
+#pragma unroll
+  for (int it = 0; it < (C4 + kWaves - 1) / kWaves; it++) {
+    const int cq = wave + it * kWaves;
+    if (cq >= C4) break;
+    f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+    for (int r0 = 0; r0 < ROWS; r0 += 128) {
+      const int r = r0 + lane;
+      if (r < ROWS) a0 += ld4<SP>(L + OFF, A + OFF, r * ST + cq * 4);
+      if (r0 + 64 < ROWS && r + 64 < ROWS) a1 += ld4<SP>(L + OFF, A + OFF, (r + 64) * ST + cq * 4);
+    }
+    a0 += a1;
+    float t = wave_total_scatter(a0, lane);
+    if (lane < 4) {                                                 // lane e holds the total of channel 4 cq + e
+      t /= (float)HW;
+      if (ACCUM) t += L[MEAN_OFF + COFF + cq * 4 + lane];            // GAP(a + b) as GAP(a) + GAP(b): the same lane wrote the first part
+      L[MEAN_OFF + COFF + cq * 4 + lane] = t;
+    }
+  }
+}
+
+// ---- fully connected layer of a squeeze-excite / gate chain: each output = dot product over LK aligned lanes + DPP reduction ------
+// weights [co][ci] rows with the bias in front, either staged in LDS (W_SP = LDS: offsets into the LDS block) or in the weight arena
+template <int CIN, int COUT, int ACT, int W_SP, int W_OFF, int B_OFF, int X_OFF, int Y_SP, int Y_OFF>
+__device__ __forceinline__ void fc_layer(lds_f* L, glb_f* A, const glb_f* Wg) {
+  constexpr int LK = (CIN % 32 == 0) ? 8 : ((CIN % 16 == 0) ? 4 : ((CIN % 8 == 0) ? 2 : 1)), KLEN = CIN / LK, PER = kThreads / LK;
+  const int sub = threadIdx.x & (LK - 1), co0 = threadIdx.x / LK;
+#pragma unroll
+  for (int it = 0; it < (COUT + PER - 1) / PER; it++) {
+    const int co = co0 + it * PER;
+    if (co < COUT) {
+      f4v wv[KLEN / 4];
+#pragma unroll
+      for (int q = 0; q < KLEN / 4; q++) wv[q] = ld4<W_SP>(L, Wg, W_OFF + co * CIN + sub * KLEN + 4 * q);
+      const float bias = ld1<W_SP>(L, Wg, B_OFF + co);
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < KLEN / 4; q++) {
+        const f4v xv = *(const lds_v4*)(L + X_OFF + sub * KLEN + 4 * q);
+        a0 = fmaf(xv.x, wv[q].x, a0); a1 = fmaf(xv.y, wv[q].y, a1); a0 = fmaf(xv.z, wv[q].z, a0); a1 = fmaf(xv.w, wv[q].w, a1);
+      }
+      float acc = a0 + a1;
+      if constexpr (LK >= 2) acc += dpp<kQuadXor1>(acc);
+      if constexpr (LK >= 4) acc += dpp<kQuadXor2>(acc);
+      if constexpr (LK >= 8) acc += dpp<kHalfMirror>(acc);
+      if (sub == 0) st1<Y_SP>(L + Y_OFF, A + Y_OFF, co, act1<ACT>(acc + bias));
+    }
+  }
+}
+
+// ---- bilinear resize (TFLite reference association) ------------------------------------------------------------------------------------
+// Traits: H W OH OW C HALF_PIXEL ALIGN | X_SP X_OFF X_ST | Y_SP Y_OFF Y_ST
+__device__ __forceinline__ void interp(int o, float scale, bool half_pixel, int in_size, float* frac, int* lo, int* hi) {
+  const float v = half_pixel ? __fadd_rn(__fmul_rn((float)o + 0.5f, scale), -0.5f) : __fmul_rn((float)o, scale);
+  const float fl = __builtin_floorf(v);
+  *lo = max((int)fl, 0);
+  *hi = min((int)__builtin_ceilf(v), in_size - 1);
+  *frac = v - (float)*lo;
+}
+__device__ __forceinline__ float bilerp(float x00, float x10, float x01, float x11, float dy, float dx) {
+  const float a = __fmul_rn(__fmul_rn(x00, 1.f - dy), 1.f - dx), b = __fmul_rn(__fmul_rn(x10, dy), 1.f - dx);
+  const float c = __fmul_rn(__fmul_rn(x01, 1.f - dy), dx), d = __fmul_rn(__fmul_rn(x11, dy), dx);
+  return __fadd_rn(__fadd_rn(__fadd_rn(a, b), c), d);
+}
+template <class T> __device__ __forceinline__ void op_resize(lds_f* L, glb_f* A) {
+  constexpr int CV = T::C / 4, TOTAL = T::OH * T::OW * CV;
+  const float hs = (T::ALIGN && T::OH > 1) ? (float)(T::H - 1) / (float)(T::OH - 1) : (float)T::H / (float)T::OH;
+  const float ws = (T::ALIGN && T::OW > 1) ? (float)(T::W - 1) / (float)(T::OW - 1) : (float)T::W / (float)T::OW;
+#pragma unroll
+  for (int it = 0; it < (TOTAL + kThreads - 1) / kThreads; it++) {
+    const int item = (int)threadIdx.x + it * kThreads;
+    if (item >= TOTAL) break;
+    const int p = item / CV, ch = (item - p * CV) * 4, oy = p / T::OW, ox = p - oy * T::OW;
+    float dy, dx; int y0, y1, x0, x1;
+    interp(oy, hs, T::HALF_PIXEL, T::H, &dy, &y0, &y1);
+    interp(ox, ws, T::HALF_PIXEL, T::W, &dx, &x0, &x1);
+    const f4v a = ld4<T::X_SP>(L + T::X_OFF, A + T::X_OFF, (y0 * T::W + x0) * T::X_ST + ch), b = ld4<T::X_SP>(L + T::X_OFF, A + T::X_OFF, (y1 * T::W + x0) * T::X_ST + ch);
+    const f4v c = ld4<T::X_SP>(L + T::X_OFF, A + T::X_OFF, (y0 * T::W + x1) * T::X_ST + ch), d = ld4<T::X_SP>(L + T::X_OFF, A + T::X_OFF, (y1 * T::W + x1) * T::X_ST + ch);
+    const f4v v = {bilerp(a.x, b.x, c.x, d.x, dy, dx), bilerp(a.y, b.y, c.y, d.y, dy, dx), bilerp(a.z, b.z, c.z, d.z, dy, dx), bilerp(a.w, b.w, c.w, d.w, dy, dx)};
+    st4<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, p * T::Y_ST + ch, v);
+  }
+}
+
+}  // namespace bsxm

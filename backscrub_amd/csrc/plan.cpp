@@ -78,9 +78,9 @@ std::string Plan::describe() const {
   char line[512];
   int i = 0;
   for (const Step& st : steps) {
-    snprintf(line, sizeof line, "%3d %-7s %-26s in %dx%dx%d -> out %dx%dx%d k%dx%d s%d d%d act=%s res=%d scale=%d macs=%.0f\n", i++,
+    snprintf(line, sizeof line, "%3d %-7s %-26s in %dx%dx%d -> out %dx%dx%d k%dx%d s%d d%d act=%s res=%d scale=%d macs=%.0f t%d->t%d\n", i++,
              kn[(int)st.kind], st.label.c_str(), st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.kh, st.kw, st.sh, st.dh, act_name(st.act),
-             st.residual, st.in_scale, st.macs);
+             st.residual, st.in_scale, st.macs, st.in0, st.out);
     s += line;
     if (st.fuse_head0) { s += "      ^ fused with steps 1 and 2 (stem + depthwise + 1x1 in one tiled kernel)\n"; }
     if (st.fuse_dw >= 0) {
@@ -492,7 +492,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   if (uses_of(B) != 3 || uses_of(up2) != 2 || uses_of(kp1.out) != 2 || uses_of(kd.out) != 1 || uses_of(kf2.out) != 1 || uses_of(lo) != 1 || uses_of(lo2) != 1) return seg_fail(21);
   if (!resize_weights_uniform(kr.H, kr.OH, kr.align_corners, kr.half_pixel) || !resize_weights_uniform(kr.W, kr.OW, kr.align_corners, kr.half_pixel)) return seg_fail(22);
   if (uses_of(c0) != 1) return seg_fail(23);
-  // activations the kernels implement: a clamp (none / relu / relu6) everywhere, hard-swish also on the stem, the logistic also on the output
+  // activations the kernels implement: a clamp (none / relu / relu6) everywhere, hard-swish also on the stem; the transpose convolution: none or the logistic
   auto clampish = [](int a) { return a == kActNone || a == kActRelu || a == kActRelu6; };
   if (!(clampish(stem.act) || stem.act == kActHswish) || !(ttc.act == kActNone || ttc.act == kActSigmoid) || (ttc.act == kActSigmoid && ttc.Cout != 1)) return seg_fail(34);
   for (const Step* q : {&hpw, &hdw, &pwa, &pwb, &kdw, &kp1, &kd, &kp2, &tpw, &tdw}) if (!clampish(q->act)) return seg_fail(35);
@@ -1037,6 +1037,13 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
     for (int t : st.concat_in) touch(t, s);
     touch(st.out, s);
   }
+  // The per-launch path fuses neighbouring steps into one kernel AFTER this allocation (expand 1x1 + depthwise: ir_expand_dw_k; stem +
+  // depthwise + 1x1: dl_head0_k): such a kernel writes the LAST step's output while other workgroups still read the FIRST step's input.
+  // An output placed over a tensor whose last reader is the step before it (the expand's input in a block without a residual) is then a
+  // race between workgroups — found by the full-batch twin test at 1024 DeepLab streams: 3 % of the streams wrong, every 2-8 stream test
+  // green.  A convolution-type step's output therefore becomes live two steps early, i.e. from the first step any fusion can start at.
+  for (int s = 0; s < NS; s++)
+    if ((steps[s].kind == StepKind::DwConv || steps[s].kind == StepKind::PwConv) && first[steps[s].out] == s) first[steps[s].out] = std::max(0, s - 2);
   first[g.input] = -1;
   last[g.output] = NS + 1;  // keep the network output alive for the decode stage
   last[g.input] = std::max(last[g.input], 0);

@@ -1,0 +1,110 @@
+// rtc.cpp — hipRTC compilation + on-disk cache of the graph-specialised kernels (see rtc.hpp).
+#include "rtc.hpp"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+
+namespace bsx {
+namespace {
+
+// 128-bit FNV-1a style digest as two independent 64-bit lanes: cache keys only, not cryptography
+std::string digest(const std::string& s) {
+  unsigned long long a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
+  for (unsigned char ch : s) { a = (a ^ ch) * 0x100000001b3ull; b = (b ^ (ch + 0x9e)) * 0x100000001b3ull; b ^= b >> 29; }
+  char buf[40];
+  snprintf(buf, sizeof buf, "%016llx%016llx", a, b);
+  return buf;
+}
+
+bool writable_dir(const std::string& d) {
+  struct stat st;
+  if (stat(d.c_str(), &st) != 0 && mkdir(d.c_str(), 0755) != 0) return false;
+  return access(d.c_str(), W_OK | X_OK) == 0;
+}
+
+std::string lib_dir() {
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(&rtc_cache_dir), &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    if (k != std::string::npos) return p.substr(0, k);
+  }
+  return ".";
+}
+
+std::mutex g_mu;
+
+}  // namespace
+
+std::string rtc_cache_dir() {
+  if (const char* e = getenv("BSX_KERNEL_CACHE")) { if (*e && writable_dir(e)) return e; }
+  const std::string d = lib_dir() + "/kcache";
+  if (writable_dir(d)) return d;
+  const std::string t = "/tmp/bsx_kcache_" + std::to_string((long)getuid());
+  writable_dir(t);
+  return t;
+}
+
+bool rtc_build(const std::string& source, const std::string& arch_in, std::vector<char>* code, std::string* log, bool* cached) {
+  std::string arch = arch_in.substr(0, arch_in.find(':'));
+  if (arch.empty()) arch = "gfx950";
+  int rtc_major = 0, rtc_minor = 0;
+  hiprtcVersion(&rtc_major, &rtc_minor);
+  const std::string opts_key = arch + "|O3|no-contract|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
+  const std::string path = rtc_cache_dir() + "/" + digest(opts_key + "\n" + source) + ".hsaco";
+  if (cached) *cached = false;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (!getenv("BSX_KERNEL_CACHE_OFF")) {
+    std::ifstream f(path, std::ios::binary);
+    if (f) {
+      code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      if (code->size() > 64 && memcmp(code->data(), "\x7f" "ELF", 4) == 0) { if (cached) *cached = true; return true; }
+    }
+  }
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, source.c_str(), "bsx_specialised.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { if (log) *log = "hiprtcCreateProgram failed"; return false; }
+  const std::string a = "--offload-arch=" + arch;
+  const char* opts[] = {a.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+  size_t ls = 0;
+  hiprtcGetProgramLogSize(prog, &ls);
+  if (log && ls > 1) { log->assign(ls, '\0'); hiprtcGetProgramLog(prog, &(*log)[0]); }
+  if (r != HIPRTC_SUCCESS) { if (log && log->empty()) *log = hiprtcGetErrorString(r); hiprtcDestroyProgram(&prog); return false; }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code->assign(cs, '\0');
+  hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  if (!getenv("BSX_KERNEL_CACHE_OFF")) {                          // write to a temporary name, then rename: concurrent contexts / ranks never see half a file
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    std::ofstream o(tmp, std::ios::binary);
+    if (o) {
+      o.write(code->data(), (std::streamsize)code->size());
+      o.close();
+      if (!o || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+    }
+  }
+  return true;
+}
+
+hipError_t rtc_load(const std::vector<char>& code, const char* kernel, RtcKernel* out) {
+  hipError_t e = hipModuleLoadData(&out->mod, code.data());
+  if (e != hipSuccess) return e;
+  e = hipModuleGetFunction(&out->fn, out->mod, kernel);
+  if (e != hipSuccess) { (void)hipModuleUnload(out->mod); out->mod = nullptr; out->fn = nullptr; }
+  return e;
+}
+
+void rtc_unload(RtcKernel* k) {
+  if (k && k->mod) { (void)hipModuleUnload(k->mod); k->mod = nullptr; k->fn = nullptr; }
+}
+
+}  // namespace bsx

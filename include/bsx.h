@@ -192,6 +192,8 @@ const char* bsx_plan_describe(bsx_ctx* ctx);
 /* Copy out the value of graph tensor `tensor_idx` for stream 0 after an infer (only tensors that survive
  * fusion are available); returns element count or negative error.  h_out may be NULL to query the size. */
 long bsx_debug_tensor(bsx_ctx* ctx, int tensor_idx, float* h_out, long cap);
+/* The same for stream `stream_idx` of the last batch (full-batch parity tests: every stream against its twin). */
+long bsx_debug_tensor_of(bsx_ctx* ctx, int tensor_idx, int stream_idx, float* h_out, long cap);
 
 /* Per-frame-program timeline: runs the network once for n streams and returns, for workgroup 0, the wall-clock
  * (100 MHz constant-rate counter) ticks at the start of every micro-op plus one final tick; ticks[i+1]-ticks[i] = op i.
@@ -202,6 +204,14 @@ int bsx_debug_program_timeline(bsx_ctx* ctx, int n, unsigned long long* ticks, i
  * ("ops=<n> nodes=<n> steps=<n> macs=<per frame> arena_floats=<per stream>" then one line per launch)
  * into buf (NUL-terminated, truncated to cap).  Returns 0, or BSX_EMODEL with the reason in buf. */
 int bsx_model_describe(const char* model_path, char* buf, size_t cap);
+/* Host only, no GPU: build the plan of `model_path`, emit the kernel specialised to that graph (the per-frame program of the Meet / MLKit
+ * family as straight-line code: csrc/gen_mid.cpp) and compile it with hipRTC for `arch` (NULL = "gfx950") into the code-object cache, so
+ * that bsx_new on the GPU box only loads it.  This replaces what InterpreterBuilder / AllocateTensors do when the reference creates its
+ * context (lib/libbackscrub.cc:205-217).  msg receives "compiled" / "cached" / why the graph stays interpreted.  Returns 0, or BSX_EMODEL. */
+int bsx_model_precompile(const char* model_path, const char* arch, char* msg, size_t cap);
+/* The generated source itself (tests, inspection): returns its length (without NUL), copies at most cap - 1 bytes; 0 when the graph has no
+ * specialised form (reason in buf), negative on a model error. */
+long bsx_model_kernel_source(const char* model_path, char* buf, size_t cap);
 
 /* ---- measurement ---- */
 typedef struct bsx_launch_stat {

@@ -17,7 +17,7 @@ _f32p = C.POINTER(C.c_float)
 
 
 def build(quiet=True):
-    subprocess.check_call(["make", "-C", _HERE, "libbs_oracle.so", "libbs_oracle_fast.so", "ref-models", "ref-lib"],
+    subprocess.check_call(["make", "-C", _HERE, "libbs_oracle.so", "libbs_oracle_fast.so", "ref-lib"],
                           stdout=subprocess.DEVNULL if quiet else None)
 
 

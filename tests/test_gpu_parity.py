@@ -221,9 +221,14 @@ def test_generic_mask_kernel_matches_tile_kernel(bs, oracle, res, monkeypatch):
 
 NETWORK_PATHS = {
     # the Meet / MLKit graphs have three executions of the same fused plan; all must meet the logit tolerance against the oracle
-    "lite": [("segments + middle program", {}, "segment head"), ("whole-network program", {"BSX_NO_SEGMENTS": "1"}, "frame program: ON"),
+    # (the middle program itself in two forms: the graph-specialised kernel compiled by hipRTC at bsx_new — the default — and the micro-op interpreter)
+    "lite": [("segments + specialised middle kernel (hipRTC)", {}, "program execution: specialised kernel"),
+             ("segments + interpreted middle program", {"BSX_NO_RTC": "1"}, "program execution: interpreted (BSX_NO_RTC)"),
+             ("whole-network program", {"BSX_NO_SEGMENTS": "1"}, "frame program: ON"),
              ("one launch per step", {"BSX_NO_FRAME_PROGRAM": "1"}, "frame program: off")],
-    "mlkit": [("segments + middle program", {}, "segment head"), ("whole-network program", {"BSX_NO_SEGMENTS": "1"}, "frame program: ON"),
+    "mlkit": [("segments + specialised middle kernel (hipRTC)", {}, "program execution: specialised kernel"),
+              ("segments + interpreted middle program", {"BSX_NO_RTC": "1"}, "program execution: interpreted (BSX_NO_RTC)"),
+              ("whole-network program", {"BSX_NO_SEGMENTS": "1"}, "frame program: ON"),
               ("one launch per step", {"BSX_NO_FRAME_PROGRAM": "1"}, "frame program: off")],
     # DeepLab runs per launch: the split-f16 MFMA GEMM (default) and the f32 MFMA GEMM, with and without the planner's rewrites
     "deeplab": [("split-f16 MFMA GEMM, fused head and expand+depthwise kernels", {}, "fused with step"), ("f32 MFMA GEMM", {"BSX_F16_GEMM": "off"}, "conv#66-pool"),
@@ -243,7 +248,7 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc = oracle.Ctx(path, W, H)
     oc.prep(f)
     want = oc.infer()
-    knobs = ("BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
+    knobs = ("BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
     for name, env, marker in NETWORK_PATHS[key]:
         for k in knobs:
             monkeypatch.delenv(k, raising=False)

@@ -11,8 +11,29 @@ import sqlite3
 import sys
 
 
+_DEMANGLED = {}
+
+
+def demangle(name):
+    """rocprofv3 leaves long template instantiations mangled in the counter tables: c++filt them (cached)."""
+    if not name.startswith("_Z"):
+        return name
+    if name not in _DEMANGLED:
+        import subprocess
+        try:
+            sym = name[:-3] if name.endswith(".kd") else name          # kernel-descriptor symbol: the function's name + ".kd"
+            _DEMANGLED[name] = subprocess.run(["c++filt", sym], capture_output=True, text=True, timeout=10).stdout.strip() or name
+        except Exception:
+            _DEMANGLED[name] = name
+    return _DEMANGLED[name]
+
+
+def is_ours(name):
+    return "bsx::" in name or name.startswith("_ZN3bsx")
+
+
 def short(name):
-    name = name.replace("bsx::(anonymous namespace)::", "").replace("void ", "")
+    name = demangle(name).replace("bsx::(anonymous namespace)::", "").replace("void ", "")
     return name.split("(")[0][:60]
 
 
@@ -47,7 +68,7 @@ def pmc_json(tag, paths):
         q = ("select kernel_name, counter_name, avg(v) from (select kernel_name, counter_name, dispatch_id, sum(value) v "
              "from counters_collection group by kernel_name, counter_name, dispatch_id) group by kernel_name, counter_name")
         for n, cn, v in db.execute(q).fetchall():
-            if cn in ("FETCH_SIZE", "WRITE_SIZE") and "bsx::" in n:
+            if cn in ("FETCH_SIZE", "WRITE_SIZE") and is_ours(n):
                 kernels.setdefault(short(n), {})[cn + "_KiB"] = round(v, 1)
     print(json.dumps({"round": tag, "workload": {"batch": 256, "width": 640, "height": 480, "model": "segm_lite_v681.tflite"},
                       "note": "avg per dispatch; traffic bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section",
@@ -59,7 +80,7 @@ def step_sequence(path, counter, first="prep_resize_k"):
     (the last complete step of the run) → [(kernel, counter value)]."""
     db = sqlite3.connect(path)
     q = ("select dispatch_id, kernel_name, sum(value) from counters_collection where counter_name = ? group by dispatch_id, kernel_name order by dispatch_id")
-    rows = [(short(n), v) for _, n, v in db.execute(q, (counter,)).fetchall() if "bsx::" in n]
+    rows = [(short(n), v) for _, n, v in db.execute(q, (counter,)).fetchall() if is_ours(n)]
     starts = [i for i, (n, _) in enumerate(rows) if n.startswith(first)]
     if len(starts) < 6:
         return []
@@ -79,7 +100,7 @@ def pmc_json2(tag, desc, fetch_db, write_db):
         q = ("select kernel_name, counter_name, avg(v) from (select kernel_name, counter_name, dispatch_id, sum(value) v "
              "from counters_collection group by kernel_name, counter_name, dispatch_id) group by kernel_name, counter_name")
         for n, cn, v in db.execute(q).fetchall():
-            if cn in ("FETCH_SIZE", "WRITE_SIZE") and "bsx::" in n:
+            if cn in ("FETCH_SIZE", "WRITE_SIZE") and is_ours(n):
                 kernels.setdefault(short(n), {})[cn + "_KiB"] = round(v, 1)
     f, w = step_sequence(fetch_db, "FETCH_SIZE"), step_sequence(write_db, "WRITE_SIZE")
     seq = []
