@@ -116,6 +116,8 @@ struct bsx_ctx {
   std::string last_error, plan_text;
   bool keep_logits = false;            // BSX_KEEP_LOGITS: segmented plans write the logits and run the stand-alone decode (A/B, debugging)
   bool no_mask_blend_fusion = false;   // BSX_NO_MASK_BLEND_FUSION, read once at bsx_new (no getenv on the per-step path)
+  bool no_mask_tile = false;           // BSX_NO_MASK_TILE (tests: the generic mask kernel), likewise
+  bool tail_generic = false;           // BSX_TAIL_GENERIC (tests: the scalar argmax scan of the DeepLab tail), likewise
 
   // stream-0 view of a graph tensor (network input/output have dedicated buffers; intermediates are batch-major in
   // the per-launch path and frame-major — frame 0 first — in the per-frame program)
@@ -163,7 +165,7 @@ void report(bsx_ctx* c, bsx_debug_fn fn, void* user, const char* fmt, ...) {
 int upload_tab(bsx_ctx* c, const HostResizeTab& h, DevResizeTab* d) {
   d->tab.sw = h.sw; d->tab.sh = h.sh; d->tab.dw = h.dw; d->tab.dh = h.dh; d->tab.mode = h.mode;
   if (h.mode != 0) return BSX_OK;
-  d->tab.tile_ok = mask_tile_fits(h.xofs.data(), h.yofs.data(), h.sw, h.sh, h.dw, h.dh) ? 1 : 0;
+  d->tab.tile_ok = (mask_tile_fits(h.xofs.data(), h.yofs.data(), h.sw, h.sh, h.dw, h.dh) && !c->no_mask_tile) ? 1 : 0;
   size_t b_xofs = h.xofs.size() * 4, b_yofs = h.yofs.size() * 4, b_xa = h.xa.size() * 2, b_ya = h.ya.size() * 2;
   auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
   size_t total = up16(b_xofs) + up16(b_yofs) + up16(b_xa) + up16(b_ya);
@@ -312,7 +314,7 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
   if (fused_tail) {
     const Step& last = c->plan.steps.back();
     BSX_HIP(c, launch_resize_argmax_iir(last, c->d_arena + (size_t)c->plan.tensor_off[last.in0] * (size_t)c->n_streams,
-                                        c->d_ofinal + (size_t)slot * c->outW * c->outH, n, s));
+                                        c->d_ofinal + (size_t)slot * c->outW * c->outH, n, s, c->tail_generic));
   }
   return BSX_OK;
 }
@@ -401,6 +403,8 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     return nullptr;
   }
   c->no_mask_blend_fusion = getenv("BSX_NO_MASK_BLEND_FUSION") != nullptr;
+  c->no_mask_tile = getenv("BSX_NO_MASK_TILE") != nullptr;
+  c->tail_generic = getenv("BSX_TAIL_GENERIC") != nullptr;
   c->keep_logits = getenv("BSX_KEEP_LOGITS") != nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -654,7 +658,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       for (size_t si = 0; si + (atail ? 1 : 0) < c->plan.steps.size(); si++)
         BSX_TIMED(launch_step(c->plan.steps[si], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms));
       if (atail) BSX_TIMED(launch_resize_argmax_iir(c->plan.steps.back(), c->d_arena + (size_t)c->plan.tensor_off[c->plan.steps.back().in0] * (size_t)c->n_streams,
-                                                    c->d_ofinal, n, s));
+                                                    c->d_ofinal, n, s, c->tail_generic));
     }
     if (!fused_decode) BSX_TIMED(launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal, c->outW * c->outH, c->outC, n, s));
     if (fuse_tail) {
@@ -678,8 +682,10 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   };
   int j = 0;
   const double canvas = (double)c->inW * c->inH;
-  // prep_resize: reads the touched part of the ROI (<= 3 B/px of the ROI), writes the 4 B/px canvas
-  put(j++, "prep_resize", N * (3.0 * c->roi.w * c->roi.h + 4.0 * canvas), 0);
+  // prep_resize: reads the TOUCHED source pixels of the ROI — a bilinear tap pair per destination column / row, i.e. at most 2 x 2 source
+  // pixels per canvas pixel of in_roi (a 5x down-scale touches 16 % of the ROI) — and writes the 4 B/px canvas with its apron
+  const double touched = (double)std::min(c->roi.w, 2 * c->in_roi.w) * (double)std::min(c->roi.h, 2 * c->in_roi.h);
+  put(j++, "prep_resize", N * (3.0 * touched + 4.0 * (double)canvas_elems(c->inW, c->inH)), 0);
   put(j++, "prep_bilateral", N * (4.0 * canvas + 12.0 * canvas), 0);
   if (seg) {
     // algorithmic bytes of each segment = the tensors it must read once + write once (f32); flops from the fused steps it covers

@@ -24,7 +24,8 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
 
 // DeepLab tail: the graph's final RESIZE_BILINEAR fused with the 21-way argmax + temporal IIR (the full-resolution logits never exist)
 bool resize_argmax_fusable(const Step& st);
-hipError_t launch_resize_argmax_iir(const Step& st, const float* lowres_logits, uint8_t* ofinal, int n, hipStream_t s);
+// generic = the scalar first-maximum scan (what more than 24 classes take; tests force it for the 21-class graph)
+hipError_t launch_resize_argmax_iir(const Step& st, const float* lowres_logits, uint8_t* ofinal, int n, hipStream_t s, bool generic = false);
 
 // Whole-network per-frame program (kernels_frame.hip): one 1024-lane workgroup per stream.
 hipError_t frame_program_prepare(int lds_floats);

@@ -728,8 +728,8 @@ bool mask_tile_fits(const int* xofs, const int* yofs, int sw, int sh, int dw, in
   return max_rows <= kMaxSrcRows && max_rows * max_cols <= kSrcBlockBytes;
 }
 
-// BSX_NO_MASK_TILE=1 (read at every launch) forces the generic kernel: the parity tests use it to cover both.
-static bool mask_tile_usable(const ResizeTab& tab) { return tab.mode == 0 && tab.tile_ok && !getenv("BSX_NO_MASK_TILE"); }
+// BSX_NO_MASK_TILE=1 (read ONCE, when the context builds its resize tables: it clears ResizeTab::tile_ok) forces the generic kernel: the parity tests use it to cover both.
+static bool mask_tile_usable(const ResizeTab& tab) { return tab.mode == 0 && tab.tile_ok; }
 
 hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                                     int n, hipStream_t s) {

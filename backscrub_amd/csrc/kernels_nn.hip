@@ -1551,13 +1551,12 @@ bool resize_argmax_fusable(const Step& st) {
   const int rows = (kFusedTH * st.H + st.OH - 1) / st.OH + 2, cols = (kFusedTW * st.W + st.OW - 1) / st.OW + 2;
   return rows * cols <= kFusedMaxSrc;
 }
-hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofinal, int n, hipStream_t s) {
+hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofinal, int n, hipStream_t s, bool generic) {
   float hs = (float)st.H / (float)st.OH, ws = (float)st.W / (float)st.OW;
   if (st.align_corners && st.OH > 1) hs = (float)(st.H - 1) / (float)(st.OH - 1);
   if (st.align_corners && st.OW > 1) ws = (float)(st.W - 1) / (float)(st.OW - 1);
   dim3 grid((st.OW + kFusedTW - 1) / kFusedTW, (st.OH + kFusedTH - 1) / kFusedTH, n);
   const int person = 15;                                           // lib/libbackscrub.cc:330 (pascal VOC class 15)
-  const bool generic = getenv("BSX_TAIL_GENERIC") != nullptr;             // (read per launch) tests: the scalar argmax scan over 32-float LDS pixels (what more than 24 classes take)
   if (!generic && st.Cin <= 24 && person < st.Cin) resize_argmax_iir_k<true><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person);
   else resize_argmax_iir_k<false><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, generic ? -1 - person : person);
   return hipGetLastError();

@@ -125,22 +125,34 @@ def parity_sample(model_path, width, height, frames, bg, gpu_masks, gpu_out, nee
 
 
 def cpu_baseline(model_path, width, height, target_s):
-    """Time the CPU oracle port (all host cores, OpenMP over streams) on a bounded sample."""
+    """Time the CPU oracle port on a bounded sample: all host cores (the `value`), plus the 1-thread and 2-thread legs SURVEY §8(d) asks
+    for (2 = the reference's default `threads`, app/deepseg.cc:362).  The port parallelises with OpenMP ACROSS streams (one stream per thread);
+    the reference's threads are TFLite intra-op threads of ONE stream — a scalar port has no intra-op parallelism, so the t-thread leg is the
+    throughput of t cores running t streams."""
     from backscrub_amd import synth
     from oracle import oracle_py
     cores = os.cpu_count() or 1
-    frames = synth.frames(cores, width, height, distinct=min(cores, 4))
     bg = synth.background(width, height)
-    oracle_py.baseline_run(model_path, frames, bg, 1, cores)                 # warm-up (page faults, thread pool)
-    sec, _, _ = oracle_py.baseline_run(model_path, frames, bg, 3, cores)     # calibration
-    per_iter = max(sec / 3, 1e-3)
-    iters = int(max(2, min(200, target_s / per_iter)))
-    sec, stages, _ = oracle_py.baseline_run(model_path, frames, bg, iters, cores)
-    fps = cores * iters / sec
+
+    def leg(threads, budget_s):
+        frames = synth.frames(threads, width, height, distinct=min(threads, 4))
+        oracle_py.baseline_run(model_path, frames, bg, 1, threads)                 # warm-up (page faults, thread pool)
+        sec, _, _ = oracle_py.baseline_run(model_path, frames, bg, 2, threads)     # calibration
+        iters = int(max(2, min(200, budget_s / max(sec / 2, 1e-3))))
+        sec, stages, _ = oracle_py.baseline_run(model_path, frames, bg, iters, threads)
+        return threads * iters / sec, iters, sec, stages
+
+    legs = []
+    for t in sorted({1, min(2, cores)}):
+        fps, iters, sec, _ = leg(t, max(1.5, 0.15 * target_s))
+        legs.append({"threads": t, "value": round(fps, 2), "unit": "frames/s", "sample": "%d stream(s) x %d frames, %.1f s" % (t, iters, sec)})
+    fps, iters, sec, stages = leg(cores, 0.7 * target_s)
+    legs.append({"threads": cores, "value": round(fps, 2), "unit": "frames/s", "sample": "%d streams x %d frames, %.1f s" % (cores, iters, sec)})
     tot = sum(stages) or 1.0
     return {"value": round(fps, 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d streams x %d frames of %dx%d through oracle/libbs_oracle_fast.so (-O3 -mavx2 -mfma, OpenMP over streams), %.1f s"
                       % (cores, iters, width, height, sec),
+            "legs": legs,
             "stage_share": {k: round(v / tot, 3) for k, v in zip(("prep", "infer", "mask", "blend"), stages)}}
 
 
@@ -148,31 +160,57 @@ def cpu_baseline(model_path, width, height, target_s):
 # one measured configuration
 # ------------------------------------------------------------------------------------------------------------------------------
 def load_pmc(B, W, H, model_name):
+    """HBM-traffic counters of this workload from the COMMITTED rocprofv3 passes (profiles/pmc_latest.json: one entry per workload,
+    tools/profile_config.sh) — not measured in this run; the line says so in `traffic_source`."""
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        wl = pj.get("workload", {})
-        if (wl.get("batch"), wl.get("width"), wl.get("height"), wl.get("model")) == (B, W, H, model_name):
-            return pj["kernels"]
+        for e in pj.get("workloads", [pj]):
+            wl = e.get("workload", {})
+            if (wl.get("batch"), wl.get("width"), wl.get("height"), wl.get("model")) == (B, W, H, model_name):
+                return e
     except Exception:
         pass
     return {}
 
 
-def roofline_of(s, pmc, mode_dtype):
+def traffic_of(pmc, launch_index, n_launches, name):
+    """(2 * FETCH_SIZE + WRITE_SIZE) KiB of one launch: by position in the step when the profiled step has the same number of launches
+    (layers that share a kernel instantiation — DeepLab's GEMMs — keep their own figure), else by kernel name."""
+    seq = []
+    for e in pmc.get("step_launches") or []:              # the fused mask + blend launch is two dispatches when the ROI does not cover the frame
+        if seq and seq[-1]["kernel"].startswith("outside_roi"):
+            seq[-1] = {"kernel": seq[-1]["kernel"] + " + " + e["kernel"], "FETCH_SIZE_KiB": seq[-1]["FETCH_SIZE_KiB"] + e["FETCH_SIZE_KiB"],
+                       "WRITE_SIZE_KiB": seq[-1]["WRITE_SIZE_KiB"] + e["WRITE_SIZE_KiB"]}
+        else:
+            seq.append(dict(e))
+    k = None
+    if len(seq) == n_launches and 0 <= launch_index < n_launches:
+        k = seq[launch_index]
+    else:
+        want = PMC_NAMES.get(name, "")
+        kern = pmc.get("kernels", {})
+        k = kern.get(want) or next((v for n_, v in kern.items() if want and n_.startswith(want)), None)
+    if k and "FETCH_SIZE_KiB" in k and "WRITE_SIZE_KiB" in k:
+        return int((2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024), k.get("kernel")
+    return None, None
+
+
+def roofline_of(s, pmc, mode_dtype, launch_index=-1, n_launches=0):
     """achieved = ALGORITHMIC bytes (or flops) of the launch / its mean hipEvent duration; traffic = HBM bytes per launch from
-    the committed rocprofv3 PMC passes (profiles/pmc_latest.json): (2*FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE doubled per
-    MI355X_MICROARCH.md §HBM (gfx950 counts 128-B reads at 64 B)."""
-    want = PMC_NAMES.get(s["name"], "")
-    k = pmc.get(want) or next((v for n_, v in pmc.items() if want and n_.startswith(want)), None)      # template arguments follow the base name
-    traffic = int((2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024) if k and "FETCH_SIZE_KiB" in k and "WRITE_SIZE_KiB" in k else None
+    the committed rocprofv3 PMC passes: (2*FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 counts
+    128-B reads at 64 B)."""
+    traffic, kern = traffic_of(pmc, launch_index, n_launches, s["name"]) if pmc else (None, None)
+    src = {"traffic_source": "committed rocprofv3 --pmc passes (profiles/pmc_latest.json, round %s), not measured in this run" % pmc.get("round", "?")} if traffic is not None else {}
+    if kern:
+        src["traffic_kernel"] = kern
     peak_tf = F16_PEAK_TFLOPS if mode_dtype == "f16" else FP32_PEAK_TFLOPS
     if s["flops"] > 0 and s["flops"] / max(s["bytes"], 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
         a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
         return {"kernel": s["name"], "bound": "mfma", "achieved": round(a, 3), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(a / peak_tf, 4),
-                "traffic": traffic, "avg_ms": round(s["avg_ms"], 4), "algorithmic_flops_per_launch": int(s["flops"]),
+                "traffic": traffic, **src, "avg_ms": round(s["avg_ms"], 4), "algorithmic_flops_per_launch": int(s["flops"]),
                 "algorithmic_bytes_per_launch": int(s["bytes"])}
     return {"kernel": s["name"], "bound": "hbm", "achieved": round(s["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(s["avg_ms"], 4),
+            "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, **src, "avg_ms": round(s["avg_ms"], 4),
             "algorithmic_bytes_per_launch": int(s["bytes"])}
 
 
@@ -273,7 +311,7 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
                  "mask_blend": "blend"}.get(s["name"], "network")
             groups[g] += s["avg_ms"]
         net = [s for s in stats if {"prep_resize": 1, "prep_bilateral": 1, "prep": 1, "decode_iir": 1, "mask_upscale_blur": 1, "blend": 1, "mask_blend": 1}.get(s["name"]) is None]
-        res.update(stats=stats, extra=extra, groups=groups, net_ms=sum(s["avg_ms"] for s in net), net_flops=sum(s["flops"] for s in net),
+        res.update(stats=stats, extra=extra, groups=groups, net=net, net_ms=sum(s["avg_ms"] for s in net), net_flops=sum(s["flops"] for s in net),
                    net_launches=len(net))
     return res
 
@@ -283,14 +321,18 @@ def summarize(res, pmc, mode_dtype="f32"):
     stats, extra = res["stats"], res["extra"]
     dom = max(stats, key=lambda s: s["avg_ms"])
     blend = dict((extra or [s for s in stats if s["name"] in ("blend", "mask_blend")])[0], name="blend")
+    n_l = len(stats)
     out = {"value": round(res["fps"], 1), "unit": "frames/s", "ms_per_step": round(res["ms_per_step"], 4),
-           "roofline": roofline_of(dom, pmc, mode_dtype), "roofline_blend": roofline_of(blend, pmc, mode_dtype)}
+           "roofline": roofline_of(dom, pmc, mode_dtype, stats.index(dom), n_l), "roofline_blend": roofline_of(blend, pmc, mode_dtype)}
     if extra:
         out["roofline_blend"]["note"] = "bsx_composite_batch kernel timed stand-alone; inside the step the blend is fused with mask upscale+blur (mask_blend)"
     if res["net_launches"] > 1:              # per-launch network (DeepLab): the whole network as one roofline line as well
         a = res["net_flops"] / (res["net_ms"] * 1e-3) / 1e12
+        net_traffic = [traffic_of(pmc, i, n_l, s_["name"])[0] for i, s_ in enumerate(stats) if s_ in res["net"]] if pmc and len(pmc.get("step_launches") or []) else []
         out["roofline_network"] = {"kernel": "network (%d launches)" % res["net_launches"], "bound": "mfma", "achieved": round(a, 3), "peak": FP32_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(a / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_ms": round(res["net_ms"], 4)}
+                                   "unit": "TFLOP/s", "frac": round(a / FP32_PEAK_TFLOPS, 4),
+                                   "traffic": int(sum(net_traffic)) if net_traffic and all(t is not None for t in net_traffic) else None,
+                                   "avg_ms": round(res["net_ms"], 4)}
     out["stage_ms"] = {k: round(v, 4) for k, v in res["groups"].items()}
     out["stage_ms"]["sum_of_launches"] = round(sum(s["avg_ms"] for s in stats), 4)
     out["top_launches"] = [{"name": s["name"], "ms": round(s["avg_ms"], 4), "GBps": round(s["GBps"], 1)} for s in sorted(stats, key=lambda s: -s["avg_ms"])[:8]]
@@ -499,7 +541,7 @@ def main():
                 try:
                     n_steps = max(3, args.steps // 4)
                     r = measure(steps=n_steps, warmup=2, rank=0, world=1, local_rank=local_rank, profile_iters=2, **kw)
-                    frag = summarize(r, {})
+                    frag = summarize(r, load_pmc(kw["B"], kw["W"], kw["H"], r["model_name"]))
                     frag = {"baseline_config": tag, "workload": desc, "steps": n_steps, "warmup": 2, **frag}
                     samples = (r["model_path"], r["host"][:2].copy(), r["bg_host"], r["masks_k"], r["out_k"], r["photo"])
                     release(r)

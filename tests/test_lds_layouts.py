@@ -23,12 +23,29 @@ def extra_cycles(addr_of_lane):
     return tot
 
 
-def hsw(row):      # f16 operand rows of 64 bytes (4 chunks of 8 halves)
-    return (4 - ((row >> 2) & 3)) & 3
+def _device_fn(name):
+    """The swizzle function AS WRITTEN in csrc/kernels_nn.hip: `__device__ __forceinline__ int <name>(int row) { return <expr>; }` — the
+    expression is C integer arithmetic that is also valid Python, so the test evaluates the kernel's own source, not a copy of it."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "backscrub_amd", "csrc", "kernels_nn.hip")).read()
+    m = re.search(r"__device__\s+__forceinline__\s+int\s+%s\(int row\)\s*\{\s*return\s+([^;]+);\s*\}" % name, src)
+    assert m, "%s(int row) not found in kernels_nn.hip" % name
+    expr = m.group(1)
+    assert re.fullmatch(r"[\s\d()row&|^<>+\-]+", expr), "unexpected tokens in %s: %r" % (name, expr)
+    return eval("lambda row: " + expr)                      # noqa: S307 — the character class above admits integer operators only
 
 
-def asw(row):      # f32 activation rows of 128 bytes (8 chunks of 4 floats)
-    return ((row >> 1) & 1) | (((row >> 3) & 1) << 2)
+hsw = _device_fn("hsw")      # f16 operand rows of 64 bytes (4 chunks of 8 halves)
+asw = _device_fn("asw")      # f32 activation rows of 128 bytes (8 chunks of 4 floats)
+
+
+def test_the_kernels_use_the_swizzles_where_the_model_says():
+    """the address expressions of the ring GEMM / the fused kernel's re-order buffers, as written in the source"""
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "backscrub_amd", "csrc", "kernels_nn.hip")).read()
+    for needle in ("li * 128 + (((2 * g) ^ asw(li)) << 4)", "li * 64 + ((g ^ hsw(li)) << 4)", "(lane & 7) ^ asw(r & 15)", "(lane & 3) ^ hsw(r)"):
+        assert needle in src, needle
 
 
 def test_weight_rows_are_conflict_free_with_hsw_and_not_without():
