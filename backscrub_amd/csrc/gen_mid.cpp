@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace bsx {
 namespace {
@@ -39,6 +40,9 @@ std::string generate_mid_source(const Plan& plan, std::string* why) {
   auto fail = [&](const std::string& m) { if (why) *why = m; return std::string(); };
   const std::vector<MicroOp>& P = plan.program;
   if (P.empty()) return fail("no program");
+  // BSX_RTC_FINE=1 (timing experiments, tools/program_timeline.py --fine): per-wave shader-clock stamps around the barrier and the body of every op
+  // (a different source, i.e. a different cache entry, from the product kernel)
+  const bool fine = getenv("BSX_RTC_FINE") != nullptr;
   Out o;
   o.s.reserve(sizeof kPrelude + 64 * 1024);
   o.s += kPrelude;
@@ -59,9 +63,36 @@ std::string generate_mid_source(const Plan& plan, std::string* why) {
   for (int i = 0; i < n; i++) {
     const MicroOp& m = P[i];
     for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.scale, &m.out}) if (!plain(*l)) return fail("operand in the network input / output buffer");
-    k.f("  // ---- P%d %s\n  op_barrier();\n  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[%d] = __builtin_amdgcn_s_memrealtime();\n", i,
-        i < (int)plan.program_labels.size() ? plan.program_labels[i].c_str() : "", i);
+    if (fine && i > 0 && i <= 64) k.f("  FINE_END(%d);\n", i - 1);
+    k.f("  // ---- P%d %s\n", i, i < (int)plan.program_labels.size() ? plan.program_labels[i].c_str() : "");
+    if (fine) k.f("  f_a = __builtin_readcyclecounter();\n");
+    k.f("  op_barrier();\n  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[%d] = __builtin_amdgcn_s_memrealtime();\n", i);
+    if (fine) k.f("  f_b = __builtin_readcyclecounter();\n");
     if (i + 1 < n) stage_of(i + 1, k);
+    // The FC weights of a squeeze-excite op come from L2 (64 KB per 128 x 128 layer, the same bytes for every workgroup): requested ONE OP EARLY,
+    // into registers that stay live across the depthwise / 1x1 op in front of it, their delivery overlaps that op instead of stalling the FCs.
+    auto fc_loads = [&](int j) {
+      const MicroOp& q = P[j];
+      auto fcl = [&](int which, int cin, int cout, int stage, int lds, long long w2, long long b) {
+        k.f("  FcRegs<%d, %d> fc%d_%d;\n", cin, cout, j, which);
+        if (stage > 0) k.f("  fc_load<%d, %d, SP_LDS, %d, %d>(L, W, fc%d_%d);\n", cin, cout, lds + (int)(w2 - b), lds, j, which);
+        else k.f("  fc_load<%d, %d, SP_GLB, %lld, %lld>(L, W, fc%d_%d);\n", cin, cout, w2, b, j, which);
+      };
+      fcl(1, q.Cin, q.C1, q.fc_stage[0], q.fc_lds[0], q.w2_off, q.b_off);
+      if (q.n_fc == 2) fcl(2, q.C1, q.C2, q.fc_stage[1], q.fc_lds[1], q.w3_off, q.b3_off);
+    };
+    auto early = [&](int j) {        // may the loads of SE op j be issued at the top of op j - 1?  (unstaged weights only: a staged block lands at j's barrier)
+      if (j <= 0 || j >= n || P[j].kind != kMicroSe || P[j].fc_stage[0] > 0 || P[j].fc_stage[1] > 0) return false;
+      if (getenv("BSX_RTC_NO_EARLY_FC")) return false;
+      // register budget: up to 34 live FC registers + the op's own.  1x1 ops need ~35; the depthwise bodies 60-78 in their fully unrolled LDS form
+      // (op_dw: K (NIN + K) V <= 144) and ~105 in the one-row-ahead form, which would spill
+      const MicroOp& pv = P[j - 1];
+      if (pv.kind == (int)StepKind::PwConv && pv.mfma && !pv.gemv) return true;
+      if (pv.kind != (int)StepKind::DwConv || pv.in0.space != kLocLds) return false;
+      const int K = pv.kh, S = pv.sh, V = K == 5 ? 2 : 4, TX = (S == 1 && !(pv.OW % 5 != 0 && pv.OW % 4 == 0)) ? 5 : 4, NIN = (TX - 1) * S + K;
+      return K * (NIN + K) * V <= 144;
+    };
+    if (early(i + 1)) fc_loads(i + 1);
     if (m.kind == (int)StepKind::PwConv && m.mfma && !m.gemv) {
       if (m.Cin % 4 || m.cout_pad % 16 || m.stage_floats <= 0) return fail("pw: channel counts / unstaged weights");
       if (m.scale.space != kLocNone && m.scale.space != kLocLds) return fail("pw: scale vector outside LDS");
@@ -87,6 +118,8 @@ std::string generate_mid_source(const Plan& plan, std::string* why) {
       k.f("  op_dw<Op%d>(L, A, W);\n", i);
     } else if (m.kind == kMicroSe) {
       if (m.in1.space != kLocLds || (m.n_fc == 2 && m.in2.space != kLocLds) || m.Cin % 4 || m.C1 % 1) return fail("se: mean / hidden vectors outside LDS");
+      if (m.w2_off > 0x7fffffffll || m.w3_off > 0x7fffffffll) return fail("se: weight offset");
+      if (!early(i)) fc_loads(i);        // staged weights (LDS) or no op in front: requested here, ahead of the pooling
       // pooling parts → mean vector (LDS, at in1)
       const int mean = m.in1.off;
       auto part = [&](const Loc& l, int rows, int C, int hw, int coff, bool accum, bool partials) {
@@ -106,15 +139,10 @@ std::string generate_mid_source(const Plan& plan, std::string* why) {
       }
       k.f("  __syncthreads();\n");
       const Loc& y1 = m.n_fc == 1 ? m.out : m.in2;
-      auto fc = [&](int cin, int cout, int act, int stage, int lds, long long w2, long long b, int x_off, const Loc& y) {
-        if (stage > 0) k.f("  fc_layer<%d, %d, %d, SP_LDS, %d, %d, %d, %d, %d>(L, A, W);\n", cin, cout, act, lds + (int)(w2 - b), lds, x_off, sp_of(y), y.off);
-        else k.f("  fc_layer<%d, %d, %d, SP_GLB, %lld, %lld, %d, %d, %d>(L, A, W);\n", cin, cout, act, w2, b, x_off, sp_of(y), y.off);
-      };
-      if (m.w2_off > 0x7fffffffll || m.w3_off > 0x7fffffffll) return fail("se: weight offset");
-      fc(m.Cin, m.C1, m.act, m.fc_stage[0], m.fc_lds[0], m.w2_off, m.b_off, mean, y1);
+      k.f("  fc_apply<%d, %d, %d, %d, %d, %d>(L, A, fc%d_1);\n", m.Cin, m.C1, m.act, mean, sp_of(y1), y1.off, i);
       if (m.n_fc == 2) {
         k.f("  __syncthreads();\n");
-        fc(m.C1, m.C2, m.act2, m.fc_stage[1], m.fc_lds[1], m.w3_off, m.b3_off, m.in2.off, m.out);
+        k.f("  fc_apply<%d, %d, %d, %d, %d, %d>(L, A, fc%d_2);\n", m.C1, m.C2, m.act2, m.in2.off, sp_of(m.out), m.out.off, i);
       }
     } else if (m.kind == (int)StepKind::Resize) {
       if (m.Cin % 4) return fail("resize: channels");
@@ -131,7 +159,11 @@ std::string generate_mid_source(const Plan& plan, std::string* why) {
   o.f("extern \"C\" __global__ void __launch_bounds__(1024) bsx_mid(float* __restrict__ arena, long per_frame, const float* __restrict__ weights, unsigned long long* tl) {\n");
   o.f("  __shared__ __attribute__((aligned(16))) float smem[%d];\n", plan.program_lds_floats);
   o.f("  lds_f* L = (lds_f*)smem;\n  glb_f* A = (glb_f*)(arena + (size_t)blockIdx.x * (size_t)per_frame);\n  const glb_f* W = (const glb_f*)weights;\n");
+  if (fine) o.f("  unsigned long long f_a = 0, f_b = 0;\n"
+                "#define FINE_END(i) do { const unsigned long long f_d = __builtin_readcyclecounter(); if (tl && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { "
+                "unsigned long long* f4 = tl + 1024 + ((i) * 16 + (threadIdx.x >> 6)) * 4; f4[0] = f_b - f_a; f4[1] = 0; f4[2] = f_d - f_b; f4[3] = f_a; } } while (0)\n");
   o.s += k.s;
+  if (fine && n <= 64) o.f("  FINE_END(%d);\n", n - 1);
   o.f("  op_barrier();\n  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[%d] = __builtin_amdgcn_s_memrealtime();\n}\n", n);
   return o.s;
 }

@@ -33,27 +33,32 @@ typedef __attribute__((address_space(3))) f4v lds_v4;
 typedef __attribute__((address_space(1))) f4v glb_v4;
 typedef __attribute__((address_space(3))) f2v lds_v2;
 typedef __attribute__((address_space(1))) f2v glb_v2;
+typedef __attribute__((address_space(1))) char glb_c;
+// uniform base + zero-extended 32-bit BYTE offset (computed in 32 bits: every arena slice is far below 4 GB)
+#define BSXM_G(T, g, off) ((T*)((glb_c*)(g) + (unsigned)((off) * 4)))
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// compile-time address-space loads / stores: one ds_* or global_* instruction, never a flat access and never a branch
+// compile-time address-space loads / stores: one ds_* or global_* instruction, never a flat access and never a branch.  Global offsets are
+// UNSIGNED: uniform base + zero-extended 32-bit lane offset is the `global_load … v_off, s[base]` form — a signed offset makes the compiler
+// build a 64-bit address pair per access (nine taps = 18 more registers in the depthwise bodies: spills).
 template <int SP> __device__ __forceinline__ f4v ld4(const lds_f* l, const glb_f* g, int off) {
-  if constexpr (SP == SP_LDS) return *(const lds_v4*)(l + off); else return *(const glb_v4*)(g + off);
+  if constexpr (SP == SP_LDS) return *(const lds_v4*)(l + off); else return *BSXM_G(const glb_v4, g, off);
 }
 template <int SP> __device__ __forceinline__ void st4(lds_f* l, glb_f* g, int off, f4v v) {
-  if constexpr (SP == SP_LDS) *(lds_v4*)(l + off) = v; else *(glb_v4*)(g + off) = v;
+  if constexpr (SP == SP_LDS) *(lds_v4*)(l + off) = v; else *BSXM_G(glb_v4, g, off) = v;
 }
 template <int SP> __device__ __forceinline__ f2v ld2(const lds_f* l, const glb_f* g, int off) {
-  if constexpr (SP == SP_LDS) return *(const lds_v2*)(l + off); else return *(const glb_v2*)(g + off);
+  if constexpr (SP == SP_LDS) return *(const lds_v2*)(l + off); else return *BSXM_G(const glb_v2, g, off);
 }
 template <int SP> __device__ __forceinline__ void st2(lds_f* l, glb_f* g, int off, f2v v) {
-  if constexpr (SP == SP_LDS) *(lds_v2*)(l + off) = v; else *(glb_v2*)(g + off) = v;
+  if constexpr (SP == SP_LDS) *(lds_v2*)(l + off) = v; else *BSXM_G(glb_v2, g, off) = v;
 }
 template <int SP> __device__ __forceinline__ float ld1(const lds_f* l, const glb_f* g, int off) {
-  if constexpr (SP == SP_LDS) return l[off]; else return g[off];
+  if constexpr (SP == SP_LDS) return l[off]; else return *BSXM_G(const glb_f, g, off);
 }
 template <int SP> __device__ __forceinline__ void st1(lds_f* l, glb_f* g, int off, float v) {
-  if constexpr (SP == SP_LDS) l[off] = v; else g[off] = v;
+  if constexpr (SP == SP_LDS) l[off] = v; else *BSXM_G(glb_f, g, off) = v;
 }
 
 // activations: hardware exp2 / rcp (≈1 ulp), the same forms as the interpreter (kernels_frame.hip: fp_act)
@@ -241,24 +246,25 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
         for (int fx = 0; fx < K; fx++) acc[k] = __builtin_elementwise_fma(xin[k * S + fx], wv[fx], acc[k]);
       }
     };
-    if constexpr (T::X_SP == SP_LDS) {
-      // LDS input: fully unrolled — the scheduler overlaps the next rows' ds_reads with this row's FMAs
+    if constexpr (T::X_SP == SP_LDS && K * (NIN + K) * V <= 144) {
+      // LDS input: fully unrolled — the scheduler overlaps the next rows' ds_reads with this row's FMAs (the 5x5 stride-2 form would hold
+      // 5 x 16 x 2 registers that way and spills: it takes the one-row-ahead loop below)
 #pragma unroll
       for (int fy = 0; fy < K; fy++) { vec_t xin[NIN], wv[K]; load_row(fy, xin, wv); fma_row(xin, wv); }
     } else {
-      // global input: exactly ONE row ahead in flight (all K rows at once — what full unrolling turns into — needs K (NIN + K) V registers: spills)
-      vec_t xa[NIN], wa[K];
-      load_row(0, xa, wa);
+      // exactly ONE row ahead in flight (all K rows at once — what plain unrolling turns into — needs K (NIN + K) V registers: spills).
+      // Two register sets alternate by filter-row parity.
+      vec_t x0[NIN], w0[K], x1[NIN], w1[K];
+      static_assert(K % 2 == 1, "op_dw: odd filter sizes");
+      load_row(0, x0, w0);
 #pragma unroll 1
-      for (int fy = 0; fy < K; fy++) {
-        vec_t xb[NIN], wb[K];
-        load_row(fy + 1 < K ? fy + 1 : fy, xb, wb);               // the last trip re-requests its own row (cached) instead of branching
-        fma_row(xa, wa);
-#pragma unroll
-        for (int j = 0; j < NIN; j++) xa[j] = xb[j];
-#pragma unroll
-        for (int fx = 0; fx < K; fx++) wa[fx] = wb[fx];
+      for (int fy = 0; fy + 1 < K; fy += 2) {                       // a real loop: nothing is hoisted across its back edge, no register copies
+        load_row(fy + 1, x1, w1);
+        fma_row(x0, w0);
+        load_row(fy + 2, x0, w0);
+        fma_row(x1, w1);
       }
+      fma_row(x0, w0);
     }
     const vec_t bq = ldw(T::B_OFF + ch);
 #pragma unroll
@@ -303,31 +309,59 @@ __device__ __forceinline__ void gap_part(lds_f* L, glb_f* A) {
 }
 
 // ---- fully connected layer of a squeeze-excite / gate chain: each output = dot product over LK aligned lanes + DPP reduction ------
-// weights [co][ci] rows with the bias in front, either staged in LDS (W_SP = LDS: offsets into the LDS block) or in the weight arena
-template <int CIN, int COUT, int ACT, int W_SP, int W_OFF, int B_OFF, int X_OFF, int Y_SP, int Y_OFF>
-__device__ __forceinline__ void fc_layer(lds_f* L, glb_f* A, const glb_f* Wg) {
-  constexpr int LK = (CIN % 32 == 0) ? 8 : ((CIN % 16 == 0) ? 4 : ((CIN % 8 == 0) ? 2 : 1)), KLEN = CIN / LK, PER = kThreads / LK;
-  const int sub = threadIdx.x & (LK - 1), co0 = threadIdx.x / LK;
+// weights [co][ci] rows with the bias in front, either staged in LDS (W_SP = LDS: offsets into the LDS block) or in the weight arena.
+// Two halves: fc_load requests a lane's weight slice (registers) — called at the TOP of the squeeze-excite op, so that the L2 round trip of
+// both layers' weights hides behind the pooling and its barrier — and fc_apply does the arithmetic once the input vector is complete.
+// Eight lanes per output whenever the input splits into equal slices of whole float4s (KLEN = 4 ceil(CIN / 32): 72 = 6 x 12, 24 = 6 x 4 — the
+// lanes past the last slice add zeros), otherwise the largest power-of-two split.  (A 72-channel layer on 2 lanes per output kept 144 of the
+// 1024 lanes busy with 36 MACs each.)
+template <int CIN, int COUT> struct FcGeom {
+  static constexpr int K8 = 4 * ((CIN + 31) / 32);
+  static constexpr bool EIGHT = CIN % K8 == 0;
+  static constexpr int LK = EIGHT ? 8 : ((CIN % 16 == 0) ? 4 : ((CIN % 8 == 0) ? 2 : 1)), KLEN = EIGHT ? K8 : CIN / LK, NSUB = CIN / KLEN;   // NSUB <= LK active lanes
+  static constexpr int PER = kThreads / LK, IT = (COUT + PER - 1) / PER, Q = KLEN / 4;
+};
+template <int CIN, int COUT> struct FcRegs { f4v w[FcGeom<CIN, COUT>::IT][FcGeom<CIN, COUT>::Q]; float b[FcGeom<CIN, COUT>::IT]; };
+template <int CIN, int COUT, int W_SP, int W_OFF, int B_OFF>
+__device__ __forceinline__ void fc_load(const lds_f* L, const glb_f* Wg, FcRegs<CIN, COUT>& r) {
+  typedef FcGeom<CIN, COUT> G;
+  const int sub = threadIdx.x & (G::LK - 1), co0 = threadIdx.x / G::LK;
+  // The weights are read-only memory: left alone, the compiler hoists these loads above the barrier into the op in front — wherever IT likes,
+  // e.g. into a 91-register depthwise body, which then spills.  Where the loads go is the generator's decision (gen_mid.cpp: `early`): the
+  // base pointer passes through an opaque asm here, so they stay behind whatever precedes this call.
+  asm volatile("" : "+s"(Wg));
 #pragma unroll
-  for (int it = 0; it < (COUT + PER - 1) / PER; it++) {
-    const int co = co0 + it * PER;
-    if (co < COUT) {
-      f4v wv[KLEN / 4];
+  for (int it = 0; it < G::IT; it++) {
+    const int co = min(co0 + it * G::PER, COUT - 1);               // lanes past the last output re-read a valid row; their result is dropped
+    const int ks = min(sub, G::NSUB - 1) * G::KLEN;                // lanes past the last slice re-read the last one; fc_apply zeroes their input
 #pragma unroll
-      for (int q = 0; q < KLEN / 4; q++) wv[q] = ld4<W_SP>(L, Wg, W_OFF + co * CIN + sub * KLEN + 4 * q);
-      const float bias = ld1<W_SP>(L, Wg, B_OFF + co);
-      float a0 = 0.f, a1 = 0.f;
+    for (int q = 0; q < G::Q; q++) r.w[it][q] = ld4<W_SP>(L, Wg, W_OFF + co * CIN + ks + 4 * q);
+    r.b[it] = ld1<W_SP>(L, Wg, B_OFF + co);
+  }
+}
+template <int CIN, int COUT, int ACT, int X_OFF, int Y_SP, int Y_OFF>
+__device__ __forceinline__ void fc_apply(lds_f* L, glb_f* A, const FcRegs<CIN, COUT>& r) {
+  typedef FcGeom<CIN, COUT> G;
+  const int sub = threadIdx.x & (G::LK - 1), co0 = threadIdx.x / G::LK;
+  f4v xv[G::Q];
 #pragma unroll
-      for (int q = 0; q < KLEN / 4; q++) {
-        const f4v xv = *(const lds_v4*)(L + X_OFF + sub * KLEN + 4 * q);
-        a0 = fmaf(xv.x, wv[q].x, a0); a1 = fmaf(xv.y, wv[q].y, a1); a0 = fmaf(xv.z, wv[q].z, a0); a1 = fmaf(xv.w, wv[q].w, a1);
-      }
-      float acc = a0 + a1;
-      if constexpr (LK >= 2) acc += dpp<kQuadXor1>(acc);
-      if constexpr (LK >= 4) acc += dpp<kQuadXor2>(acc);
-      if constexpr (LK >= 8) acc += dpp<kHalfMirror>(acc);
-      if (sub == 0) st1<Y_SP>(L + Y_OFF, A + Y_OFF, co, act1<ACT>(acc + bias));
+  for (int q = 0; q < G::Q; q++) {
+    xv[q] = *(const lds_v4*)(L + X_OFF + min(sub, G::NSUB - 1) * G::KLEN + 4 * q);
+    if (G::NSUB < G::LK && sub >= G::NSUB) xv[q] = (f4v)(0.f);
+  }
+#pragma unroll
+  for (int it = 0; it < G::IT; it++) {
+    const int co = co0 + it * G::PER;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < G::Q; q++) {
+      a0 = fmaf(xv[q].x, r.w[it][q].x, a0); a1 = fmaf(xv[q].y, r.w[it][q].y, a1); a0 = fmaf(xv[q].z, r.w[it][q].z, a0); a1 = fmaf(xv[q].w, r.w[it][q].w, a1);
     }
+    float acc = a0 + a1;
+    if constexpr (G::LK >= 2) acc += dpp<kQuadXor1>(acc);
+    if constexpr (G::LK >= 4) acc += dpp<kQuadXor2>(acc);
+    if constexpr (G::LK >= 8) acc += dpp<kHalfMirror>(acc);
+    if (sub == 0 && co < COUT) st1<Y_SP>(L + Y_OFF, A + Y_OFF, co, act1<ACT>(acc + r.b[it]));
   }
 }
 

@@ -99,9 +99,10 @@ std::string Plan::describe() const {
 // `steps`: the step list to lower (the whole network, or the middle of a segmented plan).  `ext`: tensors that cross the
 // program's boundary (produced or consumed by a segment kernel) — they live at their arena offset, never in LDS.
 // `part_n[t]` > 0 marks tensor t of a pooling step as "already pooled per tile": [part_n][C] partial sums at tensor_off[t].
-static void build_frame_program(const Graph& g, Plan* plan, const std::vector<Step>& steps, const std::vector<int>& ext = {},
-                                const std::map<int, int>& part_n = {}, const std::map<int, int>& part_hw = {}) {
+static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<Step>& steps, const std::vector<int>& ext, const std::map<int, int>& part_n,
+                                const std::map<int, int>& part_hw, const int scratch) {
   plan->program.clear();
+  plan->program_scratch_floats = scratch;
   plan->program_labels.clear();
   plan->program_blocks.clear();
   plan->program_check.clear();
@@ -123,8 +124,26 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
   std::vector<Loc> loc(NT);
   struct Blk { int off, len, until; };
   std::vector<Blk> live;
-  const int cap = kLdsTotalFloats;
-  int high = kLdsScratchFloats;
+  // ---- reserved zone for the long-lived tensors (see place()): stacked from the top of the block, at most a quarter of it
+  std::map<int, int> reserved_at;
+  int reserved = 0;
+  if (!getenv("BSX_PLAN_NO_TOPDOWN")) {
+    std::vector<int> firstdef(NT, -1);
+    for (int s = 0; s < NS; s++) if (steps[s].out >= 0 && firstdef[steps[s].out] < 0) firstdef[steps[s].out] = s;
+    for (int t = 0; t < NT; t++) {
+      if (firstdef[t] < 0 || last[t] - firstdef[t] <= 8 || t == g.input || t == g.output) continue;
+      if (std::find(ext.begin(), ext.end(), t) != ext.end()) continue;
+      const TensorInfo& ti = g.tensors[t];
+      const int C = ti.dims[3], P = ti.dims[1] * ti.dims[2];
+      if (C % 4 || P <= 1) continue;
+      const int pad = ((C / 4) % 2 == 0) ? 4 : 8, need = (P * (C + pad) + 3) / 4 * 4;
+      if (reserved + need > kLdsTotalFloats / 4) continue;
+      reserved += need;
+      reserved_at[t] = kLdsTotalFloats - reserved;
+    }
+  }
+  const int cap = kLdsTotalFloats - reserved;      // everything that is not reserved allocates in [scratch, cap)
+  int high = scratch;
   auto place = [&](int t, int s) {
     if (t < 0 || loc[t].space != kLocNone) return;
     const TensorInfo& ti = g.tensors[t];
@@ -137,15 +156,22 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
     int need = (P * stride + 3) / 4 * 4;
     // a tensor that would leave no room for the weight slots of the ops around it turns those ops into their slow unstaged
     // forms (MLKit's 16x16x128 tensors are 132 KB): such a tensor goes to HBM instead
-    if (need > kLdsTotalFloats - kLdsScratchFloats - 2 * kLdsMaxStageFloats && !getenv("BSX_PLAN_NO_SLOT_RESERVE")) lds_ok = false;
+    if (need > kLdsTotalFloats - scratch - 2 * kLdsMaxStageFloats && !getenv("BSX_PLAN_NO_SLOT_RESERVE")) lds_ok = false;
     if (lds_ok) {
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
-      int pos = kLdsScratchFloats;
+      int pos = scratch;
+      // Long-lived tensors (skip connections: alive across more than 8 steps) own a RESERVED zone at the top of the block for the whole program
+      // (`reserved`, computed below; everything else allocates below it): a skip tensor dropped by first-fit into the middle of the block splits
+      // the free space for its whole lifetime (segm_lite: the level-3 skip `C` sat at 62 KB and the 96 KB expanded tensor two steps later went to
+      // HBM although 110 KB were free).
+      auto rz = reserved_at.find(t);
+      if (rz != reserved_at.end()) pos = rz->second;
+      else
       for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
-      if (pos + need <= cap) {
+      if (rz != reserved_at.end() || pos + need <= cap) {
         l.space = kLocLds; l.off = pos; l.stride = stride;
-        live.push_back({pos, need, last[t]});
+        if (rz == reserved_at.end()) live.push_back({pos, need, last[t]});
         plan->program_blocks.push_back({pos, need, s, last[t], "tensor " + std::to_string(t)});
         high = std::max(high, pos + need);
         plan->program_lds_tensors++;
@@ -170,7 +196,7 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
   }
   // Weight staging slots.  stage[s] floats of step s are DMA'd to LDS while the PREVIOUS micro-op runs, so the slot must be
   // free from the first step of that previous micro-op (q) to s.  q is conservative: a GAP → FC.. chain may fuse into one op.
-  auto gemv_form = [&](const Step& st) { return st.kind == StepKind::PwConv && st.OH * st.OW <= 4 && st.OH * st.OW * st.Cout * 16 <= kLdsScratchFloats; };
+  auto gemv_form = [&](const Step& st) { return st.kind == StepKind::PwConv && st.OH * st.OW <= 4 && st.OH * st.OW * st.Cout * 16 <= kLdsScratchFloats; };   // (a lowering with reduced scratch never contains one: see build_frame_program)
   std::vector<int> stage(NS, 0), slot(NS, 0);
   std::vector<std::vector<int>> slots_from(NS);
   for (int s = 0; s < NS; s++) {
@@ -223,8 +249,20 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
       const int need = (stage[s2] + 3) / 4 * 4;
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
-      int pos = kLdsScratchFloats;
-      for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
+      // weight slots live for two steps and are small: placed from the TOP of the block (like the skip tensors) they leave the bottom
+      // contiguous for the large activation tensors (a 9.6 KB slot at 54 KB kept segm_lite's 96 KB expanded tensor out of LDS)
+      int pos = -1, hi = cap;
+      if (!getenv("BSX_PLAN_NO_TOPDOWN")) {
+        for (int k = (int)live.size() - 1; k >= -1; k--) {
+          const int lo = k >= 0 ? live[k].off + live[k].len : scratch;
+          if (hi - lo >= need) { pos = hi - need; break; }
+          if (k >= 0) hi = std::min(hi, live[k].off);
+        }
+        if (pos < 0) pos = cap;
+      } else {
+        pos = scratch;
+        for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
+      }
       if (pos + need <= cap) {
         slot[s2] = pos; live.push_back({pos, need, s2}); high = std::max(high, pos + need);
         plan->program_blocks.push_back({pos, need, s, s2, "weights of step " + std::to_string(s2)});
@@ -242,7 +280,7 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
       for (int R = rmax; R >= 1 && tail_ws[s] < 0; R = R > 4 ? R - 2 : R - 1) {
         const int need = need_for(R);
         if ((R + 2) * st.W > 64 * 16 * 4) continue;           // phase A: <= 4 tiles per wave and band
-        int pos = kLdsScratchFloats;
+        int pos = scratch;
         for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
         if (pos + need <= cap) {
           tail_ws[s] = pos; tail_rows[s] = R; live.push_back({pos, need, s + 2}); high = std::max(high, pos + need);
@@ -295,7 +333,7 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
       const int need = (need_for(band) + 3) / 4 * 4;
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
-      int pos = kLdsScratchFloats;
+      int pos = scratch;
       for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
       if (pos + need <= cap && band_floats(band) <= 8192) {
         m.mfma = 1; m.ws_off = pos; m.band_rows = band;
@@ -372,8 +410,23 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
   plan->program = std::move(prog);
   plan->program_labels = std::move(labels);
   plan->program_lds_floats = high;
+  if (getenv("BSX_PLAN_DEBUG"))
+    for (const auto& b : plan->program_blocks) fprintf(stderr, "lds block [%6d, %6d) steps [%2d, %2d] %s\n", b.off, b.off + b.len, b.from, b.until, b.what.c_str());
   plan->program_check = verify_program_lds(*plan);
   if (plan->program_check != "ok") plan->program.clear();      // never run a program whose LDS reservations collide
+}
+
+// The reduction scratch at the bottom of the LDS block (frame_program.hpp: kLdsScratchFloats, 8 KB) is used by the single-pixel GEMV form and by the
+// fused decoder tail only.  A lowering that contains neither (every FC folded into a squeeze-excite op: the middle of a segmented plan) is
+// repeated with 256 bytes of scratch — segm_lite's 6x10x96 tensor missed LDS by 1.2 KB.
+static void build_frame_program(const Graph& g, Plan* plan, const std::vector<Step>& steps, const std::vector<int>& ext = {},
+                                const std::map<int, int>& part_n = {}, const std::map<int, int>& part_hw = {}) {
+  lower_frame_program(g, plan, steps, ext, part_n, part_hw, kLdsScratchFloats);
+  if (plan->program.empty() || getenv("BSX_PLAN_FULL_SCRATCH")) return;
+  for (const MicroOp& m : plan->program)
+    if ((m.kind == (int)StepKind::PwConv && m.gemv) || m.kind == kMicroTail || m.kind == (int)StepKind::Conv) return;
+  lower_frame_program(g, plan, steps, ext, part_n, part_hw, 64);
+  if (plan->program.empty()) lower_frame_program(g, plan, steps, ext, part_n, part_hw, kLdsScratchFloats);
 }
 
 // Independent check of the lowering: no two LDS reservations that are alive at the same step may share a float, every block
@@ -381,7 +434,7 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
 std::string verify_program_lds(const Plan& plan) {
   const auto& b = plan.program_blocks;
   for (size_t i = 0; i < b.size(); i++) {
-    if (b[i].off < kLdsScratchFloats || b[i].off + b[i].len > kLdsTotalFloats || b[i].len <= 0 || b[i].from > b[i].until)
+    if (b[i].off < plan.program_scratch_floats || b[i].off + b[i].len > kLdsTotalFloats || b[i].len <= 0 || b[i].from > b[i].until)
       return "block out of range: " + b[i].what;
     for (size_t j = i + 1; j < b.size(); j++) {
       const bool time = b[i].from <= b[j].until && b[j].from <= b[i].until;
@@ -392,8 +445,8 @@ std::string verify_program_lds(const Plan& plan) {
   }
   for (const MicroOp& m : plan.program) {
     for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.scale, &m.out})
-      if (l->space == kLocLds && (l->off < kLdsScratchFloats || l->off >= plan.program_lds_floats)) return "operand outside the LDS block area";
-    if (m.stage_floats > 0 && (m.w_lds < kLdsScratchFloats || m.w_lds + m.stage_floats > plan.program_lds_floats)) return "weight slot outside the LDS block area";
+      if (l->space == kLocLds && (l->off < plan.program_scratch_floats || l->off >= plan.program_lds_floats)) return "operand outside the LDS block area";
+    if (m.stage_floats > 0 && (m.w_lds < plan.program_scratch_floats || m.w_lds + m.stage_floats > plan.program_lds_floats)) return "weight slot outside the LDS block area";
   }
   return "ok";
 }

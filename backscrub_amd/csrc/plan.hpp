@@ -121,6 +121,7 @@ struct Plan {
   std::vector<MicroOp> program;
   std::vector<std::string> program_labels;
   int program_lds_floats = 0;         // dynamic LDS the program needs (scratch included)
+  int program_scratch_floats = 0;     // reduction scratch at the bottom of the LDS block: kLdsScratchFloats, or 64 when no micro-op of the lowering uses it
   int program_lds_tensors = 0, program_global_tensors = 0;
   // every LDS reservation of the program: [off, off+len) floats, alive for steps [from, until] (tensors, weight slots,
   // band workspaces) — checked for overlap by verify_program_lds() at the end of the lowering and by the tests

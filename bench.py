@@ -39,7 +39,7 @@ F16_PEAK_TFLOPS = 2500.0   # dense f16 MFMA peak
 METRIC = "composited frames/sec at 640×480 (batch), 1/2/4/8 MI355X + mask IoU vs CPU ref"
 NAMES = {"lite": "segm_lite_v681.tflite", "full": "segm_full_v679.tflite",
          "mlkit": "selfiesegmentation_mlkit-256x256-2021_01_19-v1215.f16.tflite", "deeplab": "deeplabv3_257_mv_gpu.tflite"}
-PMC_NAMES = {"frame_program": "frame_program_k", "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
+PMC_NAMES = {"frame_program": ("bsx_mid", "frame_program_k"), "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
              "mask_upscale_blur": "mask_tile_k<false>", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k",
              "seg_head": "seg_head_k", "seg_k2": "seg_k2_k", "seg_k3": "seg_k3_k", "seg_tail": "seg_tail_k", "seg_tail+decode": "seg_tail_k"}
 
@@ -187,9 +187,10 @@ def traffic_of(pmc, launch_index, n_launches, name):
     if len(seq) == n_launches and 0 <= launch_index < n_launches:
         k = seq[launch_index]
     else:
-        want = PMC_NAMES.get(name, "")
+        wants = PMC_NAMES.get(name, ())
+        wants = (wants,) if isinstance(wants, str) else wants          # the specialised (hipRTC) and the interpreted program are different kernels
         kern = pmc.get("kernels", {})
-        k = kern.get(want) or next((v for n_, v in kern.items() if want and n_.startswith(want)), None)
+        k = next((v for want in wants for n_, v in kern.items() if n_ == want or n_.startswith(want)), None)
     if k and "FETCH_SIZE_KiB" in k and "WRITE_SIZE_KiB" in k:
         return int((2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024), k.get("kernel")
     return None, None

@@ -18,6 +18,16 @@ head, kern = src.split('extern "C" __global__', 1)
 sig, body = kern.split("{\n", 1)
 pre = body.split("  // ---- P0", 1)[0]
 ops = [o for o in re.split(r"(?=  // ---- P\d+ )", body[len(pre):]) if o.strip()]
+# the FC weight loads of a squeeze-excite op are emitted one op early (they stay in registers across the op in front of it): for the
+# isolated view they move back to their own op
+for i in range(len(ops)):
+    mine = re.findall(r"  FcRegs<[^\n]*> fc(\d+)_\d;\n  fc_load<[^\n]*\n", ops[i])
+    for m in re.finditer(r"(  FcRegs<[^\n]*> fc(\d+)_\d;\n  fc_load<[^\n]*\n)", ops[i]):
+        j = int(m.group(2))
+        if j != i and j < len(ops):
+            ops[i] = ops[i].replace(m.group(1), "")
+            head_, rest_ = ops[j].split("\n", 1)
+            ops[j] = head_ + "\n" + m.group(1) + rest_
 tmp = tempfile.mkdtemp()
 rows = []
 for i, op in enumerate(ops):

@@ -28,12 +28,40 @@ def demangle(name):
     return _DEMANGLED[name]
 
 
+def demangle_ours(name):
+    """`_ZN3bsx12_GLOBAL__N_1<len><kernel>I<Li<int>E | Lb<0|1>E ...>E...` → `kernel<3, 1, false>`: binutils' c++filt gives up on signatures that
+    contain _Float16 (DF16_), which is every split-f16 kernel of kernels_nn.hip."""
+    import re
+    m = re.match(r"_ZN3bsx12_GLOBAL__N_1(\d+)", name)
+    if not m:
+        return None
+    n = int(m.group(1))
+    rest = name[m.end():]
+    kern, rest = rest[:n], rest[n:]
+    if not rest.startswith("I"):
+        return kern
+    args, rest = [], rest[1:]
+    while rest and not rest.startswith("E"):
+        a = re.match(r"L([ib])(n?\d+)E", rest)
+        if not a:
+            return kern + "<...>"
+        v = a.group(2).replace("n", "-")
+        args.append(("true" if v != "0" else "false") if a.group(1) == "b" else v)
+        rest = rest[a.end():]
+    return kern + "<" + ", ".join(args) + ">"
+
+
 def is_ours(name):
-    return "bsx::" in name or name.startswith("_ZN3bsx")
+    return "bsx::" in name or name.startswith("_ZN3bsx") or name.startswith("bsx_")      # bsx_mid: the hipRTC-compiled specialised program
 
 
 def short(name):
+    own = demangle_ours(name)
+    if own:
+        return own[:60]
     name = demangle(name).replace("bsx::(anonymous namespace)::", "").replace("void ", "")
+    if name.endswith(".kd"):
+        name = name[:-3]
     return name.split("(")[0][:60]
 
 
