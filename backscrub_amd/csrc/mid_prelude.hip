@@ -246,7 +246,24 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
         for (int fx = 0; fx < K; fx++) acc[k] = __builtin_elementwise_fma(xin[k * S + fx], wv[fx], acc[k]);
       }
     };
-    if constexpr (T::X_SP == SP_LDS && K * (NIN + K) * V <= 144) {
+    if constexpr (T::X_SP == SP_GLB) {
+      // global input (a tensor that does not fit LDS): exactly ONE row ahead in flight, in a real loop with a register copy per row.  Measured
+      // alternatives: two alternating register sets without copies (100-121 registers: spills in the whole kernel, segm_full program 213 -> 404 us),
+      // every row requested up front over a short strip (126 registers, spills everywhere).  These ops are bound by the HBM round trip per row;
+      // the real fix is not to have such tensors in HBM (a tiled level-3 kernel — DESIGN.md, "next").
+      vec_t xa[NIN], wa[K];
+      load_row(0, xa, wa);
+#pragma unroll 1
+      for (int fy = 0; fy < K; fy++) {
+        vec_t xb[NIN], wb[K];
+        load_row(fy + 1 < K ? fy + 1 : fy, xb, wb);               // the last trip re-requests its own row (cached) instead of branching
+        fma_row(xa, wa);
+#pragma unroll
+        for (int j = 0; j < NIN; j++) xa[j] = xb[j];
+#pragma unroll
+        for (int fx = 0; fx < K; fx++) wa[fx] = wb[fx];
+      }
+    } else if constexpr (K * (NIN + K) * V <= 144) {
       // LDS input: fully unrolled — the scheduler overlaps the next rows' ds_reads with this row's FMAs (the 5x5 stride-2 form would hold
       // 5 x 16 x 2 registers that way and spills: it takes the one-row-ahead loop below)
 #pragma unroll
