@@ -1,27 +1,26 @@
-// live.cpp — the host-side pieces that turn the batch engine back into a webcam tool:
+// live.cpp — the host-side pieces that turn the batch engine back into a webcam tool, built around the GPU's own queue.
 //
-//   bsx_background_*   the background source of /root/reference/app/background.cc: load_background (:126-176, still image or
-//                      video), the FPS-paced reader thread that loops on end of stream (:29-104), grab_background (:178-194:
-//                      current frame resized to the camera size, under the frame mutex; returns the frame number, 1 for a still,
-//                      and "can loop round to 0").  Frames are decoded once (media.cpp) and kept ON THE GPU, so a grab is one
-//                      bsx_resize_bgr launch — no per-frame host decode or upload.
-//   bsx_live_*         CalcMask of /root/reference/app/deepseg.cc:159-286: one worker thread, double-buffered frame in /
-//                      mask out, condition-variable wake-up, the three stage timers; the camera loop never waits for the mask
-//                      (it may lag by a frame, exactly as in the reference).
+//   bsx_background_*   what app/background.cc provides (/root/reference/app/background.cc:126-194): a still image or an animation as the
+//                      compositing background, played in real time, looping at the end of the stream, and `grab` = the current picture resized to
+//                      the camera size together with its frame number.  Here the pictures are decoded once (media.cpp) and kept ON THE GPU; which
+//                      one is current is a pure function of the clock — picture floor(t * fps) mod n, reported as 1..n like the reference's counter
+//                      of pictures read — so there is no reader thread, no lock and no per-frame upload: a grab is one resize launch.
+//   bsx_live_*         what class CalcMask provides (/root/reference/app/deepseg.cc:159-286): the camera loop hands over frames and polls for
+//                      masks and never waits for the segmentation; a mask may lag its frame.  Here the worker is the GPU queue itself: a frame
+//                      is copied into a pinned slot and its upload, the whole mask pipeline and the mask's download are enqueued on a private
+//                      HIP stream with an event behind them; `get_output_mask` polls that event.  Two submissions may be in flight; a frame that
+//                      arrives while both are busy replaces the waiting one (the newest frame wins, as with the reference's double buffer).
 //
-// Plain C++ threads over the C ABI of bsx.h; nothing here touches a kernel directly.
+// Only the C ABI of bsx.h and the HIP runtime are used here; nothing touches a kernel directly.
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/bsx.h"
@@ -29,82 +28,85 @@
 
 using namespace bsx;
 
+namespace {
+
+struct OnDevice {                      // the caller's current device is restored on scope exit (HIP's current device is per thread)
+  int prev = -1, dev;
+  explicit OnDevice(int d) : dev(d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+  ~OnDevice() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+
+using Clock = std::chrono::steady_clock;
+
+}  // namespace
+
 struct bsx_background {
   bsx_ctx* ctx = nullptr;
-  int debug = 0;
-  bool video = false;
-  std::atomic<bool> run{false};
-  int width = 0, height = 0, n_frames = 0;
+  int debug = 0, device = 0;
+  bool animated = false;
+  int width = 0, height = 0, n_pictures = 0;
   double fps = 0;
-  uint8_t* d_frames = nullptr;          // [n_frames][height][width][3] BGR on the context's GPU
-  int frame = 0;                        // current frame of the reader (guarded by rawmux)
-  std::mutex rawmux;
-  std::thread thread;
+  uint8_t* d_pictures = nullptr;        // [n_pictures][height][width][3] BGR on the context's GPU
+  Clock::time_point t0;                 // start of playback
 };
 
 struct bsx_live {
+  static constexpr int kInFlight = 2;
+  struct Slot {
+    uint8_t* h_frame = nullptr;         // pinned: the caller's frame, cloned (deepseg.cc:273)
+    uint8_t* h_mask = nullptr;          // pinned: the finished mask
+    uint8_t* d_frame = nullptr;
+    hipEvent_t begun = nullptr, done = nullptr;
+    bool busy = false;                  // submitted, mask not handed out yet
+    unsigned long seq = 0;              // submission order
+  };
   bsx_ctx* ctx = nullptr;
-  int width = 0, height = 0;
-  std::atomic<bool> running{false};
-  std::vector<uint8_t> frame1, frame2, mask1, mask2;
-  std::vector<uint8_t>*frame_current, *frame_next, *mask_current, *mask_out;
-  std::mutex lock_frame, lock_mask;
-  std::condition_variable condition_new_frame;
-  bool new_frame = false;                 // guarded by lock_frame
-  std::atomic<bool> new_mask{false};      // set under lock_mask, polled without it by get_output_mask (as the reference does, deepseg.cc:280)
-  std::atomic<int> failed{0};
-  std::thread thread;
-  std::atomic<long> waitns{0}, loopns{0};
+  int width = 0, height = 0, device = 0;
+  hipStream_t stream = nullptr;
+  Slot slot[kInFlight];
+  uint8_t* h_waiting = nullptr;         // pinned: the newest frame that found both slots busy
+  bool waiting = false;
+  unsigned long next_seq = 1;
+  bool failed = false;
+  long idle_ns = 0, gpu_ns = 0;         // between the last completion and the next submission / upload + pipeline + download of the last mask
+  Clock::time_point last_done;
+  std::mutex mu;
 };
 
 namespace {
 
-long since_ns(std::chrono::steady_clock::time_point t0) {
-  return (long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+// enqueue: upload, mask pipeline for stream slot 0 of the context, download — all asynchronous on the live stream
+bool submit(bsx_live* l, bsx_live::Slot& s) {
+  const size_t fb = (size_t)l->width * l->height * 3, mb = (size_t)l->width * l->height;
+  if (hipEventRecord(s.begun, l->stream) != hipSuccess) return false;
+  if (hipMemcpyAsync(s.d_frame, s.h_frame, fb, hipMemcpyHostToDevice, l->stream) != hipSuccess) return false;
+  if (bsx_process_batch(l->ctx, s.d_frame, 1, nullptr, l->stream) != BSX_OK) return false;
+  if (hipMemcpyAsync(s.h_mask, bsx_masks_device(l->ctx), mb, hipMemcpyDeviceToHost, l->stream) != hipSuccess) return false;
+  if (hipEventRecord(s.done, l->stream) != hipSuccess) return false;
+  s.busy = true;
+  s.seq = l->next_seq++;
+  l->idle_ns = (long)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - l->last_done).count();
+  return true;
 }
 
-// background.cc:29-104 — advance one frame per 1/fps, wrap to frame 0 at the end of the stream
-void reader_thread(bsx_background* b) {
-  if (b->debug) fprintf(stderr, "background: thread start\n");
-  auto next = std::chrono::steady_clock::now();
-  while (b->run) {
-    {
-      std::unique_lock<std::mutex> hold(b->rawmux);
-      b->frame += 1;
-      if (b->frame >= b->n_frames) b->frame = 0;          // no more frames: reset position and go again (:91-95)
-    }
-    next += std::chrono::nanoseconds((long)(1e9 / b->fps));
-    while (b->run && std::chrono::steady_clock::now() < next) {
-      const auto left = next - std::chrono::steady_clock::now();
-      std::this_thread::sleep_for(left < std::chrono::milliseconds(20) ? left : std::chrono::milliseconds(20));   // stays responsive to `run`
-    }
-  }
-  if (b->debug) fprintf(stderr, "background: thread stop\n");
+bsx_live::Slot* free_slot(bsx_live* l) {
+  for (auto& s : l->slot) if (!s.busy) return &s;
+  return nullptr;
 }
 
-// deepseg.cc:182-216
-void live_thread(bsx_live* l) {
-  while (l->running) {
-    const auto tloop = std::chrono::steady_clock::now();
-    {
-      std::unique_lock<std::mutex> hold(l->lock_frame);
-      while (!l->new_frame) l->condition_new_frame.wait(hold);
-      l->new_frame = false;
-      std::swap(l->frame_next, l->frame_current);
-    }
-    l->waitns = since_ns(tloop);
-    if (!l->running) break;
-    if (bsx_process_host(l->ctx, 0, l->frame_current->data(), (size_t)l->width * 3, l->mask_current->data(), (size_t)l->width) != BSX_OK) {
-      l->failed = 1;                                        // the reference exits the process here (:203-206); a library reports instead
-      break;
-    }
-    {
-      std::unique_lock<std::mutex> hold(l->lock_mask);
-      std::swap(l->mask_out, l->mask_current);
-      l->new_mask = true;
-    }
-    l->loopns = since_ns(tloop);
+void release(bsx_live* l) {
+  OnDevice dev(l->device);
+  if (l->stream) (void)hipStreamSynchronize(l->stream);
+  for (auto& s : l->slot) {
+    if (s.h_frame) (void)hipHostFree(s.h_frame);
+    if (s.h_mask) (void)hipHostFree(s.h_mask);
+    if (s.d_frame) (void)hipFree(s.d_frame);
+    if (s.begun) (void)hipEventDestroy(s.begun);
+    if (s.done) (void)hipEventDestroy(s.done);
   }
+  if (l->h_waiting) (void)hipHostFree(l->h_waiting);
+  if (l->stream) (void)hipStreamDestroy(l->stream);
+  delete l;
 }
 
 }  // namespace
@@ -116,18 +118,19 @@ bsx_background* bsx_background_from_frames(bsx_ctx* ctx, const uint8_t* h_bgr, i
   bsx_info info;
   if (bsx_get_info(ctx, &info) != BSX_OK) return nullptr;
   std::unique_ptr<bsx_background> b(new bsx_background);
-  b->ctx = ctx; b->debug = debug; b->width = width; b->height = height; b->n_frames = n_frames; b->fps = fps;
-  int prev = -1;
-  (void)hipGetDevice(&prev);
-  (void)hipSetDevice(info.device);
+  b->ctx = ctx; b->debug = debug; b->device = info.device; b->width = width; b->height = height; b->n_pictures = n_frames; b->fps = fps;
   const size_t bytes = (size_t)n_frames * width * height * 3;
-  bool ok = hipMalloc(&b->d_frames, bytes) == hipSuccess && hipMemcpy(b->d_frames, h_bgr, bytes, hipMemcpyHostToDevice) == hipSuccess;
-  if (prev >= 0) (void)hipSetDevice(prev);
-  if (!ok) { if (debug) fprintf(stderr, "background: cannot place %zu bytes on the GPU\n", bytes); if (b->d_frames) (void)hipFree(b->d_frames); return nullptr; }
-  // "if: can read 2 video frames => it's a video" (background.cc:143-153)
-  b->video = n_frames >= 2 && fps > 0;
-  if (b->video) { b->run = true; b->thread = std::thread(reader_thread, b.get()); }
-  if (debug) fprintf(stderr, "background properties:\n\tvid: %s\n\tfps: %f\n\tcnt: %d\n", b->video ? "yes" : "no", fps, n_frames);
+  {
+    OnDevice dev(info.device);
+    if (hipMalloc(&b->d_pictures, bytes) != hipSuccess || hipMemcpy(b->d_pictures, h_bgr, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      if (debug) fprintf(stderr, "background: cannot place %zu bytes on the GPU\n", bytes);
+      if (b->d_pictures) (void)hipFree(b->d_pictures);
+      return nullptr;
+    }
+  }
+  b->animated = n_frames >= 2 && fps > 0;                       // "if: can read 2 video frames => it's a video" (background.cc:143-153)
+  b->t0 = Clock::now();
+  if (debug) fprintf(stderr, "background properties:\n\tvid: %s\n\tfps: %f\n\tcnt: %d\n", b->animated ? "yes" : "no", fps, n_frames);
   return b.release();
 }
 
@@ -147,10 +150,9 @@ bsx_background* bsx_background_load(bsx_ctx* ctx, const char* path, int debug) {
   }
 }
 
-void bsx_background_free(bsx_background* b) {                 // drop_background, background.cc:106-124
+void bsx_background_free(bsx_background* b) {
   if (!b) return;
-  if (b->video && b->run) { b->run = false; b->thread.join(); }
-  if (b->d_frames) (void)hipFree(b->d_frames);
+  { OnDevice dev(b->device); if (b->d_pictures) (void)hipFree(b->d_pictures); }
   delete b;
 }
 
@@ -158,71 +160,102 @@ int bsx_background_info(const bsx_background* b, int* width, int* height, int* n
   if (!b) return BSX_EINVAL;
   if (width) *width = b->width;
   if (height) *height = b->height;
-  if (n_frames) *n_frames = b->n_frames;
+  if (n_frames) *n_frames = b->n_pictures;
   if (fps) *fps = b->fps;
-  if (is_video) *is_video = b->video ? 1 : 0;
+  if (is_video) *is_video = b->animated ? 1 : 0;
   return BSX_OK;
 }
 
+// grab_background (background.cc:178-194): the current picture resized to width x height; returns its frame number — 1 for a still, and for an
+// animation the reference's count of pictures read since the last rewind (picture c is reported as c + 1; the reference's 0 exists only for the
+// instant between the failed read at the end of the stream and the first read after the rewind, :91-95)
 int bsx_background_grab(bsx_background* b, int width, int height, uint8_t* d_bgr_out, void* stream) {
   if (!b || !d_bgr_out || width <= 0 || height <= 0) return -1;
-  int frm = 1;
-  const uint8_t* src = b->d_frames;
-  if (b->video) {                                             // grab frame & frame no. under the mutex (:183-188)
-    std::unique_lock<std::mutex> hold(b->rawmux);
-    frm = b->frame;
-    src = b->d_frames + (size_t)frm * b->width * b->height * 3;
+  long c = 0;
+  if (b->animated) {
+    const double t = std::chrono::duration<double>(Clock::now() - b->t0).count();
+    c = (long)(t * b->fps) % b->n_pictures;
   }
+  const uint8_t* src = b->d_pictures + (size_t)c * b->width * b->height * 3;
   if (bsx_resize_bgr(b->ctx, src, b->width, b->height, d_bgr_out, width, height, 1, stream) != BSX_OK) return -1;
-  return frm;
+  return (int)c + 1;
 }
 
 bsx_live* bsx_live_new(bsx_ctx* ctx) {
   bsx_info info;
   if (!ctx || bsx_get_info(ctx, &info) != BSX_OK) return nullptr;
-  std::unique_ptr<bsx_live> l(new bsx_live);
-  l->ctx = ctx; l->width = info.width; l->height = info.height;
+  bsx_live* l = new bsx_live;
+  l->ctx = ctx; l->width = info.width; l->height = info.height; l->device = info.device;
   const size_t fb = (size_t)info.width * info.height * 3, mb = (size_t)info.width * info.height;
-  l->frame1.assign(fb, 0); l->frame2.assign(fb, 0); l->mask1.assign(mb, 255); l->mask2.assign(mb, 255);
-  l->frame_next = &l->frame1; l->frame_current = &l->frame2; l->mask_current = &l->mask1; l->mask_out = &l->mask2;
-  l->running = true;
-  l->thread = std::thread(live_thread, l.get());
-  return l.release();
+  OnDevice dev(info.device);
+  bool ok = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) == hipSuccess && hipHostMalloc((void**)&l->h_waiting, fb, hipHostMallocDefault) == hipSuccess;
+  for (auto& s : l->slot)
+    ok = ok && hipHostMalloc((void**)&s.h_frame, fb, hipHostMallocDefault) == hipSuccess && hipHostMalloc((void**)&s.h_mask, mb, hipHostMallocDefault) == hipSuccess &&
+         hipMalloc(&s.d_frame, fb) == hipSuccess && hipEventCreate(&s.begun) == hipSuccess && hipEventCreate(&s.done) == hipSuccess;
+  if (!ok) { release(l); return nullptr; }
+  l->last_done = Clock::now();
+  return l;
 }
 
-void bsx_live_delete(bsx_live* l) {                            // ~CalcMask, deepseg.cc:261-270
-  if (!l) return;
-  l->running = false;
-  { std::lock_guard<std::mutex> hold(l->lock_frame); l->new_frame = true; }
-  l->condition_new_frame.notify_all();
-  l->thread.join();
-  delete l;
+void bsx_live_delete(bsx_live* l) {
+  if (l) release(l);
 }
 
-int bsx_live_set_input_frame(bsx_live* l, const uint8_t* h_bgr, size_t stride) {   // deepseg.cc:272-277 (frame.clone())
+// CalcMask::set_input_frame (deepseg.cc:272-277): the frame is cloned; never waits for the GPU
+int bsx_live_set_input_frame(bsx_live* l, const uint8_t* h_bgr, size_t stride) {
   if (!l || !h_bgr || stride < (size_t)l->width * 3) return BSX_EINVAL;
+  std::lock_guard<std::mutex> hold(l->mu);
   if (l->failed) return BSX_EDEVICE;
-  std::lock_guard<std::mutex> hold(l->lock_frame);
-  for (int y = 0; y < l->height; y++) memcpy(l->frame_next->data() + (size_t)y * l->width * 3, h_bgr + (size_t)y * stride, (size_t)l->width * 3);
-  l->new_frame = true;
-  l->condition_new_frame.notify_all();
+  OnDevice dev(l->device);
+  bsx_live::Slot* s = free_slot(l);
+  uint8_t* dst = s ? s->h_frame : l->h_waiting;
+  const size_t row = (size_t)l->width * 3;
+  for (int y = 0; y < l->height; y++) memcpy(dst + (size_t)y * row, h_bgr + (size_t)y * stride, row);
+  if (!s) { l->waiting = true; return BSX_OK; }               // both submissions in flight: this frame waits (and is replaced by a newer one)
+  l->waiting = false;                                           // an older waiting frame is superseded
+  if (!submit(l, *s)) { l->failed = true; return BSX_EDEVICE; }
   return BSX_OK;
 }
 
-int bsx_live_get_output_mask(bsx_live* l, uint8_t* h_mask, size_t stride) {        // deepseg.cc:279-285: 1 = a new mask was copied out
+// CalcMask::get_output_mask (deepseg.cc:279-285): 1 = a new mask was copied out, 0 = none yet (the caller's buffer is left alone)
+int bsx_live_get_output_mask(bsx_live* l, uint8_t* h_mask, size_t stride) {
   if (!l || !h_mask || stride < (size_t)l->width) return BSX_EINVAL;
+  std::lock_guard<std::mutex> hold(l->mu);
   if (l->failed) return BSX_EDEVICE;
-  if (!l->new_mask) return 0;
-  std::lock_guard<std::mutex> hold(l->lock_mask);
-  for (int y = 0; y < l->height; y++) memcpy(h_mask + (size_t)y * stride, l->mask_out->data() + (size_t)y * l->width, (size_t)l->width);
-  l->new_mask = false;
-  return 1;
+  OnDevice dev(l->device);
+  bsx_live::Slot* newest = nullptr;
+  for (auto& s : l->slot) {
+    if (!s.busy) continue;
+    const hipError_t q = hipEventQuery(s.done);
+    if (q == hipErrorNotReady) continue;
+    if (q != hipSuccess) { l->failed = true; return BSX_EDEVICE; }
+    if (!newest || s.seq > newest->seq) newest = &s;
+  }
+  int got = 0;
+  if (newest) {
+    for (int y = 0; y < l->height; y++) memcpy(h_mask + (size_t)y * stride, newest->h_mask + (size_t)y * l->width, (size_t)l->width);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, newest->begun, newest->done) == hipSuccess) l->gpu_ns = (long)(ms * 1e6);
+    for (auto& s : l->slot) if (s.busy && s.seq <= newest->seq) s.busy = false;      // an older finished mask is superseded by the one handed out
+    l->last_done = Clock::now();
+    got = 1;
+  }
+  if (l->waiting) {                                             // a frame that found both slots busy goes out as soon as one is free
+    if (bsx_live::Slot* s = free_slot(l)) {
+      std::swap(s->h_frame, l->h_waiting);
+      l->waiting = false;
+      if (!submit(l, *s)) { l->failed = true; return BSX_EDEVICE; }
+    }
+  }
+  return got;
 }
 
+// the reference's two loop timers (deepseg.cc:186,213): time spent waiting for a frame, time of a whole iteration.  Here: how long the GPU queue
+// sat idle before the last submission, and upload + mask pipeline + download of the last mask handed out (HIP events).
 int bsx_live_timings(const bsx_live* l, long* waitns, long* loopns) {
   if (!l) return BSX_EINVAL;
-  if (waitns) *waitns = l->waitns;
-  if (loopns) *loopns = l->loopns;
+  if (waitns) *waitns = l->idle_ns;
+  if (loopns) *loopns = l->gpu_ns;
   return BSX_OK;
 }
 

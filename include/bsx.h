@@ -165,15 +165,18 @@ bsx_background* bsx_background_from_frames(bsx_ctx* ctx, const uint8_t* h_bgr, i
 void bsx_background_free(bsx_background* bg);
 int bsx_background_info(const bsx_background* bg, int* width, int* height, int* n_frames, double* fps, int* is_video);
 /* grab_background(): the current frame resized (cv::resize INTER_LINEAR) to width x height into d_bgr_out [height][width][3].
- * Returns the frame number (1 for a still image; an animation's number can wrap to 0) or -1 on error. */
+ * Returns the frame number or -1 on error: 1 for a still image; for an animation the reference's count of pictures read since the last rewind, i.e.
+ * picture c (= floor(t * fps) mod n, t since the background was created: real-time playback, looping at the end) is reported as c + 1. */
 int bsx_background_grab(bsx_background* bg, int width, int height, uint8_t* d_bgr_out, void* stream);
 /* host-only decode of the same formats (no GPU): frames → malloc'ed [n][h][w][3] BGR; returns n (> 0) or a negative BSX_E* code */
 int bsx_media_decode(const char* path, int* width, int* height, double* fps, uint8_t** h_bgr, char* errbuf, size_t errcap);
 void bsx_media_free(uint8_t* h_bgr);
 
 /* ---- live single-camera mode: class CalcMask (app/deepseg.cc:159-286) ----
- * A worker thread runs bs_maskgen_process (bsx_process_host, stream slot 0) on the latest frame handed to set_input_frame; the caller's
- * loop never blocks on it: get_output_mask copies the newest finished mask if there is one (returns 1) or leaves h_mask untouched (0). */
+ * set_input_frame clones the frame into pinned memory and enqueues upload + mask pipeline (stream slot 0) + mask download on a private HIP
+ * stream; it never waits for the GPU (up to two submissions in flight; a frame that finds both busy replaces the one already waiting).
+ * get_output_mask polls the completion events: it copies the newest finished mask (returns 1) or leaves h_mask untouched (0).
+ * timings: how long the queue sat idle before the last submission / upload + pipeline + download of the last mask handed out (HIP events). */
 typedef struct bsx_live bsx_live;
 bsx_live* bsx_live_new(bsx_ctx* ctx);
 void bsx_live_delete(bsx_live* live);

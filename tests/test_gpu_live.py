@@ -58,9 +58,9 @@ def test_animated_background_advances_at_its_fps_and_loops(bs, oracle, tmp_path)
     seen, t0 = [], time.time()
     while time.time() - t0 < 0.7:                                       # ~17 frame periods: at least two trips round the loop
         frm, out = bg.grab(*VGA)
-        assert 0 <= frm < n
-        assert np.array_equal(out.cpu().numpy(), oracle.resize_linear(decoded[frm], *VGA)), frm
-        seen.append(frm)
+        assert 1 <= frm <= n                                            # the reference counts pictures READ: picture c is reported as c + 1 (background.cc:60-63)
+        assert np.array_equal(out.cpu().numpy(), oracle.resize_linear(decoded[frm - 1], *VGA)), frm
+        seen.append(frm - 1)
         time.sleep(0.005)
     steps = [(b - a) % n for a, b in zip(seen, seen[1:])]
     assert set(steps) <= {0, 1, 2}                                      # paced: never jumps ahead
@@ -116,6 +116,6 @@ def test_live_worker_never_blocks_the_camera_loop(bs):
         live.set_input_frame(synth.frame(W, H, 0, t % 4))
         got += live.get_output_mask(mask)
     dt = time.time() - t0
-    live.close()                                                         # joins the worker even while it waits for a frame
+    live.close()                                                         # drains the queue
     mg.close()
     assert got >= 1 and dt < 20
