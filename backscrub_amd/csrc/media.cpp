@@ -4,8 +4,9 @@
 // /root/reference/app/background.cc:126-176).  Neither library exists in this image, so the formats the reference's own
 // `backgrounds/` directory uses and that can be decoded without a codec library are implemented here from their public
 // specifications: GIF87a/89a (LZW, interlace, local palettes, transparency, disposal methods — `animated.gif`), PNG (8-bit
-// grey / RGB / palette / grey+alpha / RGBA, non-interlaced, inflate through zlib — `*.png`) and binary PPM.  JPEG and WebM
-// are reported as unsupported (the caller hands decoded frames to bsx_background_from_frames instead).
+// grey / RGB / palette / grey+alpha / RGBA, non-interlaced, inflate through zlib — `*.png`), JPEG (jpeg.cpp: sequential and progressive
+// Huffman, libjpeg's default reconstruction — `*.jpg`) and binary PPM.  WebM is reported as unsupported (VP8/VP9: the caller hands
+// decoded frames to bsx_background_from_frames instead).
 // Output convention = cv::imread(IMREAD_COLOR) / VideoCapture with CONVERT_RGB: packed 8-bit BGR, alpha dropped.
 #include "media.hpp"
 
@@ -254,11 +255,10 @@ bool media_load(const std::string& path, Media* m, std::string* err) {
   if (!read_file(path, &file)) { if (err) *err = "cannot open: " + path; return false; }
   bool ok = false;
   try {
-    ok = decode_gif(file, m, &e) || (e.empty() && decode_png(file, m, &e)) || (e.empty() && decode_ppm(file, m, &e));
+    ok = decode_gif(file, m, &e) || (e.empty() && decode_png(file, m, &e)) || (e.empty() && decode_jpeg(file, m, &e)) || (e.empty() && decode_ppm(file, m, &e));
   } catch (const std::exception& ex) { e = ex.what(); ok = false; }
   if (!ok) {
-    if (e.empty()) e = (file.size() > 3 && file[0] == 0xFF && file[1] == 0xD8) ? "JPEG is not decodable here (no codec library): pass decoded frames instead"
-                     : (file.size() > 4 && file[0] == 0x1A && file[1] == 0x45) ? "WebM/Matroska is not decodable here (no codec library): pass decoded frames instead"
+    if (e.empty()) e = (file.size() > 4 && file[0] == 0x1A && file[1] == 0x45) ? "WebM/Matroska is not decodable here (no codec library): pass decoded frames instead"
                      : "unrecognised media format";
     if (err) *err = e + " (" + path + ")";
   }

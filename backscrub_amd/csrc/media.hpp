@@ -13,7 +13,10 @@ struct Media {
   std::vector<std::vector<uint8_t>> frames;         // [n][height][width][3] BGR
 };
 
-// GIF87a/89a, PNG (8-bit, non-interlaced), binary PPM.  false + reason otherwise (JPEG / WebM: no codec library in this build).
+// GIF87a/89a, PNG (non-interlaced), JPEG (Huffman, sequential / progressive, 8-bit), binary PPM.  false + reason otherwise (WebM: no VP8/VP9
+// decoder in this build).
 bool media_load(const std::string& path, Media* m, std::string* err);
+// jpeg.cpp: false with *err empty when the bytes are not a JPEG stream at all
+bool decode_jpeg(const std::vector<uint8_t>& file, Media* m, std::string* err);
 
 }  // namespace bsx

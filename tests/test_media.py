@@ -193,6 +193,100 @@ def test_gif_restore_to_background_of_a_frame_with_transparency_follows_libavcod
     assert np.array_equal(got[2], c)
 
 
+# ---- JPEG (jpeg.cpp): the checker is Pillow's libjpeg-turbo — the library cv::imread decodes JPEG with — on the same bytes ----
+def _photo_like(rng, h, w):
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    a = np.stack([128 + 100 * np.sin(x / 9.0 + y / 17.0), 128 + 90 * np.cos(x / 5.0) * np.sin(y / 7.0), (x * 3 + y * 2) % 256], -1)
+    a += rng.normal(0, 12, a.shape)
+    a[h // 3: h // 2, w // 4: w // 2] = (250, 10, 30)                 # saturated patch: hard chroma edges through the up-sampling filter
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("progressive", [False, True])
+@pytest.mark.parametrize("subsampling", ["4:4:4", "4:2:2", "4:2:0"])
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (5, 4), (17, 13), (64, 48), (161, 97)])
+def test_jpeg_matches_libjpeg(tmp_path, progressive, subsampling, size):
+    rng = np.random.default_rng(size[0] * 7 + size[1])
+    w, h = size
+    path = tmp_path / "a.jpg"
+    Image.fromarray(_photo_like(rng, h, w), "RGB").save(path, "JPEG", quality=int(rng.integers(30, 96)), subsampling=subsampling, progressive=progressive, optimize=bool(w & 1))
+    frames, fps = backscrub_amd.media_decode(str(path))
+    want = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1]
+    assert fps == 0 and frames.shape == (1, h, w, 3)
+    assert np.array_equal(frames[0], want)
+
+
+@pytest.mark.parametrize("kw", [dict(quality=100, subsampling="4:4:4"), dict(quality=3), dict(quality=75, restart_marker_blocks=3), dict(quality=60, restart_marker_rows=1, progressive=True),
+                                dict(quality=85, keep_rgb=True), dict(quality=50, qtables="web_high")])
+def test_jpeg_encoder_variants(tmp_path, kw):
+    rng = np.random.default_rng(21)
+    path = tmp_path / "v.jpg"
+    Image.fromarray(_photo_like(rng, 75, 131), "RGB").save(path, "JPEG", **kw)
+    frames, _ = backscrub_amd.media_decode(str(path))
+    assert np.array_equal(frames[0], np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+
+
+@pytest.mark.parametrize("progressive", [False, True])
+def test_jpeg_greyscale_expands_to_bgr(tmp_path, progressive):
+    rng = np.random.default_rng(2)
+    path = tmp_path / "g.jpg"
+    Image.fromarray(_photo_like(rng, 50, 70)[:, :, 0], "L").save(path, "JPEG", quality=80, progressive=progressive)
+    frames, _ = backscrub_amd.media_decode(str(path))
+    want = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1]                 # cv::imread(IMREAD_COLOR): grey replicated
+    assert np.array_equal(frames[0], want)
+
+
+@pytest.mark.parametrize("orientation", range(1, 9))
+def test_jpeg_exif_orientation_is_applied_as_imread_does(tmp_path, orientation):
+    from PIL import ImageOps
+    rng = np.random.default_rng(orientation)
+    im = Image.fromarray(_photo_like(rng, 40, 56), "RGB")
+    exif = Image.Exif()
+    exif[0x0112] = orientation
+    path = tmp_path / "o.jpg"
+    im.save(path, "JPEG", quality=90, exif=exif)
+    frames, _ = backscrub_amd.media_decode(str(path))
+    want = np.asarray(ImageOps.exif_transpose(Image.open(path)).convert("RGB"))[:, :, ::-1]
+    assert frames.shape[1:] == want.shape
+    assert np.array_equal(frames[0], want)
+
+
+def test_jpeg_reference_style_background(tmp_path):
+    """the shape of the reference's own `backgrounds/total_landscaping.jpg`: 1280x720, progressive, 4:2:0, JFIF"""
+    rng = np.random.default_rng(8)
+    path = tmp_path / "bg.jpg"
+    Image.fromarray(_photo_like(rng, 720, 1280), "RGB").save(path, "JPEG", quality=82, subsampling="4:2:0", progressive=True)
+    frames, _ = backscrub_amd.media_decode(str(path))
+    assert np.array_equal(frames[0], np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+
+
+@pytest.mark.parametrize("name", ["total_landscaping.jpg", "screenshot.jpg"])
+def test_jpeg_the_reference_backgrounds_where_present(name):
+    path = os.path.join("/root/reference/backgrounds", name)
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present on this machine")
+    frames, _ = backscrub_amd.media_decode(path)
+    assert np.array_equal(frames[0], np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+
+
+def test_jpeg_unsupported_processes_are_refused(tmp_path):
+    rng = np.random.default_rng(1)
+    b = io.BytesIO()
+    Image.fromarray(_photo_like(rng, 16, 16), "RGB").convert("CMYK").save(b, "JPEG")
+    p = tmp_path / "cmyk.jpg"
+    p.write_bytes(b.getvalue())
+    with pytest.raises(backscrub_amd.BsxError, match="CMYK"):
+        backscrub_amd.media_decode(str(p))
+    b = io.BytesIO()
+    Image.fromarray(_photo_like(rng, 16, 16), "RGB").save(b, "JPEG")
+    a = bytearray(b.getvalue())
+    i = a.find(b"\xff\xc0")
+    a[i + 1] = 0xC9                                          # arithmetic-coded sequential DCT
+    p.write_bytes(bytes(a))
+    with pytest.raises(backscrub_amd.BsxError, match="arithmetic"):
+        backscrub_amd.media_decode(str(p))
+
+
 @pytest.mark.parametrize("blob", [b"", b"GIF89a", b"\x89PNG\r\n\x1a\n", b"P6\n1 1\n255\n", b"\xff\xd8\xff\xe0JFIF", b"RIFF....WEBP", b"\x1a\x45\xdf\xa3"])
 def test_truncated_and_unsupported_files_are_rejected(tmp_path, blob):
     p = tmp_path / "bad.bin"
@@ -205,9 +299,9 @@ def test_corrupted_files_never_crash(tmp_path):
     rng = np.random.default_rng(11)
     im = Image.fromarray(_rand_rgb(rng, 40, 50), "RGB")
     bufs = []
-    for fmt, kw in (("PNG", {}), ("GIF", {})):
+    for fmt, kw in (("PNG", {}), ("GIF", {}), ("JPEG", {}), ("JPEG", dict(progressive=True, subsampling="4:2:0")), ("JPEG", dict(restart_marker_blocks=2))):
         b = io.BytesIO()
-        (im if fmt == "PNG" else im.quantize(64)).save(b, fmt, **kw)
+        (im.quantize(64) if fmt == "GIF" else im).save(b, fmt, **kw)
         bufs.append(b.getvalue())
     p = tmp_path / "c.bin"
     for base in bufs:
