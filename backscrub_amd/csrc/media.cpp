@@ -87,14 +87,15 @@ bool decode_gif(const std::vector<uint8_t>& file, Media* m, std::string* err) {
   if (flags & 0x80) { gpal_n = 2 << (flags & 7); if (!r.skip(0)) return false; if (r.at + 3 * (size_t)gpal_n > r.n) { *err = "GIF: truncated palette"; return false; } memcpy(gpal.data(), r.p + r.at, 3 * (size_t)gpal_n); r.at += 3 * (size_t)gpal_n; }
   // Canvas in RGB.  cv::VideoCapture reads GIFs through libavcodec's decoder, whose compositing rules are followed here: the logical
   // screen starts as the background colour when the first image carries no transparent index (and a global palette exists), else as
-  // transparent — which the BGRA→BGR conversion shows as black; "restore to background" fills the frame's rectangle the same way.
+  // transparent; "restore to background" fills the frame's rectangle the same way.  libavcodec's transparent pixel is "transparent WHITE"
+  // (0x00ffffff, chosen there so that formats without alpha show white, not black), so dropping alpha (BGRA→BGR) leaves 255,255,255.
   uint8_t bgc[3] = {0, 0, 0};
   if ((flags & 0x80) && bg_index < gpal_n) memcpy(bgc, &gpal[3 * bg_index], 3);
-  std::vector<uint8_t> canvas((size_t)W * H * 3, 0), restore;
+  std::vector<uint8_t> canvas((size_t)W * H * 3, 255), restore;
   auto fill = [&](int x0, int y0, int w, int h, const uint8_t* c) {
     for (int y = y0; y < y0 + h; y++) for (int x = x0; x < x0 + w; x++) memcpy(&canvas[((size_t)y * W + x) * 3], c, 3);
   };
-  static const uint8_t black[3] = {0, 0, 0};
+  static const uint8_t clear[3] = {255, 255, 255};
   int transparent = -1, disposal = 0, delay_cs = 0;
   long total_delay = 0;
   m->width = W; m->height = H; m->frames.clear();
@@ -141,7 +142,7 @@ bool decode_gif(const std::vector<uint8_t>& file, Media* m, std::string* err) {
     for (size_t i = 0; i < (size_t)W * H; i++) { bgr[3 * i] = canvas[3 * i + 2]; bgr[3 * i + 1] = canvas[3 * i + 1]; bgr[3 * i + 2] = canvas[3 * i]; }
     m->frames.push_back(std::move(bgr));
     total_delay += delay_cs < 2 ? 10 : delay_cs;            // browsers / ffmpeg play delays below 2 cs as 10 cs
-    if (disposal == 2) fill(fx, fy, fw, fh, transparent >= 0 ? black : bgc);
+    if (disposal == 2) fill(fx, fy, fw, fh, transparent >= 0 ? clear : bgc);
     else if (disposal == 3) canvas = restore;
     transparent = -1; disposal = 0; delay_cs = 0;
     if (m->frames.size() > 4096 || m->frames.size() * (size_t)W * H * 3 > (size_t)1 << 30) { *err = "GIF: animation larger than 1 GiB decoded"; return false; }

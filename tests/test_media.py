@@ -168,7 +168,8 @@ def test_gif_real_lzw_with_growing_codes(tmp_path):
 
 def test_gif_restore_to_background_of_a_frame_with_transparency_follows_libavcodec(tmp_path):
     # where decoders disagree (Pillow fills with the transparent index's colour): cv::VideoCapture's GIF decoder is libavcodec's, which
-    # fills with TRANSPARENT, shown black after BGRA→BGR; and a first frame smaller than the screen leaves background colour around it
+    # fills with its TRANSPARENT colour — 0x00ffffff, white once BGRA→BGR drops the alpha; and a first frame smaller than the screen leaves
+    # background colour around it
     rng = np.random.default_rng(4)
     pal = rng.integers(1, 256, (256, 3), dtype=np.uint8)
     W, H = 16, 12
@@ -188,7 +189,7 @@ def test_gif_restore_to_background_of_a_frame_with_transparency_follows_libavcod
     c[2:6, 3:7] = bgr[f1]
     c[3, 4] = keep                                        # transparent pixel shows what was there
     assert np.array_equal(got[1], c)
-    c[2:6, 3:7] = 0                                       # restored to "background" = transparent = black
+    c[2:6, 3:7] = 255                                     # restored to "background" = transparent = libavcodec's transparent white
     c[0:2, 0:2] = bgr[f2]
     assert np.array_equal(got[2], c)
 
