@@ -118,6 +118,7 @@ struct bsx_ctx {
   bool no_mask_blend_fusion = false;   // BSX_NO_MASK_BLEND_FUSION, read once at bsx_new (no getenv on the per-step path)
   bool no_mask_tile = false;           // BSX_NO_MASK_TILE (tests: the generic mask kernel), likewise
   bool tail_generic = false;           // BSX_TAIL_GENERIC (tests: the scalar argmax scan of the DeepLab tail), likewise
+  bool act16 = false;                  // BSX_ACT16=1: 16-bit activation STORAGE for the segmented Meet / MLKit networks (g1) — opt-in, IoU-gated; needs the specialised middle kernel
 
   // stream-0 view of a graph tensor (network input/output have dedicated buffers; intermediates are batch-major in
   // the per-launch path and frame-major — frame 0 first — in the per-frame program)
@@ -211,9 +212,11 @@ int init_device_state(bsx_ctx* c) {
     // Specialise the program to this graph: straight-line code with compile-time geometry instead of the interpreted micro-op table.
     // Compiled by hipRTC for this device's architecture (cached on disk; bsx_model_precompile fills the cache without a GPU).
     // Anything the generator does not cover, or a failed compilation, leaves the interpreter in charge — never an error.
+    const char* a16 = getenv("BSX_ACT16");
+    c->act16 = a16 && atoi(a16) != 0 && c->plan.seg.on;
     if (!getenv("BSX_NO_RTC")) {
       std::string why, log;
-      const std::string src = generate_mid_source(c->plan, &why);
+      const std::string src = generate_mid_source(c->plan, &why, c->act16);
       if (src.empty()) c->mid_note = "interpreted (" + why + ")";
       else {
         hipDeviceProp_t prop;
@@ -225,6 +228,11 @@ int init_device_state(bsx_ctx* c) {
         else c->mid_note = std::string("specialised kernel (hipRTC") + (cached ? ", from the cache)" : ", compiled now)");
       }
     } else c->mid_note = "interpreted (BSX_NO_RTC)";
+    if (c->act16 && !c->mid.fn) {            // the interpreter has f32 tensors only: the mode needs the generated kernel
+      c->last_error = "BSX_ACT16: the specialised middle kernel is not available (" + c->mid_note + ")";
+      return BSX_EDEVICE;
+    }
+    if (c->act16) c->mid_note += ", 16-bit activation storage";
   } else {
     BSX_HIP(c, nn_prepare());                 // per-launch path: the fused kernels' dynamic-LDS limits on this device
   }
@@ -296,11 +304,11 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
   if (c->use_program && c->plan.seg.on) {
     const SegPlan& sp = c->plan.seg;
     const long pf = (long)c->plan.arena_floats_per_stream;
-    BSX_HIP(c, launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s));
-    BSX_HIP(c, launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s));
+    BSX_HIP(c, launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s, c->act16));
+    BSX_HIP(c, launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16));
     BSX_HIP(c, launch_program(c, n, s));
-    BSX_HIP(c, launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s));
-    BSX_HIP(c, launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal + (size_t)slot * c->outW * c->outH, c->d_weights, logits, n, s));
+    BSX_HIP(c, launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
+    BSX_HIP(c, launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal + (size_t)slot * c->outW * c->outH, c->d_weights, logits, n, s, c->act16));
     return BSX_OK;
   }
   if (c->use_program) {
@@ -647,11 +655,11 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     const long pf = (long)c->plan.arena_floats_per_stream;
     if (seg) {
       const SegPlan& sp = c->plan.seg;
-      BSX_TIMED(launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s));
-      BSX_TIMED(launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s));
+      BSX_TIMED(launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s, c->act16));
+      BSX_TIMED(launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16));
       BSX_TIMED(launch_program(c, n, s));
-      BSX_TIMED(launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s));
-      BSX_TIMED(launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal, c->d_weights, !fused_decode, n, s));
+      BSX_TIMED(launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
+      BSX_TIMED(launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal, c->d_weights, !fused_decode, n, s, c->act16));
     } else if (c->use_program)
       BSX_TIMED(launch_program(c, n, s));
     else {
@@ -791,7 +799,8 @@ long bsx_model_kernel_source(const char* model_path, char* buf, size_t cap) {
     Graph g; Plan p;
     std::string err, why;
     if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { snprintf(buf, cap, "%s", err.c_str()); return BSX_EMODEL; }
-    const std::string src = generate_mid_source(p, &why);
+    const char* a16 = getenv("BSX_ACT16");
+    const std::string src = generate_mid_source(p, &why, a16 && atoi(a16) != 0 && p.seg.on);
     if (src.empty()) { snprintf(buf, cap, "%s", why.c_str()); return 0; }
     snprintf(buf, cap, "%s", src.c_str());
     return (long)src.size();
@@ -804,7 +813,8 @@ int bsx_model_precompile(const char* model_path, const char* arch, char* msg, si
     Graph g; Plan p;
     std::string err, why, log;
     if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { snprintf(msg, cap, "%s", err.c_str()); return BSX_EMODEL; }
-    const std::string src = generate_mid_source(p, &why);
+    const char* a16 = getenv("BSX_ACT16");                         // the variant a context created under the same environment would ask for
+    const std::string src = generate_mid_source(p, &why, a16 && atoi(a16) != 0 && p.seg.on);
     if (src.empty()) { snprintf(msg, cap, "interpreted (%s)", why.c_str()); return BSX_OK; }
     std::vector<char> code;
     bool cached = false;

@@ -32,11 +32,13 @@ struct Out {
 int sp_of(const Loc& l) { return l.space == kLocNone ? 0 : (l.space == kLocLds ? 1 : 2); }      // SP_NONE / SP_LDS / SP_GLB
 bool plain(const Loc& l) { return l.space == kLocNone || l.space == kLocLds || l.space == kLocGlobal; }   // no network input / output buffers in a middle program
 
-void loc(Out& o, const char* p, const Loc& l) { o.f("  static constexpr int %s_SP = %d, %s_OFF = %d, %s_ST = %d;\n", p, sp_of(l), p, l.off, p, l.stride); }
 
 }  // namespace
 
-std::string generate_mid_source(const Plan& plan, std::string* why) {
+std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) {
+  // address space of an ACTIVATION tensor operand: arena tensors are packed halves in the 16-bit storage mode (mid_prelude.hip: SP_GLB16)
+  auto asp = [&](const Loc& l) { const int sp = sp_of(l); return (sp == 2 && act16) ? 3 : sp; };
+  auto loc = [&](Out& o, const char* p, const Loc& l) { o.f("  static constexpr int %s_SP = %d, %s_OFF = %d, %s_ST = %d;\n", p, asp(l), p, l.off, p, l.stride); };
   auto fail = [&](const std::string& m) { if (why) *why = m; return std::string(); };
   const std::vector<MicroOp>& P = plan.program;
   if (P.empty()) return fail("no program");
@@ -124,7 +126,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why) {
       const int mean = m.in1.off;
       auto part = [&](const Loc& l, int rows, int C, int hw, int coff, bool accum, bool partials) {
         const int st = partials ? C : l.stride;
-        k.f("  gap_part<%d, %d, %d, %d, %d, %d, %d, %s, %d>(L, A);\n", partials ? 2 : sp_of(l), l.off, st, rows, C, hw, coff, accum ? "true" : "false", mean);
+        k.f("  gap_part<%d, %d, %d, %d, %d, %d, %d, %s, %d>(L, A);\n", partials ? 2 : asp(l), l.off, st, rows, C, hw, coff, accum ? "true" : "false", mean);
       };
       if (m.n_cat == 0) part(m.in0, m.H * m.W, m.Cin, m.H * m.W, 0, false, false);
       else {

@@ -8,6 +8,8 @@ namespace bsx {
 
 // HIP source of the kernel `bsx_mid(float* arena, long per_frame, const float* weights, unsigned long long* timeline)` specialised to
 // plan.program (one 1024-lane workgroup per frame, static LDS of plan.program_lds_floats floats), or "" with the reason in *why.
-std::string generate_mid_source(const Plan& plan, std::string* why);
+// act16: the 16-bit activation storage mode — every activation tensor of the program that lives in the arena is read / written as packed halves
+// (the segment kernels either side are launched with h16 = true to match).
+std::string generate_mid_source(const Plan& plan, std::string* why, bool act16 = false);
 
 }  // namespace bsx

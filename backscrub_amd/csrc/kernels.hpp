@@ -35,11 +35,11 @@ hipError_t launch_frame_program(const MicroOp* d_ops, int n_ops, int lds_floats,
 // Spatially-parallel segment kernels around the per-frame program (kernels_seg.hip, segments.hpp)
 hipError_t seg_prepare();
 hipError_t nn_prepare();          // dynamic-LDS limits of the fused per-launch kernels (kernels_nn.hip), for the current device
-hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const float* net_in, const float* weights, int n, hipStream_t s);
-hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s);
-hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s);
+hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const float* net_in, const float* weights, int n, hipStream_t s, bool h16 = false);
+hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16 = false);
+hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16 = false);
 // logits = true: write the network output tensor (debug / stage tests); false: decode + temporal IIR straight into `ofinal`
-hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s);
+hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s, bool h16 = false);
 
 // ---- image path ----------------------------------------------------------------------
 // Fixed-point bilinear tables of cv::resize(INTER_LINEAR, 8u) for one (src,dst) size pair

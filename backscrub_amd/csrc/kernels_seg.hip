@@ -32,6 +32,18 @@ constexpr int kScrFloats = kSegScratchFloats;  // tiles start here
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Activation tensors that cross a kernel boundary (A, b0, B, c0, lo2, lo — SURVEY Appendix B.1) are f32 by default; H16 = the 16-bit activation
+// STORAGE mode (BSX_ACT16=1, what SetAllowFp16PrecisionForFp32 permits: /root/reference/lib/libbackscrub.cc:225): the same tensor at the same
+// arena offset as packed halves (round to nearest even on store), all arithmetic still f32.  `idx` = element index inside the tensor.
+typedef _Float16 h4s __attribute__((ext_vector_type(4)));
+template <bool H16> __device__ __forceinline__ float4 ldg4(const float* base, unsigned idx) {
+  if (H16) { const h4s h = *reinterpret_cast<const h4s*>(reinterpret_cast<const _Float16*>(base) + idx); return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w); }
+  return *reinterpret_cast<const float4*>(base + idx);
+}
+template <bool H16> __device__ __forceinline__ void stg4(float* base, unsigned idx, float4 v) {
+  if (H16) *reinterpret_cast<h4s*>(reinterpret_cast<_Float16*>(base) + idx) = h4s{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  else *reinterpret_cast<float4*>(base + idx) = v;
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) { return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)); }
@@ -237,7 +249,7 @@ __device__ __forceinline__ RowTile row_tile(int t, int ctiles, unsigned m_ct) {
 // head: stem conv3x3/s2 (3 → 16) → 1x1 (16 → 16) → depthwise 3x3/s2; writes A (skip of the last decoder level), b0, and the
 // pooled partial sums of both.  Tile = TR (<= 4) x TC (<= 15) pixels of b0.
 // ==================================================================================================================================
-template <bool STEM_HSWISH>
+template <bool STEM_HSWISH, bool H16>
 __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float* __restrict__ arena, long per_frame, const float* __restrict__ net_in,
                                                           const float* __restrict__ w) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
       st4(a_t + (rt.row * RW + x2) * 16 + cq4, v);
       const bool row_owned = gy >= max(2 * r0, 0) && gy < min(2 * r0 + 2 * d.TR, d.H1);          // scalar
       if (row_owned && gx >= 2 * c0 && gx < min(2 * c0 + 2 * d.TC, d.W1)) {                      // each A pixel is stored by exactly one tile
-        st4(A_out + (unsigned)((gy * d.W1 + gx) * 16 + cq4), v);
+        stg4<H16>(A_out, (unsigned)((gy * d.W1 + gx) * 16 + cq4), v);
         sumA = f4add(sumA, v);
       }
     }
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
     if (r0 + py >= d.H2) break;
     if (px < d.TC && c0 + px < d.W2) {
       const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
-      st4(b0_out + (unsigned)(((r0 + py) * d.W2 + c0 + px) * 16 + 4 * quad), v);
+      stg4<H16>(b0_out, (unsigned)(((r0 + py) * d.W2 + c0 + px) * 16 + 4 * quad), v);
       sumB = f4add(sumB, v);
     }
   }
@@ -384,6 +396,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 // k2: s = gate(GAP(b0)); B = pw_a(b0 * s) (skip of decoder level 2); x = act(pw_b(B)); c0 = act(dw3x3/s2(x)).  Tile = TR x TC of c0.
 // The expanded tensor x (72 channels) exists only 16 channels at a time, in LDS.
 // ==================================================================================================================================
+template <bool H16>
 __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC;
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
     if (t < ntile) {
       const RowTile rt = row_tile(t, ctiles, d.m_ct);
       const int gy = br0 + rt.row, gx = bc0 + 16 * rt.ct + li;
-      if (gy >= 0 && gy < d.H2 && gx >= 0 && gx < d.W2) b0v[j] = ld4(b0_in + (unsigned)((gy * d.W2 + gx) * 16 + 4 * g));
+      if (gy >= 0 && gy < d.H2 && gx >= 0 && gx < d.W2) b0v[j] = ldg4<H16>(b0_in, (unsigned)((gy * d.W2 + gx) * 16 + 4 * g));
     }
   }
   seg_gate(d.gate, fa, w, seg_smem, B_t);
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
       st4(B_t + (rt.row * RW + x2) * 16 + cq4, v);
       const bool row_owned = hy >= max(2 * r0, 0) && hy < min(2 * r0 + 2 * d.TR, d.H2);
       if (row_owned && hx >= 2 * c0 && hx < min(2 * c0 + 2 * d.TC, d.W2)) {
-        st4(B_out + (unsigned)((hy * d.W2 + hx) * 16 + cq4), v);
+        stg4<H16>(B_out, (unsigned)((hy * d.W2 + hx) * 16 + cq4), v);
         sumB = f4add(sumB, v);
       }
     }
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
     if (ch < C && px < d.TC && c0 + px < d.W3)
       for (int py = wave; py < d.TR && r0 + py < d.H3; py += 4) {
         const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
-        st4(c0_out + (unsigned)(((r0 + py) * d.W3 + c0 + px) * C + ch), v);
+        stg4<H16>(c0_out, (unsigned)(((r0 + py) * d.W3 + c0 + px) * C + ch), v);
       }
     __syncthreads();
   }
@@ -488,6 +501,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
 constexpr int kGatedRows = 5;           // region rows per wave: (TR + 2 + 3) / 4 <= 5  →  TR <= 18
 constexpr int kLoStride = 20;           // floats per staged low-resolution pixel (16 + 4: spreads the 16-byte tap reads over the banks)
 struct GatedPre { float4 s[kGatedRows]; int ly0, lx0, LC; };
+template <bool H16>
 __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ skip, const float* __restrict__ lo, int H, int W, int HL, int WL, bool half_pixel,
                                                    bool align, int r0, int c0, int ZH, int ZC, float* l_t) {
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4;
@@ -498,7 +512,7 @@ __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ ski
   for (int j = 0; j < kGatedRows; j++) {
     const int zy = wave + 4 * j, iy = r0 - 1 + zy;
     pre.s[j] = f4zero();
-    if (zy < ZH && iy >= 0 && iy < H && col_in) pre.s[j] = ld4(skip + (unsigned)((iy * W + ix) * 16 + 4 * g));
+    if (zy < ZH && iy >= 0 && iy < H && col_in) pre.s[j] = ldg4<H16>(skip, (unsigned)((iy * W + ix) * 16 + 4 * g));
   }
   // low-resolution window: rows y0(first image row of the region) .. y1(last), columns likewise (monotone maps)
   const float hs = up_scale(HL, H, align), wsc = up_scale(WL, W, align);
@@ -515,7 +529,7 @@ __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ ski
   for (int j = 0; j < 3; j++) {
     const int ly = wave + 4 * j;
     v[j] = f4zero();
-    if (ly < LR && lane < LC * 4) v[j] = ld4(lo + (unsigned)(((ly0 + ly) * WL + lx0 + (lane >> 2)) * 16 + 4 * (lane & 3)));
+    if (ly < LR && lane < LC * 4) v[j] = ldg4<H16>(lo, (unsigned)(((ly0 + ly) * WL + lx0 + (lane >> 2)) * 16 + 4 * (lane & 3)));
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) {
@@ -569,6 +583,7 @@ __device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* 
 // ==================================================================================================================================
 // k3 (decoder level 2): z = act(pw1(B * g + up(lo2))); t = z + act(dw3x3(z)); lo = pw2(t).  Tile = TR x TC (<= 14) at the B resolution.
 // ==================================================================================================================================
+template <bool H16>
 __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC, ZH = d.TR + 2, ZC = d.TC + 2;
@@ -578,7 +593,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
   float* l_t = t_t + d.TR * 256;                                    // staged window of lo2
   float* lo_out = fa + d.lo_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
-  const GatedPre pre = gated_prefetch(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
+  const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
   if (tid < 16) seg_smem[kScrGate + tid] = fa[d.g_off + tid];
   __syncthreads();
   gated_compute(pre, l_t, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw1, w, r0, c0, ZH, ZC, z_t);
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
     float4 v = quad_transpose(acc, q);
     if (xe < d.TC && c0 + xe < d.W2) {
       v = clamp4(f4add(v, bias2), cl_2);
-      st4(lo_out + (unsigned)(((r0 + py) * d.W2 + c0 + xe) * 16 + cq4), v);
+      stg4<H16>(lo_out, (unsigned)(((r0 + py) * d.W2 + c0 + xe) * 16 + cq4), v);
       sum = f4add(sum, v);
     }
   }
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
 // depthwise runs on the lane's 4 channels, the 4 x CO transpose-conv dot products are split over the quad and reduce-scattered so
 // that lane `quad` ends up with output position (fy, fx) = (quad >> 1, quad & 1) of its pixel.
 // ==================================================================================================================================
-template <int CO, bool LOGITS, bool SIGMOID>
+template <int CO, bool LOGITS, bool SIGMOID, bool H16>
 __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float* __restrict__ arena, long per_frame, float* __restrict__ net_out,
                                                           uint8_t* __restrict__ ofinal, const float* __restrict__ w) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
   const int fy = quad >> 1, fx = quad & 1, ix = c0 + px;
   // every global read of the workgroup is requested here, before the first wait: skip operands, the window of lo, the temporal
   // state bytes this lane will update, then (inside seg_gate) the pooled partial sums and the gate weights
-  const GatedPre pre = gated_prefetch(fa + d.skip_off, fa + d.lo_off, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
+  const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo_off, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
   constexpr int kRowsB = 5;                                          // TR <= 18 → <= 5 tile rows per wave in phase B
   uint8_t prev[kRowsB];
   if (!LOGITS) {
@@ -706,50 +721,61 @@ hipError_t allow_lds(K kernel, int lds_bytes) {
 
 hipError_t seg_prepare() {
   const int full = 160 * 1024;     // process-global kernel attributes: always the full LDS (cf. frame_program_prepare)
-  hipError_t e;
-  if ((e = allow_lds(seg_head_k<true>, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_head_k<false>, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_k2_k, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_k3_k, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_tail_k<1, false, true>, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_tail_k<1, true, true>, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_tail_k<1, false, false>, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_tail_k<1, true, false>, full)) != hipSuccess) return e;
-  if ((e = allow_lds(seg_tail_k<2, false, false>, full)) != hipSuccess) return e;
-  return allow_lds(seg_tail_k<2, true, false>, full);
+  hipError_t e = hipSuccess;
+  auto one = [&](auto k) { if (e == hipSuccess) e = allow_lds(k, full); };
+  one(seg_head_k<true, false>); one(seg_head_k<false, false>); one(seg_head_k<true, true>); one(seg_head_k<false, true>);
+  one(seg_k2_k<false>); one(seg_k2_k<true>); one(seg_k3_k<false>); one(seg_k3_k<true>);
+  one(seg_tail_k<1, false, true, false>); one(seg_tail_k<1, true, true, false>); one(seg_tail_k<1, false, false, false>); one(seg_tail_k<1, true, false, false>);
+  one(seg_tail_k<2, false, false, false>); one(seg_tail_k<2, true, false, false>);
+  one(seg_tail_k<1, false, true, true>); one(seg_tail_k<1, true, true, true>); one(seg_tail_k<1, false, false, true>); one(seg_tail_k<1, true, false, true>);
+  one(seg_tail_k<2, false, false, true>); one(seg_tail_k<2, true, false, true>);
+  return e;
 }
 
-hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const float* net_in, const float* weights, int n, hipStream_t s) {
+// h16: the boundary tensors are stored as halves (BSX_ACT16; the middle program must have been generated for the same storage)
+hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const float* net_in, const float* weights, int n, hipStream_t s, bool h16) {
   const dim3 grid(d.tiles_y * d.tiles_x, n);
-  if (d.stem.act == kActHswish) seg_head_k<true><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, net_in, weights);
-  else seg_head_k<false><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, net_in, weights);
+  const size_t lds = (size_t)d.lds_floats * sizeof(float);
+  const bool hs = d.stem.act == kActHswish;
+  if (hs && !h16) seg_head_k<true, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_in, weights);
+  else if (hs) seg_head_k<true, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_in, weights);
+  else if (!h16) seg_head_k<false, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_in, weights);
+  else seg_head_k<false, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_in, weights);
   return hipGetLastError();
 }
-hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s) {
-  seg_k2_k<<<dim3(d.tiles_y * d.tiles_x, n), kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
+hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16) {
+  const dim3 grid(d.tiles_y * d.tiles_x, n);
+  if (h16) seg_k2_k<true><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
+  else seg_k2_k<false><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
   return hipGetLastError();
 }
-hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s) {
-  seg_k3_k<<<dim3(d.tiles_y * d.tiles_x, n), kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
+hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16) {
+  const dim3 grid(d.tiles_y * d.tiles_x, n);
+  if (h16) seg_k3_k<true><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
+  else seg_k3_k<false><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
   return hipGetLastError();
 }
-hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s) {
+template <bool H16>
+static hipError_t launch_seg_tail_t(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s) {
   const dim3 grid(d.tiles_y * d.tiles_x, n);
   const size_t lds = (size_t)d.lds_floats * sizeof(float);
   const bool sig = d.act3 == kActSigmoid;
   if (d.Co == 2 && !sig) {
-    if (logits) seg_tail_k<2, true, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
-    else seg_tail_k<2, false, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    if (logits) seg_tail_k<2, true, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    else seg_tail_k<2, false, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
   } else if (d.Co == 1 && sig) {
-    if (logits) seg_tail_k<1, true, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
-    else seg_tail_k<1, false, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    if (logits) seg_tail_k<1, true, true, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    else seg_tail_k<1, false, true, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
   } else if (d.Co == 1) {
-    if (logits) seg_tail_k<1, true, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
-    else seg_tail_k<1, false, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    if (logits) seg_tail_k<1, true, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    else seg_tail_k<1, false, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
   } else {
     return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s, bool h16) {
+  return h16 ? launch_seg_tail_t<true>(d, arena, per_frame, net_out, ofinal, weights, logits, n, s) : launch_seg_tail_t<false>(d, arena, per_frame, net_out, ofinal, weights, logits, n, s);
 }
 
 }  // namespace bsx

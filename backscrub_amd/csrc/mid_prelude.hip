@@ -21,7 +21,10 @@
 
 namespace bsxm {
 
-enum { SP_NONE = 0, SP_LDS = 1, SP_GLB = 2 };                                   // operand address spaces (frame_program.hpp: LocSpace)
+// operand address spaces (frame_program.hpp: LocSpace).  SP_GLB16: an ACTIVATION tensor in the arena stored as packed halves — the 16-bit activation
+// storage mode (BSX_ACT16: every activation tensor that leaves LDS, i.e. the tensors exchanged with the segment kernels and the ones that do not
+// fit; arithmetic stays f32, stores round to nearest even).  Weights, pooled partial sums and gate vectors in the arena are always f32 (SP_GLB).
+enum { SP_NONE = 0, SP_LDS = 1, SP_GLB = 2, SP_GLB16 = 3 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 3, ACT_HSWISH = 100, ACT_SIGMOID = 101 };   // tflite_model.hpp: Activation
 constexpr int kThreads = 1024, kWaves = 16;
 
@@ -34,8 +37,14 @@ typedef __attribute__((address_space(1))) f4v glb_v4;
 typedef __attribute__((address_space(3))) f2v lds_v2;
 typedef __attribute__((address_space(1))) f2v glb_v2;
 typedef __attribute__((address_space(1))) char glb_c;
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) h4v glb_h4;
+typedef __attribute__((address_space(1))) h2v glb_h2;
+typedef __attribute__((address_space(1))) _Float16 glb_h;
 // uniform base + zero-extended 32-bit BYTE offset (computed in 32 bits: every arena slice is far below 4 GB)
 #define BSXM_G(T, g, off) ((T*)((glb_c*)(g) + (unsigned)((off) * 4)))
+#define BSXM_H(T, g, off) ((T*)((glb_c*)(g) + (unsigned)((off) * 2)))          // the same tensor (same arena offset) as halves: element `off` at 2 * off bytes
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
@@ -43,22 +52,34 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // UNSIGNED: uniform base + zero-extended 32-bit lane offset is the `global_load … v_off, s[base]` form — a signed offset makes the compiler
 // build a 64-bit address pair per access (nine taps = 18 more registers in the depthwise bodies: spills).
 template <int SP> __device__ __forceinline__ f4v ld4(const lds_f* l, const glb_f* g, int off) {
-  if constexpr (SP == SP_LDS) return *(const lds_v4*)(l + off); else return *BSXM_G(const glb_v4, g, off);
+  if constexpr (SP == SP_LDS) return *(const lds_v4*)(l + off);
+  else if constexpr (SP == SP_GLB16) return __builtin_convertvector(*BSXM_H(const glb_h4, g, off), f4v);
+  else return *BSXM_G(const glb_v4, g, off);
 }
 template <int SP> __device__ __forceinline__ void st4(lds_f* l, glb_f* g, int off, f4v v) {
-  if constexpr (SP == SP_LDS) *(lds_v4*)(l + off) = v; else *BSXM_G(glb_v4, g, off) = v;
+  if constexpr (SP == SP_LDS) *(lds_v4*)(l + off) = v;
+  else if constexpr (SP == SP_GLB16) *BSXM_H(glb_h4, g, off) = __builtin_convertvector(v, h4v);
+  else *BSXM_G(glb_v4, g, off) = v;
 }
 template <int SP> __device__ __forceinline__ f2v ld2(const lds_f* l, const glb_f* g, int off) {
-  if constexpr (SP == SP_LDS) return *(const lds_v2*)(l + off); else return *BSXM_G(const glb_v2, g, off);
+  if constexpr (SP == SP_LDS) return *(const lds_v2*)(l + off);
+  else if constexpr (SP == SP_GLB16) return __builtin_convertvector(*BSXM_H(const glb_h2, g, off), f2v);
+  else return *BSXM_G(const glb_v2, g, off);
 }
 template <int SP> __device__ __forceinline__ void st2(lds_f* l, glb_f* g, int off, f2v v) {
-  if constexpr (SP == SP_LDS) *(lds_v2*)(l + off) = v; else *BSXM_G(glb_v2, g, off) = v;
+  if constexpr (SP == SP_LDS) *(lds_v2*)(l + off) = v;
+  else if constexpr (SP == SP_GLB16) *BSXM_H(glb_h2, g, off) = __builtin_convertvector(v, h2v);
+  else *BSXM_G(glb_v2, g, off) = v;
 }
 template <int SP> __device__ __forceinline__ float ld1(const lds_f* l, const glb_f* g, int off) {
-  if constexpr (SP == SP_LDS) return l[off]; else return *BSXM_G(const glb_f, g, off);
+  if constexpr (SP == SP_LDS) return l[off];
+  else if constexpr (SP == SP_GLB16) return (float)*BSXM_H(const glb_h, g, off);
+  else return *BSXM_G(const glb_f, g, off);
 }
 template <int SP> __device__ __forceinline__ void st1(lds_f* l, glb_f* g, int off, float v) {
-  if constexpr (SP == SP_LDS) l[off] = v; else *BSXM_G(glb_f, g, off) = v;
+  if constexpr (SP == SP_LDS) l[off] = v;
+  else if constexpr (SP == SP_GLB16) *BSXM_H(glb_h, g, off) = (_Float16)v;
+  else *BSXM_G(glb_f, g, off) = v;
 }
 
 // activations: hardware exp2 / rcp (≈1 ulp), the same forms as the interpreter (kernels_frame.hip: fp_act)
@@ -246,7 +267,7 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
         for (int fx = 0; fx < K; fx++) acc[k] = __builtin_elementwise_fma(xin[k * S + fx], wv[fx], acc[k]);
       }
     };
-    if constexpr (T::X_SP == SP_GLB) {
+    if constexpr (T::X_SP == SP_GLB || T::X_SP == SP_GLB16) {
       // global input (a tensor that does not fit LDS): exactly ONE row ahead in flight, in a real loop with a register copy per row.  Measured
       // alternatives: two alternating register sets without copies (100-121 registers: spills in the whole kernel, segm_full program 213 -> 404 us),
       // every row requested up front over a short strip (126 registers, spills everywhere).  These ops are bound by the HBM round trip per row;

@@ -573,6 +573,27 @@ def main():
                     result["gemm_modes"].append({"BSX_F16_GEMM": mode, "error": repr(e)})
                 finally:
                     os.environ.pop("BSX_F16_GEMM", None)
+            # g1 for Meet / MLKit: 16-bit activation STORAGE (BSX_ACT16=1: the tensors that cross kernel boundaries or spill out of LDS as halves, f32
+            # arithmetic), next to the f32 default that `value` / `configs[2]` report — opt-in, each with its own parity sample
+            result["act_modes"] = []
+            for tag, kw in (("configs[1]", dict(model_key="lite", W=640, H=480, B=256)), ("configs[2]", dict(model_key="mlkit", W=1280, H=720, B=256))):
+                try:
+                    os.environ["BSX_ACT16"] = "1"
+                    n_steps = max(3, args.steps // 4)
+                    r = measure(steps=n_steps, warmup=3, rank=0, world=1, local_rank=local_rank, profile_iters=2, **kw)
+                    frag = {"BSX_ACT16": 1, "what": "activation tensors in HBM stored as f16 (A, b0, B, c0, lo2, lo + the middle program's spilled tensors); arithmetic f32",
+                            "workload": tag + " geometry", "value": round(r["fps"], 1), "unit": "frames/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": n_steps,
+                            "top_launches": [{"name": t["name"], "ms": round(t["avg_ms"], 4)} for t in sorted(r["stats"], key=lambda t: -t["avg_ms"])[:6]]}
+                    samples = (r["model_path"], r["host"][:2].copy(), r["bg_host"], r["masks_k"], r["out_k"], r["photo"])
+                    release(r)
+                    if not args.no_cpu_baseline:
+                        mp_, fr_, bg_, mk_, out_, photo_ = samples
+                        frag["parity_sample"] = parity_sample(mp_, kw["W"], kw["H"], fr_, bg_, mk_, out_, need_person=photo_)
+                    result["act_modes"].append(frag)
+                except Exception as e:
+                    result["act_modes"].append({"BSX_ACT16": 1, "workload": tag + " geometry", "error": repr(e)})
+                finally:
+                    os.environ.pop("BSX_ACT16", None)
             try:
                 result["single_stream"] = {"what": "bsx_process_host per call (= bs_maskgen_process through the C++ shim): H2D frame, whole mask pipeline, D2H mask, synchronous",
                                            "runs": [single_stream_latency("lite", 640, 480, 200), single_stream_latency("deeplab", 640, 480, 60)],

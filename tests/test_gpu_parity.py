@@ -248,7 +248,7 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc = oracle.Ctx(path, W, H)
     oc.prep(f)
     want = oc.infer()
-    knobs = ("BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
+    knobs = ("BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
     for name, env, marker in NETWORK_PATHS[key]:
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
@@ -319,6 +319,61 @@ def test_deeplab_f16_storage_mode_is_gated_by_iou(bs, oracle, monkeypatch):
         assert agree >= 0.995, "stream %d: argmax agreement %.5f" % (i, agree)
     assert max(errs) < 2e-2 and max(errs) > 1e-5, errs                # close, and visibly NOT the f32-grade default
     oc.close()
+    mg.close()
+
+
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", HD), ("full", HD)])
+def test_act16_storage_mode_of_the_segmented_networks_is_gated(bs, oracle, monkeypatch, key, res):
+    """BSX_ACT16=1 (g1 for Meet / MLKit): every activation tensor that crosses a kernel boundary or spills out of LDS is STORED as f16
+    (A, b0, B, c0, lo2, lo and the 12x20 / 16x16 level tensors of the middle program); arithmetic stays f32.  Opt-in and gated like the
+    DeepLab modes: logits within 2e-2 of the oracle, decisions agree on >= 99.5 % of the model pixels, end-to-end IoU >= 0.99 on the photo
+    fixture — and visibly NOT the f32 default, which must stay the default."""
+    from backscrub_amd import synth
+    from tools import make_photo_fixture as P
+    path = model_path(key)
+    W, H = res
+    n = 3
+    frames = np.stack([synth.frame(W, H, i, i) for i in range(n)])
+    monkeypatch.setenv("BSX_ACT16", "1")
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    monkeypatch.delenv("BSX_ACT16")
+    assert "16-bit activation storage" in mg.plan()
+    mg.run_stage(0, _dev(frames))
+    mg.run_stage(1, n=n)
+    got = mg.output_tensor().cpu().numpy()
+    oc = oracle.Ctx(path, W, H)
+    errs = []
+    for i in range(n):
+        oc.prep(frames[i])
+        want = oc.infer()
+        errs.append(float(np.abs(got[i] - want).max()) / max(1.0, float(np.abs(want).max())))
+        dec = (lambda t: t[..., 1] > t[..., 0]) if want.shape[-1] == 2 else (lambda t: t[..., 0] > 0.65)
+        agree = (dec(got[i]) == dec(want)).mean()
+        assert agree >= 0.995, "stream %d: decisions agree on %.5f" % (i, agree)
+    assert max(errs) < 2e-2 and max(errs) > 1e-5, errs                # close, and visibly not the f32 default
+    oc.close()
+    mg.close()
+    default = bs.MaskGen(path, W, H, n_streams=1)
+    assert "16-bit activation storage" not in default.plan()
+    default.close()
+    if "synthetic" in os.path.basename(path) or res != VGA:
+        return
+    # end to end on the photo fixture (real weights, a real person in the frame)
+    photo = P.load_frames()
+    monkeypatch.setenv("BSX_ACT16", "1")
+    mg = bs.MaskGen(path, W, H, n_streams=photo.shape[0])
+    monkeypatch.delenv("BSX_ACT16")
+    ocs = [oracle.Ctx(path, W, H) for _ in range(photo.shape[0])]
+    bg = synth.background(W, H)
+    out = torch.empty((photo.shape[0], H, W, 3), dtype=torch.uint8, device="cuda")
+    for t in range(3):
+        mg.step(_dev(photo), _dev(bg), out)
+        masks = mg.masks().cpu().numpy()
+        for i, c in enumerate(ocs):
+            iou = _iou_fg(masks[i], c.process(photo[i]), need_person=(t == 2))
+            assert iou >= 0.99, "%s t=%d frame %d IoU %.5f" % (key, t, i, iou)
+    for c in ocs:
+        c.close()
     mg.close()
 
 

@@ -44,6 +44,27 @@ def test_generated_kernel_compiles_without_spills(api, key, tmp_path):
     assert "v_mfma_f32_16x16x4" in asm and "global_load_lds_dwordx4" in asm      # matrix cores and the LDS-DMA weight staging are really in there
 
 
+@pytest.mark.parametrize("key", ["lite", "mlkit"])
+def test_act16_variant_stores_arena_activations_as_halves(api, key, tmp_path, monkeypatch):
+    """BSX_ACT16: same program, but every activation operand that lives in the arena is address space 3 (packed halves); pooled partial sums,
+    gate vectors and weights stay f32.  It compiles within the same register budget and really contains 16-bit global accesses."""
+    plain = api.model_kernel_source(model_path(key))
+    monkeypatch.setenv("BSX_ACT16", "1")
+    src = api.model_kernel_source(model_path(key))
+    monkeypatch.delenv("BSX_ACT16")
+    assert src != plain and re.search(r"_SP = 3\b", src) and not re.search(r"_SP = 3\b", plain)
+    assert len(re.findall(r"_SP = 2\b", plain)) == len(re.findall(r"_SP = 3\b", src)) + len(re.findall(r"_SP = 2\b", src))
+    p = tmp_path / "mid16.hip"
+    p.write_text(src)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", str(p) + ".s", str(p)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    asm = (tmp_path / "mid16.hip.s").read_text()
+    get = lambda k: int(re.search(r"; %s: *(\d+)" % k, asm).group(1))
+    assert get("ScratchSize") <= SCRATCH_LIMIT[key] and get("NumVgprs") <= 128
+    assert "v_cvt_f16_f32" in asm or "v_cvt_pk" in asm
+
+
 def test_precompile_fills_the_cache_without_a_gpu(api, tmp_path, monkeypatch):
     monkeypatch.setenv("BSX_KERNEL_CACHE", str(tmp_path))
     first = api.model_precompile(model_path("lite"))
