@@ -96,6 +96,9 @@ struct bsx_ctx {
   hipStream_t own_stream = nullptr;
   float* d_arena = nullptr;
   float* d_net_in = nullptr;        // network input  [n][inH][inW][inC] f32 (written by the prep kernels)
+  uint32_t* d_net_in_u8 = nullptr;  // the same tensor before convertTo: [n][inH][inW] R | G<<8 | B<<16 — what the stems with a byte path read (in_u8)
+  bool in_u8 = false;               // the step's prep writes ONLY the 8-bit form and the stem normalises on load (seg_head_k / dl_head0_k; bit-identical).
+                                    //   BSX_F32_INPUT=1 (read at bsx_new) keeps the f32 tensor for A/B timing; the stage-debug entry writes both.
   float* d_net_out = nullptr;       // network output [n][outH][outW][outC] f32 (read by the decode kernel)
   float* d_weights = nullptr;
   uint16_t* d_weights16 = nullptr;   // split-f16 copies of the large pointwise-conv weights (Plan::weights16)
@@ -192,6 +195,7 @@ int init_device_state(bsx_ctx* c) {
   const size_t N = (size_t)c->n_streams;
   BSX_HIP(c, hipMalloc(&c->d_arena, c->plan.arena_floats_per_stream * N * sizeof(float)));
   BSX_HIP(c, hipMalloc(&c->d_net_in, N * c->inW * c->inH * c->inC * sizeof(float)));
+  BSX_HIP(c, hipMalloc(&c->d_net_in_u8, N * c->inW * c->inH * sizeof(uint32_t)));
   BSX_HIP(c, hipMalloc(&c->d_net_out, N * c->outW * c->outH * c->outC * sizeof(float)));
   BSX_HIP(c, hipMalloc(&c->d_weights, std::max<size_t>(c->plan.weights.size(), 4) * sizeof(float)));
   BSX_HIP(c, hipMemcpy(c->d_weights, c->plan.weights.data(), c->plan.weights.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -236,6 +240,8 @@ int init_device_state(bsx_ctx* c) {
   } else {
     BSX_HIP(c, nn_prepare());                 // per-launch path: the fused kernels' dynamic-LDS limits on this device
   }
+  // stems with a byte path take the 8-bit network input: the segmented Meet / MLKit head and DeepLab's fused head kernel
+  c->in_u8 = getenv("BSX_F32_INPUT") == nullptr && ((c->use_program && c->plan.seg.on) || (!c->use_program && head0_u8_ok(c->plan)));
   BSX_HIP(c, hipMalloc(&c->d_canvas, N * canvas_elems(c->inW, c->inH) * sizeof(uint32_t)));
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
   BSX_HIP(c, hipMalloc(&c->d_masks, N * c->width * c->height));
@@ -275,9 +281,11 @@ int init_device_state(bsx_ctx* c) {
 // non-blocking stream is only used by the synchronous host path.
 hipStream_t pick(bsx_ctx*, void* s) { return (hipStream_t)s; }
 
-int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s) {
+// with_f32: also materialise the f32 input tensor when the stem reads the 8-bit form (the stage-debug entry: tests inspect the tensor)
+int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s, bool with_f32 = false) {
   BSX_HIP(c, launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
-  BSX_HIP(c, launch_prep_bilateral(c->d_canvas, c->tensor_ptr(c->plan.input), c->inW, c->inH, c->bilateral, n, s));
+  BSX_HIP(c, launch_prep_bilateral(c->d_canvas, (!c->in_u8 || with_f32) ? c->tensor_ptr(c->plan.input) : nullptr, c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH,
+                                   c->bilateral, n, s));
   return BSX_OK;
 }
 // logits = true: the network output tensor is written (stage tests, the stand-alone decode follows); false: the tail kernel of a
@@ -304,7 +312,7 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
   if (c->use_program && c->plan.seg.on) {
     const SegPlan& sp = c->plan.seg;
     const long pf = (long)c->plan.arena_floats_per_stream;
-    BSX_HIP(c, launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s, c->act16));
+    BSX_HIP(c, launch_seg_head(sp.head, c->d_arena, pf, c->in_u8 ? (const void*)c->d_net_in_u8 : (const void*)c->d_net_in, c->d_weights, n, s, c->act16, c->in_u8, c->norm_scale, c->norm_offset));
     BSX_HIP(c, launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16));
     BSX_HIP(c, launch_program(c, n, s));
     BSX_HIP(c, launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
@@ -318,7 +326,7 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
   const bool fused_tail = !logits && argmax_tail(c);
   const size_t ns = c->plan.steps.size() - (fused_tail ? 1 : 0);
   for (size_t i = 0; i < ns; i++)
-    BSX_HIP(c, launch_step(c->plan.steps[i], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms));
+    BSX_HIP(c, launch_step(c->plan.steps[i], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms, c->in_u8 ? c->d_net_in_u8 : nullptr, c->norm_scale, c->norm_offset));
   if (fused_tail) {
     const Step& last = c->plan.steps.back();
     BSX_HIP(c, launch_resize_argmax_iir(last, c->d_arena + (size_t)c->plan.tensor_off[last.in0] * (size_t)c->n_streams,
@@ -445,7 +453,7 @@ void bsx_delete(bsx_ctx* c) {
   DeviceGuard guard(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   rtc_unload(&c->mid);
-  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
+  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -616,7 +624,7 @@ int bsx_debug_run_stage(bsx_ctx* c, int stage, const uint8_t* d_frames, int n, v
   DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   switch (stage) {
-    case 0: if (!d_frames) return BSX_EINVAL; return run_prep(c, d_frames, n, s);
+    case 0: if (!d_frames) return BSX_EINVAL; return run_prep(c, d_frames, n, s, true);
     case 1: return run_infer(c, n, s);
     case 2: return run_decode(c, n, s);
     case 3: return run_mask(c, n, s);
@@ -651,11 +659,11 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       k++;                                                 \
     } while (0)
     BSX_TIMED(launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
-    BSX_TIMED(launch_prep_bilateral(c->d_canvas, c->tensor_ptr(c->plan.input), c->inW, c->inH, c->bilateral, n, s));
+    BSX_TIMED(launch_prep_bilateral(c->d_canvas, c->in_u8 ? nullptr : c->tensor_ptr(c->plan.input), c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH, c->bilateral, n, s));
     const long pf = (long)c->plan.arena_floats_per_stream;
     if (seg) {
       const SegPlan& sp = c->plan.seg;
-      BSX_TIMED(launch_seg_head(sp.head, c->d_arena, pf, c->d_net_in, c->d_weights, n, s, c->act16));
+      BSX_TIMED(launch_seg_head(sp.head, c->d_arena, pf, c->in_u8 ? (const void*)c->d_net_in_u8 : (const void*)c->d_net_in, c->d_weights, n, s, c->act16, c->in_u8, c->norm_scale, c->norm_offset));
       BSX_TIMED(launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16));
       BSX_TIMED(launch_program(c, n, s));
       BSX_TIMED(launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
@@ -664,7 +672,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       BSX_TIMED(launch_program(c, n, s));
     else {
       for (size_t si = 0; si + (atail ? 1 : 0) < c->plan.steps.size(); si++)
-        BSX_TIMED(launch_step(c->plan.steps[si], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms));
+        BSX_TIMED(launch_step(c->plan.steps[si], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms, c->in_u8 ? c->d_net_in_u8 : nullptr, c->norm_scale, c->norm_offset));
       if (atail) BSX_TIMED(launch_resize_argmax_iir(c->plan.steps.back(), c->d_arena + (size_t)c->plan.tensor_off[c->plan.steps.back().in0] * (size_t)c->n_streams,
                                                     c->d_ofinal, n, s, c->tail_generic));
     }
@@ -694,7 +702,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   // pixels per canvas pixel of in_roi (a 5x down-scale touches 16 % of the ROI) — and writes the 4 B/px canvas with its apron
   const double touched = (double)std::min(c->roi.w, 2 * c->in_roi.w) * (double)std::min(c->roi.h, 2 * c->in_roi.h);
   put(j++, "prep_resize", N * (3.0 * touched + 4.0 * (double)canvas_elems(c->inW, c->inH)), 0);
-  put(j++, "prep_bilateral", N * (4.0 * canvas + 12.0 * canvas), 0);
+  put(j++, "prep_bilateral", N * (4.0 * canvas + (c->in_u8 ? 4.0 : 12.0) * canvas), 0);
   if (seg) {
     // algorithmic bytes of each segment = the tensors it must read once + write once (f32); flops from the fused steps it covers
     const std::vector<Step>& S = c->plan.steps;
@@ -704,7 +712,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     const double eA = 16.0 * sp.head.H1 * sp.head.W1, eb0 = 16.0 * sp.head.H2 * sp.head.W2, ec0 = (double)sp.k2.dw.C * sp.k2.H3 * sp.k2.W3;
     const double elo2 = 16.0 * sp.k3.HL * sp.k3.WL, elo = 16.0 * sp.k3.H2 * sp.k3.W2;
     const double ein = (double)c->inW * c->inH * c->inC, eout = (double)c->outW * c->outH * c->outC;
-    put(j++, "seg_head", N * 4.0 * (ein + eA + eb0), N * 2.0 * macs(0, 2));
+    put(j++, "seg_head", N * ((c->in_u8 ? 4.0 * c->inW * c->inH : 4.0 * ein) + 4.0 * (eA + eb0)), N * 2.0 * macs(0, 2));
     put(j++, "seg_k2", N * 4.0 * (eb0 + eb0 + ec0), N * 2.0 * macs(3, 8));
     put(j++, "frame_program", N * 4.0 * (ec0 + elo2) + 4.0 * c->plan.weights.size(), N * 2.0 * macs(9, NS - 11));
     put(j++, "seg_k3", N * 4.0 * (eb0 + elo2 + elo), N * 2.0 * macs(NS - 10, NS - 8));
@@ -730,7 +738,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     if (st.fuse_head0 && h0) {                                   // stem + depthwise + 1x1: reads the network input, writes the 1x1's output
       const Step& d1 = c->plan.steps[1];
       const Step& p2 = c->plan.steps[2];
-      put(j++, st.label + "+" + d1.label + "+" + p2.label, N * 4.0 * (in + (double)p2.OH * p2.OW * p2.Cout), N * 2.0 * (st.macs + d1.macs + p2.macs));
+      put(j++, st.label + "+" + d1.label + "+" + p2.label, N * ((c->in_u8 ? 4.0 * st.H * st.W : 4.0 * in) + 4.0 * (double)p2.OH * p2.OW * p2.Cout), N * 2.0 * (st.macs + d1.macs + p2.macs));
       continue;
     }
     if (st.fuse_dw >= 0 && ir_on) {                              // expand + depthwise in one launch: reads the expand's input, writes the depthwise's output

@@ -20,7 +20,13 @@ namespace bsx {
 // f16_terms: low nibble = MFMA terms (0: f32 MFMA kernels, 1: plain f16 operands, 3: split f16); bit 4 (with 1 term only) = the fused expand+depthwise
 // kernels store their output as f16 and the project GEMM that consumes it reads f16 (opt-in reduced-precision storage, BSX_F16_GEMM=fast16)
 hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
-                       hipStream_t s, const uint16_t* weights16 = nullptr, int f16_terms = 0);
+                       hipStream_t s, const uint16_t* weights16 = nullptr, int f16_terms = 0, const uint32_t* net_in_u8 = nullptr, float in_scale = 0.f, float in_offset = 0.f);
+// net_in_u8: the network input as 8-bit pixels (prep_bilateral_k<2>) — taken by the fused DeepLab head (dl_head0_k<true>), which normalises on load
+inline bool head0_u8_ok(const Plan& plan) {
+  if (plan.steps.empty() || !plan.steps[0].fuse_head0) return false;
+  const Step& st = plan.steps[0];
+  return st.in0 == plan.input && (long)(2 * (head0_band_rows(st.W, st.OW) + 2) + 1) * st.W <= 4 * 3 * 512;
+}
 
 // DeepLab tail: the graph's final RESIZE_BILINEAR fused with the 21-way argmax + temporal IIR (the full-resolution logits never exist)
 bool resize_argmax_fusable(const Step& st);
@@ -35,7 +41,8 @@ hipError_t launch_frame_program(const MicroOp* d_ops, int n_ops, int lds_floats,
 // Spatially-parallel segment kernels around the per-frame program (kernels_seg.hip, segments.hpp)
 hipError_t seg_prepare();
 hipError_t nn_prepare();          // dynamic-LDS limits of the fused per-launch kernels (kernels_nn.hip), for the current device
-hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const float* net_in, const float* weights, int n, hipStream_t s, bool h16 = false);
+hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const void* net_in, const float* weights, int n, hipStream_t s, bool h16 = false, bool u8 = false,
+                           float in_scale = 0.f, float in_offset = 0.f);
 hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16 = false);
 hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16 = false);
 // logits = true: write the network output tensor (debug / stage tests); false: decode + temporal IIR straight into `ofinal`
@@ -72,7 +79,8 @@ bool bilateral_taps_match(const BilateralParams& bp);   // host table order == t
 hipError_t launch_prep_resize(const uint8_t* frames, int W, int H, Rect4 roi, uint32_t* canvas, int inW, int inH, Rect4 in_roi,
                               ResizeTab tab, int n, hipStream_t s);
 // bilateral(5,100,100) + convertTo f32 → network input [n][inH][inW][3].  libbackscrub.cc:295-302
-hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, int inW, int inH, BilateralParams bp, int n, hipStream_t s);
+// input (f32 [n][inH][inW][3]) and / or input_u8 (R|G<<8|B<<16 [n][inH][inW]): whichever is non-null is written
+hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, uint32_t* input_u8, int inW, int inH, BilateralParams bp, int n, hipStream_t s);
 // decode + temporal IIR on the model-resolution mask.  libbackscrub.cc:317-357
 hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, int npix, int nch, int n, hipStream_t s);
 // ofinal(in_roi) ↑ roi size, 5x5 box blur (REFLECT_101 on the ROI), write into mask(roi).  libbackscrub.cc:367-371

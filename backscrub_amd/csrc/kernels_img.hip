@@ -107,7 +107,11 @@ constexpr int kBilPix = 4;   // pixels per lane: amortises the 768-entry LUT fil
 // and refuses to start if its table ever disagrees (bilateral_taps_match)
 __device__ constexpr int kTapY[13] = {-2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2};
 __device__ constexpr int kTapX[13] = {0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0};
-__global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __restrict__ canvas, float* __restrict__ input, int inW, int inH,
+// OUT bit 0: the network input as f32 [n][inH][inW][3] = convertTo (libbackscrub.cc:302) — what stems without a byte path and the stage tests read;
+// bit 1: the filtered pixel itself, R | G<<8 | B<<16 [n][inH][inW] u32 — the stems that take it (seg_head_k, dl_head0_k) apply the SAME two roundings
+// `fadd(fmul(float(q), scale), offset)` when they stage their input window, so the 12 B/px tensor never exists (bit-identical by construction).
+template <int OUT>
+__global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __restrict__ canvas, float* __restrict__ input, uint32_t* __restrict__ input_u8, int inW, int inH,
                                                             BilateralParams bp) {
   __shared__ float lut[768];
   for (int k = threadIdx.x; k < 768; k += kThreads) lut[k] = bp.color_lut[k];
@@ -142,10 +146,13 @@ __global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __r
     ws = __fdiv_rn(1.f, ws);
     int qr = __float2int_rn(__fmul_rn(sr, ws)), qg = __float2int_rn(__fmul_rn(sg, ws)), qb = __float2int_rn(__fmul_rn(sb, ws));
     qr = min(max(qr, 0), 255); qg = min(max(qg, 0), 255); qb = min(max(qb, 0), 255);
-    float* o = input + (n * (long)inW * inH + p) * 3;
-    o[0] = __fadd_rn(__fmul_rn((float)qr, bp.scale), bp.offset);
-    o[1] = __fadd_rn(__fmul_rn((float)qg, bp.scale), bp.offset);
-    o[2] = __fadd_rn(__fmul_rn((float)qb, bp.scale), bp.offset);
+    if (OUT & 1) {
+      float* o = input + (n * (long)inW * inH + p) * 3;
+      o[0] = __fadd_rn(__fmul_rn((float)qr, bp.scale), bp.offset);
+      o[1] = __fadd_rn(__fmul_rn((float)qg, bp.scale), bp.offset);
+      o[2] = __fadd_rn(__fmul_rn((float)qb, bp.scale), bp.offset);
+    }
+    if (OUT & 2) input_u8[n * (long)inW * inH + p] = (uint32_t)qr | ((uint32_t)qg << 8) | ((uint32_t)qb << 16);
   }
 }
 
@@ -349,14 +356,27 @@ __device__ __forceinline__ void tile_hsum5(const uint8_t* up, uint16_t* hs, int 
 // Step 5: vertical 5-sums (packed u16 adds: five sums <= 25*255 stay inside a u16 lane), (s + 12) / 25 as
 // ((s + 12) * 5243) >> 17 (exhaustively checked for s <= 25*255), mask store, and with BLEND the composite of the same
 // 4 pixels (W, roi.x and roi.w multiples of 4, checked by the launcher: 12 bytes = 3 aligned words per image).
+// four packed BGR pixels (12 bytes in three words) in reverse pixel order: cv::flip(.., 1) of a 4-pixel group
+__device__ __forceinline__ void reverse4px(uint32_t (&w)[3]) {
+  const uint32_t n0 = (w[2] >> 8) | ((w[1] & 0x00FF0000u) << 8);
+  const uint32_t n1 = (w[1] >> 24) | ((w[2] & 255u) << 8) | ((w[0] >> 24) << 16) | (w[1] << 24);
+  const uint32_t n2 = ((w[1] >> 8) & 255u) | (w[0] << 8);
+  w[0] = n0; w[1] = n1; w[2] = n2;
+}
+// flip (yuyv bits 1-2: 2 = horizontal, 4 = vertical): cv::flip of the COMPOSITE (deepseg.cc:667-673) folded into where the tile stores it — the lane's four
+// pixels go to the mirrored column group in reverse order, the row to the mirrored row; the persistent mask is the unflipped frame's and stays put.
 template <bool BLEND>
 __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __restrict__ mask, uint8_t* __restrict__ outp, const TileBlendOperands& o,
-                                                 int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int yuyv) {
+                                                 int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int yuyv_flip) {
   const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
   const int gx = tx0 + lx;
+  const int yuyv = yuyv_flip & 1;
+  const bool fh = (yuyv_flip & 2) != 0, fv = (yuyv_flip & 4) != 0;
   const int obpp = yuyv ? 2 : 3;                                 // composite written as packed BGR or as YUYV 4:2:2 (convert_rgb_to_yuyv fused in)
   uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx;
-  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx) * obpp : nullptr;
+  const int oy0 = fv ? H - 1 - (roi.y + ty0 + ly0) : roi.y + ty0 + ly0, ox = fh ? W - 4 - (roi.x + gx) : roi.x + gx;
+  const long orow = fv ? -(long)W : (long)W;                     // output row step per tile row
+  uint8_t* const out0 = BLEND ? outp + ((long)n * W * H + (long)oy0 * W + ox) * obpp : nullptr;
 #pragma unroll
   for (int i = 0; i < kTileItems; i++) {
     const int ly = ly0 + 8 * i, gy = ty0 + ly;
@@ -375,9 +395,10 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
     if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
     else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
     if constexpr (BLEND) {
-      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * W * obpp);
+      uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * orow * obpp);
       uint32_t o3[3];
       blend_quad(o.a[i], o.b[i], packed, o3);
+      if (fh) reverse4px(o3);
       if (yuyv) {                                                  // deepseg.cc:87-106 on the four composited pixels: 8 bytes instead of 12
         __builtin_nontemporal_store(yuyv_pair(o3[0] & 255u, (o3[0] >> 8) & 255u, (o3[0] >> 16) & 255u, o3[0] >> 24, o3[1] & 255u, (o3[1] >> 8) & 255u), op);
         __builtin_nontemporal_store(yuyv_pair((o3[1] >> 16) & 255u, o3[1] >> 24, o3[2] & 255u, (o3[2] >> 8) & 255u, (o3[2] >> 16) & 255u, o3[2] >> 24), op + 1);
@@ -630,6 +651,27 @@ __global__ __launch_bounds__(kThreads) void yuyv_k(const uint8_t* __restrict__ i
   out[i] = yuyv_pair(p[0], p[1], p[2], p[3], p[4], p[5]);
 }
 // composite outside the ROI in YUYV form = the background converted: lane = one pixel pair of the frame, pairs inside the ROI belong to the tiles
+// outside the ROI when the composite is flipped: one lane per group of four pixels of the frame (the ROI's groups return at once); BGR or YUYV out
+__global__ __launch_bounds__(kThreads) void outside_roi_flip_k(const uint8_t* __restrict__ bg, long bg_stride, uint8_t* __restrict__ out, int W, int H, Rect4 roi, int yuyv_flip) {
+  const unsigned i = blockIdx.x * kThreads + threadIdx.x, gpr = (unsigned)W / 4;
+  if (i >= gpr * (unsigned)H) return;
+  const int row = (int)(i / gpr), x = (int)(i - (unsigned)row * gpr) * 4;
+  if (row >= roi.y && row < roi.y + roi.h && x >= roi.x && x < roi.x + roi.w) return;
+  const long n = blockIdx.y;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(bg + (bg_stride ? n * bg_stride : 0) + ((long)row * W + x) * 3);
+  uint32_t w[3] = {p[0], p[1], p[2]};
+  const bool fh = (yuyv_flip & 2) != 0, fv = (yuyv_flip & 4) != 0;
+  if (fh) reverse4px(w);
+  const int oy = fv ? H - 1 - row : row, ox = fh ? W - 4 - x : x;
+  if (yuyv_flip & 1) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + (n * (long)W * H + (long)oy * W + ox) * 2);
+    o[0] = yuyv_pair(w[0] & 255u, (w[0] >> 8) & 255u, (w[0] >> 16) & 255u, w[0] >> 24, w[1] & 255u, (w[1] >> 8) & 255u);
+    o[1] = yuyv_pair((w[1] >> 16) & 255u, w[1] >> 24, w[2] & 255u, (w[2] >> 8) & 255u, (w[2] >> 16) & 255u, w[2] >> 24);
+  } else {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + (n * (long)W * H + (long)oy * W + ox) * 3);
+    o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+  }
+}
 __global__ __launch_bounds__(kThreads) void outside_roi_yuyv_k(const uint8_t* __restrict__ bg, long bg_stride, uint32_t* __restrict__ out, int W, int H, Rect4 roi) {
   const unsigned i = blockIdx.x * kThreads + threadIdx.x, ppr = (unsigned)W / 2;
   if (i >= ppr * (unsigned)H) return;
@@ -690,13 +732,19 @@ bool bilateral_taps_match(const BilateralParams& bp) {
   return true;
 }
 
-hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, int inW, int inH, BilateralParams bp, int n, hipStream_t s) {
+hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, uint32_t* input_u8, int inW, int inH, BilateralParams bp, int n, hipStream_t s) {
   const long per_frame = (long)inW * inH;
+  if (!input && !input_u8) return hipErrorInvalidValue;
   for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
     const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
     static_assert(kBilPix * (kThreads / 32) == 32, "32 x 32 pixel workgroup tile");
-    prep_bilateral_k<<<dim3((inW + 31) / 32, (inH + 31) / 32, nn), kThreads, 0, s>>>(canvas + (size_t)n0 * canvas_elems(inW, inH),
-                                                                                                    input + (size_t)n0 * per_frame * 3, inW, inH, bp);
+    const dim3 grid((inW + 31) / 32, (inH + 31) / 32, nn);
+    const uint32_t* cv = canvas + (size_t)n0 * canvas_elems(inW, inH);
+    float* f = input ? input + (size_t)n0 * per_frame * 3 : nullptr;
+    uint32_t* u = input_u8 ? input_u8 + (size_t)n0 * per_frame : nullptr;
+    if (f && u) prep_bilateral_k<3><<<grid, kThreads, 0, s>>>(cv, f, u, inW, inH, bp);
+    else if (u) prep_bilateral_k<2><<<grid, kThreads, 0, s>>>(cv, f, u, inW, inH, bp);
+    else prep_bilateral_k<1><<<grid, kThreads, 0, s>>>(cv, f, u, inW, inH, bp);
   }
   return hipGetLastError();
 }
@@ -748,7 +796,10 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
                              const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s, int yuyv) {
   // outside the ROI the persistent mask is 255 forever (libbackscrub.cc:248-249), i.e. the composite there IS the background
   // ((a*255 + b*0)/255 == a): those strips are copied, the ROI is composited by the mask tiles
-  if (yuyv && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
+  // `yuyv`: bit 0 = YUYV output, bits 1-2 = horizontal / vertical flip of the composite (kernels.hpp: kStepYuyv, kStepFlipH, kStepFlipV)
+  if ((yuyv & 6) && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
+    outside_roi_flip_k<<<dim3(blocks_for((long)(W / 4) * H), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H, roi, yuyv);
+  else if ((yuyv & 1) && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
     outside_roi_yuyv_k<<<dim3(blocks_for((long)(W / 2) * H), n), kThreads, 0, s>>>(bg, (long)bg_stride, reinterpret_cast<uint32_t*>(out), W, H, roi);
   else if (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H)
     outside_roi_copy_k<<<dim3(blocks_for((long)(H - roi.h) * (W * 3 / 4) + (long)roi.h * ((W - roi.w) * 3 / 4)), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H,

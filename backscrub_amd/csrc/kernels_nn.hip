@@ -901,11 +901,15 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 || (SLABS == 1 && CH == 1
 // depthwise = zero rows outside the image) and the depthwise's band live in LDS; only the C2-channel result is written.  Unfused, the two
 // 16-channel tensors at stem resolution (1 MB per frame each at 129x129) were written and read back: 5.6 MB of traffic per frame for 0.8 MB
 // of input and 0.5 MB of output.  Plain f32 FMAs (3 / 16 input channels: an MFMA slab would be mostly padding), (fy, fx, ci) ascending, bias last.
+// U8IN: x is the 8-bit network input (one u32 R | G<<8 | B<<16 per pixel, prep_bilateral_k<2>), normalised while it is staged with convertTo's two
+// roundings fadd(fmul(float(q), in_scale), in_offset) (libbackscrub.cc:302): a quarter of the bytes of the f32 tensor, the same values bit for bit.
 constexpr int kH0Threads = 512;
+template <bool U8IN>
 __global__ __launch_bounds__(kH0Threads) void dl_head0_k(const float* __restrict__ x, const float* __restrict__ ws, const float* __restrict__ bs,
                                                         const float* __restrict__ wd, const float* __restrict__ bd, const float* __restrict__ wp,
                                                         const float* __restrict__ bp, float* __restrict__ y, int H0, int W0, int H1, int W1, int pt, int pl,
-                                                        int C2, int pw_cout_pad, int act_s, int act_d, int act_p, int BH, int nbands, int phases) {
+                                                        int C2, int pw_cout_pad, int act_s, int act_d, int act_p, int BH, int nbands, int phases, float in_scale,
+                                                        float in_offset) {
   extern __shared__ __attribute__((aligned(16))) float h0_lds[];
   const int tid = threadIdx.x;
   const long frame = blockIdx.x / nbands;
@@ -930,7 +934,45 @@ __global__ __launch_bounds__(kH0Threads) void dl_head0_k(const float* __restrict
     wl[i] = v;
   }
   const float* xf = x + (size_t)frame * (size_t)H0 * W0 * 3;
-  if (phases & 1) {
+  if (U8IN && (phases & 1)) {
+    // the band's rows as ONE flat stream of pixels (u32 each), four per 16-byte load; in_t pixel j = image column j - 1
+    const uint32_t* xu = reinterpret_cast<const uint32_t*>(x) + (size_t)frame * (size_t)H0 * W0;
+    const int gy_lo = max(iy0, 0), gy_hi = min(iy0 + IR, H0);
+    const int r_off = gy_lo - iy0, np = max(gy_hi - gy_lo, 0) * W0, nq = np >> 2;
+    const uint32_t* src = xu + (size_t)gy_lo * W0;
+    constexpr int kMaxQ = 3;                                              // 21 rows x 257 pixels / 4 / 512 lanes
+    u4v v[kMaxQ];
+#pragma unroll
+    for (int k = 0; k < kMaxQ; k++) {
+      const int i = tid + k * kH0Threads;
+      v[k] = *reinterpret_cast<const u4v*>(src + 4 * (size_t)min(i, max(nq - 1, 0)));
+    }
+    uint32_t tailv = 0u;
+    if (tid < (np & 3)) tailv = src[4 * nq + tid];
+    for (int i = tid; i < IR * 6; i += kH0Threads) { const int r = i / 6, e = i - 6 * r; in_t[r * rowf + (e < 3 ? e : rowf - 6 + e)] = 0.f; }
+    for (int r = 0; r < IR; r++) {
+      if (r >= r_off && r < r_off + (gy_hi - gy_lo)) continue;          // (uniform)
+      for (int e = tid; e < W0 * 3; e += kH0Threads) in_t[r * rowf + 3 + e] = 0.f;
+    }
+    const unsigned gmagic = 0xFFFFFFFFu / (unsigned)W0 + 1u;              // p / W0 for p < 2^16
+    auto put = [&](int p, uint32_t px) {
+      const int r = (int)__umulhi((unsigned)p, gmagic), e = p - r * W0;
+      float* o = in_t + (r_off + r) * rowf + 3 + 3 * e;
+      o[0] = __fadd_rn(__fmul_rn((float)(px & 255u), in_scale), in_offset);
+      o[1] = __fadd_rn(__fmul_rn((float)((px >> 8) & 255u), in_scale), in_offset);
+      o[2] = __fadd_rn(__fmul_rn((float)((px >> 16) & 255u), in_scale), in_offset);
+    };
+#pragma unroll
+    for (int k = 0; k < kMaxQ; k++) {
+      const int i = tid + k * kH0Threads;
+      if (i < nq) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) put(4 * i + c, v[k][c]);
+      }
+    }
+    if (tid < (np & 3)) put(4 * nq + tid, tailv);
+  }
+  if (!U8IN && (phases & 1)) {
     // The band's input rows are ONE contiguous piece of the frame (rows iy0 .. iy0 + IR - 1, clipped to the image: up to 21 x 771 floats): read it as
     // a flat stream of 16-byte quads — all of a lane's quads requested before the first LDS store — and scatter the floats to their (row, column)
     // in LDS.  (Row by row with one float per lane it took 22 dword loads per lane: 477 us of the kernel's 1024 just to bring the input in.)
@@ -1573,7 +1615,8 @@ hipError_t nn_prepare() {
 #define BSX_ATTR_IR16(T, SL) BSX_ATTR((ir_expand_dw_k<T, SL, 32, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 24, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 16, true>))
   BSX_ATTR_IR16(1, 1); BSX_ATTR_IR16(1, 2); BSX_ATTR_IR16(1, 3); BSX_ATTR_IR16(3, 1); BSX_ATTR_IR16(3, 2); BSX_ATTR_IR16(3, 3);
 #undef BSX_ATTR_IR16
-  BSX_ATTR(dl_head0_k);
+  BSX_ATTR(dl_head0_k<false>);
+  BSX_ATTR(dl_head0_k<true>);
   BSX_ATTR((ir_expand_dw_k<3, 1, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 2, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 3, 32, false, 1024>));
   BSX_ATTR((pw_gemm_ring_k<3, 3>)); BSX_ATTR((pw_gemm_ring_k<3, 4>)); BSX_ATTR((pw_gemm_ring_k<3, 5>));
   BSX_ATTR((pw_gemm_ring_k<1, 3>)); BSX_ATTR((pw_gemm_ring_k<1, 4>)); BSX_ATTR((pw_gemm_ring_k<1, 5>));
@@ -1583,7 +1626,7 @@ hipError_t nn_prepare() {
 }
 
 hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
-                       hipStream_t s, const uint16_t* weights16, int f16_terms) {
+                       hipStream_t s, const uint16_t* weights16, int f16_terms, const uint32_t* net_in_u8, float in_scale, float in_offset) {
   auto P = [&](int t) -> float* {
     if (t < 0) return nullptr;
     if (t == plan.input) return net_in;
@@ -1694,9 +1737,16 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const int BH = head0_band_rows(st.W, st.OW), nb = (st.OH + BH - 1) / BH;
         const size_t fl = (size_t)head0_lds_floats(st.W, st.OW, BH);
         static const int h0_phases = getenv("BSX_H0_PHASES") ? atoi(getenv("BSX_H0_PHASES")) : 15;   // timing experiments
-        dl_head0_k<<<(unsigned)nb * (unsigned)n, kH0Threads, fl * sizeof(float), s>>>(P(st.in0), w, b, weights + d1.w_off, weights + d1.b_off, weights + p2.w_off,
-                                                                                    weights + p2.b_off, P(p2.out), st.H, st.W, st.OH, st.OW, st.pad_t, st.pad_l, p2.Cout,
-                                                                                    p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases);
+        const bool u8_fits = (long)(2 * (BH + 2) + 1) * st.W <= 4 * 3 * kH0Threads;                // three 4-pixel loads per lane cover the band's rows
+        if (net_in_u8 && st.in0 == plan.input && !u8_fits) return hipErrorInvalidValue;            // (bsx_api decides with the same rule: head0_u8_ok)
+        if (net_in_u8 && st.in0 == plan.input)
+          dl_head0_k<true><<<(unsigned)nb * (unsigned)n, kH0Threads, fl * sizeof(float), s>>>(reinterpret_cast<const float*>(net_in_u8), w, b, weights + d1.w_off, weights + d1.b_off,
+                                                                                            weights + p2.w_off, weights + p2.b_off, P(p2.out), st.H, st.W, st.OH, st.OW, st.pad_t,
+                                                                                            st.pad_l, p2.Cout, p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases, in_scale, in_offset);
+        else
+          dl_head0_k<false><<<(unsigned)nb * (unsigned)n, kH0Threads, fl * sizeof(float), s>>>(P(st.in0), w, b, weights + d1.w_off, weights + d1.b_off, weights + p2.w_off,
+                                                                                             weights + p2.b_off, P(p2.out), st.H, st.W, st.OH, st.OW, st.pad_t, st.pad_l, p2.Cout,
+                                                                                             p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases, 0.f, 0.f);
         break;
       }
       long M = (long)n * st.OH * st.OW;

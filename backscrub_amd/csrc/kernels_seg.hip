@@ -249,9 +249,11 @@ __device__ __forceinline__ RowTile row_tile(int t, int ctiles, unsigned m_ct) {
 // head: stem conv3x3/s2 (3 → 16) → 1x1 (16 → 16) → depthwise 3x3/s2; writes A (skip of the last decoder level), b0, and the
 // pooled partial sums of both.  Tile = TR (<= 4) x TC (<= 15) pixels of b0.
 // ==================================================================================================================================
-template <bool STEM_HSWISH, bool H16>
+// U8IN: the network input arrives as the filtered 8-bit pixels (R | G<<8 | B<<16 per pixel, prep_bilateral_k<2>) and is normalised here with the
+// same two roundings convertTo applies (libbackscrub.cc:302): fadd(fmul(float(q), scale), offset) — bit-identical to reading the f32 tensor.
+template <bool STEM_HSWISH, bool H16, bool U8IN>
 __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float* __restrict__ arena, long per_frame, const float* __restrict__ net_in,
-                                                          const float* __restrict__ w) {
+                                                          const float* __restrict__ w, float in_scale, float in_offset) {
   const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC;
   const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, ar0 = 2 * r0 - d.dw_pt, ac0 = 2 * c0 - d.dw_pl, RW = d.rw, ctiles = RW >> 4;
@@ -267,7 +269,29 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 
   // 1. input tile (zero outside the image: SAME padding of the stem): wave = rows, lane = row elements; every load of the lane is
   //    in flight before its first LDS store
-  {
+  if (U8IN) {                                                       // lane = pixel of the row (IC <= 63): one dword = three input values
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(net_in) + (size_t)f * (size_t)(d.H0 * d.W0);
+    const bool colok = lane < IC && ic0 + lane >= 0 && ic0 + lane < d.W0;
+    uint32_t v[5];
+    bool ok[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int row = wave + 4 * j, gy = ir0 + row;
+      ok[j] = row < IR && gy >= 0 && gy < d.H0 && colok;
+      v[j] = 0u;
+      if (ok[j]) v[j] = src[(unsigned)(gy * d.W0 + ic0 + lane)];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int row = wave + 4 * j;
+      if (row < IR && lane < IC) {
+        float* o = in_t + row * rowf + 3 * lane;
+        o[0] = ok[j] ? __fadd_rn(__fmul_rn((float)(v[j] & 255u), in_scale), in_offset) : 0.f;
+        o[1] = ok[j] ? __fadd_rn(__fmul_rn((float)((v[j] >> 8) & 255u), in_scale), in_offset) : 0.f;
+        o[2] = ok[j] ? __fadd_rn(__fmul_rn((float)((v[j] >> 16) & 255u), in_scale), in_offset) : 0.f;
+      }
+    }
+  } else {
     const float* src = net_in + (size_t)f * (size_t)(d.H0 * d.W0 * 3);
     const int lo_rem = max(0, -ic0) * 3, hi_rem = min(IC, d.W0 - ic0) * 3;
     float v[5][3];
@@ -723,7 +747,8 @@ hipError_t seg_prepare() {
   const int full = 160 * 1024;     // process-global kernel attributes: always the full LDS (cf. frame_program_prepare)
   hipError_t e = hipSuccess;
   auto one = [&](auto k) { if (e == hipSuccess) e = allow_lds(k, full); };
-  one(seg_head_k<true, false>); one(seg_head_k<false, false>); one(seg_head_k<true, true>); one(seg_head_k<false, true>);
+  one(seg_head_k<true, false, false>); one(seg_head_k<false, false, false>); one(seg_head_k<true, true, false>); one(seg_head_k<false, true, false>);
+  one(seg_head_k<true, false, true>); one(seg_head_k<false, false, true>); one(seg_head_k<true, true, true>); one(seg_head_k<false, true, true>);
   one(seg_k2_k<false>); one(seg_k2_k<true>); one(seg_k3_k<false>); one(seg_k3_k<true>);
   one(seg_tail_k<1, false, true, false>); one(seg_tail_k<1, true, true, false>); one(seg_tail_k<1, false, false, false>); one(seg_tail_k<1, true, false, false>);
   one(seg_tail_k<2, false, false, false>); one(seg_tail_k<2, true, false, false>);
@@ -733,14 +758,18 @@ hipError_t seg_prepare() {
 }
 
 // h16: the boundary tensors are stored as halves (BSX_ACT16; the middle program must have been generated for the same storage)
-hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const float* net_in, const float* weights, int n, hipStream_t s, bool h16) {
+// u8: net_in points at the 8-bit network input ([n][H0][W0] u32 pixels, prep_bilateral_k<2>) and (scale, offset) is the model's normalisation
+hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const void* net_in, const float* weights, int n, hipStream_t s, bool h16, bool u8, float in_scale,
+                           float in_offset) {
   const dim3 grid(d.tiles_y * d.tiles_x, n);
   const size_t lds = (size_t)d.lds_floats * sizeof(float);
   const bool hs = d.stem.act == kActHswish;
-  if (hs && !h16) seg_head_k<true, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_in, weights);
-  else if (hs) seg_head_k<true, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_in, weights);
-  else if (!h16) seg_head_k<false, false><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_in, weights);
-  else seg_head_k<false, true><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_in, weights);
+  const float* in = static_cast<const float*>(net_in);
+  if (u8 && 2 * (2 * d.TC + 1) + 1 > 64) return hipErrorInvalidValue;          // one lane per pixel of an input-tile row (the planner's TC <= 15)
+#define BSX_HEAD(HS, H, U) seg_head_k<HS, H, U><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, in, weights, in_scale, in_offset)
+  if (hs) { if (h16) { if (u8) BSX_HEAD(true, true, true); else BSX_HEAD(true, true, false); } else { if (u8) BSX_HEAD(true, false, true); else BSX_HEAD(true, false, false); } }
+  else { if (h16) { if (u8) BSX_HEAD(false, true, true); else BSX_HEAD(false, true, false); } else { if (u8) BSX_HEAD(false, false, true); else BSX_HEAD(false, false, false); } }
+#undef BSX_HEAD
   return hipGetLastError();
 }
 hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16) {

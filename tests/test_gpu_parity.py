@@ -248,7 +248,7 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc = oracle.Ctx(path, W, H)
     oc.prep(f)
     want = oc.infer()
-    knobs = ("BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
+    knobs = ("BSX_F32_INPUT", "BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
     for name, env, marker in NETWORK_PATHS[key]:
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
@@ -320,6 +320,31 @@ def test_deeplab_f16_storage_mode_is_gated_by_iou(bs, oracle, monkeypatch):
     assert max(errs) < 2e-2 and max(errs) > 1e-5, errs                # close, and visibly NOT the f32-grade default
     oc.close()
     mg.close()
+
+
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", HD), ("full", HD), ("deeplab", VGA)])
+def test_stems_that_read_the_8bit_input_are_bit_identical_to_the_f32_tensor(bs, monkeypatch, key, res):
+    """The step's prep hands the stem the filtered 8-bit pixels and the stem applies convertTo's two roundings while it stages its input window
+    (seg_head_k<.., U8IN>, dl_head0_k<true>): the 12 B/px f32 input tensor of libbackscrub.cc:302 is never written.  Same logits, bit for bit, as
+    the form that reads the f32 tensor (BSX_F32_INPUT=1) — incl. a stream of pure noise and a partial batch."""
+    from backscrub_amd import synth
+    path = model_path(key)
+    W, H = res
+    n = 5
+    rng = np.random.default_rng(3)
+    frames = np.stack([synth.frame(W, H, i, 2 * i) for i in range(n - 1)] + [rng.integers(0, 256, (H, W, 3), dtype=np.uint8)])
+    outs = []
+    for f32 in (False, True):
+        if f32:
+            monkeypatch.setenv("BSX_F32_INPUT", "1")
+        mg = bs.MaskGen(path, W, H, n_streams=8)
+        monkeypatch.delenv("BSX_F32_INPUT", raising=False)
+        mg.run_stage(0, _dev(frames))
+        mg.run_stage(1, n=n)
+        outs.append((mg.input_tensor()[:n].clone(), mg.output_tensor()[:n].clone()))
+        mg.close()
+    assert torch.equal(outs[0][0], outs[1][0])            # the stage entry materialises the f32 tensor in both forms (what stage-0 tests read)
+    assert torch.equal(outs[0][1], outs[1][1]), "logits differ between the 8-bit and the f32 network input"
 
 
 @pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", HD), ("full", HD)])
