@@ -107,7 +107,8 @@ struct bsx_ctx {
   uint8_t* d_ofinal = nullptr;
   uint8_t* d_masks = nullptr;
   uint8_t* d_host_frame = nullptr;  // staging for bsx_process_host
-  uint8_t* d_bgr_scratch = nullptr; // BGR composite of bsx_step_batch_yuyv when the fused YUYV epilogue does not apply (lazy)
+  uint8_t* d_bgr_scratch = nullptr; // BGR composite of bsx_step_batch_yuyv / _ex when the fused epilogue does not apply (lazy)
+  uint8_t* d_bgr_scratch2 = nullptr; // ... its flipped copy when a YUYV pack follows (lazy)
   float* d_color_lut = nullptr;
   MicroOp* d_program = nullptr;     // per-frame network program (kernels_frame.hip)
   bool use_program = false;
@@ -121,6 +122,11 @@ struct bsx_ctx {
   bool no_mask_blend_fusion = false;   // BSX_NO_MASK_BLEND_FUSION, read once at bsx_new (no getenv on the per-step path)
   bool no_mask_tile = false;           // BSX_NO_MASK_TILE (tests: the generic mask kernel), likewise
   bool tail_generic = false;           // BSX_TAIL_GENERIC (tests: the scalar argmax scan of the DeepLab tail), likewise
+  // Lanes (BSX_LANES=k, experiment): the fused step splits its batch into k contiguous groups of streams and runs each group's launch sequence on its own
+  // HIP stream — streams are independent, so the HBM-bound tail of one group (mask + blend) can overlap the latency-bound network kernels of another.
+  int lanes = 1;
+  hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   bool act16 = false;                  // BSX_ACT16=1: 16-bit activation STORAGE for the segmented Meet / MLKit networks (g1) — opt-in, IoU-gated; needs the specialised middle kernel
 
   // stream-0 view of a graph tensor (network input/output have dedicated buffers; intermediates are batch-major in
@@ -239,6 +245,14 @@ int init_device_state(bsx_ctx* c) {
     if (c->act16) c->mid_note += ", 16-bit activation storage";
   } else {
     BSX_HIP(c, nn_prepare());                 // per-launch path: the fused kernels' dynamic-LDS limits on this device
+  }
+  if (const char* l = getenv("BSX_LANES")) c->lanes = std::min(4, std::max(1, atoi(l)));
+  if (c->lanes > 1) {
+    BSX_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int k = 1; k < c->lanes; k++) {
+      BSX_HIP(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+      BSX_HIP(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+    }
   }
   // stems with a byte path take the 8-bit network input: the segmented Meet / MLKit head and DeepLab's fused head kernel
   c->in_u8 = getenv("BSX_F32_INPUT") == nullptr && ((c->use_program && c->plan.seg.on) || (!c->use_program && head0_u8_ok(c->plan)));
@@ -453,10 +467,12 @@ void bsx_delete(bsx_ctx* c) {
   DeviceGuard guard(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   rtc_unload(&c->mid);
-  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
+  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  for (int k = 1; k < 4; k++) { if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   delete c;
 }
 
@@ -523,9 +539,28 @@ int bsx_composite_batch(bsx_ctx* c, const uint8_t* d_bg, size_t bg_frame_stride,
 }
 
 namespace {
-// yuyv: the composite leaves as YUYV 4:2:2 (2 B/px) — convert_rgb_to_yuyv (deepseg.cc:87-106) applied in the blend's epilogue
-int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, int yuyv) {
-  if (!c || !d_frames || !d_bg || !d_out || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+// The context's batch buffers re-based to streams [f0, f0 + cap) for the launches enqueued inside the scope (one host thread enqueues a context's work).
+// Frame-major buffers simply start at stream f0; the batch-major arena of the per-launch path becomes the group's own compact arena laid out for `cap` streams.
+struct LaneView {
+  bsx_ctx* c; uint32_t* canvas; float* net_in; uint32_t* net_in_u8; float* net_out; float* arena; int n_streams;
+  LaneView(bsx_ctx* ctx, int f0, int cap) : c(ctx), canvas(ctx->d_canvas), net_in(ctx->d_net_in), net_in_u8(ctx->d_net_in_u8), net_out(ctx->d_net_out), arena(ctx->d_arena),
+                                            n_streams(ctx->n_streams) {
+    c->d_canvas += (size_t)f0 * canvas_elems(c->inW, c->inH);
+    c->d_net_in += (size_t)f0 * c->inW * c->inH * c->inC;
+    c->d_net_in_u8 += (size_t)f0 * c->inW * c->inH;
+    c->d_net_out += (size_t)f0 * c->outW * c->outH * c->outC;
+    c->d_arena += (size_t)f0 * c->plan.arena_floats_per_stream;
+    c->n_streams = cap;
+  }
+  ~LaneView() { c->d_canvas = canvas; c->d_net_in = net_in; c->d_net_in_u8 = net_in_u8; c->d_net_out = net_out; c->d_arena = arena; c->n_streams = n_streams; }
+};
+
+// flags (bsx.h): BSX_STEP_YUYV — the composite leaves as YUYV 4:2:2 (2 B/px), convert_rgb_to_yuyv (deepseg.cc:87-106) applied in the blend's epilogue;
+// BSX_STEP_FLIP_H / _V — cv::flip of the composite (deepseg.cc:667-673) folded into the epilogue's store addresses
+int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, unsigned flags) {
+  if (!c || !d_frames || !d_bg || !d_out || n <= 0 || n > c->n_streams || (flags & ~7u)) return BSX_EINVAL;
+  const int yuyv = (int)(flags & BSX_STEP_YUYV);
+  const unsigned flip = flags & (BSX_STEP_FLIP_H | BSX_STEP_FLIP_V);
   if (yuyv && (c->width & 1)) return BSX_EINVAL;                // 4:2:2 pairs pixels horizontally
   DeviceGuard guard(c->device);
   const bool fuse = !c->onmask && !c->no_mask_blend_fusion && (!yuyv || ((uintptr_t)d_out & 3) == 0) &&
@@ -533,17 +568,47 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
   if (!fuse) {
     int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
     if (rc) return rc;
-    if (!yuyv) return bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, d_out, n, stream);
-    // unfused geometry: composite into a context-owned BGR scratch, then pack
+    if (!yuyv && !flip) return bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, d_out, n, stream);
+    // unfused geometry: composite into a context-owned BGR scratch, then flip and / or pack as separate passes
     const size_t need = (size_t)c->n_streams * c->width * c->height * 3;
     if (!c->d_bgr_scratch) BSX_HIP(c, hipMalloc(&c->d_bgr_scratch, need));
     rc = bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, c->d_bgr_scratch, n, stream);
     if (rc) return rc;
-    return bsx_bgr_to_yuyv(c, c->d_bgr_scratch, d_out, c->width, c->height, n, stream);
+    const uint8_t* bgr = c->d_bgr_scratch;
+    if (flip) {
+      const int code = flip == (BSX_STEP_FLIP_H | BSX_STEP_FLIP_V) ? -1 : (flip == BSX_STEP_FLIP_H ? 1 : 0);
+      uint8_t* dst = d_out;
+      if (yuyv) { if (!c->d_bgr_scratch2) BSX_HIP(c, hipMalloc(&c->d_bgr_scratch2, need)); dst = c->d_bgr_scratch2; }
+      if ((rc = bsx_flip_bgr(c, bgr, dst, c->width, c->height, n, code, stream))) return rc;
+      bgr = dst;
+    }
+    return yuyv ? bsx_bgr_to_yuyv(c, bgr, d_out, c->width, c->height, n, stream) : BSX_OK;
   }
   // process (prep → network → decode), then mask-upscale+blur and alpha blend of each tile in ONE launch
   hipStream_t s = pick(c, stream);
   int rc;
+  if (c->lanes > 1 && n >= 16 * c->lanes && !c->onprep && !c->oninfer && !c->keep_logits) {
+    const int K = c->lanes, per = (n + K - 1) / K;
+    const bool fd = infer_decodes(c);
+    const size_t fb = (size_t)c->width * c->height * 3, ob = (size_t)c->width * c->height * (yuyv ? 2 : 3), sm = (size_t)c->outW * c->outH;
+    BSX_HIP(c, hipEventRecord(c->ev_fork, s));
+    for (int k = 0; k < K; k++) {
+      const int f0 = k * per, nb = std::min(per, n - f0);
+      if (nb <= 0) break;
+      hipStream_t ls = k == 0 ? s : c->lane_stream[k];
+      if (k > 0) BSX_HIP(c, hipStreamWaitEvent(ls, c->ev_fork, 0));
+      {
+        LaneView view(c, f0, per);
+        if ((rc = run_prep(c, d_frames + (size_t)f0 * fb, nb, ls))) return rc;
+        if ((rc = run_infer(c, nb, ls, !fd, f0))) return rc;
+        if (!fd && (rc = run_decode(c, nb, ls, f0))) return rc;
+      }
+      BSX_HIP(c, launch_mask_blend(c->d_ofinal + (size_t)f0 * sm, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks + (size_t)f0 * c->width * c->height, c->width, c->height,
+                                   c->roi, d_bg + (size_t)f0 * bg_frame_stride, bg_frame_stride, d_frames + (size_t)f0 * fb, d_out + (size_t)f0 * ob, nb, ls, (int)flags));
+      if (k > 0) { BSX_HIP(c, hipEventRecord(c->ev_join[k], ls)); BSX_HIP(c, hipStreamWaitEvent(s, c->ev_join[k], 0)); }
+    }
+    return BSX_OK;
+  }
   if ((rc = run_prep(c, d_frames, n, s))) return rc;
   if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }
   const bool fused_decode = infer_decodes(c);
@@ -551,16 +616,19 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
   if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); }
   if (!fused_decode && (rc = run_decode(c, n, s))) return rc;
   BSX_HIP(c, launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg,
-                               bg_frame_stride, d_frames, d_out, n, s, yuyv));
+                               bg_frame_stride, d_frames, d_out, n, s, (int)flags));
   return BSX_OK;
 }
 }  // namespace
 
 int bsx_step_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream) {
-  return step_impl(c, d_frames, d_bg, bg_frame_stride, d_out, n, stream, 0);
+  return step_impl(c, d_frames, d_bg, bg_frame_stride, d_out, n, stream, 0u);
 }
 int bsx_step_batch_yuyv(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out_yuyv, int n, void* stream) {
-  return step_impl(c, d_frames, d_bg, bg_frame_stride, d_out_yuyv, n, stream, 1);
+  return step_impl(c, d_frames, d_bg, bg_frame_stride, d_out_yuyv, n, stream, BSX_STEP_YUYV);
+}
+int bsx_step_batch_ex(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, unsigned flags) {
+  return step_impl(c, d_frames, d_bg, bg_frame_stride, d_out, n, stream, flags);
 }
 
 int bsx_resize_bgr(bsx_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream) {

@@ -17,6 +17,7 @@
  *   bsx_composite_batch    alpha_blend()                  app/deepseg.cc:108-134 (file-static)
  *   bsx_step_batch         one main-loop iteration        app/deepseg.cc:634-661
  *   bsx_step_batch_yuyv    … with convert_rgb_to_yuyv fused app/deepseg.cc:634-681
+ *   bsx_step_batch_ex      … with cv::flip (and YUYV) fused  app/deepseg.cc:667-681
  *                          (set_input_frame → mask → alpha_blend), batched
  *   bsx_resize_bgr         grab_background() cv::resize   app/background.cc:178-194
  *   bsx_bgr_to_yuyv        convert_rgb_to_yuyv()          app/deepseg.cc:87-106
@@ -135,6 +136,17 @@ int bsx_step_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, s
  * pass over the composite — for callers that feed a V4L2 YUYV sink.  Bit-identical to bsx_step_batch followed by bsx_bgr_to_yuyv.  width even. */
 int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                         uint8_t* d_out_yuyv, int n, void* stream);
+
+/* The same iteration with the post steps of the main loop that sit between alpha_blend and the device write folded into WHERE the blend stores
+ * its result (app/deepseg.cc:667-681): flags = BSX_STEP_FLIP_H | BSX_STEP_FLIP_V (cv::flip(raw, raw, 1 / 0 / -1) of the composite: the four pixels
+ * a lane composites go to the mirrored column group in reverse order, the row to the mirrored row — no extra pass over the frame) and / or
+ * BSX_STEP_YUYV (convert_rgb_to_yuyv of the — flipped — composite, as bsx_step_batch_yuyv).  flags = 0 is bsx_step_batch.  The persistent masks
+ * are those of the unflipped camera frame, as in the reference.  Bit-identical to bsx_step_batch + bsx_flip_bgr [+ bsx_bgr_to_yuyv]. */
+#define BSX_STEP_YUYV 1u
+#define BSX_STEP_FLIP_H 2u
+#define BSX_STEP_FLIP_V 4u
+int bsx_step_batch_ex(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
+                      uint8_t* d_out, int n, void* stream, unsigned flags);
 
 /* cv::resize(src, dst, Size(dw,dh)) with INTER_LINEAR on packed BGR u8 (device pointers, n images). */
 int bsx_resize_bgr(bsx_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream);

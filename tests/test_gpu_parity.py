@@ -648,6 +648,46 @@ def test_step_with_fused_yuyv_output(bs, oracle, key, res):
     mg_b.close()
 
 
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA), ("full", (1280, 720)), ("lite", (322, 242))])
+def test_step_with_flips_folded_into_the_blend(bs, oracle, key, res):
+    """bsx_step_batch_ex: cv::flip of the composite (app/deepseg.cc:667-673) costs no pass of its own — the blend's tiles store to the mirrored
+    position.  Bit-identical to step + cv::flip (numpy) [+ the oracle's YUYV packer] for all three flip codes, with and without the YUYV epilogue,
+    on a full-frame ROI, a ROI with background strips outside, HD, and a geometry that takes the unfused fallback; masks stay unflipped."""
+    import torch
+    from backscrub_amd import synth
+    W, H = res
+    n = 3
+    mg_a = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    mg_b = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    bg = _dev(synth.random_u8((n, H, W, 3), 78))
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    got3 = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    got2 = torch.empty((n, H, W, 2), dtype=torch.uint8, device="cuda")
+    t = 0
+    for fh, fv in ((True, False), (False, True), (True, True)):
+        for yuyv in (False, True):
+            frames = _dev(np.stack([synth.frame(W, H, i, t) for i in range(n)]))
+            t += 1
+            mg_a.step(frames, bg, out)
+            mg_b.step_ex(frames, bg, got2 if yuyv else got3, flip_h=fh, flip_v=fv, yuyv=yuyv)
+            want = out.cpu().numpy()
+            if fh:
+                want = want[:, :, ::-1]
+            if fv:
+                want = want[:, ::-1]
+            want = np.ascontiguousarray(want)
+            if yuyv:
+                want = np.stack([oracle.bgr_to_yuyv(w) for w in want])
+            got = (got2 if yuyv else got3).cpu().numpy()
+            assert np.array_equal(got, want), "flip_h=%s flip_v=%s yuyv=%s: %d bytes differ" % (fh, fv, yuyv, (got != want).sum())
+            assert np.array_equal(mg_a.masks().cpu().numpy(), mg_b.masks().cpu().numpy())
+    mg_b.step_ex(frames, bg, got3)                                        # no flags = bsx_step_batch
+    mg_a.step(frames, bg, out)
+    assert torch.equal(got3, out)
+    mg_a.close()
+    mg_b.close()
+
+
 def test_yuyv_to_bgr_matches_oracle(bs, oracle):
     from backscrub_amd import synth
     img = synth.random_u8((2, 480, 640, 2), 13)
