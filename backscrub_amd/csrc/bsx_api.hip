@@ -809,6 +809,15 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       put(j++, st.label + "+" + d1.label + "+" + p2.label, N * ((c->in_u8 ? 4.0 * st.H * st.W : 4.0 * in) + 4.0 * (double)p2.OH * p2.OW * p2.Cout), N * 2.0 * (st.macs + d1.macs + p2.macs));
       continue;
     }
+    const bool block_on = c->d_weights16 && (c->f16_terms & 15) > 0 && !(c->f16_terms & 16);
+    if (st.fused_into_block && block_on) { put(j++, st.label + " (inside the launch before)", 0, 0); continue; }
+    if (st.fuse_proj >= 0 && block_on) {                         // the whole block in one launch: reads the block's input (+ residual), writes the project's output
+      const Step& dd = c->plan.steps[st.fuse_dw];
+      const Step& pj = c->plan.steps[st.fuse_proj];
+      const double po = (double)pj.OH * pj.OW * pj.Cout;
+      put(j++, st.label + "+" + dd.label + "+" + pj.label, N * 4.0 * (in + po + (pj.residual >= 0 ? po : 0)), N * 2.0 * (st.macs + dd.macs + pj.macs));
+      continue;
+    }
     if (st.fuse_dw >= 0 && ir_on) {                              // expand + depthwise in one launch: reads the expand's input, writes the depthwise's output
       const Step& dd = c->plan.steps[st.fuse_dw];
       put(j++, st.label + "+" + dd.label, N * 4.0 * (in + (double)dd.OH * dd.OW * dd.Cout), N * 2.0 * (st.macs + dd.macs));

@@ -896,6 +896,229 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 || (SLABS == 1 && CH == 1
   }
 }
 
+// ---- a WHOLE inverted-residual block as one kernel, for the layers whose input is small: expand 1x1 → depthwise 3x3 → project 1x1 (+ residual) ----
+// ir_expand_dw_k keeps the expanded tensor out of HBM; its depthwise output — still the block's largest tensor (0.8 - 1.2 MB per frame at 65 x 65) — made
+// one HBM round trip into the project GEMM.  Here a workgroup owns (frame, band of output rows) and LOOPS over the chunks of CH expanded channels:
+//   phase 1  expand chunk of the band's rows (+ the rows the 3x3 window reaches) → LDS E, split-f16 MFMA exactly as in ir_expand_dw_k;
+//   phase 2  depthwise from E → LDS D ([band pixel][CH + 4]: the pad makes the 16-byte fragment reads of 8 consecutive pixels hit distinct banks);
+//   phase 3  project: acc += D · Wp[chunk] on the matrix cores (A fragments = a lane's 8 depthwise values of one pixel, split hi + lo in registers;
+//            K = 32 per instruction with the slots past CH zeroed), accumulators in registers across the chunk loop;
+// then bias, activation, residual and ONE store of the block's output.  The block input is re-read once per chunk, which is why this form is for
+// Cin <= 16 (8 / 12 channels at 129 x 129 / 65 x 65: the band's input is a few KB and stays in L2): at 33 x 33 x 80 the same loop re-reads 348 KB per chunk
+// and the project accumulators alone are 348 KB — see DESIGN.md §8.  Two barriers per chunk; <= 80 KB of LDS so that two workgroups share a CU.
+constexpr int kIrbMT = 3;                 // project m-tiles per wave: band pixels <= 8 waves x 3 x 16
+template <int TERMS, int CH>
+__global__ __launch_bounds__(kIrThreads, 4) void ir_block_k(const float* __restrict__ x, const _Float16* __restrict__ w16e, const float* __restrict__ be,
+                                                          const float* __restrict__ dww, const float* __restrict__ dwb, const _Float16* __restrict__ w16p,
+                                                          const float* __restrict__ bp, const float* __restrict__ res, float* __restrict__ y, int H, int W, int Cin,
+                                                          int Kpe, int Cexp, int cpad_e, int act1, int act2, int d, int S, int pt, int pl, int OH, int OW, int BH,
+                                                          int nbands, int rows_cap, int Cout, int Kpp, int cpad_p, int act3) {
+  extern __shared__ __attribute__((aligned(16))) float ir_ex[];
+  constexpr int NT = (CH + 15) / 16, CQ = CH / 4, CHP = CH + 4, THREADS = kIrThreads;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4, q = li & 3;
+  unsigned band; long frame;
+  xcd_tile((unsigned)nbands, &band, &frame);                               // a frame's bands run back to back on one XCD: halo rows are L2 hits
+  const int oy0 = (int)band * BH, oy1 = min(oy0 + BH, OH);
+  const int e0 = max(S * oy0 - pt, 0), e1 = min(S * (oy1 - 1) - pt + 2 * d + 1, H);      // expanded rows [e0, e1) of this band
+  const int HWb = (e1 - e0) * W, OPX = (oy1 - oy0) * OW;
+  const ClampK k1 = clamp_of(act1), k2 = clamp_of(act2), k3 = clamp_of(act3);
+  const float* xf = x + ((size_t)frame * (size_t)H + (size_t)e0) * (size_t)W * Cin;
+  float* dwl = ir_ex + (size_t)rows_cap * W * CH;                          // [9][CH] weights, [CH] bias, a quad of zeros
+  float* Dl = dwl + 10 * CH + 4;                                           // [BH * OW][CHP]
+  f4acc pacc[kIrbMT];
+#pragma unroll
+  for (int t = 0; t < kIrbMT; t++) pacc[t] = f4acc{0.f, 0.f, 0.f, 0.f};
+  const _Float16* wh = w16e;
+  const _Float16* wl = w16e + (size_t)cpad_e * Kpe;
+  const _Float16* wph = w16p;
+  const _Float16* wpl = w16p + (size_t)cpad_p * Kpp;
+  const f4v zero = {0.f, 0.f, 0.f, 0.f};
+  const int nchunks = Cexp / CH;
+  for (int chunk = 0; chunk < nchunks; chunk++) {
+    const int n_base = chunk * CH;
+    // ---- phase 1: expand chunk → E (one K slab: Cin <= 32)
+    {
+      h8v bh[NT], bl[NT];
+      float bch[NT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ni++) {
+        bh[ni] = h8v{0, 0, 0, 0, 0, 0, 0, 0}; bl[ni] = bh[ni]; bch[ni] = 0.f;
+        if (16 * ni + li < CH) {
+          bh[ni] = *reinterpret_cast<const h8v*>(wh + (size_t)(n_base + 16 * ni + li) * Kpe + 8 * g);
+          if (TERMS == 3) bl[ni] = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + 16 * ni + li) * Kpe + 8 * g);
+          bch[ni] = be[n_base + 16 * ni + li];
+        }
+      }
+      const int ntile = (HWb + 15) >> 4, nw = THREADS >> 6;
+      constexpr int kPf = 2;
+      f4v ra[kPf][2];
+      int koff[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) { const int k = 8 * g + 4 * h; koff[h] = k < Cin ? k : 0; }      // quads past Cin: any finite value, their weights are zero
+      auto fetch = [&](f4v (&dst)[2], int rt) {
+        const float* rp = xf + (size_t)min(rt * 16 + li, HWb - 1) * Cin;
+        dst[0] = *reinterpret_cast<const f4v*>(rp + koff[0]);
+        dst[1] = *reinterpret_cast<const f4v*>(rp + koff[1]);
+      };
+      const int cnt = wave < ntile ? (ntile - wave + nw - 1) / nw : 0;
+#pragma unroll
+      for (int j = 0; j < kPf; j++) if (j < cnt) fetch(ra[j], wave + j * nw);
+      auto tile = [&](int j, int k) {
+        const int rt = wave + k * nw;
+        h8v ah, al;
+        split8<TERMS>(ra[j][0], ra[j][1], ah, al);
+        if (k + kPf < cnt) fetch(ra[j], wave + (k + kPf) * nw);
+        f4acc acc[NT];
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) {
+          acc[ni] = f4acc{0.f, 0.f, 0.f, 0.f};
+          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ni], acc[ni], 0, 0, 0);
+          if (TERMS == 3) {
+            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ni], acc[ni], 0, 0, 0);
+            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ni], acc[ni], 0, 0, 0);
+          }
+        }
+        const int pb = rt * 16 + 4 * g;
+#pragma unroll
+        for (int ni = 0; ni < NT; ni++) {
+          if (CH % 16 != 0 && 16 * ni + li >= CH) continue;
+          float* dst = ir_ex + (size_t)pb * CH + 16 * ni + li;
+#pragma unroll
+          for (int r = 0; r < 4; r++) if (pb + r < HWb) dst[r * CH] = clampf(acc[ni][r] + bch[ni], k1);
+        }
+      };
+      for (int k0 = 0; k0 < cnt; k0 += kPf) {
+#pragma unroll
+        for (int j = 0; j < kPf; j++) {
+          if (k0 + j >= cnt) break;
+          tile(j, k0 + j);
+        }
+      }
+    }
+    if (tid < 4) dwl[10 * CH + tid] = 0.f;
+    for (int i = tid; i < 10 * CQ; i += THREADS) {
+      const int k = i / CQ, cq = i - k * CQ;
+      *reinterpret_cast<f4v*>(dwl + k * CH + 4 * cq) = k < 9 ? *reinterpret_cast<const f4v*>(dww + (size_t)k * Cexp + n_base + 4 * cq)
+                                                             : *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
+    }
+    __syncthreads();                       // E and the depthwise weights are complete; every wave is past its phase 3 of the previous chunk (D is free)
+    // ---- phase 2: depthwise → D
+    if (S == 1) {
+      const int L = (oy1 - oy0 + d - 1) / d, nseg = (L + kIrSeg - 1) / kIrSeg, cols = d * W, total = nseg * cols * CQ;
+      const unsigned mcols = 0xFFFFFFFFu / (unsigned)cols + 1u, mw = 0xFFFFFFFFu / (unsigned)W + 1u;
+      const float* zq = dwl + 10 * CH;
+      for (int item = tid; item < total; item += THREADS) {
+        const int t = item / CQ, cq = item - t * CQ, seg = (int)__umulhi((unsigned)t, mcols), rc = t - seg * cols, r = (int)__umulhi((unsigned)rc, mw), xx = rc - r * W;
+        f4v wq[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) wq[k] = *reinterpret_cast<const f4v*>(dwl + k * CH + 4 * cq);
+        const f4v bq = *reinterpret_cast<const f4v*>(dwl + 9 * CH + 4 * cq);
+        const bool vl = xx - d >= 0, vr = xx + d < W;
+        if (!vl) { wq[0] = zero; wq[3] = zero; wq[6] = zero; }
+        if (!vr) { wq[2] = zero; wq[5] = zero; wq[8] = zero; }
+        const int xl = vl ? xx - d : xx, xr = vr ? xx + d : xx, rstep = d * W * CH;
+        const float* col = ir_ex + (size_t)xx * CH + 4 * cq;
+        const float* coll = ir_ex + (size_t)xl * CH + 4 * cq;
+        const float* colr = ir_ex + (size_t)xr * CH + 4 * cq;
+        auto row = [&](int yy, int off, f4v (&o)[3]) {
+          const bool in = yy >= 0 && yy < H;
+          o[0] = *reinterpret_cast<const f4v*>(in ? coll + off : zq);
+          o[1] = *reinterpret_cast<const f4v*>(in ? col + off : zq);
+          o[2] = *reinterpret_cast<const f4v*>(in ? colr + off : zq);
+        };
+        int yy = oy0 + r + seg * kIrSeg * d;
+        int off = (yy - e0) * W * CH;
+        f4v pa[3], pb3[3], pc[3];
+        row(yy - d, off - rstep, pa); row(yy, off, pb3);
+        for (int left = kIrSeg; left > 0 && yy < oy1; left--) {
+          row(yy + d, off + rstep, pc);
+          f4v acc = zero;
+#pragma unroll
+          for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(pa[fx], wq[fx], acc);
+#pragma unroll
+          for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(pb3[fx], wq[3 + fx], acc);
+#pragma unroll
+          for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(pc[fx], wq[6 + fx], acc);
+          acc += bq;
+          *reinterpret_cast<f4v*>(Dl + (size_t)((yy - oy0) * OW + xx) * CHP + 4 * cq) = f4v{clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2)};
+#pragma unroll
+          for (int fx = 0; fx < 3; fx++) { pa[fx] = pb3[fx]; pb3[fx] = pc[fx]; }
+          yy += d; off += rstep;
+        }
+      }
+    } else {
+      const int total = OPX * CQ;
+      for (int item = tid; item < total; item += THREADS) {
+        const int t = item / CQ, cq = item - t * CQ, oyl = t / OW, ox = t - oyl * OW, oy = oy0 + oyl;
+        f4v acc = zero;
+#pragma unroll
+        for (int fy = 0; fy < 3; fy++) {
+          const int iy = S * oy - pt + fy;
+#pragma unroll
+          for (int fx = 0; fx < 3; fx++) {
+            const int ix = S * ox - pl + fx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+              const f4v xv = *reinterpret_cast<const f4v*>(ir_ex + ((size_t)(iy - e0) * W + ix) * CH + 4 * cq);
+              const f4v wv = *reinterpret_cast<const f4v*>(dwl + (fy * 3 + fx) * CH + 4 * cq);
+              acc = __builtin_elementwise_fma(xv, wv, acc);
+            }
+          }
+        }
+        acc += *reinterpret_cast<const f4v*>(dwl + 9 * CH + 4 * cq);
+        *reinterpret_cast<f4v*>(Dl + (size_t)t * CHP + 4 * cq) = f4v{clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2)};
+      }
+    }
+    __syncthreads();                       // D is complete; E and the depthwise weights are free for the next chunk's phase 1
+    // ---- phase 3: project, accumulators in registers
+    {
+      const bool kv = 8 * g < CH;                                           // this lane's 8 K slots are inside the chunk (CH is a multiple of 8)
+      const int kofs = kv ? n_base + 8 * g : 0;
+      h8v bh = h8v{0, 0, 0, 0, 0, 0, 0, 0}, bl = bh;
+      if (li < cpad_p) {
+        bh = *reinterpret_cast<const h8v*>(wph + (size_t)li * Kpp + kofs);
+        if (TERMS == 3) bl = *reinterpret_cast<const h8v*>(wpl + (size_t)li * Kpp + kofs);
+      }
+      const int ntile3 = (OPX + 15) >> 4;
+#pragma unroll
+      for (int t = 0; t < kIrbMT; t++) {
+        const int mt = wave + 8 * t;
+        if (mt < ntile3) {
+          const float* dp = Dl + (size_t)min(16 * mt + li, OPX - 1) * CHP + (kv ? 8 * g : 0);
+          f4v v0 = *reinterpret_cast<const f4v*>(dp), v1 = *reinterpret_cast<const f4v*>(dp + 4);
+          if (!kv) { v0 = zero; v1 = zero; }
+          h8v ah, al;
+          split8<TERMS>(v0, v1, ah, al);
+          pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, pacc[t], 0, 0, 0);
+          if (TERMS == 3) {
+            pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, pacc[t], 0, 0, 0);
+            pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, pacc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- bias, activation, residual, store: lane (g, li) owns pixel 4g + (li & 3) of its tiles, channels (li & ~3) .. +3
+  {
+    const int c0 = li & ~3, ntile3 = (OPX + 15) >> 4;
+    const float4 b4 = c0 < Cout ? *reinterpret_cast<const float4*>(bp + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t px0 = ((size_t)frame * OH + (size_t)oy0) * (size_t)OW;
+#pragma unroll
+    for (int t = 0; t < kIrbMT; t++) {
+      const int mt = wave + 8 * t;
+      if (mt < ntile3) {
+        const float4 v = quad_transpose(pacc[t], q);
+        const int px = 16 * mt + 4 * g + q;
+        if (px < OPX && c0 < Cout) {
+          const size_t o = (px0 + (size_t)px) * (size_t)Cout + c0;
+          float4 r = make_float4(clampf(v.x + b4.x, k3), clampf(v.y + b4.y, k3), clampf(v.z + b4.z, k3), clampf(v.w + b4.w, k3));
+          if (res) { const float4 e = *reinterpret_cast<const float4*>(res + o); r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w; }
+          *reinterpret_cast<float4*>(y + o) = r;
+        }
+      }
+    }
+  }
+}
+
 // ---- DeepLab's first three layers in one kernel: stem conv 3x3/s2 (3 → 16) → depthwise 3x3 → 1x1 (16 → C2 <= 16) ------------------------
 // Workgroup = (frame, band of BH output rows).  The input rows the band needs, the stem's band (+1 halo row each side: SAME padding of the
 // depthwise = zero rows outside the image) and the depthwise's band live in LDS; only the C2-channel result is written.  Unfused, the two
@@ -1615,6 +1838,7 @@ hipError_t nn_prepare() {
 #define BSX_ATTR_IR16(T, SL) BSX_ATTR((ir_expand_dw_k<T, SL, 32, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 24, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 16, true>))
   BSX_ATTR_IR16(1, 1); BSX_ATTR_IR16(1, 2); BSX_ATTR_IR16(1, 3); BSX_ATTR_IR16(3, 1); BSX_ATTR_IR16(3, 2); BSX_ATTR_IR16(3, 3);
 #undef BSX_ATTR_IR16
+  BSX_ATTR((ir_block_k<3, 24>)); BSX_ATTR((ir_block_k<3, 16>)); BSX_ATTR((ir_block_k<1, 24>)); BSX_ATTR((ir_block_k<1, 16>));
   BSX_ATTR(dl_head0_k<false>);
   BSX_ATTR(dl_head0_k<true>);
   BSX_ATTR((ir_expand_dw_k<3, 1, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 2, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 3, 32, false, 1024>));
@@ -1642,6 +1866,27 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       int HW = st.OH * st.OW;
       if (st.fused_away && plan.steps[0].fuse_head0) break;          // ran inside dl_head0_k (the planner decides: BSX_NO_HEAD0 is read there)
       static const bool no_gemm = getenv("BSX_NO_PW_GEMM") != nullptr;
+      // the whole inverted-residual block (expand + depthwise + project + residual) in one kernel: whenever the split / plain f16 GEMM modes are on and
+      // the reduced-precision STORAGE mode (bit 4: f16 depthwise tensors in HBM — there is no such tensor here) is not what is being measured
+      const bool block_on = weights16 && (f16_terms & 15) > 0 && !(f16_terms & 16);
+      if (st.fused_into_block && block_on) break;                    // ran inside ir_block_k, launched by the expand step two steps before
+      if (st.fuse_proj >= 0 && block_on) {
+        const Step& dws = plan.steps[st.fuse_dw];
+        const Step& pj = plan.steps[st.fuse_proj];
+        const IrGeom bg = ir_block_geometry(st.OH, st.OW, st.Cout, dws.OH, dws.OW, dws.sh, dws.dh);
+        if (bg.CH == 0 || (long)bg.rows * st.OW * dws.dh >= 65536) return hipErrorInvalidValue;      // the planner checked the same function
+        const _Float16* w16e = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
+        const _Float16* w16p = reinterpret_cast<const _Float16*>(weights16) + pj.w16_off;
+        const size_t lds = (size_t)ir_block_lds_bytes(bg.rows, st.OW, bg.CH, bg.BH, dws.OW);
+        const dim3 gb((unsigned)bg.nbands * (unsigned)n);
+#define BSX_IRB(T, C) ir_block_k<T, C><<<gb, kIrThreads, lds, s>>>(P(st.in0), w16e, b, weights + dws.w_off, weights + dws.b_off, w16p, weights + pj.b_off, P(pj.residual), P(pj.out), \
+                                                                 st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, \
+                                                                 bg.BH, bg.nbands, bg.rows, pj.Cout, pj.k16_pad, pj.cout_pad, pj.act)
+        if ((f16_terms & 15) == 3) { if (bg.CH == 24) BSX_IRB(3, 24); else BSX_IRB(3, 16); }
+        else { if (bg.CH == 24) BSX_IRB(1, 24); else BSX_IRB(1, 16); }
+#undef BSX_IRB
+        break;
+      }
       if (st.fuse_dw >= 0 && weights16 && f16_terms > 0) {          // expand 1x1 + depthwise 3x3 of an inverted-residual block in one kernel
         const Step& dws = plan.steps[st.fuse_dw];
         const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dws.OH, dws.sh, dws.dh);

@@ -83,6 +83,14 @@ std::string Plan::describe() const {
              st.residual, st.in_scale, st.macs, st.in0, st.out);
     s += line;
     if (st.fuse_head0) { s += "      ^ fused with steps 1 and 2 (stem + depthwise + 1x1 in one tiled kernel)\n"; }
+    if (st.fuse_proj >= 0) {
+      const Step& dd = steps[st.fuse_dw];
+      const IrGeom bg = ir_block_geometry(st.OH, st.OW, st.Cout, dd.OH, dd.OW, dd.sh, dd.dh);
+      char line[200];
+      snprintf(line, sizeof line, "      ^ fused with steps %d and %d (the whole inverted-residual block in one kernel: %d channels x %d rows per chunk and band, %d band(s))\n", st.fuse_dw, st.fuse_proj, bg.CH,
+               bg.BH, bg.nbands);
+      s += line;
+    } else
     if (st.fuse_dw >= 0) {
       const Step& dd = steps[st.fuse_dw];
       const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dd.OH, dd.sh, dd.dh);
@@ -1173,6 +1181,19 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
         if (pj.kind == StepKind::PwConv && pj.in0 == d.out && uses(d.out) == 1 && pj.k16_pad > 0 && pj.in_scale < 0 && pj.in2 < 0 && (pj.Cin & 3) == 0 &&
             pj.cout_pad % 16 == 0 && pj.OH == d.OH && pj.OW == d.OW)
           pj.in_from_fused_dw = true;
+        // the WHOLE block in one kernel where its input is small (ir_block_k): one K slab of <= 16 input channels, <= 16 output channels.
+        // OPT-IN (BSX_IR_BLOCK=1): parity-green but measured SLOWER than expand+depthwise kernel + project GEMM on every layer it applies to (1024 streams:
+        // conv#6 block 0.897 vs 0.496 + 0.371 ms, conv#3 block 1.507 vs 0.829 + 0.195, conv#10 0.642 vs 0.311 + 0.086, conv#13 0.347 vs 0.137 + 0.141 —
+        // profiles/r03l): the chunk loop serialises three phases behind two barriers per chunk in a workgroup that has to share its 80 KB between the
+        // expanded band and the depthwise band (smaller bands = more halo rows), where the two-kernel form runs three times as many independent workgroups.
+        static const int block_minw = getenv("BSX_IR_BLOCK_MINW") ? atoi(getenv("BSX_IR_BLOCK_MINW")) : 0;      // A/B timing: only layers at least this wide
+        static const bool block_on = getenv("BSX_IR_BLOCK") != nullptr && atoi(getenv("BSX_IR_BLOCK")) != 0;
+        if (pj.in_from_fused_dw && block_on && a.OW >= block_minw && a.k16_pad == 32 && a.Cin <= 16 && pj.cout_pad == 16 && pj.Cout % 4 == 0 && pj.out_bias < 0 &&
+            pj.act < kActHswish && pj.out != g.output && a.OW == d.W && (long)a.OH * a.OW * d.dh < 65536 &&
+            ir_block_geometry(a.OH, a.OW, a.Cout, d.OH, d.OW, d.sh, d.dh).CH != 0) {
+          a.fuse_proj = (int)i + 2;
+          pj.fused_into_block = true;
+        }
       }
     }
   }

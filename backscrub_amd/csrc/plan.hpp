@@ -51,6 +51,8 @@ struct Step {
   int last_node = -1;                 // file operator index of the last fused op
   int fuse_dw = -1;                   // per-launch path, PwConv: index of the depthwise step this expand convolution is fused with (ir_expand_dw_k)
   bool in_from_fused_dw = false;      // per-launch path, PwConv: in0 is the output of a fused expand+depthwise pair and has no other reader (may be stored as f16)
+  int fuse_proj = -1;                 // per-launch path, PwConv with fuse_dw: index of the project 1x1 that ALSO runs in the same kernel (ir_block_k: the whole inverted-residual block)
+  bool fused_into_block = false;      // per-launch path, PwConv: this project convolution runs inside the block kernel of the expand step two steps before
   bool fused_away = false;            // per-launch path: the step runs inside an earlier one
   bool fuse_head0 = false;            // per-launch path, stem Conv: runs together with the depthwise and the 1x1 after it (dl_head0_k)
 };
@@ -89,6 +91,27 @@ inline IrGeom ir_geometry(int H, int W, int Cexp, int OH, int S, int d) {
     if (ir_lds_bytes(rows_for(BH), W, CH) > 80 * 1024 || BH < 2) continue;
     const int nb = (OH + BH - 1) / BH;
     BH = (OH + nb - 1) / nb;                             // even bands
+    const double score = (double)(S * BH) / rows_for(BH) * CH / ((CH + 15) / 16 * 16);
+    if (score > best_score) { best_score = score; best.CH = CH; best.BH = BH; best.nbands = nb; best.rows = rows_for(BH); }
+  }
+  return best;
+}
+
+// Geometry of the whole-block kernel (kernels_nn.hip: ir_block_k): expanded band chunk + depthwise weights + the depthwise chunk of the band ([px][CH + 4]) in
+// at most 80 KB (two workgroups per CU), at most 384 output pixels per band (3 project tiles per wave).  CH = 0: the block does not fit.
+inline long ir_block_lds_bytes(int rows, int W, int CH, int BH, int OW) { return ((long)rows * W * CH + 10 * CH + 4 + (long)BH * OW * (CH + 4)) * 4; }
+inline IrGeom ir_block_geometry(int H, int W, int Cexp, int OH, int OW, int S, int d) {
+  auto rows_for = [&](int bh) { const int r = S * (bh - 1) + 2 * d + 1; return r < H ? r : H; };
+  IrGeom best;
+  double best_score = 0;
+  for (int CH : {24, 16}) {
+    if (Cexp % CH) continue;
+    int BH = OH;
+    auto fits = [&](int bh) { return ir_block_lds_bytes(rows_for(bh), W, CH, bh, OW) <= 80 * 1024 && (long)bh * OW <= 384; };
+    while (BH > 1 && !fits(BH)) BH--;
+    if (BH < 2 || !fits(BH)) continue;
+    const int nb = (OH + BH - 1) / BH;
+    BH = (OH + nb - 1) / nb;
     const double score = (double)(S * BH) / rows_for(BH) * CH / ((CH + 15) / 16 * 16);
     if (score > best_score) { best_score = score; best.CH = CH; best.BH = BH; best.nbands = nb; best.rows = rows_for(BH); }
   }

@@ -231,7 +231,9 @@ NETWORK_PATHS = {
               ("whole-network program", {"BSX_NO_SEGMENTS": "1"}, "frame program: ON"),
               ("one launch per step", {"BSX_NO_FRAME_PROGRAM": "1"}, "frame program: off")],
     # DeepLab runs per launch: the split-f16 MFMA GEMM (default) and the f32 MFMA GEMM, with and without the planner's rewrites
-    "deeplab": [("split-f16 MFMA GEMM, fused head and expand+depthwise kernels", {}, "fused with step"), ("f32 MFMA GEMM", {"BSX_F16_GEMM": "off"}, "conv#66-pool"),
+    "deeplab": [("split-f16 MFMA GEMM, fused head and expand+depthwise kernels", {}, "fused with step"),
+                ("whole inverted-residual blocks as one kernel where the block input is small (opt-in: measured slower)", {"BSX_IR_BLOCK": "1"}, "the whole inverted-residual block in one kernel"),
+                ("f32 MFMA GEMM", {"BSX_F16_GEMM": "off"}, "conv#66-pool"),
                 ("no graph rewrites", {"BSX_NO_REWRITES": "1"}, "concat#65"),
                 ("one launch per layer (no fused head, no fused expand+depthwise)", {"BSX_NO_IR_FUSE": "1", "BSX_NO_HEAD0": "1"}, "conv#66-pool")],
 }
@@ -248,7 +250,7 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc = oracle.Ctx(path, W, H)
     oc.prep(f)
     want = oc.infer()
-    knobs = ("BSX_F32_INPUT", "BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
+    knobs = ("BSX_F32_INPUT", "BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0", "BSX_IR_BLOCK", "BSX_IR_BLOCK_MINW")
     for name, env, marker in NETWORK_PATHS[key]:
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
