@@ -97,6 +97,7 @@ struct bsx_ctx {
   float* d_arena = nullptr;
   float* d_net_in = nullptr;        // network input  [n][inH][inW][inC] f32 (written by the prep kernels)
   uint32_t* d_net_in_u8 = nullptr;  // the same tensor before convertTo: [n][inH][inW] R | G<<8 | B<<16 — what the stems with a byte path read (in_u8)
+  bool prep_split = false;          // BSX_PREP_SPLIT=1 (read at bsx_new): resize and bilateral as two launches through the canvas buffer (A/B timing; the default is prep_fused_k)
   bool in_u8 = false;               // the step's prep writes ONLY the 8-bit form and the stem normalises on load (seg_head_k / dl_head0_k; bit-identical).
                                     //   BSX_F32_INPUT=1 (read at bsx_new) keeps the f32 tensor for A/B timing; the stage-debug entry writes both.
   float* d_net_out = nullptr;       // network output [n][outH][outW][outC] f32 (read by the decode kernel)
@@ -255,6 +256,7 @@ int init_device_state(bsx_ctx* c) {
     }
   }
   // stems with a byte path take the 8-bit network input: the segmented Meet / MLKit head and DeepLab's fused head kernel
+  c->prep_split = getenv("BSX_PREP_SPLIT") != nullptr;
   c->in_u8 = getenv("BSX_F32_INPUT") == nullptr && ((c->use_program && c->plan.seg.on) || (!c->use_program && head0_u8_ok(c->plan)));
   BSX_HIP(c, hipMalloc(&c->d_canvas, N * canvas_elems(c->inW, c->inH) * sizeof(uint32_t)));
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
@@ -297,9 +299,14 @@ hipStream_t pick(bsx_ctx*, void* s) { return (hipStream_t)s; }
 
 // with_f32: also materialise the f32 input tensor when the stem reads the 8-bit form (the stage-debug entry: tests inspect the tensor)
 int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s, bool with_f32 = false) {
+  float* f32 = (!c->in_u8 || with_f32) ? c->tensor_ptr(c->plan.input) : nullptr;
+  uint32_t* u8 = c->in_u8 ? c->d_net_in_u8 : nullptr;
+  if (!c->prep_split) {
+    BSX_HIP(c, launch_prep_fused(d_frames, c->width, c->height, c->roi, f32, u8, c->inW, c->inH, c->in_roi, c->tab_down.tab, c->bilateral, n, s));
+    return BSX_OK;
+  }
   BSX_HIP(c, launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
-  BSX_HIP(c, launch_prep_bilateral(c->d_canvas, (!c->in_u8 || with_f32) ? c->tensor_ptr(c->plan.input) : nullptr, c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH,
-                                   c->bilateral, n, s));
+  BSX_HIP(c, launch_prep_bilateral(c->d_canvas, f32, u8, c->inW, c->inH, c->bilateral, n, s));
   return BSX_OK;
 }
 // logits = true: the network output tensor is written (stage tests, the stand-alone decode follows); false: the tail kernel of a
@@ -711,7 +718,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   const int n_net = c->use_program ? (seg ? 5 : 1) : (int)c->plan.steps.size();
   const bool fuse_tail = !c->onmask && !c->no_mask_blend_fusion &&
                          mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
-  const int L = 2 + n_net + (fused_decode ? 0 : 1) + (fuse_tail ? 1 : 2) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
+  const int L = (c->prep_split ? 2 : 1) + n_net + (fused_decode ? 0 : 1) + (fuse_tail ? 1 : 2) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
   if (cap < L) return BSX_EINVAL;
   std::vector<hipEvent_t> ev((size_t)2 * L);
   for (auto& e : ev) BSX_HIP(c, hipEventCreate(&e));
@@ -726,8 +733,12 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       BSX_HIP(c, hipEventRecord(ev[2 * k + 1], s));        \
       k++;                                                 \
     } while (0)
-    BSX_TIMED(launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
-    BSX_TIMED(launch_prep_bilateral(c->d_canvas, c->in_u8 ? nullptr : c->tensor_ptr(c->plan.input), c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH, c->bilateral, n, s));
+    if (c->prep_split) {
+      BSX_TIMED(launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
+      BSX_TIMED(launch_prep_bilateral(c->d_canvas, c->in_u8 ? nullptr : c->tensor_ptr(c->plan.input), c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH, c->bilateral, n, s));
+    } else
+      BSX_TIMED(launch_prep_fused(d_frames, c->width, c->height, c->roi, c->in_u8 ? nullptr : c->tensor_ptr(c->plan.input), c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH, c->in_roi,
+                                  c->tab_down.tab, c->bilateral, n, s));
     const long pf = (long)c->plan.arena_floats_per_stream;
     if (seg) {
       const SegPlan& sp = c->plan.seg;
@@ -769,8 +780,11 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   // prep_resize: reads the TOUCHED source pixels of the ROI — a bilinear tap pair per destination column / row, i.e. at most 2 x 2 source
   // pixels per canvas pixel of in_roi (a 5x down-scale touches 16 % of the ROI) — and writes the 4 B/px canvas with its apron
   const double touched = (double)std::min(c->roi.w, 2 * c->in_roi.w) * (double)std::min(c->roi.h, 2 * c->in_roi.h);
-  put(j++, "prep_resize", N * (3.0 * touched + 4.0 * (double)canvas_elems(c->inW, c->inH)), 0);
-  put(j++, "prep_bilateral", N * (4.0 * canvas + (c->in_u8 ? 4.0 : 12.0) * canvas), 0);
+  if (c->prep_split) {
+    put(j++, "prep_resize", N * (3.0 * touched + 4.0 * (double)canvas_elems(c->inW, c->inH)), 0);
+    put(j++, "prep_bilateral", N * (4.0 * canvas + (c->in_u8 ? 4.0 : 12.0) * canvas), 0);
+  } else
+    put(j++, "prep", N * (3.0 * touched + (c->in_u8 ? 4.0 : 12.0) * canvas), 0);       // fused: touched source pixels in, the network input out
   if (seg) {
     // algorithmic bytes of each segment = the tensors it must read once + write once (f32); flops from the fused steps it covers
     const std::vector<Step>& S = c->plan.steps;

@@ -79,6 +79,9 @@ bool bilateral_taps_match(const BilateralParams& bp);   // host table order == t
 hipError_t launch_prep_resize(const uint8_t* frames, int W, int H, Rect4 roi, uint32_t* canvas, int inW, int inH, Rect4 in_roi,
                               ResizeTab tab, int n, hipStream_t s);
 // bilateral(5,100,100) + convertTo f32 → network input [n][inH][inW][3].  libbackscrub.cc:295-302
+// launch_prep_resize + launch_prep_bilateral as ONE kernel (no canvas in memory); outputs as in launch_prep_bilateral
+hipError_t launch_prep_fused(const uint8_t* frames, int W, int H, Rect4 roi, float* input, uint32_t* input_u8, int inW, int inH, Rect4 in_roi, ResizeTab tab,
+                             BilateralParams bp, int n, hipStream_t s);
 // input (f32 [n][inH][inW][3]) and / or input_u8 (R|G<<8|B<<16 [n][inH][inW]): whichever is non-null is written
 hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, uint32_t* input_u8, int inW, int inH, BilateralParams bp, int n, hipStream_t s);
 // decode + temporal IIR on the model-resolution mask.  libbackscrub.cc:317-357

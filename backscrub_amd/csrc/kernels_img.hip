@@ -156,6 +156,76 @@ __global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __r
   }
 }
 
+// ---- prep, both steps in ONE kernel: the workgroup resizes the (TW + 4) x (TH + 4) canvas pixels its bilateral tile reads straight into LDS -------
+// (every sample of a lane requested before its first use: <= 6 independent tap pairs in flight per lane, where prep_resize_k had one), filters from LDS and
+// writes the network input.  The 4 B/px canvas with its stored apron — one write and one read of it, a launch boundary, and a kernel whose lanes each waited
+// for one dependent pair of loads — is gone; the halo is recomputed (1.27x the samples of a 32 x 32 tile, L2 hits).  Same arithmetic as the two-kernel form
+// (sample_linear, the tap order and roundings of prep_bilateral_k): bit-identical, and the stage-0 tests read its output.  Tile sizes are chosen per model so
+// that the tiles cover the canvas without a sliver (257 = 9 x 29, not 8 x 32 + 1).
+constexpr int kPfS = 36;                    // LDS row stride of the tile (TW <= 32)
+template <int OUT>
+__global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restrict__ frames, int W, int H, Rect4 roi, float* __restrict__ input, uint32_t* __restrict__ input_u8,
+                                                        int inW, int inH, Rect4 q, ResizeTab tab, BilateralParams bp, int TW, int TH) {
+  __shared__ float lut[768];
+  __shared__ uint32_t tile[kPfS * kPfS];
+  const int tid = threadIdx.x;
+  const long n = blockIdx.z;
+  const int tx0 = (int)blockIdx.x * TW, ty0 = (int)blockIdx.y * TH;
+  const int SW = TW + 2 * kCanvasPad, total = SW * (TH + 2 * kCanvasPad);
+  const uint8_t* src = frames + n * (long)W * H * 3 + ((long)roi.y * W + roi.x) * 3;
+  const unsigned msw = 0xFFFFFFFFu / (unsigned)SW + 1u;                    // i / SW for i < 2^16
+#pragma unroll
+  for (int k = 0; k < (kPfS * kPfS + kThreads - 1) / kThreads; k++) {
+    const int i = tid + k * kThreads;
+    if (i < total) {
+      const int ly = (int)__umulhi((unsigned)i, msw), lx = i - ly * SW;
+      const int dx = reflect101(tx0 + lx - kCanvasPad, inW) - q.x, dy = reflect101(ty0 + ly - kCanvasPad, inH) - q.y;
+      uint32_t v = 0;                                                      // the model canvas outside in_roi (the bars) is 0
+      if (dx >= 0 && dx < q.w && dy >= 0 && dy < q.h) {
+        int bgr[3];
+        sample_linear<3>(src, (long)W * 3, tab, dx, dy, bgr);
+        v = (uint32_t)bgr[2] | ((uint32_t)bgr[1] << 8) | ((uint32_t)bgr[0] << 16);  // BGR2RGB
+      }
+      tile[ly * kPfS + lx] = v;
+    }
+  }
+  for (int k = tid; k < 768; k += kThreads) lut[k] = bp.color_lut[k];
+  __syncthreads();
+  const int lx = tid & 31, x = tx0 + lx;
+  if (lx >= TW || x >= inW) return;
+#pragma unroll 2
+  for (int it = 0; it < kBilPix; it++) {
+    const int ly = (tid >> 5) + 8 * it, y = ty0 + ly;
+    if (ly >= TH || y >= inH) return;
+    const unsigned p = (unsigned)(y * inW + x);
+    const uint32_t* row[5];
+#pragma unroll
+    for (int d = 0; d < 5; d++) row[d] = tile + (ly + d) * kPfS + (lx + kCanvasPad);     // tile rows ly-2 .. ly+2 (canvas rows y-2 .. y+2) at column x
+    const uint32_t c0 = row[2][0];
+    float sr = 0.f, sg = 0.f, sb = 0.f, ws = 0.f;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+      const uint32_t c = row[kTapY[k] + 2][kTapX[k]];
+      const float w = __fmul_rn(bp.space_w[k], lut[__builtin_amdgcn_sad_u8(c, c0, 0u)]);
+      const float rr = (float)(c & 255), gg = (float)((c >> 8) & 255), bb = (float)((c >> 16) & 255);
+      sr = __fadd_rn(sr, __fmul_rn(rr, w));
+      sg = __fadd_rn(sg, __fmul_rn(gg, w));
+      sb = __fadd_rn(sb, __fmul_rn(bb, w));
+      ws = __fadd_rn(ws, w);
+    }
+    ws = __fdiv_rn(1.f, ws);
+    int qr = __float2int_rn(__fmul_rn(sr, ws)), qg = __float2int_rn(__fmul_rn(sg, ws)), qb = __float2int_rn(__fmul_rn(sb, ws));
+    qr = min(max(qr, 0), 255); qg = min(max(qg, 0), 255); qb = min(max(qb, 0), 255);
+    if (OUT & 1) {
+      float* o = input + (n * (long)inW * inH + p) * 3;
+      o[0] = __fadd_rn(__fmul_rn((float)qr, bp.scale), bp.offset);
+      o[1] = __fadd_rn(__fmul_rn((float)qg, bp.scale), bp.offset);
+      o[2] = __fadd_rn(__fmul_rn((float)qb, bp.scale), bp.offset);
+    }
+    if (OUT & 2) input_u8[n * (long)inW * inH + p] = (uint32_t)qr | ((uint32_t)qg << 8) | ((uint32_t)qb << 16);
+  }
+}
+
 // ---- decode + temporal IIR -------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void decode_k(int type, const float* __restrict__ t, uint8_t* __restrict__ out, long total, int nch) {
   long i = (long)blockIdx.x * kThreads + threadIdx.x;
@@ -722,6 +792,25 @@ hipError_t launch_prep_resize(const uint8_t* frames, int W, int H, Rect4 roi, ui
     const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
     prep_resize_k<<<dim3(blocks_for((long)canvas_elems(inW, inH)), nn), kThreads, 0, s>>>(frames + (size_t)n0 * W * H * 3, W, H, roi,
                                                                                           canvas + (size_t)n0 * canvas_elems(inW, inH), inW, inH, in_roi, tab);
+  }
+  return hipGetLastError();
+}
+
+// resize + bilateral in one launch (prep_fused_k); input / input_u8 as in launch_prep_bilateral
+hipError_t launch_prep_fused(const uint8_t* frames, int W, int H, Rect4 roi, float* input, uint32_t* input_u8, int inW, int inH, Rect4 in_roi, ResizeTab tab,
+                             BilateralParams bp, int n, hipStream_t s) {
+  if (!input && !input_u8) return hipErrorInvalidValue;
+  const int ntx = (inW + 31) / 32, nty = (inH + 31) / 32, TW = (inW + ntx - 1) / ntx, TH = (inH + nty - 1) / nty;      // even tiles, <= 32 x 32
+  const long per_frame = (long)inW * inH;
+  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
+    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
+    const dim3 grid(ntx, nty, nn);
+    const uint8_t* fr = frames + (size_t)n0 * W * H * 3;
+    float* f = input ? input + (size_t)n0 * per_frame * 3 : nullptr;
+    uint32_t* u = input_u8 ? input_u8 + (size_t)n0 * per_frame : nullptr;
+    if (f && u) prep_fused_k<3><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH);
+    else if (u) prep_fused_k<2><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH);
+    else prep_fused_k<1><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH);
   }
   return hipGetLastError();
 }

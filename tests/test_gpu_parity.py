@@ -250,7 +250,7 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc = oracle.Ctx(path, W, H)
     oc.prep(f)
     want = oc.infer()
-    knobs = ("BSX_F32_INPUT", "BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0", "BSX_IR_BLOCK", "BSX_IR_BLOCK_MINW")
+    knobs = ("BSX_PREP_SPLIT", "BSX_F32_INPUT", "BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0", "BSX_IR_BLOCK", "BSX_IR_BLOCK_MINW")
     for name, env, marker in NETWORK_PATHS[key]:
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
@@ -322,6 +322,29 @@ def test_deeplab_f16_storage_mode_is_gated_by_iou(bs, oracle, monkeypatch):
     assert max(errs) < 2e-2 and max(errs) > 1e-5, errs                # close, and visibly NOT the f32-grade default
     oc.close()
     mg.close()
+
+
+@pytest.mark.parametrize("key,res", CASES + [("lite", (322, 242)), ("deeplab", (641, 479))])
+def test_prep_in_one_kernel_equals_prep_through_the_canvas(bs, monkeypatch, key, res):
+    """prep_fused_k (resize of the tile + halo into LDS, bilateral from LDS: the default) against the two-launch form through the stored canvas
+    (BSX_PREP_SPLIT=1): the same f32 input tensor and the same 8-bit pixels, bit for bit, on every geometry incl. odd frame sizes and a noise stream.
+    (Both forms are also held to the oracle: test_stages_match_oracle runs the default.)"""
+    from backscrub_amd import synth
+    path = model_path(key)
+    W, H = res
+    frames = np.stack([synth.frame(W, H, 0), synth.frame(W, H, 1, 3), synth.random_u8((H, W, 3), 7)])
+    outs = []
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("BSX_PREP_SPLIT", "1")
+        mg = bs.MaskGen(path, W, H, n_streams=4)
+        monkeypatch.delenv("BSX_PREP_SPLIT", raising=False)
+        mg.run_stage(0, _dev(frames))
+        mg.run_stage(1, n=3)
+        outs.append((mg.input_tensor()[:3].clone(), mg.output_tensor()[:3].clone()))
+        mg.close()
+    assert torch.equal(outs[0][0], outs[1][0]), "f32 network input differs"
+    assert torch.equal(outs[0][1], outs[1][1]), "logits differ (the stems read the 8-bit form)"
 
 
 @pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", HD), ("full", HD), ("deeplab", VGA)])

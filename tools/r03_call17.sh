@@ -1,0 +1,18 @@
+#!/bin/bash
+# fused prep kernel (resize + bilateral in one launch): parity (stage tests + split-vs-fused), then A/B on four configs
+cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "prep_in_one_kernel or stages_match or end_to_end_on_the_photo" > gpurun_out/r03m_pytest.txt 2>&1; tail -8 gpurun_out/r03m_pytest.txt
+run() { local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 300 python bench.py --no-extra-configs --no-cpu-baseline --profile-iters 2 "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('${envs[*]} $*', round(d['value']), d['ms_per_step'], [(t['name'],t['ms']) for t in d['top_launches'] if 'prep' in t['name']], d['stage_ms'].get('prep'))"; }
+for rep in 1 2; do
+run X=0 -- --steps 200 --warmup 20 --ramp-seconds 1
+run BSX_PREP_SPLIT=1 -- --steps 200 --warmup 20 --ramp-seconds 1
+done
+run X=0 -- --model mlkit --width 1280 --height 720 --steps 30 --warmup 5 --ramp-seconds 1
+run BSX_PREP_SPLIT=1 -- --model mlkit --width 1280 --height 720 --steps 30 --warmup 5 --ramp-seconds 1
+run X=0 -- --model full --batch 1024 --width 1280 --height 720 --steps 20 --warmup 5 --ramp-seconds 1
+run BSX_PREP_SPLIT=1 -- --model full --batch 1024 --width 1280 --height 720 --steps 20 --warmup 5 --ramp-seconds 1
+run X=0 -- --model deeplab --batch 1024 --bg-ring --steps 10 --warmup 3 --ramp-seconds 1
+run BSX_PREP_SPLIT=1 -- --model deeplab --batch 1024 --bg-ring --steps 10 --warmup 3 --ramp-seconds 1

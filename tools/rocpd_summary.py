@@ -103,13 +103,13 @@ def pmc_json(tag, paths):
                       "kernels": kernels}, indent=1))
 
 
-def step_sequence(path, counter, first="prep_resize_k"):
+def step_sequence(path, counter, first=("prep_fused_k", "prep_resize_k")):
     """Dispatches of ONE bench step in launch order: the kernels between two consecutive dispatches of the step's first kernel
     (the last complete step of the run) → [(kernel, counter value)]."""
     db = sqlite3.connect(path)
     q = ("select dispatch_id, kernel_name, sum(value) from counters_collection where counter_name = ? group by dispatch_id, kernel_name order by dispatch_id")
     rows = [(short(n), v) for _, n, v in db.execute(q, (counter,)).fetchall() if is_ours(n)]
-    starts = [i for i, (n, _) in enumerate(rows) if n.startswith(first)]
+    starts = [i for i, (n, _) in enumerate(rows) if n.startswith(first)]      # the step's first kernel: the fused prep (or, with BSX_PREP_SPLIT=1, the resize)
     if len(starts) < 6:
         return []
     seq = rows[starts[3]:starts[4]]        # the second timed step of `bench.py --warmup 2` (the per-launch profile loop comes after the timed steps)
