@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "kernels.hpp"
+#include "mfma_tile.hpp"
 
 namespace bsx {
 namespace {
@@ -165,12 +166,15 @@ __global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __r
 constexpr int kPfS = 36;                    // LDS row stride of the tile (TW <= 32)
 template <int OUT>
 __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restrict__ frames, int W, int H, Rect4 roi, float* __restrict__ input, uint32_t* __restrict__ input_u8,
-                                                        int inW, int inH, Rect4 q, ResizeTab tab, BilateralParams bp, int TW, int TH) {
+                                                        int inW, int inH, Rect4 q, ResizeTab tab, BilateralParams bp, int TW, int TH, int ntx, int nty, int n_frames) {
   __shared__ float lut[768];
   __shared__ uint32_t tile[kPfS * kPfS];
   const int tid = threadIdx.x;
-  const long n = blockIdx.z;
-  const int tx0 = (int)blockIdx.x * TW, ty0 = (int)blockIdx.y * TH;
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)(ntx * nty), (unsigned)n_frames, &f_, &t_);      // a frame's tiles on ONE XCD: their shared halo lines are L2 hits
+  const long n = f_;
+  const int tby = (int)t_ / ntx, tbx = (int)t_ - tby * ntx;
+  const int tx0 = tbx * TW, ty0 = tby * TH;
   const int SW = TW + 2 * kCanvasPad, total = SW * (TH + 2 * kCanvasPad);
   const uint8_t* src = frames + n * (long)W * H * 3 + ((long)roi.y * W + roi.x) * 3;
   const unsigned msw = 0xFFFFFFFFu / (unsigned)SW + 1u;                    // i / SW for i < 2^16
@@ -802,15 +806,17 @@ hipError_t launch_prep_fused(const uint8_t* frames, int W, int H, Rect4 roi, flo
   if (!input && !input_u8) return hipErrorInvalidValue;
   const int ntx = (inW + 31) / 32, nty = (inH + 31) / 32, TW = (inW + ntx - 1) / ntx, TH = (inH + nty - 1) / nty;      // even tiles, <= 32 x 32
   const long per_frame = (long)inW * inH;
-  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
-    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
-    const dim3 grid(ntx, nty, nn);
+  static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
+  const int chunk = 1 << 20;                                            // frames per launch: keeps the 1-D grid far below 2^31 workgroups
+  for (int n0 = 0; n0 < n; n0 += chunk) {
+    const int nn = n - n0 < chunk ? n - n0 : chunk;
+    const dim3 grid((unsigned)(ntx * nty) * (unsigned)nn);
     const uint8_t* fr = frames + (size_t)n0 * W * H * 3;
     float* f = input ? input + (size_t)n0 * per_frame * 3 : nullptr;
     uint32_t* u = input_u8 ? input_u8 + (size_t)n0 * per_frame : nullptr;
-    if (f && u) prep_fused_k<3><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH);
-    else if (u) prep_fused_k<2><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH);
-    else prep_fused_k<1><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH);
+    if (f && u) prep_fused_k<3><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0);
+    else if (u) prep_fused_k<2><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0);
+    else prep_fused_k<1><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0);
   }
   return hipGetLastError();
 }

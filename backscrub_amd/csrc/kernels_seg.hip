@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.hpp"
 #include "mfma_tile.hpp"
@@ -253,8 +254,10 @@ __device__ __forceinline__ RowTile row_tile(int t, int ctiles, unsigned m_ct) {
 // same two roundings convertTo applies (libbackscrub.cc:302): fadd(fmul(float(q), scale), offset) — bit-identical to reading the f32 tensor.
 template <bool STEM_HSWISH, bool H16, bool U8IN>
 __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float* __restrict__ arena, long per_frame, const float* __restrict__ net_in,
-                                                          const float* __restrict__ w, float in_scale, float in_offset) {
-  const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
+                                                          const float* __restrict__ w, float in_scale, float in_offset, int n_frames) {
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
+  const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC;
   const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, ar0 = 2 * r0 - d.dw_pt, ac0 = 2 * c0 - d.dw_pl, RW = d.rw, ctiles = RW >> 4;
   const int IR = 2 * AR + 1, IC = 2 * AC + 1, ir0 = 2 * ar0 - d.stem_pt, ic0 = 2 * ac0 - d.stem_pl, rowf = IC * 3;
@@ -412,8 +415,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   wave_reduce16<0>(sumA, s_red, wave, lane);
   wave_reduce16<1>(sumB, s_red + 256, wave, lane);
   __syncthreads();
-  store_partials(s_red, fa + d.part_a_off + (long)blockIdx.x * 16);
-  store_partials(s_red + 256, fa + d.part_b0_off + (long)blockIdx.x * 16);
+  store_partials(s_red, fa + d.part_a_off + (long)t_ * 16);
+  store_partials(s_red + 256, fa + d.part_b0_off + (long)t_ * 16);
 }
 
 // ==================================================================================================================================
@@ -421,8 +424,10 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 // The expanded tensor x (72 channels) exists only 16 channels at a time, in LDS.
 // ==================================================================================================================================
 template <bool H16>
-__global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w) {
-  const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
+__global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w, int n_frames) {
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
+  const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC;
   const int BR = 2 * d.TR + 1, BC = 2 * d.TC + 1, br0 = 2 * r0 - d.dw_pt, bc0 = 2 * c0 - d.dw_pl, RW = d.rw, ctiles = RW >> 4;
   float* fa = arena + (size_t)f * (size_t)per_frame;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
   float* s_red = seg_smem + kScrRed;
   wave_reduce16<0>(sumB, s_red, wave, lane);
   __syncthreads();
-  store_partials(s_red, fa + d.part_B_off + (long)blockIdx.x * 16);
+  store_partials(s_red, fa + d.part_B_off + (long)t_ * 16);
 
   // 2. 16 expanded channels at a time: x = act(pw_b(B)) → depthwise 3x3/s2 → c0
   const int C = d.dw.C, ngrp = (C + 15) >> 4, quad = lane & 3, px = lane >> 2;
@@ -608,8 +613,10 @@ __device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* 
 // k3 (decoder level 2): z = act(pw1(B * g + up(lo2))); t = z + act(dw3x3(z)); lo = pw2(t).  Tile = TR x TC (<= 14) at the B resolution.
 // ==================================================================================================================================
 template <bool H16>
-__global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w) {
-  const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
+__global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w, int n_frames) {
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
+  const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC, ZH = d.TR + 2, ZC = d.TC + 2;
   float* fa = arena + (size_t)f * (size_t)per_frame;
   float* z_t = seg_smem + kScrFloats;                               // [ZH][16][16]
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
   float* s_red = seg_smem + kScrRed;
   wave_reduce16<0>(sum, s_red, wave, lane);
   __syncthreads();
-  store_partials(s_red, fa + d.part_lo_off + (long)blockIdx.x * 16);
+  store_partials(s_red, fa + d.part_lo_off + (long)t_ * 16);
 }
 
 // ==================================================================================================================================
@@ -664,8 +671,10 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
 // ==================================================================================================================================
 template <int CO, bool LOGITS, bool SIGMOID, bool H16>
 __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float* __restrict__ arena, long per_frame, float* __restrict__ net_out,
-                                                          uint8_t* __restrict__ ofinal, const float* __restrict__ w) {
-  const int f = blockIdx.y, ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
+                                                          uint8_t* __restrict__ ofinal, const float* __restrict__ w, int n_frames) {
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
+  const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
   const int r0 = ty * d.TR, c0 = tx * d.TC, ZH = d.TR + 2, ZC = d.TC + 2;
   float* fa = arena + (size_t)f * (size_t)per_frame;
   float* z_t = seg_smem + kScrFloats;                               // [ZH][16][16]
@@ -757,47 +766,50 @@ hipError_t seg_prepare() {
   return e;
 }
 
+// n_frames = 0 tells xcd_frame_tile to keep the plain (frame-major) workgroup order: BSX_XCD_TILES=0, read once per process, for A/B timing
+static int xcd_frames(int n) { static const bool on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0); return on ? n : 0; }
+
 // h16: the boundary tensors are stored as halves (BSX_ACT16; the middle program must have been generated for the same storage)
 // u8: net_in points at the 8-bit network input ([n][H0][W0] u32 pixels, prep_bilateral_k<2>) and (scale, offset) is the model's normalisation
 hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const void* net_in, const float* weights, int n, hipStream_t s, bool h16, bool u8, float in_scale,
                            float in_offset) {
-  const dim3 grid(d.tiles_y * d.tiles_x, n);
+  const dim3 grid((unsigned)(d.tiles_y * d.tiles_x) * (unsigned)n);
   const size_t lds = (size_t)d.lds_floats * sizeof(float);
   const bool hs = d.stem.act == kActHswish;
   const float* in = static_cast<const float*>(net_in);
   if (u8 && 2 * (2 * d.TC + 1) + 1 > 64) return hipErrorInvalidValue;          // one lane per pixel of an input-tile row (the planner's TC <= 15)
-#define BSX_HEAD(HS, H, U) seg_head_k<HS, H, U><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, in, weights, in_scale, in_offset)
+#define BSX_HEAD(HS, H, U) seg_head_k<HS, H, U><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, in, weights, in_scale, in_offset, xcd_frames(n))
   if (hs) { if (h16) { if (u8) BSX_HEAD(true, true, true); else BSX_HEAD(true, true, false); } else { if (u8) BSX_HEAD(true, false, true); else BSX_HEAD(true, false, false); } }
   else { if (h16) { if (u8) BSX_HEAD(false, true, true); else BSX_HEAD(false, true, false); } else { if (u8) BSX_HEAD(false, false, true); else BSX_HEAD(false, false, false); } }
 #undef BSX_HEAD
   return hipGetLastError();
 }
 hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16) {
-  const dim3 grid(d.tiles_y * d.tiles_x, n);
-  if (h16) seg_k2_k<true><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
-  else seg_k2_k<false><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
+  const dim3 grid((unsigned)(d.tiles_y * d.tiles_x) * (unsigned)n);
+  if (h16) seg_k2_k<true><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights, xcd_frames(n));
+  else seg_k2_k<false><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights, xcd_frames(n));
   return hipGetLastError();
 }
 hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16) {
-  const dim3 grid(d.tiles_y * d.tiles_x, n);
-  if (h16) seg_k3_k<true><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
-  else seg_k3_k<false><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights);
+  const dim3 grid((unsigned)(d.tiles_y * d.tiles_x) * (unsigned)n);
+  if (h16) seg_k3_k<true><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights, xcd_frames(n));
+  else seg_k3_k<false><<<grid, kSegThreads, (size_t)d.lds_floats * sizeof(float), s>>>(d, arena, per_frame, weights, xcd_frames(n));
   return hipGetLastError();
 }
 template <bool H16>
 static hipError_t launch_seg_tail_t(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s) {
-  const dim3 grid(d.tiles_y * d.tiles_x, n);
+  const dim3 grid((unsigned)(d.tiles_y * d.tiles_x) * (unsigned)n);
   const size_t lds = (size_t)d.lds_floats * sizeof(float);
   const bool sig = d.act3 == kActSigmoid;
   if (d.Co == 2 && !sig) {
-    if (logits) seg_tail_k<2, true, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
-    else seg_tail_k<2, false, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    if (logits) seg_tail_k<2, true, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights, xcd_frames(n));
+    else seg_tail_k<2, false, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights, xcd_frames(n));
   } else if (d.Co == 1 && sig) {
-    if (logits) seg_tail_k<1, true, true, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
-    else seg_tail_k<1, false, true, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    if (logits) seg_tail_k<1, true, true, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights, xcd_frames(n));
+    else seg_tail_k<1, false, true, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights, xcd_frames(n));
   } else if (d.Co == 1) {
-    if (logits) seg_tail_k<1, true, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
-    else seg_tail_k<1, false, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights);
+    if (logits) seg_tail_k<1, true, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights, xcd_frames(n));
+    else seg_tail_k<1, false, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights, xcd_frames(n));
   } else {
     return hipErrorInvalidValue;
   }

@@ -25,4 +25,22 @@ __device__ __forceinline__ float4 quad_transpose(const f4acc acc, int q) {
   return hi ? make_float4(r0, r1, t2, t3) : make_float4(t0, t1, r0, r1);
 }
 
+// XCD-aware (frame, tile) order for kernels whose workgroups are tiles of independent frames and read a halo of their neighbours' input.  The dispatcher
+// places workgroup b of a 1-D grid on XCD b % 8 and every XCD has its own L2: with the plain order the tiles of one frame are spread over all eight L2s and
+// every halo line is fetched from HBM once per XCD that touches it (PMC: prep_fused_k fetched 147 MB for 94 MB of touched pixels).  Here XCD k walks frames
+// k, k + 8, k + 16, … tile by tile, so a frame's tiles — and their shared halo lines — meet in ONE L2.  Bijective for any frame count (the last n % 8 frames
+// keep the plain order); speed only, never correctness.
+__device__ __forceinline__ void xcd_frame_tile(unsigned tiles, unsigned n_frames, unsigned* frame, unsigned* tile) {
+  const unsigned id = blockIdx.x, full = (n_frames & ~7u) * tiles;
+  if (id < full) {
+    const unsigned xcd = id & 7u, local = id >> 3, g = local / tiles;
+    *frame = 8u * g + xcd;
+    *tile = local - g * tiles;
+  } else {
+    const unsigned r = id - full, f = r / tiles;
+    *frame = (n_frames & ~7u) + f;
+    *tile = r - f * tiles;
+  }
+}
+
 }  // namespace bsx

@@ -1186,8 +1186,8 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
         // conv#6 block 0.897 vs 0.496 + 0.371 ms, conv#3 block 1.507 vs 0.829 + 0.195, conv#10 0.642 vs 0.311 + 0.086, conv#13 0.347 vs 0.137 + 0.141 —
         // profiles/r03l): the chunk loop serialises three phases behind two barriers per chunk in a workgroup that has to share its 80 KB between the
         // expanded band and the depthwise band (smaller bands = more halo rows), where the two-kernel form runs three times as many independent workgroups.
-        static const int block_minw = getenv("BSX_IR_BLOCK_MINW") ? atoi(getenv("BSX_IR_BLOCK_MINW")) : 0;      // A/B timing: only layers at least this wide
-        static const bool block_on = getenv("BSX_IR_BLOCK") != nullptr && atoi(getenv("BSX_IR_BLOCK")) != 0;
+        const int block_minw = getenv("BSX_IR_BLOCK_MINW") ? atoi(getenv("BSX_IR_BLOCK_MINW")) : 0;      // A/B timing: only layers at least this wide
+        const bool block_on = getenv("BSX_IR_BLOCK") != nullptr && atoi(getenv("BSX_IR_BLOCK")) != 0;       // (plan time: read per plan, like the planner's other switches)
         if (pj.in_from_fused_dw && block_on && a.OW >= block_minw && a.k16_pad == 32 && a.Cin <= 16 && pj.cout_pad == 16 && pj.Cout % 4 == 0 && pj.out_bias < 0 &&
             pj.act < kActHswish && pj.out != g.output && a.OW == d.W && (long)a.OH * a.OW * d.dh < 65536 &&
             ir_block_geometry(a.OH, a.OW, a.Cout, d.OH, d.OW, d.sh, d.dh).CH != 0) {
