@@ -487,7 +487,7 @@ template <bool BLEND>
 __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                                uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                                const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
-                                                               uint8_t* __restrict__ outp, int yuyv) {
+                                                               uint8_t* __restrict__ outp, int yuyv, int ntx, int nty, int n_frames) {
   // coefficients are 0..2048: kept as 16-bit so that every product below is a full-rate 24-bit multiply
   __shared__ int col_sx[kHW], col_sx1[kHW], row_s0[kHH], row_s1[kHH];
   __shared__ short col_a0[kHW], col_a1[kHW], row_b0[kHH], row_b1[kHH];
@@ -497,8 +497,10 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
   uint16_t* const hq = hq_hs;
   uint16_t* const hs = hq_hs;
   __shared__ int s_min, s_max;
-  const int n = blockIdx.z;
-  const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)(ntx * nty), (unsigned)n_frames, &f_, &t_);
+  const int n = (int)f_, tby = (int)t_ / ntx, tbx = (int)t_ - tby * ntx;
+  const int tx0 = tbx * kTW, ty0 = tby * kTH;
   const uint8_t* src = ofinal + (long)n * outW * outH + (long)q.y * outW + q.x;
   const int tid = threadIdx.x;
   TileBlendOperands ops;
@@ -579,7 +581,7 @@ template <bool BLEND>
 __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                        uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                        const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
-                                                       uint8_t* __restrict__ outp, int yuyv) {
+                                                       uint8_t* __restrict__ outp, int yuyv, int ntx, int nty, int n_frames) {
   __shared__ short col_c0[kHW], col_c1[kHW], col_a0[kHW], col_a1[kHW];     // block-relative tap columns, coefficients
   __shared__ short row_r0[kHH], row_r1[kHH], row_b0[kHH], row_b1[kHH];     // block-relative tap rows, coefficients
   __shared__ __attribute__((aligned(16))) uint16_t hq_hs[kMaxSrcRows * kHW > kHH * kTW ? kMaxSrcRows * kHW : kHH * kTW];
@@ -587,8 +589,12 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   uint16_t* const hq = hq_hs;
   uint16_t* const hs = hq_hs;
   uint8_t* const blk = up;
-  const int n = blockIdx.z, tid = threadIdx.x;
-  const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
+  // XCD-aware order: a frame's tiles run on ONE XCD.  Where the ROI does not start on a 128-byte line (roi.x = 80 / 280: DeepLab, MLKit) the 384-byte row
+  // segments of neighbouring tiles share cache lines — fetched once per L2 that touches them (PMC: 1.8x the frame bytes in the plain order).
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)(ntx * nty), (unsigned)n_frames, &f_, &t_);
+  const int n = (int)f_, tid = threadIdx.x, tby = (int)t_ / ntx, tbx = (int)t_ - tby * ntx;
+  const int tx0 = tbx * kTW, ty0 = tby * kTH;
   // extents of the source block: xofs / yofs are monotonic, so the extreme destination rows / columns give them
   const int gy_lo = max(ty0 - 2, 0), gy_hi = min(ty0 + kTH + 1, roi.h - 1);
   const int gx_lo = max(tx0 - 2, 0), gx_hi = min(tx0 + kTW + 1, roi.w - 1);
@@ -876,9 +882,16 @@ static bool mask_tile_usable(const ResizeTab& tab) { return tab.mode == 0 && tab
 
 hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                                     int n, hipStream_t s) {
-  dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
-  if (mask_tile_usable(tab)) mask_tile_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0);
-  else mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0);
+  const int ntx = (roi.w + kTW - 1) / kTW, nty = (roi.h + kTH - 1) / kTH;
+  if ((unsigned long long)ntx * nty * (unsigned long long)n >= (1ull << 31)) return hipErrorInvalidValue;
+  static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
+  // one-XCD-per-frame order only where neighbouring tiles SHARE cache lines, i.e. the ROI's rows do not start on a 128-byte line (roi.x = 80 / 280: measured
+  // mask+blend 0.480 -> 0.464 ms at 256 HD MLKit streams); on line-aligned geometries nothing is shared and the plain order measured 2-3 % faster (profiles/r03o)
+  const bool shared_lines = ((roi.x * 3) & 127) != 0 || ((W * 3) & 127) != 0;
+  const int nf = (xcd_on && shared_lines) ? n : 0;
+  dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
+  if (mask_tile_usable(tab)) mask_tile_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0, ntx, nty, nf);
+  else mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0, ntx, nty, nf);
   return hipGetLastError();
 }
 
@@ -899,9 +912,16 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   else if (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H)
     outside_roi_copy_k<<<dim3(blocks_for((long)(H - roi.h) * (W * 3 / 4) + (long)roi.h * ((W - roi.w) * 3 / 4)), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H,
                                                                                                                                  roi);
-  dim3 grid((roi.w + kTW - 1) / kTW, (roi.h + kTH - 1) / kTH, n);
-  if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv);
-  else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv);
+  const int ntx = (roi.w + kTW - 1) / kTW, nty = (roi.h + kTH - 1) / kTH;
+  if ((unsigned long long)ntx * nty * (unsigned long long)n >= (1ull << 31)) return hipErrorInvalidValue;
+  static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
+  // one-XCD-per-frame order only where neighbouring tiles SHARE cache lines, i.e. the ROI's rows do not start on a 128-byte line (roi.x = 80 / 280: measured
+  // mask+blend 0.480 -> 0.464 ms at 256 HD MLKit streams); on line-aligned geometries nothing is shared and the plain order measured 2-3 % faster (profiles/r03o)
+  const bool shared_lines = ((roi.x * 3) & 127) != 0 || ((W * 3) & 127) != 0;
+  const int nf = (xcd_on && shared_lines) ? n : 0;
+  dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
+  if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
+  else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   return hipGetLastError();
 }
 

@@ -1132,11 +1132,13 @@ __global__ __launch_bounds__(kH0Threads) void dl_head0_k(const float* __restrict
                                                         const float* __restrict__ wd, const float* __restrict__ bd, const float* __restrict__ wp,
                                                         const float* __restrict__ bp, float* __restrict__ y, int H0, int W0, int H1, int W1, int pt, int pl,
                                                         int C2, int pw_cout_pad, int act_s, int act_d, int act_p, int BH, int nbands, int phases, float in_scale,
-                                                        float in_offset) {
+                                                        float in_offset, int n_frames) {
   extern __shared__ __attribute__((aligned(16))) float h0_lds[];
   const int tid = threadIdx.x;
-  const long frame = blockIdx.x / nbands;
-  const int band = (int)(blockIdx.x - frame * nbands);
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)nbands, (unsigned)n_frames, &f_, &t_);              // a frame's bands on one XCD: the halo rows two bands share are L2 hits
+  const long frame = f_;
+  const int band = (int)t_;
   const int oy0 = band * BH, oy1 = min(oy0 + BH, H1), SR = oy1 - oy0 + 2, sy0 = oy0 - 1;      // stem rows [sy0, sy0 + SR)
   const int IR = 2 * SR + 1, iy0 = 2 * sy0 - pt, rowf = (W0 + 2) * 3;                          // input rows [iy0, iy0 + IR), one zero pixel left and right
   float* in_t = h0_lds;                                         // [IR][W0 + 2][3]
@@ -1675,10 +1677,13 @@ __global__ __launch_bounds__(kThreads) void resize_px_k(const float* __restrict_
 constexpr int kFusedTW = 64, kFusedTH = 16, kFusedMaxSrc = 160;    // source pixels per tile (rows x cols), C <= kResizePxMaxC
 template <bool PERSON_ONLY>      // true: only "is the first maximum the person class?" is formed (two running maxima), not the argmax itself
 __global__ __launch_bounds__(kThreads) void resize_argmax_iir_k(const float* __restrict__ x, uint8_t* __restrict__ ofinal, int H, int W, int C, int OH, int OW,
-                                                               float hs, float ws, int half_pixel, int person) {
+                                                               float hs, float ws, int half_pixel, int person, int ntx, int nty, int n_frames) {
   __shared__ float src[kFusedMaxSrc * kResizePxMaxC];
-  const long n = blockIdx.z;
-  const int ox0 = blockIdx.x * kFusedTW, oy0 = blockIdx.y * kFusedTH;
+  unsigned f_, t_;
+  xcd_frame_tile((unsigned)(ntx * nty), (unsigned)n_frames, &f_, &t_);      // a frame's tiles on one XCD: the 91 KB logits tensor is fetched into ONE L2 (PMC: 2.7x over-fetch in the plain order)
+  const long n = f_;
+  const int tby = (int)t_ / ntx, tbx = (int)t_ - tby * ntx;
+  const int ox0 = tbx * kFusedTW, oy0 = tby * kFusedTH;
   const int tx = threadIdx.x & (kFusedTW - 1), ty = threadIdx.x >> 6;
   // source window of the tile (monotone maps)
   float fr; int a0, a1, sy0, sy1, sx0, sx1;
@@ -1820,10 +1825,14 @@ hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofi
   float hs = (float)st.H / (float)st.OH, ws = (float)st.W / (float)st.OW;
   if (st.align_corners && st.OH > 1) hs = (float)(st.H - 1) / (float)(st.OH - 1);
   if (st.align_corners && st.OW > 1) ws = (float)(st.W - 1) / (float)(st.OW - 1);
-  dim3 grid((st.OW + kFusedTW - 1) / kFusedTW, (st.OH + kFusedTH - 1) / kFusedTH, n);
+  const int ntx = (st.OW + kFusedTW - 1) / kFusedTW, nty = (st.OH + kFusedTH - 1) / kFusedTH;
+  if ((unsigned long long)ntx * nty * (unsigned long long)n >= (1ull << 31)) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
+  static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
+  const int nf = xcd_on ? n : 0;
   const int person = 15;                                           // lib/libbackscrub.cc:330 (pascal VOC class 15)
-  if (!generic && st.Cin <= 24 && person < st.Cin) resize_argmax_iir_k<true><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person);
-  else resize_argmax_iir_k<false><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, generic ? -1 - person : person);
+  if (!generic && st.Cin <= 24 && person < st.Cin) resize_argmax_iir_k<true><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person, ntx, nty, nf);
+  else resize_argmax_iir_k<false><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, generic ? -1 - person : person, ntx, nty, nf);
   return hipGetLastError();
 }
 
@@ -1982,16 +1991,17 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const int BH = head0_band_rows(st.W, st.OW), nb = (st.OH + BH - 1) / BH;
         const size_t fl = (size_t)head0_lds_floats(st.W, st.OW, BH);
         static const int h0_phases = getenv("BSX_H0_PHASES") ? atoi(getenv("BSX_H0_PHASES")) : 15;   // timing experiments
+        static const bool h0_xcd = getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 2;      // one-XCD-per-frame band order: measured SLOWER here (0.927 vs 0.908 ms, profiles/r03o) — only with BSX_XCD_TILES=2
         const bool u8_fits = (long)(2 * (BH + 2) + 1) * st.W <= 4 * 3 * kH0Threads;                // three 4-pixel loads per lane cover the band's rows
         if (net_in_u8 && st.in0 == plan.input && !u8_fits) return hipErrorInvalidValue;            // (bsx_api decides with the same rule: head0_u8_ok)
         if (net_in_u8 && st.in0 == plan.input)
           dl_head0_k<true><<<(unsigned)nb * (unsigned)n, kH0Threads, fl * sizeof(float), s>>>(reinterpret_cast<const float*>(net_in_u8), w, b, weights + d1.w_off, weights + d1.b_off,
                                                                                             weights + p2.w_off, weights + p2.b_off, P(p2.out), st.H, st.W, st.OH, st.OW, st.pad_t,
-                                                                                            st.pad_l, p2.Cout, p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases, in_scale, in_offset);
+                                                                                            st.pad_l, p2.Cout, p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases, in_scale, in_offset, h0_xcd ? n : 0);
         else
           dl_head0_k<false><<<(unsigned)nb * (unsigned)n, kH0Threads, fl * sizeof(float), s>>>(P(st.in0), w, b, weights + d1.w_off, weights + d1.b_off, weights + p2.w_off,
                                                                                              weights + p2.b_off, P(p2.out), st.H, st.W, st.OH, st.OW, st.pad_t, st.pad_l, p2.Cout,
-                                                                                             p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases, 0.f, 0.f);
+                                                                                             p2.cout_pad, st.act, d1.act, p2.act, BH, nb, h0_phases, 0.f, 0.f, h0_xcd ? n : 0);
         break;
       }
       long M = (long)n * st.OH * st.OW;
