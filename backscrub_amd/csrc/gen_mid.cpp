@@ -100,7 +100,8 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
       if (m.scale.space != kLocNone && m.scale.space != kLocLds) return fail("pw: scale vector outside LDS");
       o.f("struct Op%d {\n  static constexpr int P = %d, CIN = %d, COUT = %d, CPAD = %d, ACT = %d;\n", i, m.OH * m.OW, m.Cin, m.Cout, m.cout_pad, m.act);
       loc(o, "X", m.in0); loc(o, "Y", m.out); loc(o, "R", m.res); loc(o, "D", m.in2);
-      o.f("  static constexpr int S_OFF = %d, W_LDS = %d, B_LDS = %d;\n};\n", m.scale.space == kLocLds ? m.scale.off : -1, m.w_lds, m.w_lds + (int)(m.b_off - m.w_off));
+      o.f("  static constexpr int S_OFF = %d, W_LDS = %d, B_LDS = %d;\n", m.scale.space == kLocLds ? m.scale.off : -1, m.w_lds, m.w_lds + (int)(m.b_off - m.w_off));
+      o.f("  static constexpr bool NFAST = %s;\n};\n", (m.out.space == kLocGlobal && !getenv("BSX_RTC_NO_NFAST")) ? "true" : "false");
       k.f("  op_pw<Op%d>(L, A);\n", i);
     } else if (m.kind == (int)StepKind::DwConv) {
       const bool ok = m.strip && m.dh == 1 && m.dw == 1 && m.kh == m.kw && (m.kh == 3 || m.kh == 5) && m.sh == m.sw && (m.sh == 1 || m.sh == 2) && m.Cin % 4 == 0;

@@ -164,7 +164,10 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
   for (int it = 0; it < (TILES + kWaves - 1) / kWaves; it++) {
     const int wi = wave + it * kWaves;
     if (wi >= TILES) break;
-    const int tn = wi / MT, tm = wi - tn * MT, m0 = tm << 4, n0 = tn << 4;
+    // tile order.  LDS output: M-tile fastest (the 16 waves of a round share one B tile).  Output in the ARENA (a tensor that does not fit LDS): N-tile
+    // fastest (T::NFAST) — the waves of a round then write ADJACENT 64-byte pieces of the same 16 pixel rows at the same time, which the L2 merges into
+    // whole lines, instead of sixteen isolated 64-byte pieces 4 * COUT bytes apart each; the shared A rows are read once per round.
+    const int tn = T::NFAST ? wi % NT : wi / MT, tm = T::NFAST ? wi / NT : wi - tn * MT, m0 = tm << 4, n0 = tn << 4;
     const int arow = (P % 16 == 0) ? m0 + li : min(m0 + li, P - 1);      // rows past the end read a valid pixel; results are dropped
     const int xo = arow * T::X_ST + 4 * g;
     const lds_f* bp = wl + (4 * g) * CPAD + n0 + li;
