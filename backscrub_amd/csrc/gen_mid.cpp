@@ -101,7 +101,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
       o.f("struct Op%d {\n  static constexpr int P = %d, CIN = %d, COUT = %d, CPAD = %d, ACT = %d;\n", i, m.OH * m.OW, m.Cin, m.Cout, m.cout_pad, m.act);
       loc(o, "X", m.in0); loc(o, "Y", m.out); loc(o, "R", m.res); loc(o, "D", m.in2);
       o.f("  static constexpr int S_OFF = %d, W_LDS = %d, B_LDS = %d;\n", m.scale.space == kLocLds ? m.scale.off : -1, m.w_lds, m.w_lds + (int)(m.b_off - m.w_off));
-      o.f("  static constexpr bool NFAST = %s;\n};\n", (m.out.space == kLocGlobal && !getenv("BSX_RTC_NO_NFAST")) ? "true" : "false");
+      o.f("  static constexpr bool NFAST = %s;\n};\n", ((m.out.space == kLocGlobal && !getenv("BSX_RTC_NO_NFAST")) || (m.in0.space == kLocGlobal && m.cout_pad > 16 && !getenv("BSX_RTC_NO_NFAST_IN"))) ? "true" : "false");      // arena INPUT: the column tiles of one row tile run back to back, its A rows are fetched once
       k.f("  op_pw<Op%d>(L, A);\n", i);
     } else if (m.kind == (int)StepKind::DwConv) {
       const bool ok = m.strip && m.dh == 1 && m.dw == 1 && m.kh == m.kw && (m.kh == 3 || m.kh == 5) && m.sh == m.sw && (m.sh == 1 || m.sh == 2) && m.Cin % 4 == 0;
@@ -110,15 +110,26 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
       int TX = S == 1 ? 5 : 4;
       if (S == 1 && m.OW % 5 != 0 && m.OW % 4 == 0) TX = 4;
       const bool staged = m.stage_floats > 0;
-      o.f("struct Op%d {\n  static constexpr int K = %d, S = %d, H = %d, W = %d, OH = %d, OW = %d, PT = %d, PL = %d, C = %d, ACT = %d, V = %d, TX = %d;\n", i, K, S, m.H, m.W,
-          m.OH, m.OW, m.pt, m.pl, m.Cin, m.act, V, TX);
-      loc(o, "X", m.in0); loc(o, "Y", m.out); loc(o, "R", m.res);
-      if (staged) o.f("  static constexpr int W_SP = SP_LDS, W_OFF = %d, B_OFF = %d;\n};\n", m.w_lds, m.w_lds + (int)(m.b_off - m.w_off));
-      else {
-        if (m.w_off > 0x7fffffffll || m.b_off > 0x7fffffffll) return fail("dw: weight offset");
-        o.f("  static constexpr int W_SP = SP_GLB, W_OFF = %lld, B_OFF = %lld;\n};\n", m.w_off, m.b_off);
+      if (!staged && (m.w_off > 0x7fffffffll || m.b_off > 0x7fffffffll)) return fail("dw: weight offset");
+      // one traits struct per channel chunk: the whole layer (CK = C), or — input in the arena and an LDS workspace planned for it (plan.cpp) — chunks of
+      // band_rows channels staged through the workspace by load_chunk
+      const bool chunked = m.in0.space == kLocGlobal && m.band_rows > 0 && m.Cin % m.band_rows == 0 && m.res.space == kLocNone && !getenv("BSX_RTC_NO_DW_STAGE");
+      const int CK = chunked ? m.band_rows : m.Cin, nch = m.Cin / CK;
+      for (int c = 0; c < nch; c++) {
+        char name[32];
+        if (chunked) snprintf(name, sizeof name, "Op%d_%d", i, c); else snprintf(name, sizeof name, "Op%d", i);
+        o.f("struct %s {\n  static constexpr int K = %d, S = %d, H = %d, W = %d, OH = %d, OW = %d, PT = %d, PL = %d, C = %d, CW = %d, YC0 = %d, ACT = %d, V = %d, TX = %d;\n", name, K, S,
+            m.H, m.W, m.OH, m.OW, m.pt, m.pl, CK, m.Cin, c * CK, m.act, V, TX);
+        if (chunked) o.f("  static constexpr int X_SP = 1, X_OFF = %d, X_ST = %d;\n", m.ws_off, CK + 4); else loc(o, "X", m.in0);
+        loc(o, "Y", m.out); loc(o, "R", m.res);
+        if (staged) o.f("  static constexpr int W_SP = SP_LDS, W_OFF = %d, B_OFF = %d;\n};\n", m.w_lds + c * CK, m.w_lds + (int)(m.b_off - m.w_off) + c * CK);
+        else o.f("  static constexpr int W_SP = SP_GLB, W_OFF = %lld, B_OFF = %lld;\n};\n", m.w_off + c * CK, m.b_off + c * CK);
+        if (chunked) {
+          if (c > 0) k.f("  __syncthreads();\n");                 // the previous chunk's taps are done with the workspace
+          k.f("  load_chunk<%d, %d, %d, %d, %d, %d, %d>(L, A);\n  __syncthreads();\n", asp(m.in0), m.in0.off, m.H * m.W, m.in0.stride, CK, c * CK, m.ws_off);
+        }
+        k.f("  op_dw<%s>(L, A, W);\n", name);
       }
-      k.f("  op_dw<Op%d>(L, A, W);\n", i);
     } else if (m.kind == kMicroSe) {
       if (m.in1.space != kLocLds || (m.n_fc == 2 && m.in2.space != kLocLds) || m.Cin % 4 || m.C1 % 1) return fail("se: mean / hidden vectors outside LDS");
       if (m.w2_off > 0x7fffffffll || m.w3_off > 0x7fffffffll) return fail("se: weight offset");

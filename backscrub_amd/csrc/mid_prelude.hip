@@ -230,12 +230,33 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
   }
 }
 
+// ---- channels [C0, C0 + CK) of an arena tensor [P][CFULL] → LDS workspace [P][CK + 4] (one coalesced pass: CK / 4 lanes read one pixel's 4 CK contiguous bytes) ----
+// A depthwise whose input lives in the arena reads every element ~10 times (K output rows x overlapping strips) through an L2 that 32 frames share; with the
+// chunk staged here each element leaves memory ONCE and the taps run from LDS.  All of a lane's loads are in flight before its first LDS store.
+template <int SP, int X_OFF, int P, int CFULL, int CK, int C0, int WS>
+__device__ __forceinline__ void load_chunk(lds_f* L, const glb_f* A) {
+  constexpr int Q = CK / 4, TOTAL = P * Q, IT = (TOTAL + kThreads - 1) / kThreads;
+  f4v v[IT];
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int i = min((int)threadIdx.x + it * kThreads, TOTAL - 1), px = i / Q, q = i - px * Q;
+    v[it] = ld4<SP>(L, A + X_OFF, px * CFULL + C0 + 4 * q);
+  }
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int i = (int)threadIdx.x + it * kThreads, px = i / Q, q = i - px * Q;
+    if (i < TOTAL) *(lds_v4*)(L + WS + px * (CK + 4) + 4 * q) = v[it];
+  }
+}
+
 // ---- depthwise k x k, register-strip form -----------------------------------------------------------------------------------------
 // lane = (channel pair / quad, strip of TX consecutive output columns, output row): per filter row the lane loads the (TX-1) S + K
 // inputs its strip touches and the K weights once and forms TX outputs from registers (kernels_frame.hip: dw_strip).  Everything
 // — the item decomposition included — is compile-time here; rows and columns outside the image contribute exact zeros.
 // FMA order per output: fy, fx ascending, bias last (TFLite reference order).
-// Traits: K S H W OH OW PT PL C ACT | X_SP X_OFF X_ST | Y_SP Y_OFF Y_ST | R_SP R_OFF R_ST | W_SP (LDS staged / GLB) W_OFF B_OFF | V TX
+// Traits: K S H W OH OW PT PL C ACT | X_SP X_OFF X_ST | Y_SP Y_OFF Y_ST | R_SP R_OFF R_ST | W_SP (LDS staged / GLB) W_OFF B_OFF | V TX | CW YC0
+// (CW = channels of the WHOLE layer = row stride of the weight block, YC0 = first output channel: C < CW when the op is one channel chunk of a layer whose input
+//  is staged through LDS chunk by chunk — load_chunk below)
 template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, const glb_f* Wg) {
   constexpr int K = T::K, S = T::S, TX = T::TX, V = T::V, C = T::C, CV = C / V, NIN = (TX - 1) * S + K;
   constexpr int NSTRIPS = (T::OW + TX - 1) / TX, TOTAL = CV * NSTRIPS * T::OH;
@@ -259,7 +280,7 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
 #pragma unroll
       for (int j = 0; j < NIN; j++) xin[j] = ldx(rowo + min(max(ix0 + j, 0), T::W - 1) * T::X_ST);
 #pragma unroll
-      for (int fx = 0; fx < K; fx++) { wv[fx] = ldw(T::W_OFF + (fy * K + fx) * C + ch); if (!vy) wv[fx] = (vec_t)(0.f); }
+      for (int fx = 0; fx < K; fx++) { wv[fx] = ldw(T::W_OFF + (fy * K + fx) * T::CW + ch); if (!vy) wv[fx] = (vec_t)(0.f); }
     };
     auto fma_row = [&](vec_t (&xin)[NIN], const vec_t (&wv)[K]) {
 #pragma unroll
@@ -312,11 +333,11 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
     for (int k = 0; k < TX; k++) {
       const int ox = ox0 + k;
       if (T::OW % TX == 0 || ox < T::OW) {
-        const int pix = oy * T::OW + ox;
+        const int pix = oy * T::OW + ox, cho = ch + T::YC0;
         vec_t v = acc[k] + bq;
         if constexpr (V == 4) v = act4<T::ACT>(v); else v = act2<T::ACT>(v);
         if constexpr (T::R_SP != SP_NONE) { if constexpr (V == 4) v += ld4<T::R_SP>(L + T::R_OFF, A + T::R_OFF, pix * T::R_ST + ch); else v += ld2<T::R_SP>(L + T::R_OFF, A + T::R_OFF, pix * T::R_ST + ch); }
-        if constexpr (V == 4) st4<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + ch, v); else st2<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + ch, v);
+        if constexpr (V == 4) st4<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + cho, v); else st2<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + cho, v);
       }
     }
   }

@@ -350,6 +350,26 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
         high = std::max(high, pos + need);
       }
     }
+    if (st.kind == StepKind::DwConv && m.strip && m.in0.space == kLocGlobal && st.dh == 1 && st.dw == 1 && st.residual < 0 && !getenv("BSX_PLAN_NO_DW_STAGE")) {
+      // Depthwise on a tensor that lives in the arena: every input element is needed by K output rows and ~2 strips, i.e. it is read ~10 times — from an L2 that
+      // 32 frames' tensors share.  Where LDS has room the specialised kernel walks the channels in chunks of CK: the chunk of the WHOLE input ([H*W][CK + 4]) is
+      // brought into an LDS workspace once, coalesced, and the taps run from there (gen_mid.cpp).  ws_off / band_rows (= CK) carry the reservation; the
+      // interpreter ignores them and keeps reading the arena.
+      live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
+      std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+      for (int CK : {32, 16}) {                      // (8-channel chunks leave most lanes without an item and cost two barriers each: the arena form is faster)
+        if (st.Cin % CK || m.band_rows) continue;
+        const int need = (st.H * st.W * (CK + 4) + 3) / 4 * 4;
+        int pos = scratch;
+        for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
+        if (pos + need <= cap) {
+          m.ws_off = pos; m.band_rows = CK;
+          live.push_back({pos, need, s});          // occupied for this step only
+          plan->program_blocks.push_back({pos, need, s, s, "depthwise input chunk of step " + std::to_string(s)});
+          high = std::max(high, pos + need);
+        }
+      }
+    }
     if (m.scale.space != kLocNone && m.scale.space != kLocLds) return;   // the pw micro-op reads SE scales with ds_read only
     if (getenv("BSX_PROGRAM_NOP")) m.kind = 99;
     if (const char* only = getenv("BSX_PROGRAM_ONLY")) { if (atoi(only) != s) m.kind = 99; }   // timing experiments: one live op
