@@ -296,6 +296,19 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
             torch.cuda.synchronize()
         res["masks_k"] = mg.masks()[:k].cpu().numpy()
         res["out_k"] = d_out[:k].cpu().numpy()
+        # EVERY stream of the batch, on the GPU: streams i and i + 16 carry the same scene (and, shared background, the same temporal history), so their
+        # masks and composites must be identical bytes whatever tile / workgroup / XCD they ran on; the first streams are then held to the oracle (parity_sample)
+        if per_stream_bg:
+            res["full_batch"] = None
+        else:
+            groups_ok = 0
+            n_groups = B // distinct
+            masks_all = mg.masks()[:B]
+            for gi in range(1, n_groups):
+                if torch.equal(d_out[gi * distinct:(gi + 1) * distinct], d_out[:distinct]) and torch.equal(masks_all[gi * distinct:(gi + 1) * distinct], masks_all[:distinct]):
+                    groups_ok += 1
+            res["full_batch"] = {"streams": B, "distinct_scenes": distinct, "groups_compared_with_group_0": max(n_groups - 1, 0), "groups_identical": groups_ok,
+                                 "all_identical": groups_ok == max(n_groups - 1, 0)}
         stats = mg.profile(d_frames, d_bg, d_out, iters=profile_iters)
         for s in stats:
             s["GBps"] = s["bytes"] / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
@@ -334,6 +347,8 @@ def summarize(res, pmc, mode_dtype="f32"):
                                    "unit": "TFLOP/s", "frac": round(a / FP32_PEAK_TFLOPS, 4),
                                    "traffic": int(sum(net_traffic)) if net_traffic and all(t is not None for t in net_traffic) else None,
                                    "avg_ms": round(res["net_ms"], 4)}
+    if res.get("full_batch") is not None:
+        out["full_batch_twin_streams"] = res["full_batch"]
     out["stage_ms"] = {k: round(v, 4) for k, v in res["groups"].items()}
     out["stage_ms"]["sum_of_launches"] = round(sum(s["avg_ms"] for s in stats), 4)
     out["top_launches"] = [{"name": s["name"], "ms": round(s["avg_ms"], 4), "GBps": round(s["GBps"], 1)} for s in sorted(stats, key=lambda s: -s["avg_ms"])[:8]]

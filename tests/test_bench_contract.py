@@ -45,3 +45,5 @@ def test_a_fresh_bench_line_has_the_contract_fields():
     assert [l["threads"] for l in c["legs"]][:2] == [1, 2] and all(l["value"] > 0 for l in c["legs"])
     p = c["parity_sample"]
     assert p["mask_iou_min"] >= 0.999 and p["composite_max_abs_diff"] <= 1
+    fb = d["full_batch_twin_streams"]                                                  # every stream of the batch was compared with its scene twin on the GPU
+    assert fb["streams"] == 256 and fb["groups_compared_with_group_0"] == 15 and fb["all_identical"] is True
