@@ -97,6 +97,11 @@ struct bsx_ctx {
   float* d_arena = nullptr;
   float* d_net_in = nullptr;        // network input  [n][inH][inW][inC] f32 (written by the prep kernels)
   uint32_t* d_net_in_u8 = nullptr;  // the same tensor before convertTo: [n][inH][inW] R | G<<8 | B<<16 — what the stems with a byte path read (in_u8)
+  // bs_maskgen_process for ONE frame is a chain of 7 (Meet / MLKit) to ~45 (DeepLab) dependent launches of a few microseconds each: launch-bound.  The chain of
+  // a stream slot is captured once into a hipGraph and replayed (BSX_NO_GRAPH=1, or any stage callback — they need host synchronisation between stages — keeps
+  // the direct launches).  graph_state: 0 = not tried, 1 = usable, -1 = capture failed on this runtime (direct launches from then on).
+  std::map<int, hipGraphExec_t> host_graphs;
+  int graph_state = 0;
   bool prep_split = false;          // BSX_PREP_SPLIT=1 (read at bsx_new): resize and bilateral as two launches through the canvas buffer (A/B timing; the default is prep_fused_k)
   bool in_u8 = false;               // the step's prep writes ONLY the 8-bit form and the stem normalises on load (seg_head_k / dl_head0_k; bit-identical).
                                     //   BSX_F32_INPUT=1 (read at bsx_new) keeps the f32 tensor for A/B timing; the stage-debug entry writes both.
@@ -257,6 +262,7 @@ int init_device_state(bsx_ctx* c) {
   }
   // stems with a byte path take the 8-bit network input: the segmented Meet / MLKit head and DeepLab's fused head kernel
   c->prep_split = getenv("BSX_PREP_SPLIT") != nullptr;
+  if (getenv("BSX_NO_GRAPH")) c->graph_state = -1;
   c->in_u8 = getenv("BSX_F32_INPUT") == nullptr && ((c->use_program && c->plan.seg.on) || (!c->use_program && head0_u8_ok(c->plan)));
   BSX_HIP(c, hipMalloc(&c->d_canvas, N * canvas_elems(c->inW, c->inH) * sizeof(uint32_t)));
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
@@ -473,6 +479,7 @@ void bsx_delete(bsx_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (auto& kv : c->host_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   rtc_unload(&c->mid);
   void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -528,7 +535,26 @@ int bsx_process_host(bsx_ctx* c, int stream_idx, const uint8_t* h_bgr, size_t bg
   if (!c->d_host_frame) BSX_HIP(c, hipMalloc(&c->d_host_frame, fbytes));
   BSX_HIP(c, hipMemcpy2DAsync(c->d_host_frame, (size_t)c->width * 3, h_bgr, bgr_stride, (size_t)c->width * 3, c->height, hipMemcpyHostToDevice, s));
   // the single frame runs against the temporal state of slot `stream_idx` (the context itself is never modified)
-  int rc = process_impl(c, c->d_host_frame, 1, stream_idx, s);
+  int rc = BSX_OK;
+  hipGraphExec_t exec = nullptr;
+  if (c->graph_state >= 0 && !c->onprep && !c->oninfer && !c->onmask) {
+    auto it = c->host_graphs.find(stream_idx);
+    if (it != c->host_graphs.end()) exec = it->second;
+    else if (c->host_graphs.size() < 64) {                          // capture this slot's launch chain (the kernels' arguments carry the slot's state pointers)
+      hipGraph_t g = nullptr;
+      bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        rc = process_impl(c, c->d_host_frame, 1, stream_idx, s);
+        ok = hipStreamEndCapture(s, &g) == hipSuccess && rc == BSX_OK && g != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
+      if (g) (void)hipGraphDestroy(g);
+      if (ok) { c->host_graphs[stream_idx] = exec; c->graph_state = 1; }
+      else { exec = nullptr; c->graph_state = -1; rc = BSX_OK; (void)hipGetLastError(); }      // nothing ran during the capture: fall through to the direct launches
+    }
+  }
+  if (exec) BSX_HIP(c, hipGraphLaunch(exec, s));
+  else rc = process_impl(c, c->d_host_frame, 1, stream_idx, s);
   if (rc) return rc;
   const uint8_t* my_mask = c->d_masks + (size_t)stream_idx * c->width * c->height;
   BSX_HIP(c, hipMemcpy2DAsync(h_mask, mask_stride, my_mask, (size_t)c->width, (size_t)c->width, c->height, hipMemcpyDeviceToHost, s));
