@@ -9,6 +9,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 namespace bsx {
 namespace {
@@ -62,6 +64,38 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
     }
   };
   stage_of(0, k);
+  // 1x1 → depthwise without the tensor in between: when op j is a 1x1 convolution whose output lives in the arena and whose only reader is the chunked
+  // depthwise j + 1 (plan.cpp reserved an LDS workspace for ITS input chunks), every chunk of the expanded tensor is COMPUTED straight into the workspace instead
+  // of being written to the arena by op j and loaded back by op j + 1.  Op j then emits nothing but its barrier.  The regions the 1x1 needs while op j + 1 runs
+  // (its input if that is in LDS, its staged weights) were planned to live until op j only: the fusion is taken only where they are disjoint from everything op j + 1
+  // places (workspace, depthwise weights, depthwise output), and the DMA of op j + 2's weights — normally issued at the top of op j + 1 — waits for the last chunk.
+  auto dw_geom_ok = [&](const MicroOp& d) { return d.strip && d.dh == 1 && d.dw == 1 && d.kh == d.kw && (d.kh == 3 || d.kh == 5) && d.sh == d.sw && (d.sh == 1 || d.sh == 2) && d.Cin % 4 == 0; };
+  auto dw_chunked = [&](const MicroOp& d) { return d.kind == (int)StepKind::DwConv && dw_geom_ok(d) && d.in0.space == kLocGlobal && d.band_rows > 0 && d.Cin % d.band_rows == 0 &&
+                                                    d.res.space == kLocNone && !getenv("BSX_RTC_NO_DW_STAGE"); };
+  auto disjoint = [](long a0, long a1, long b0, long b1) { return a1 <= b0 || b1 <= a0; };
+  auto pw_feeds_dw = [&](int j) {
+    if (fine || getenv("BSX_RTC_NO_PWDW") || j < 0 || j + 1 >= n) return false;
+    const MicroOp& a = P[j];
+    const MicroOp& d = P[j + 1];
+    if (!(a.kind == (int)StepKind::PwConv && a.mfma && !a.gemv && a.stage_floats > 0 && a.out.space == kLocGlobal && a.res.space == kLocNone) || !dw_chunked(d)) return false;
+    if (d.in0.off != a.out.off || d.Cin != a.Cout || d.band_rows % 16 || a.cout_pad < a.Cout) return false;
+    for (int q = j + 2; q < n; q++) {                               // the expanded tensor has no other reader (until its arena slot is written again: slots are re-used)
+      for (const Loc* l : {&P[q].in0, &P[q].in1, &P[q].in2, &P[q].res, &P[q].scale}) if (l->space == kLocGlobal && l->off == a.out.off) return false;
+      for (int c = 0; c < P[q].n_cat; c++) if (P[q].cat[c].space == kLocGlobal && P[q].cat[c].off == a.out.off) return false;
+      if (P[q].out.space == kLocGlobal && P[q].out.off == a.out.off) break;
+    }
+    const long pin = (long)a.H * a.W, ws0 = d.ws_off, ws1 = ws0 + (long)d.H * d.W * (d.band_rows + 4);
+    std::vector<std::pair<long, long>> keep, placed;
+    keep.push_back({a.w_lds, a.w_lds + a.stage_floats});                                   // the 1x1's staged weights
+    if (a.in0.space == kLocLds) keep.push_back({a.in0.off, a.in0.off + pin * a.in0.stride});
+    if (a.in2.space == kLocLds) keep.push_back({a.in2.off, a.in2.off + pin * a.in2.stride});
+    if (a.scale.space == kLocLds) keep.push_back({a.scale.off, a.scale.off + a.Cin});
+    placed.push_back({ws0, ws1});
+    if (d.stage_floats > 0) placed.push_back({d.w_lds, d.w_lds + d.stage_floats});
+    if (d.out.space == kLocLds) placed.push_back({d.out.off, d.out.off + (long)d.OH * d.OW * d.out.stride});
+    for (auto& kq : keep) for (auto& pq : placed) if (!disjoint(kq.first, kq.second, pq.first, pq.second)) return false;
+    return true;
+  };
   for (int i = 0; i < n; i++) {
     const MicroOp& m = P[i];
     for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.scale, &m.out}) if (!plain(*l)) return fail("operand in the network input / output buffer");
@@ -70,7 +104,8 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
     if (fine) k.f("  f_a = __builtin_readcyclecounter();\n");
     k.f("  op_barrier();\n  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[%d] = __builtin_amdgcn_s_memrealtime();\n", i);
     if (fine) k.f("  f_b = __builtin_readcyclecounter();\n");
-    if (i + 1 < n) stage_of(i + 1, k);
+    const bool fed_by_prev = i > 0 && pw_feeds_dw(i - 1);            // this depthwise computes its input chunks itself: op i + 1's weight DMA waits for the last one
+    if (i + 1 < n && !fed_by_prev) stage_of(i + 1, k);
     // The FC weights of a squeeze-excite op come from L2 (64 KB per 128 x 128 layer, the same bytes for every workgroup): requested ONE OP EARLY,
     // into registers that stay live across the depthwise / 1x1 op in front of it, their delivery overlaps that op instead of stalling the FCs.
     auto fc_loads = [&](int j) {
@@ -101,8 +136,10 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
       o.f("struct Op%d {\n  static constexpr int P = %d, CIN = %d, COUT = %d, CPAD = %d, ACT = %d;\n", i, m.OH * m.OW, m.Cin, m.Cout, m.cout_pad, m.act);
       loc(o, "X", m.in0); loc(o, "Y", m.out); loc(o, "R", m.res); loc(o, "D", m.in2);
       o.f("  static constexpr int S_OFF = %d, W_LDS = %d, B_LDS = %d;\n", m.scale.space == kLocLds ? m.scale.off : -1, m.w_lds, m.w_lds + (int)(m.b_off - m.w_off));
+      o.f("  static constexpr int N0 = 0, NCOLS = %d, YSUB = 0;\n", m.cout_pad);
       o.f("  static constexpr bool NFAST = %s;\n};\n", ((m.out.space == kLocGlobal && !getenv("BSX_RTC_NO_NFAST")) || (m.in0.space == kLocGlobal && m.cout_pad > 16 && !getenv("BSX_RTC_NO_NFAST_IN"))) ? "true" : "false");      // arena INPUT: the column tiles of one row tile run back to back, its A rows are fetched once
-      k.f("  op_pw<Op%d>(L, A);\n", i);
+      if (pw_feeds_dw(i)) k.f("  // (computed chunk by chunk inside P%d: the tensor between them is never written)\n", i + 1);
+      else k.f("  op_pw<Op%d>(L, A);\n", i);
     } else if (m.kind == (int)StepKind::DwConv) {
       const bool ok = m.strip && m.dh == 1 && m.dw == 1 && m.kh == m.kw && (m.kh == 3 || m.kh == 5) && m.sh == m.sw && (m.sh == 1 || m.sh == 2) && m.Cin % 4 == 0;
       if (!ok) return fail("dw: geometry outside the strip form");
@@ -126,7 +163,17 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
         else o.f("  static constexpr int W_SP = SP_GLB, W_OFF = %lld, B_OFF = %lld;\n};\n", m.w_off + c * CK, m.b_off + c * CK);
         if (chunked) {
           if (c > 0) k.f("  __syncthreads();\n");                 // the previous chunk's taps are done with the workspace
-          k.f("  load_chunk<%d, %d, %d, %d, %d, %d, %d>(L, A);\n  __syncthreads();\n", asp(m.in0), m.in0.off, m.H * m.W, m.in0.stride, CK, c * CK, m.ws_off);
+          if (fed_by_prev) {
+            const MicroOp& a = P[i - 1];
+            o.f("struct Op%d_%d {\n  static constexpr int P = %d, CIN = %d, COUT = %d, CPAD = %d, ACT = %d;\n", i - 1, c, a.OH * a.OW, a.Cin, a.Cout, a.cout_pad, a.act);
+            loc(o, "X", a.in0); loc(o, "R", a.res); loc(o, "D", a.in2);
+            o.f("  static constexpr int Y_SP = 1, Y_OFF = %d, Y_ST = %d;\n", m.ws_off, CK + 4);
+            o.f("  static constexpr int S_OFF = %d, W_LDS = %d, B_LDS = %d;\n", a.scale.space == kLocLds ? a.scale.off : -1, a.w_lds, a.w_lds + (int)(a.b_off - a.w_off));
+            o.f("  static constexpr int N0 = %d, NCOLS = %d, YSUB = %d;\n  static constexpr bool NFAST = true;\n};\n", c * CK, CK, c * CK);
+            k.f("  op_pw<Op%d_%d>(L, A);\n  __syncthreads();\n", i - 1, c);
+            if (c == nch - 1 && i + 1 < n) stage_of(i + 1, k);    // every wave is past the last 1x1 chunk: its weight slot is free for the next op's DMA only now
+          } else
+            k.f("  load_chunk<%d, %d, %d, %d, %d, %d, %d>(L, A);\n  __syncthreads();\n", asp(m.in0), m.in0.off, m.H * m.W, m.in0.stride, CK, c * CK, m.ws_off);
         }
         k.f("  op_dw<%s>(L, A, W);\n", name);
       }

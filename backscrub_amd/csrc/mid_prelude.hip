@@ -154,7 +154,9 @@ __device__ __forceinline__ void op_barrier() {
 // dependent f32 MFMA has 40 cycles of latency against 32 of issue).
 // Traits: P CIN COUT CPAD ACT | X_SP X_OFF X_ST | Y_SP Y_OFF Y_ST | R_SP R_OFF R_ST | S_OFF (LDS, -1: none) | D_SP D_OFF D_ST | W_LDS B_LDS
 template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
-  constexpr int P = T::P, CIN = T::CIN, CPAD = T::CPAD, MT = (P + 15) / 16, NT = CPAD / 16, TILES = MT * NT;
+  // N0 / NCOLS: the column range [N0, N0 + NCOLS) of the layer this call computes (the whole layer, or one channel chunk written straight into the LDS
+  // workspace of the depthwise that consumes it — YSUB = N0 then rebases the stored channel index); CPAD stays the row stride of the weight block
+  constexpr int P = T::P, CIN = T::CIN, CPAD = T::CPAD, MT = (P + 15) / 16, NT = T::NCOLS / 16, TILES = MT * NT;
   constexpr int NJ = CIN / 16, TAIL = CIN % 16, TM = TAIL / 4;      // TM = MFMAs of the tail (0..3)
   static_assert(CIN % 4 == 0 && CPAD % 16 == 0, "op_pw: channel counts");
   const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, wave = wave_id();
@@ -167,7 +169,7 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
     // tile order.  LDS output: M-tile fastest (the 16 waves of a round share one B tile).  Output in the ARENA (a tensor that does not fit LDS): N-tile
     // fastest (T::NFAST) — the waves of a round then write ADJACENT 64-byte pieces of the same 16 pixel rows at the same time, which the L2 merges into
     // whole lines, instead of sixteen isolated 64-byte pieces 4 * COUT bytes apart each; the shared A rows are read once per round.
-    const int tn = T::NFAST ? wi % NT : wi / MT, tm = T::NFAST ? wi / NT : wi - tn * MT, m0 = tm << 4, n0 = tn << 4;
+    const int tn = T::NFAST ? wi % NT : wi / MT, tm = T::NFAST ? wi / NT : wi - tn * MT, m0 = tm << 4, n0 = T::N0 + (tn << 4);
     const int arow = (P % 16 == 0) ? m0 + li : min(m0 + li, P - 1);      // rows past the end read a valid pixel; results are dropped
     const int xo = arow * T::X_ST + 4 * g;
     const lds_f* bp = wl + (4 * g) * CPAD + n0 + li;
@@ -225,7 +227,7 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
     if ((T::COUT % 16 == 0 || c0 < T::COUT) && (P % 16 == 0 || pix < P)) {
       v = act4<T::ACT>(v + *(const lds_v4*)(bl + c0));
       if constexpr (T::R_SP != SP_NONE) v += ld4<T::R_SP>(L + T::R_OFF, A + T::R_OFF, pix * T::R_ST + c0);
-      st4<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + c0, v);
+      st4<T::Y_SP>(L + T::Y_OFF, A + T::Y_OFF, pix * T::Y_ST + c0 - T::YSUB, v);
     }
   }
 }
