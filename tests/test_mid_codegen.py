@@ -65,6 +65,27 @@ def test_act16_variant_stores_arena_activations_as_halves(api, key, tmp_path, mo
     assert "v_cvt_f16_f32" in asm or "v_cvt_pk" in asm
 
 
+def test_arena_tensors_of_the_larger_graphs_are_staged_and_fused(api, monkeypatch):
+    """MLKit / segm_full keep their 16x16x{96,128} (9x16) level-4 tensors in the arena.  The generator then (a) stages the depthwise inputs through the LDS
+    workspace the planner reserved, chunk by chunk, and (b) where the 1x1 in front is the only producer computes each chunk straight into that workspace, so the
+    expanded tensor is never stored; (c) 1x1 convolutions that write to the arena walk N-tile fastest.  segm_lite keeps those tensors in LDS: nothing to stage."""
+    for key, fused in (("mlkit", 4), ("full", 3), ("lite", 0)):
+        src = api.model_kernel_source(model_path(key))
+        assert len(re.findall(r"computed chunk by chunk inside P\d+", src)) == fused, key
+        assert ("op_pw<Op8_0>" in src) == (fused > 0)
+        if fused:
+            assert re.search(r"struct Op8_1 \{[^}]*N0 = \d+, NCOLS = (16|32), YSUB = \d+", src) and "NFAST = true" in src
+        describe = api.model_describe(model_path(key))
+        assert "lds_check=ok" in describe
+    monkeypatch.setenv("BSX_RTC_NO_PWDW", "1")
+    src = api.model_kernel_source(model_path("mlkit"))
+    monkeypatch.delenv("BSX_RTC_NO_PWDW")
+    assert "load_chunk<" in src and "computed chunk by chunk" not in src          # staging alone: the expanded tensor is loaded back from the arena
+    monkeypatch.setenv("BSX_PLAN_NO_DW_STAGE", "1")
+    src = api.model_kernel_source(model_path("mlkit"))
+    assert "load_chunk<" not in src and "op_pw<Op8>" in src                        # the planner reserved no workspace: the plain ops
+
+
 def test_precompile_fills_the_cache_without_a_gpu(api, tmp_path, monkeypatch):
     monkeypatch.setenv("BSX_KERNEL_CACHE", str(tmp_path))
     first = api.model_precompile(model_path("lite"))
