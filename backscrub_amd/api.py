@@ -178,14 +178,14 @@ class MaskGen:
                                          C.c_void_p(out_yuyv.data_ptr()), n, _stream_ptr()), self.h, "bsx_step_batch_yuyv")
         return out_yuyv
 
-    def step_ex(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False):
+    def step_ex(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False, no_mask=False):
         """one main-loop iteration with cv::flip of the composite (app/deepseg.cc:667-673) and / or the YUYV pack folded into the blend's store"""
         n = self._n(frames)
         want = (self.height, self.width, 2 if yuyv else 3)
         if out.dim() != 4 or tuple(out.shape[1:]) != want or out.shape[0] < n or not out.is_contiguous() or not out.is_cuda or out.dtype != _torch().uint8:
             raise BsxError("out must be a contiguous cuda uint8 tensor [>=%d,%d,%d,%d]" % ((n,) + want))
         stride = 0 if bg.dim() == 3 else bg.stride(0)
-        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0)
+        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0)
         _check(lib().bsx_step_batch_ex(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride, C.c_void_p(out.data_ptr()), n, _stream_ptr(),
                                        flags), self.h, "bsx_step_batch_ex")
         return out

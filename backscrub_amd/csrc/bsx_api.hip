@@ -591,7 +591,7 @@ struct LaneView {
 // flags (bsx.h): BSX_STEP_YUYV — the composite leaves as YUYV 4:2:2 (2 B/px), convert_rgb_to_yuyv (deepseg.cc:87-106) applied in the blend's epilogue;
 // BSX_STEP_FLIP_H / _V — cv::flip of the composite (deepseg.cc:667-673) folded into the epilogue's store addresses
 int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, unsigned flags) {
-  if (!c || !d_frames || !d_bg || !d_out || n <= 0 || n > c->n_streams || (flags & ~7u)) return BSX_EINVAL;
+  if (!c || !d_frames || !d_bg || !d_out || n <= 0 || n > c->n_streams || (flags & ~15u)) return BSX_EINVAL;
   const int yuyv = (int)(flags & BSX_STEP_YUYV);
   const unsigned flip = flags & (BSX_STEP_FLIP_H | BSX_STEP_FLIP_V);
   if (yuyv && (c->width & 1)) return BSX_EINVAL;                // 4:2:2 pairs pixels horizontally

@@ -466,7 +466,8 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
     const uint32_t m2 = (__umul24(acc.y & 0xffffu, 5243u) + 12u * 5243u) >> 17, m3 = (__umul24(acc.y >> 16, 5243u) + 12u * 5243u) >> 17;
     const uint32_t packed = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
     uint8_t* dst = dst0 + (long)(8 * i) * W;
-    if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
+    if (BLEND && (yuyv_flip & 8)) { /* composite only (BSX_STEP_NO_MASK): the full-resolution mask stays in registers */ }
+    else if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
     else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
     if constexpr (BLEND) {
       uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * orow * obpp);
@@ -904,7 +905,7 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
                              const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s, int yuyv) {
   // outside the ROI the persistent mask is 255 forever (libbackscrub.cc:248-249), i.e. the composite there IS the background
   // ((a*255 + b*0)/255 == a): those strips are copied, the ROI is composited by the mask tiles
-  // `yuyv`: bit 0 = YUYV output, bits 1-2 = horizontal / vertical flip of the composite (kernels.hpp: kStepYuyv, kStepFlipH, kStepFlipV)
+  // `yuyv`: bit 0 = YUYV output, bits 1-2 = horizontal / vertical flip of the composite, bit 3 = do not store the full-resolution mask (bsx.h: BSX_STEP_*)
   if ((yuyv & 6) && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
     outside_roi_flip_k<<<dim3(blocks_for((long)(W / 4) * H), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H, roi, yuyv);
   else if ((yuyv & 1) && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))

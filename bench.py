@@ -296,6 +296,25 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
             torch.cuda.synchronize()
         res["masks_k"] = mg.masks()[:k].cpu().numpy()
         res["out_k"] = d_out[:k].cpu().numpy()
+        # the same step without STORING the full-resolution mask (BSX_STEP_NO_MASK: 6 instead of 7 HBM bytes per pixel in the last launch) — reported beside
+        # `value`, never as it: the headline materialises the mask, as bs_maskgen_process does
+        if ring is None and not per_stream_bg:
+            probe = max(3, min(steps, 100))
+            d_probe = torch.empty_like(d_out)
+            for t in range(3):
+                mg.step_ex(d_frames, d_bg, d_probe, no_mask=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for t in range(probe):
+                mg.step_ex(d_frames, d_bg, d_probe, no_mask=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            mg.step(d_frames, d_bg, d_out)                         # same temporal state → the composite must be the same bytes
+            torch.cuda.synchronize()
+            res["composite_only"] = {"what": "bsx_step_batch_ex(BSX_STEP_NO_MASK): composite written, full-resolution mask not stored", "steps": probe,
+                                     "value": round(B * probe / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / probe, 4),
+                                     "composite_identical_to_the_storing_step": bool(torch.equal(d_probe, d_out))}
+            del d_probe
         # EVERY stream of the batch, on the GPU: streams i and i + 16 carry the same scene (and, shared background, the same temporal history), so their
         # masks and composites must be identical bytes whatever tile / workgroup / XCD they ran on; the first streams are then held to the oracle (parity_sample)
         if per_stream_bg:
@@ -347,6 +366,8 @@ def summarize(res, pmc, mode_dtype="f32"):
                                    "unit": "TFLOP/s", "frac": round(a / FP32_PEAK_TFLOPS, 4),
                                    "traffic": int(sum(net_traffic)) if net_traffic and all(t is not None for t in net_traffic) else None,
                                    "avg_ms": round(res["net_ms"], 4)}
+    if res.get("composite_only") is not None:
+        out["composite_only"] = res["composite_only"]
     if res.get("full_batch") is not None:
         out["full_batch_twin_streams"] = res["full_batch"]
     out["stage_ms"] = {k: round(v, 4) for k, v in res["groups"].items()}

@@ -145,6 +145,10 @@ int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_
 #define BSX_STEP_YUYV 1u
 #define BSX_STEP_FLIP_H 2u
 #define BSX_STEP_FLIP_V 4u
+/* BSX_STEP_NO_MASK: composite only — the full-resolution mask of this frame is formed in registers, blended and NOT stored (1 of the step's 7 HBM bytes per pixel).
+ * Nothing later depends on it: every frame's mask is rebuilt from the model-resolution temporal state, which advances as usual; bsx_masks_device() then keeps
+ * the last mask a call WITHOUT this flag stored.  For main loops that only need the composite (app/deepseg.cc:661 uses the mask for nothing else unless -d -d). */
+#define BSX_STEP_NO_MASK 8u
 int bsx_step_batch_ex(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                       uint8_t* d_out, int n, void* stream, unsigned flags);
 

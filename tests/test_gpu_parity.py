@@ -713,6 +713,31 @@ def test_step_with_flips_folded_into_the_blend(bs, oracle, key, res):
     mg_b.close()
 
 
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA)])
+def test_step_without_storing_the_mask(bs, key, res):
+    """BSX_STEP_NO_MASK: the same composite bytes as bsx_step_batch, the temporal state advances identically (the next frames agree too), and the
+    full-resolution mask buffer is left as the last storing call wrote it."""
+    from backscrub_amd import synth
+    W, H = res
+    n = 3
+    mg_a = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    mg_b = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    bg = _dev(synth.random_u8((H, W, 3), 79))
+    out_a = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    out_b = torch.empty_like(out_a)
+    before = mg_b.masks().clone()
+    for t in range(4):
+        frames = _dev(np.stack([synth.frame(W, H, i, t) for i in range(n)]))
+        mg_a.step(frames, bg, out_a)
+        mg_b.step_ex(frames, bg, out_b, no_mask=(t != 3))
+        assert torch.equal(out_a, out_b), "t=%d" % t
+        if t != 3:
+            assert torch.equal(mg_b.masks(), before)             # untouched: all 255, as bsx_new left it
+    assert torch.equal(mg_a.masks(), mg_b.masks())                # the storing call writes the same mask the other context has
+    mg_a.close()
+    mg_b.close()
+
+
 def test_yuyv_to_bgr_matches_oracle(bs, oracle):
     from backscrub_amd import synth
     img = synth.random_u8((2, 480, 640, 2), 13)
