@@ -343,6 +343,7 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
     BSX_HIP(c, launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16));
     BSX_HIP(c, launch_program(c, n, s));
     BSX_HIP(c, launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
+    if (sp.tail.pre_gate_off >= 0) BSX_HIP(c, launch_seg_gate(sp.tail.gate, c->d_arena, pf, c->d_weights, sp.tail.pre_gate_off, n, s));
     BSX_HIP(c, launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal + (size_t)slot * c->outW * c->outH, c->d_weights, logits, n, s, c->act16));
     return BSX_OK;
   }
@@ -741,7 +742,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   const bool seg = c->use_program && c->plan.seg.on;
   const bool fused_decode = infer_decodes(c);
   const bool atail = argmax_tail(c);
-  const int n_net = c->use_program ? (seg ? 5 : 1) : (int)c->plan.steps.size();
+  const int n_net = c->use_program ? (seg ? (c->plan.seg.tail.pre_gate_off >= 0 ? 6 : 5) : 1) : (int)c->plan.steps.size();
   const bool fuse_tail = !c->onmask && !c->no_mask_blend_fusion &&
                          mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
   const int L = (c->prep_split ? 2 : 1) + n_net + (fused_decode ? 0 : 1) + (fuse_tail ? 1 : 2) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
@@ -772,6 +773,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       BSX_TIMED(launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16));
       BSX_TIMED(launch_program(c, n, s));
       BSX_TIMED(launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
+      if (sp.tail.pre_gate_off >= 0) BSX_TIMED(launch_seg_gate(sp.tail.gate, c->d_arena, pf, c->d_weights, sp.tail.pre_gate_off, n, s));
       BSX_TIMED(launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal, c->d_weights, !fused_decode, n, s, c->act16));
     } else if (c->use_program)
       BSX_TIMED(launch_program(c, n, s));
@@ -824,6 +826,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     put(j++, "seg_k2", N * 4.0 * (eb0 + eb0 + ec0), N * 2.0 * macs(3, 8));
     put(j++, "frame_program", N * 4.0 * (ec0 + elo2) + 4.0 * c->plan.weights.size(), N * 2.0 * macs(9, NS - 11));
     put(j++, "seg_k3", N * 4.0 * (eb0 + elo2 + elo), N * 2.0 * macs(NS - 10, NS - 8));
+    if (sp.tail.pre_gate_off >= 0) put(j++, "seg_gate", N * 4.0 * (16.0 * (sp.tail.gate.part[0].n + sp.tail.gate.part[1].n) + 16.0), 0);      // the tail's gate, once per frame
     put(j++, fused_decode ? "seg_tail+decode" : "seg_tail", N * (4.0 * (eA + elo) + (fused_decode ? 2.0 * c->outW * c->outH : 4.0 * eout)), N * 2.0 * macs(NS - 7, NS - 1));
   } else if (c->use_program) {
     // algorithmic bytes of the fused network = its input tensor + its output tensor + the weights once

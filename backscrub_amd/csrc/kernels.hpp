@@ -46,6 +46,7 @@ hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const
 hipError_t launch_seg_k2(const SegK2& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16 = false);
 hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const float* weights, int n, hipStream_t s, bool h16 = false);
 // logits = true: write the network output tensor (debug / stage tests); false: decode + temporal IIR straight into `ofinal`
+hipError_t launch_seg_gate(const SegGate& gt, float* arena, long per_frame, const float* weights, long long out_off, int n, hipStream_t s);
 hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s, bool h16 = false);
 
 // ---- image path ----------------------------------------------------------------------

@@ -99,6 +99,7 @@ __device__ __forceinline__ void load_wtile(float (&wr)[4], const float* __restri
 constexpr int kGateStageFloats = kSegGateStageFloats;
 __device__ __forceinline__ void seg_gate(const SegGate& gt, const float* __restrict__ fa, const float* __restrict__ w, float* scr, float* stage) {
   float* s_gate = scr + kScrGate;
+  if (gt.timing_skip) { if (threadIdx.x < 16) s_gate[threadIdx.x] = 0.5f; __syncthreads(); return; }      // upper bound of what hoisting the gate out could buy
   float* s_mean = scr + kScrGate + 16;
   float* s_hid = scr + kScrGate + 48;
   const int tid = threadIdx.x;
@@ -696,7 +697,10 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
       if (py < d.TR && iy < d.H1 && px < d.TC && ix < d.W1) prev[j] = of[(unsigned)((2 * iy + fy) * d.W0 + 2 * ix + fx)];
     }
   }
-  seg_gate(d.gate, fa, w, seg_smem, z_t);
+  if (d.pre_gate_off >= 0) {                                          // computed once per frame by seg_gate_k
+    if (tid < 16) seg_smem[kScrGate + tid] = fa[d.pre_gate_off + tid];
+    __syncthreads();
+  } else seg_gate(d.gate, fa, w, seg_smem, z_t);
   gated_compute(pre, l_t, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw, w, r0, c0, ZH, ZC, z_t);
   f4v wd[9];
 #pragma unroll
@@ -743,6 +747,13 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
         of[opix] = (uint8_t)((val & 0xE0u) | ((uint32_t)prev[j] >> 3));
       }
     }
+}
+
+// the gate of one decoder level, once per frame: workgroup = frame; the prologue of the tile kernels as a kernel of its own (SegTail::pre_gate_off)
+__global__ __launch_bounds__(kSegThreads) void seg_gate_k(const SegGate gt, float* __restrict__ arena, long per_frame, const float* __restrict__ w, long long out_off) {
+  float* fa = arena + (size_t)blockIdx.x * (size_t)per_frame;
+  seg_gate(gt, fa, w, seg_smem, seg_smem + kScrFloats);
+  if (threadIdx.x < 16) fa[out_off + threadIdx.x] = seg_smem[kScrGate + threadIdx.x];
 }
 
 template <class K>
@@ -813,6 +824,10 @@ static hipError_t launch_seg_tail_t(const SegTail& d, float* arena, long per_fra
   } else {
     return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+hipError_t launch_seg_gate(const SegGate& gt, float* arena, long per_frame, const float* weights, long long out_off, int n, hipStream_t s) {
+  seg_gate_k<<<n, kSegThreads, (size_t)(kSegScratchFloats + kSegGateStageFloats) * sizeof(float), s>>>(gt, arena, per_frame, weights, out_off);
   return hipGetLastError();
 }
 hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s, bool h16) {

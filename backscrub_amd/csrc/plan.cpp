@@ -630,6 +630,11 @@ static bool build_segments(Graph& g, Plan* plan) {
 
   const int pA = synth("partials(A)", h.tiles_y * h.tiles_x, 16), pb0 = synth("partials(b0)", h.tiles_y * h.tiles_x, 16);
   const int pB = synth("partials(B)", k2.tiles_y * k2.tiles_x, 16), plo = synth("partials(lo)", k3.tiles_y * k3.tiles_x, 16);
+  // The tail's gate (two pooled means → FC → FC: identical for every tile of a frame) is computed once per frame by a one-workgroup-per-frame launch between k3
+  // and the tail instead of by each of the tail's workgroups: the prologue — partial sums of two tensors, two weight blocks, three barriers — measured a quarter of
+  // the tail kernel (lite 67.7 -> 50.8 us, MLKit/HD 260 -> 192 us with the prologue skipped).  BSX_SEG_NO_GATE_KERNEL=1 keeps it inside the tail.
+  const int pgt = getenv("BSX_SEG_NO_GATE_KERNEL") ? -1 : synth("gate(tail)", 1, 16);
+  if (pgt >= 0) plan->tensor_off[pgt] = reserve(16);
   for (int t : {A, b0, B, c0, lo2, lo, kf2.out, pA, pb0, pB, plo}) plan->tensor_off[t] = reserve(g.tensors[t].elems());
   // tensors that exist only inside a segment kernel are never materialised
   for (int t : {hpw.out, g1.out, f1a.out, f1b.out, pwb.out, up2, kg.out, kf1.out, kp1.out, kd.out, up, tg.out, tf1.out, tf2.out, tpw.out, tdw.out})
@@ -648,6 +653,8 @@ static bool build_segments(Graph& g, Plan* plan) {
   tl.gate.part[0].off = plan->tensor_off[pA]; tl.gate.part[0].n = h.tiles_y * h.tiles_x; tl.gate.part[0].C = 16; tl.gate.part[0].hw = (float)(h.H1 * h.W1);
   tl.gate.part[1].off = plan->tensor_off[plo]; tl.gate.part[1].n = k3.tiles_y * k3.tiles_x; tl.gate.part[1].C = 16; tl.gate.part[1].hw = (float)(k3.H2 * k3.W2);
   tl.gate.fc[0] = fc_w(tf1); tl.gate.fc[1] = fc_w(tf2);
+  if (getenv("BSX_SEG_GATE_SKIP")) k2.gate.timing_skip = tl.gate.timing_skip = 1;
+  tl.pre_gate_off = pgt >= 0 ? plan->tensor_off[pgt] : -1;
   if (tl.gate.fc[0].Cin != (tl.gate.sum_parts ? 16 : 32) || k2.gate.fc[0].Cin != 16) return seg_fail(27);
 
   // ---- the middle: steps 9 .. NS-15, then the level-2 gate with its pooled inputs replaced: GAP(B) arrives as partial sums

@@ -31,6 +31,7 @@ struct SegFc { long long w_off = 0, b_off = 0; int Cin = 0, Cout = 0, act = 0; }
 struct SegPart { long long off = 0; int n = 0, C = 0; float hw = 1.f; };                             // partial sums [n][C] in the frame's arena slice; mean = sum / hw
 struct SegGate {                                                                                      // mean parts (concatenated or summed) → FC → [FC]
   int n_parts = 0, sum_parts = 0, n_fc = 0;
+  int timing_skip = 0;                // BSX_SEG_GATE_SKIP=1 (timing experiment, results invalid): the gate prologue is replaced by a constant vector
   SegPart part[2];
   SegFc fc[2];
 };
@@ -82,6 +83,7 @@ struct SegTail {
   long long tc_w_off = 0, tc_b_off = 0;                   // Convolution2DTransposeBias 2x2: [fy][fx][oc][ic], bias [oc]
   int Co = 0, act3 = 0, model_type = 0;
   long long skip_off = 0, lo_off = 0;
+  long long pre_gate_off = -1;                            // >= 0: the gate vector (16 floats per frame) was computed ONCE per frame by seg_gate_k and lives here in the arena
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
 };

@@ -41,7 +41,7 @@ NAMES = {"lite": "segm_lite_v681.tflite", "full": "segm_full_v679.tflite",
          "mlkit": "selfiesegmentation_mlkit-256x256-2021_01_19-v1215.f16.tflite", "deeplab": "deeplabv3_257_mv_gpu.tflite"}
 PMC_NAMES = {"frame_program": ("bsx_mid", "frame_program_k"), "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
              "mask_upscale_blur": "mask_tile_k<false>", "prep": "prep_fused_k", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k",
-             "seg_head": "seg_head_k", "seg_k2": "seg_k2_k", "seg_k3": "seg_k3_k", "seg_tail": "seg_tail_k", "seg_tail+decode": "seg_tail_k"}
+             "seg_head": "seg_head_k", "seg_k2": "seg_k2_k", "seg_k3": "seg_k3_k", "seg_tail": "seg_tail_k", "seg_tail+decode": "seg_tail_k", "seg_gate": "seg_gate_k"}
 
 
 def parse():
