@@ -273,6 +273,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 
   // 1. input tile (zero outside the image: SAME padding of the stem): wave = rows, lane = row elements; every load of the lane is
   //    in flight before its first LDS store
+  if (d.dbg_skip & 8) { /* timing: no input tile */ } else
   if (U8IN) {                                                       // lane = pixel of the row (IC <= 63): one dword = three input values
     const uint32_t* src = reinterpret_cast<const uint32_t*>(net_in) + (size_t)f * (size_t)(d.H0 * d.W0);
     const bool colok = lane < IC && ic0 + lane >= 0 && ic0 + lane < d.W0;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
       }
     }
   };
-  for (int t = wave; t < ntile; t += 8) {
+  for (int t = wave; t < ntile && !(d.dbg_skip & 1); t += 8) {
     const bool two = t + 4 < ntile;                                  // scalar
     const RowTile r0t = row_tile(t, ctiles, d.m_ct), r1t = row_tile(two ? t + 4 : t, ctiles, d.m_ct);
     const float* base0 = in_t + (2 * r0t.row) * rowf + 6 * min(16 * r0t.ct + li, AC - 1);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
       st4(x_t + (rt.row * RW + x2) * 16 + cq4, v);
     }
   };
-  for (int t = wave; t < ntile; t += 8) {
+  for (int t = wave; t < ntile && !(d.dbg_skip & 2); t += 8) {
     const bool two = t + 4 < ntile;
     const RowTile r0t = row_tile(t, ctiles, d.m_ct), r1t = row_tile(two ? t + 4 : t, ctiles, d.m_ct);
     const float4 a0 = ld4(a_t + (r0t.row * RW + min(16 * r0t.ct + li, AC - 1)) * 16 + 4 * g);
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 
   // 4. depthwise 3x3 / stride 2 → b0: one tile row per wave iteration
   float4 sumB = f4zero();
-  for (int py = wave; py < d.TR; py += 4) {
+  for (int py = wave; py < d.TR && !(d.dbg_skip & 4); py += 4) {
     if (r0 + py >= d.H2) break;
     if (px < d.TC && c0 + px < d.W2) {
       const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
 
   // 2. 16 expanded channels at a time: x = act(pw_b(B)) → depthwise 3x3/s2 → c0
   const int C = d.dw.C, ngrp = (C + 15) >> 4, quad = lane & 3, px = lane >> 2;
-  for (int grp = 0; grp < ngrp; grp++) {
+  for (int grp = 0; grp < ngrp && !(d.dbg_skip & 2); grp++) {
     load_wtile(wr, w, d.pw_b, 16 * grp, li, g);
     const float4 bias_b = ld4(w + d.pw_b.b_off + 16 * grp + cq4);
     for (int t = wave; t < ntile; t += 4) {
@@ -701,7 +702,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
     if (tid < 16) seg_smem[kScrGate + tid] = fa[d.pre_gate_off + tid];
     __syncthreads();
   } else seg_gate(d.gate, fa, w, seg_smem, z_t);
-  gated_compute(pre, l_t, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw, w, r0, c0, ZH, ZC, z_t);
+  if (!(d.dbg_skip & 1)) gated_compute(pre, l_t, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw, w, r0, c0, ZH, ZC, z_t);
+  if (d.dbg_skip & 2) return;
   f4v wd[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + 4 * quad);

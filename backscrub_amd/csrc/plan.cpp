@@ -654,6 +654,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   tl.gate.part[1].off = plan->tensor_off[plo]; tl.gate.part[1].n = k3.tiles_y * k3.tiles_x; tl.gate.part[1].C = 16; tl.gate.part[1].hw = (float)(k3.H2 * k3.W2);
   tl.gate.fc[0] = fc_w(tf1); tl.gate.fc[1] = fc_w(tf2);
   if (getenv("BSX_SEG_GATE_SKIP")) k2.gate.timing_skip = tl.gate.timing_skip = 1;
+  if (const char* e = getenv("BSX_SEG_SKIP")) sscanf(e, "%d,%d,%d,%d", &h.dbg_skip, &k2.dbg_skip, &k3.dbg_skip, &tl.dbg_skip);      // "head,k2,k3,tail" phase masks
   tl.pre_gate_off = pgt >= 0 ? plan->tensor_off[pgt] : -1;
   if (tl.gate.fc[0].Cin != (tl.gate.sum_parts ? 16 : 32) || k2.gate.fc[0].Cin != 16) return seg_fail(27);
 

@@ -47,6 +47,7 @@ struct SegHead {
   long long a_off = 0, b0_off = 0, part_a_off = 0, part_b0_off = 0;
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;           // tile of b0 pixels per workgroup
   int lds_floats = 0;
+  int dbg_skip = 0;                                       // BSX_SEG_SKIP (timing experiments, results invalid): bit mask of phases this kernel skips
   int rw = 0;                                             // LDS row width of the A region: 16 * ceil((2TC+1) / 16)
   unsigned m_ct = 0;                                      // ceil(65536 / (rw / 16))
 };
@@ -60,6 +61,7 @@ struct SegK2 {
   long long b0_off = 0, B_off = 0, c0_off = 0, part_B_off = 0;
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;           // tile of c0 pixels
   int lds_floats = 0;
+  int dbg_skip = 0;                                       // BSX_SEG_SKIP (timing experiments, results invalid): bit mask of phases this kernel skips
   int rw = 0;                                             // LDS row width of the B region: 16 * ceil((2TC+1) / 16)
   unsigned m_ct = 0;
 };
@@ -72,6 +74,7 @@ struct SegK3 {
   long long skip_off = 0, lo2_off = 0, g_off = 0, lo_off = 0, part_lo_off = 0;
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
+  int dbg_skip = 0;                                       // BSX_SEG_SKIP (timing experiments, results invalid): bit mask of phases this kernel skips
 };
 
 struct SegTail {
@@ -86,6 +89,7 @@ struct SegTail {
   long long pre_gate_off = -1;                            // >= 0: the gate vector (16 floats per frame) was computed ONCE per frame by seg_gate_k and lives here in the arena
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
+  int dbg_skip = 0;                                       // BSX_SEG_SKIP (timing experiments, results invalid): bit mask of phases this kernel skips
 };
 
 // LDS floats each kernel needs for the tile sizes in its descriptor (the planner picks the tiles against these; the kernels
