@@ -178,16 +178,19 @@ class MaskGen:
                                          C.c_void_p(out_yuyv.data_ptr()), n, _stream_ptr()), self.h, "bsx_step_batch_yuyv")
         return out_yuyv
 
-    def step_ex(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False, no_mask=False):
-        """one main-loop iteration with cv::flip of the composite (app/deepseg.cc:667-673) and / or the YUYV pack folded into the blend's store"""
+    def step_ex(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False, no_mask=False, bgblur=0):
+        """one main-loop iteration with cv::flip of the composite (app/deepseg.cc:667-673) and / or the YUYV pack folded into the blend's store;
+        bgblur=<odd ksize>: the background is GaussianBlur(the stream's own frame) (-p bgblur:<n> without -b, deepseg.cc:652-661), `bg` may be None"""
         n = self._n(frames)
         want = (self.height, self.width, 2 if yuyv else 3)
         if out.dim() != 4 or tuple(out.shape[1:]) != want or out.shape[0] < n or not out.is_contiguous() or not out.is_cuda or out.dtype != _torch().uint8:
             raise BsxError("out must be a contiguous cuda uint8 tensor [>=%d,%d,%d,%d]" % ((n,) + want))
-        stride = 0 if bg.dim() == 3 else bg.stride(0)
-        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0)
-        _check(lib().bsx_step_batch_ex(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride, C.c_void_p(out.data_ptr()), n, _stream_ptr(),
-                                       flags), self.h, "bsx_step_batch_ex")
+        if bg is None and not bgblur:
+            raise BsxError("bg is required unless bgblur is set")
+        stride = 0 if bg is None or bg.dim() == 3 else bg.stride(0)
+        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0) | ((int(bgblur) & 255) << 8)
+        _check(lib().bsx_step_batch_ex(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr() if bg is not None else None), stride,
+                                       C.c_void_p(out.data_ptr()), n, _stream_ptr(), flags), self.h, "bsx_step_batch_ex")
         return out
 
     def profile(self, frames, bg, out, iters=5):
@@ -246,11 +249,14 @@ class MaskGen:
         _check(lib().bsx_flip_bgr(self.h, C.c_void_p(bgr.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, int(code), _stream_ptr()), self.h, "bsx_flip_bgr")
         return out
 
-    def gaussian_blur(self, bgr, ksize=25):
+    def gaussian_blur(self, bgr, ksize=25, out=None):
         """cv::GaussianBlur(bgr, out, Size(ksize, ksize), 0) for [n,h,w,3] u8 device frames (deepseg.cc:657-658, -p bgblur:<ksize>)."""
         torch = _torch()
         n, h, w, _ = bgr.shape
-        out = torch.empty_like(bgr)
+        if out is None:
+            out = torch.empty_like(bgr)
+        elif out.shape != bgr.shape or out.dtype != bgr.dtype or not out.is_contiguous() or out.device != bgr.device:
+            raise BsxError("out must be a contiguous tensor shaped like the input")
         _check(lib().bsx_gaussian_blur_bgr(self.h, C.c_void_p(bgr.data_ptr()), C.c_void_p(out.data_ptr()), w, h, n, int(ksize), _stream_ptr()),
                self.h, "bsx_gaussian_blur_bgr")
         return out

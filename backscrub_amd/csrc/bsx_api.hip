@@ -115,6 +115,7 @@ struct bsx_ctx {
   uint8_t* d_host_frame = nullptr;  // staging for bsx_process_host
   uint8_t* d_bgr_scratch = nullptr; // BGR composite of bsx_step_batch_yuyv / _ex when the fused epilogue does not apply (lazy)
   uint8_t* d_bgr_scratch2 = nullptr; // ... its flipped copy when a YUYV pack follows (lazy)
+  uint8_t* d_bgblur_scratch = nullptr; // BSX_STEP_BGBLUR when the single pass does not apply: the blurred frames (lazy)
   float* d_color_lut = nullptr;
   MicroOp* d_program = nullptr;     // per-frame network program (kernels_frame.hip)
   bool use_program = false;
@@ -126,6 +127,7 @@ struct bsx_ctx {
   std::string last_error, plan_text;
   bool keep_logits = false;            // BSX_KEEP_LOGITS: segmented plans write the logits and run the stand-alone decode (A/B, debugging)
   bool no_mask_blend_fusion = false;   // BSX_NO_MASK_BLEND_FUSION, read once at bsx_new (no getenv on the per-step path)
+  bool no_bgblur_fusion = false;       // BSX_NO_BGBLUR_FUSION: BSX_STEP_BGBLUR always as blur pass + step (the A/B switch of the single-pass form)
   bool no_mask_tile = false;           // BSX_NO_MASK_TILE (tests: the generic mask kernel), likewise
   bool tail_generic = false;           // BSX_TAIL_GENERIC (tests: the scalar argmax scan of the DeepLab tail), likewise
   // Lanes (BSX_LANES=k, experiment): the fused step splits its batch into k contiguous groups of streams and runs each group's launch sequence on its own
@@ -447,6 +449,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     return nullptr;
   }
   c->no_mask_blend_fusion = getenv("BSX_NO_MASK_BLEND_FUSION") != nullptr;
+  c->no_bgblur_fusion = getenv("BSX_NO_BGBLUR_FUSION") != nullptr;
   c->no_mask_tile = getenv("BSX_NO_MASK_TILE") != nullptr;
   c->tail_generic = getenv("BSX_TAIL_GENERIC") != nullptr;
   c->keep_logits = getenv("BSX_KEEP_LOGITS") != nullptr;
@@ -482,7 +485,7 @@ void bsx_delete(bsx_ctx* c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (auto& kv : c->host_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   rtc_unload(&c->mid);
-  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
+  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_bgblur_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -592,11 +595,26 @@ struct LaneView {
 // flags (bsx.h): BSX_STEP_YUYV — the composite leaves as YUYV 4:2:2 (2 B/px), convert_rgb_to_yuyv (deepseg.cc:87-106) applied in the blend's epilogue;
 // BSX_STEP_FLIP_H / _V — cv::flip of the composite (deepseg.cc:667-673) folded into the epilogue's store addresses
 int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, unsigned flags) {
-  if (!c || !d_frames || !d_bg || !d_out || n <= 0 || n > c->n_streams || (flags & ~15u)) return BSX_EINVAL;
+  const int bgblur = (int)((flags >> 8) & 255u);                // BSX_STEP_BGBLUR(ksize): background = blur of the stream's own frame, d_bg unused
+  if (!c || !d_frames || (!d_bg && !bgblur) || !d_out || n <= 0 || n > c->n_streams || (flags & ~(15u | 0xFF00u))) return BSX_EINVAL;
+  if (bgblur && (bgblur > 31 || !(bgblur & 1) || d_frames == d_out)) return BSX_EINVAL;
   const int yuyv = (int)(flags & BSX_STEP_YUYV);
   const unsigned flip = flags & (BSX_STEP_FLIP_H | BSX_STEP_FLIP_V);
   if (yuyv && (c->width & 1)) return BSX_EINVAL;                // 4:2:2 pairs pixels horizontally
   DeviceGuard guard(c->device);
+  if (bgblur) {
+    if (!(flags & 15u) && !c->no_bgblur_fusion && gauss_blend_fusable(d_frames, c->d_masks, d_out, c->width, bgblur)) {
+      // masks as usual (prep → network → decode → upscale + blur), then ONE pass over the frames: blur tile → blend with the frame and the mask → composite
+      int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
+      if (rc) return rc;
+      BSX_HIP(c, launch_gauss_blend(d_frames, c->d_masks, d_out, c->width, c->height, bgblur, n, pick(c, stream)));
+      return BSX_OK;
+    }
+    const size_t fb = (size_t)c->width * c->height * 3;
+    if (!c->d_bgblur_scratch) BSX_HIP(c, hipMalloc(&c->d_bgblur_scratch, (size_t)c->n_streams * fb));
+    BSX_HIP(c, launch_gauss_blur(d_frames, c->d_bgblur_scratch, c->width, c->height, bgblur, n, pick(c, stream)));
+    return step_impl(c, d_frames, c->d_bgblur_scratch, fb, d_out, n, stream, flags & 15u);
+  }
   const bool fuse = !c->onmask && !c->no_mask_blend_fusion && (!yuyv || ((uintptr_t)d_out & 3) == 0) &&
                     mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, yuyv ? d_frames : d_out);
   if (!fuse) {

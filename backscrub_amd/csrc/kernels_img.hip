@@ -961,83 +961,149 @@ hipError_t launch_resize_bgr(const uint8_t* src, uint8_t* dst, ResizeTab tab, in
 constexpr int kGTW = 64, kGTH = 16, kGMaxR = 15, kGSW = kGTW + 2 * kGMaxR, kGSH = kGTH + 2 * kGMaxR;    // 94 x 46 source tile
 constexpr int kGSrcStride = 96;                  // bytes per plane row (multiple of 4)
 constexpr int kGHStride = 48;                    // u16 per hbuf column (rows of the source tile, even)
-struct GaussCoef { uint32_t c4[8]; uint32_t c2[16]; int n, r; };   // c[k] packed 4 per dword (bytes) and 2 per dword (u16), zero padded
+// hbuf column c of a plane starts 2 * (c / 8) dwords late: the horizontal pass writes 16 column groups (4 columns = 96 dwords apart: banks 0 / 32 only, an 8-way
+// conflict on every store) at once, the shift spreads them over 16 banks; the vertical pass reads 8 CONSECUTIVE columns per wave (24 dwords apart: conflict-free),
+// which share one shift.
+constexpr int kGHPlane = kGTW * kGHStride + 32;  // u16 per plane: 64 columns + the largest shift (14 dwords) rounded up
+__device__ __forceinline__ int gh_col(int plane, int col) { return plane * kGHPlane + col * kGHStride + 4 * (col >> 3); }
+// c[k] packed 4 per dword (bytes) and 2 per dword (u16), zero padded — once per output phase: c4[j] is the tap sequence delayed by j bytes, c2[s] by s halves, so that
+// the 4 neighbouring outputs of a horizontal item (2 of a vertical item) are dot products of the SAME aligned data words with different coefficient words
+// (one v_dot per word and output) instead of realigned windows with one coefficient set (v_alignbyte + v_dot per word and output).
+struct GaussCoef { uint32_t c4[4][9]; uint32_t c2[2][17]; int n, r, sh; };   // sh: the LDS planes start sh (0..3) pixels left of the tile's first source column
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int reflect101_far(int p, int len) {   // cv::borderInterpolate(BORDER_REFLECT_101) for overshoots beyond one period
   if (len == 1) return 0;
   while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
   return p;
 }
-__global__ __launch_bounds__(kThreads) void gauss_blur_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int W, int H, GaussCoef gc) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_src[3 * kGSH * kGSrcStride];          // [plane][row][col]
-  __shared__ __attribute__((aligned(16))) uint16_t s_h[3 * kGTW * kGHStride];             // [plane][col][row]
+// MODE 0: the vertical pass stores its bytes itself (any geometry).  MODE 1 (W % 4 == 0, 4-byte aligned images): the vertical pass leaves the blurred tile in LDS
+// as packed BGR rows and the workgroup writes it as whole dwords, one 4-pixel group (12 B) per lane — each lane of the vertical pass owns two ROWS of one column of
+// one plane, i.e. byte stores scattered over 16 image rows.  MODE 2 = MODE 1 with the alpha blend (deepseg.cc:108-134) applied to the group on its way out:
+// `-p bgblur` without `-b` (deepseg.cc:652-661) composites the camera frame over ITS OWN blur, so the blurred image is consumed where it is produced — it never
+// exists in HBM, and neither does the blend's second read of the frame (the lane's frame / mask words are requested at the top of the kernel).
+// NT = ceil((ksize + 3 + sh) / 4), a template parameter: the tap loops are straight-line code over NT horizontal / 2 NT - 1 vertical data words (the coefficient bytes past
+// ksize are zero, so the surplus taps add 0 whatever bytes they read), not loops predicated tap by tap.
+// The kernel is bound by VALU issue, not by memory (ksize 3 costs half of ksize 25), so the per-byte index arithmetic is what there is to save:
+//   * items advance by precomputed (row, column) steps instead of a runtime division per item, addresses are 32-bit offsets from a uniform base;
+//   * opt bit 0 (rows dword aligned), tiles whose source columns lie inside the image: the source tile is staged 4 pixels (three dwords) per item and
+//     de-interleaved with six v_perm_b32 into one dword per plane, instead of three byte loads + three byte LDS stores per pixel (rows still reflect).
+constexpr int kGOStride = 196;                   // bytes per packed output row in LDS: 64 px x 3 B + 4 (49 dwords: the 16 rows start on distinct banks)
+static_assert(kGTH * (kGTW / 4) == kThreads && kGTH * kGOStride <= 3 * kGSH * kGSrcStride, "one 4-pixel group per lane; the output tile aliases the source planes");
+template <int MODE, int NT>
+__global__ __launch_bounds__(kThreads) void gauss_blur_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint8_t* __restrict__ mask, int W, int H, GaussCoef gc,
+                                                         int opts) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[3 * kGSH * kGSrcStride];          // [plane][row][col]; MODE >= 1: later the packed output tile [row][kGOStride]
+  __shared__ __attribute__((aligned(16))) uint16_t s_h[3 * kGHPlane];                     // [plane][col][row], gh_col()
   const size_t img = (size_t)blockIdx.z * (size_t)W * H * 3;
   const uint8_t* in = src + img;
   uint8_t* out = dst + img;
-  const int x0 = blockIdx.x * kGTW, y0 = blockIdx.y * kGTH, r = gc.r, n = gc.n;
+  const int x0 = blockIdx.x * kGTW, y0 = blockIdx.y * kGTH, r = gc.r;
   const int SW = kGTW + 2 * r, SH = kGTH + 2 * r;                                          // live part of the source tile
+  // MODE >= 1: this lane's 4-pixel group of the tile
+  const int orow = threadIdx.x >> 4, ogx = x0 + 4 * (threadIdx.x & 15), ogy = y0 + orow;
+  const bool olive = MODE >= 1 && ogx < W && ogy < H;
+  uint32_t fr[3] = {0u, 0u, 0u}, mw = 0u;
+  if (MODE == 2 && olive) {
+    const uint32_t* fp = reinterpret_cast<const uint32_t*>(in + (unsigned)(ogy * W + ogx) * 3u);
+    fr[0] = fp[0]; fr[1] = fp[1]; fr[2] = fp[2];
+    mw = *reinterpret_cast<const uint32_t*>(mask + (size_t)blockIdx.z * (size_t)W * H + (unsigned)(ogy * W + ogx));
+  }
   // 1. stage + de-interleave (reflected at the image border)
-  for (int i = threadIdx.x; i < SH * SW; i += kThreads) {
-    const int row = i / SW, col = i - row * SW;
-    const int gy = reflect101_far(y0 - r + row, H), gx = reflect101_far(x0 - r + col, W);
-    const uint8_t* p = in + ((size_t)gy * W + gx) * 3;
-    const uint8_t b = p[0], g = p[1], rr = p[2];
-    s_src[(0 * kGSH + row) * kGSrcStride + col] = b;
-    s_src[(1 * kGSH + row) * kGSrcStride + col] = g;
-    s_src[(2 * kGSH + row) * kGSrcStride + col] = rr;
+  //    The planes start at source column x0 - r - sh, sh = (-r) & 3 when 4-pixel staging is on (a multiple of 4 → aligned 12-byte groups), else 0; the horizontal
+  //    pass never sees the difference: its coefficient words are delayed by sh more bytes (gauss_coefficients).
+  const int sh = gc.sh, G = (SW + sh + 3) >> 2;                        // 4-pixel groups per staged row
+  const bool xin = (opts & 1) && x0 - r - sh >= 0 && x0 - r - sh + 4 * G <= W;   // uniform: every group of every row lies inside the image row
+  if (xin) {                                                          // item = (row, group of 4 pixels): 12 source bytes → one dword per plane
+    int row = (int)threadIdx.x / G, grp = (int)threadIdx.x - row * G;
+    const int dr = kThreads / G, dc = kThreads - dr * G;
+    const unsigned xb = (unsigned)(x0 - r - sh);
+    while (row < SH) {
+      const int gy = reflect101_far(y0 - r + row, H);
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(in + ((unsigned)(gy * W) + xb + 4u * (unsigned)grp) * 3u);
+      const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];                 // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+      const uint32_t pb = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00060300u), 0x05020100u);
+      const uint32_t pg = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00070401u), 0x06020100u);
+      const uint32_t pr = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00000502u), 0x07040100u);
+      uint32_t* o = reinterpret_cast<uint32_t*>(s_src + row * kGSrcStride) + grp;
+      o[0] = pb; o[kGSH * kGSrcStride / 4] = pg; o[2 * kGSH * kGSrcStride / 4] = pr;
+      grp += dc; row += dr;
+      if (grp >= G) { grp -= G; row++; }
+    }
+  } else {
+    int row = (int)threadIdx.x / SW, col = (int)threadIdx.x - row * SW;
+    const int dr = kThreads / SW, dc = kThreads - dr * SW;
+    while (row < SH) {
+      const int gy = reflect101_far(y0 - r + row, H), gx = reflect101_far(x0 - r + col, W);
+      const uint8_t* p = in + (unsigned)(gy * W + gx) * 3u;
+      const uint8_t b = p[0], g = p[1], rr = p[2];
+      s_src[(0 * kGSH + row) * kGSrcStride + col + sh] = b;
+      s_src[(1 * kGSH + row) * kGSrcStride + col + sh] = g;
+      s_src[(2 * kGSH + row) * kGSrcStride + col + sh] = rr;
+      col += dc; row += dr;
+      if (col >= SW) { col -= SW; row++; }
+    }
   }
   __syncthreads();
-  // 2. horizontal pass: item = (plane, source row, group of 4 output columns)
-  const int NT = (n + 3) >> 2;
-  for (int i = threadIdx.x; i < 3 * SH * (kGTW / 4); i += kThreads) {
-    const int grp = i & (kGTW / 4 - 1), pr = i / (kGTW / 4), row = pr % SH, plane = pr / SH;
+  // 2. horizontal pass: item = (plane, source row, group of 4 output columns); consecutive items of a lane are kThreads / 16 = 16 rows apart (SH > 16: one wrap at most)
+  static_assert(kGTW / 4 == 16 && kThreads / 16 == kGTH && NT >= 2 && NT <= 9, "lane → (row, column group) mapping of the horizontal pass");
+  for (int grp = threadIdx.x & 15, row = threadIdx.x >> 4, plane = 0; plane < 3;) {
     const uint32_t* rowp = reinterpret_cast<const uint32_t*>(s_src + (plane * kGSH + row) * kGSrcStride) + grp;   // bytes 4*grp ..
-    uint32_t d[10];
+    uint32_t d[NT];
 #pragma unroll
-    for (int t = 0; t < 10; t++) d[t] = (t <= NT) ? rowp[t] : 0u;          // stays inside the 96-byte row: 4*15 + 4*10 = 100 > 96 only for t = 9, never needed (NT <= 8)
+    for (int t = 0; t < NT; t++) d[t] = rowp[t];                           // stays inside the 96-byte row: 4 * (15 + NT) <= 96
     uint32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      if (t < NT) {
-        const uint32_t c = gc.c4[t];
-        acc[0] = __builtin_amdgcn_udot4(d[t], c, acc[0], false);
-        acc[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d[t + 1], d[t], 1), c, acc[1], false);
-        acc[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d[t + 1], d[t], 2), c, acc[2], false);
-        acc[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d[t + 1], d[t], 3), c, acc[3], false);
-      }
+    for (int t = 0; t < NT; t++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_udot4(d[t], gc.c4[j][t], acc[j], false);
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) s_h[(plane * kGTW + 4 * grp + j) * kGHStride + row] = (uint16_t)min(acc[j], 0xFFFFu);
+    for (int j = 0; j < 4; j++) s_h[gh_col(plane, 4 * grp + j) + row] = (uint16_t)acc[j];      // sum(c) <= 257 (gauss_coefficients): 255 * 257 fits 16 bits
+    row += kGTH;
+    if (row >= SH) { row -= SH; plane++; }
   }
   __syncthreads();
   // 3. vertical pass: item = (plane, output column, pair of output rows)
-  const int NP = (n + 1) >> 1;
+  constexpr int NP = 2 * NT - 1;                                           // ksize <= 4 NT - 3: ceil((ksize + 1) / 2) data words
   for (int i = threadIdx.x; i < 3 * kGTW * (kGTH / 2); i += kThreads) {
     const int m = i & (kGTH / 2 - 1), pc = i / (kGTH / 2), col = pc & (kGTW - 1), plane = pc / kGTW;
-    const uint32_t* colp = reinterpret_cast<const uint32_t*>(s_h + (plane * kGTW + col) * kGHStride) + m;        // rows 2m ..
-    uint32_t hd[17];
+    const uint32_t* colp = reinterpret_cast<const uint32_t*>(s_h + gh_col(plane, col)) + m;                        // rows 2m ..
+    uint32_t hd[NP];
 #pragma unroll
-    for (int t = 0; t < 17; t++) hd[t] = (t <= NP) ? colp[t] : 0u;          // 2m + 2*16 + 1 <= 47 < kGHStride
+    for (int t = 0; t < NP; t++) hd[t] = colp[t];                           // 2 (m + NP - 1) + 1 <= 47 < kGHStride
     uint32_t a0 = 0, a1 = 0;
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-      if (t < NP) {
-        const us2v c = __builtin_bit_cast(us2v, gc.c2[t]);
-        a0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, hd[t]), c, a0, false);
-        a1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, __builtin_amdgcn_alignbyte(hd[t + 1], hd[t], 2)), c, a1, false);
+    for (int t = 0; t < NP; t++) {
+      a0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, hd[t]), __builtin_bit_cast(us2v, gc.c2[0][t]), a0, false);
+      a1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, hd[t]), __builtin_bit_cast(us2v, gc.c2[1][t]), a1, false);
+    }
+    const uint8_t v0 = (uint8_t)min((a0 + (1u << 15)) >> 16, 255u), v1 = (uint8_t)min((a1 + (1u << 15)) >> 16, 255u);
+    if (MODE >= 1) {
+      s_src[(2 * m) * kGOStride + 3 * col + plane] = v0;
+      s_src[(2 * m + 1) * kGOStride + 3 * col + plane] = v1;
+    } else {
+      const int gx = x0 + col, gy = y0 + 2 * m;
+      if (gx < W) {
+        if (gy < H) out[(unsigned)(gy * W + gx) * 3u + plane] = v0;
+        if (gy + 1 < H) out[(unsigned)((gy + 1) * W + gx) * 3u + plane] = v1;
       }
     }
-    const int gx = x0 + col, gy = y0 + 2 * m;
-    if (gx < W) {
-      if (gy < H) out[((size_t)gy * W + gx) * 3 + plane] = (uint8_t)min((a0 + (1u << 15)) >> 16, 255u);
-      if (gy + 1 < H) out[((size_t)(gy + 1) * W + gx) * 3 + plane] = (uint8_t)min((a1 + (1u << 15)) >> 16, 255u);
+  }
+  if (MODE >= 1) {
+    __syncthreads();
+    if (olive) {
+      const uint32_t* bp = reinterpret_cast<const uint32_t*>(s_src + orow * kGOStride + 12 * (threadIdx.x & 15));
+      uint32_t o3[3] = {bp[0], bp[1], bp[2]};
+      if (MODE == 2) { const uint32_t a[3] = {o3[0], o3[1], o3[2]}; blend_quad(a, fr, mw, o3); }    // background = the blur, foreground = the frame itself
+      uint32_t* op = reinterpret_cast<uint32_t*>(out + (unsigned)(ogy * W + ogx) * 3u);
+      op[0] = o3[0]; op[1] = o3[1]; op[2] = o3[2];
     }
   }
 }
 
 // Coefficients of cv::GaussianBlur(ksize = n, sigma = 0) for 8-bit images (OpenCV 3.4 - 4.4 rule; DESIGN.md records the
 // version ambiguity): fixed tables for n <= 7, else cvRound(exp(-x^2 / (2 sigma^2)) / sum * 256), sigma = 0.3 * ((n-1)/2 - 1) + 0.8.
-bool gauss_coefficients(int n, GaussCoef* gc) {
+bool gauss_coefficients(int n, GaussCoef* gc, int sh) {
   if (n < 1 || n > 2 * kGMaxR + 1 || !(n & 1)) return false;
   unsigned c[32] = {0};
   if (n == 1) c[0] = 256;
@@ -1055,18 +1121,56 @@ bool gauss_coefficients(int n, GaussCoef* gc) {
   for (int i = 0; i < n; i++) { if (c[i] > 255 && n > 1) return false; total += c[i]; }
   if (total > 257) return false;                          // the kernel relies on Σc·255 fitting 16 bits
   *gc = GaussCoef{};
-  gc->n = n; gc->r = n / 2;
-  if (n == 1) { gc->c4[0] = 0; gc->c2[0] = 256; return true; }   // 256 does not fit a byte: n = 1 is served as a copy by the caller
-  for (int i = 0; i < n; i++) { gc->c4[i >> 2] |= c[i] << (8 * (i & 3)); gc->c2[i >> 1] |= c[i] << (16 * (i & 1)); }
+  gc->n = n; gc->r = n / 2; gc->sh = sh;
+  if (n == 1) return true;                                // 256 does not fit a byte: n = 1 is served as a copy by the caller
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < n; i++) gc->c4[j][(i + j + sh) >> 2] |= c[i] << (8 * ((i + j + sh) & 3));
+  for (int h = 0; h < 2; h++)
+    for (int i = 0; i < n; i++) gc->c2[h][(i + h) >> 1] |= c[i] << (16 * ((i + h) & 1));
   return true;
+}
+static bool gauss_words(const void* a, const void* b, const void* c, int w) {      // whole-dword output groups: 4 pixels = 12 bytes at 4-byte aligned addresses
+  static const bool off = [] { const char* e = getenv("BSX_GAUSS_BYTE_STORE"); return e && *e == '1'; }();
+  return !off && (w & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 3) == 0;
+}
+static int gauss_opts(const void* src, int w) {                                    // bit 0: 4-pixel staging of interior tiles (dword aligned rows)
+  static const bool off = [] { const char* e = getenv("BSX_GAUSS_BYTE_STAGE"); return e && *e == '1'; }();
+  return !off && (w & 3) == 0 && (((uintptr_t)src) & 3) == 0 ? 1 : 0;
+}
+template <int MODE>
+static void gauss_launch(dim3 grid, hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* mask, int w, int h, const GaussCoef& gc, int opts) {
+  switch ((gc.n + gc.sh + 6) >> 2) {                      // NT = ceil((ksize + 3 + sh) / 4): 2 .. 9
+#define BSX_G(NT) case NT: gauss_blur_k<MODE, NT><<<grid, kThreads, 0, s>>>(src, dst, mask, w, h, gc, opts); break;
+    BSX_G(2) BSX_G(3) BSX_G(4) BSX_G(5) BSX_G(6) BSX_G(7) BSX_G(8) BSX_G(9)
+#undef BSX_G
+    default: break;
+  }
 }
 hipError_t launch_gauss_blur(const uint8_t* src, uint8_t* dst, int w, int h, int ksize, int n, hipStream_t s) {
   GaussCoef gc;
-  if (!gauss_coefficients(ksize, &gc)) return hipErrorInvalidValue;
+  const int opts = gauss_opts(src, w);
+  if (!gauss_coefficients(ksize, &gc, (opts & 1) ? (-(ksize / 2)) & 3 : 0)) return hipErrorInvalidValue;
   if (ksize == 1) return hipMemcpyAsync(dst, src, (size_t)n * w * h * 3, hipMemcpyDeviceToDevice, s);
+  const bool words = gauss_words(src, dst, nullptr, w);
   for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
     const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
-    gauss_blur_k<<<dim3((w + kGTW - 1) / kGTW, (h + kGTH - 1) / kGTH, nn), kThreads, 0, s>>>(src + (size_t)n0 * w * h * 3, dst + (size_t)n0 * w * h * 3, w, h, gc);
+    const dim3 grid((w + kGTW - 1) / kGTW, (h + kGTH - 1) / kGTH, nn);
+    if (words) gauss_launch<1>(grid, s, src + (size_t)n0 * w * h * 3, dst + (size_t)n0 * w * h * 3, nullptr, w, h, gc, opts);
+    else gauss_launch<0>(grid, s, src + (size_t)n0 * w * h * 3, dst + (size_t)n0 * w * h * 3, nullptr, w, h, gc, opts);
+  }
+  return hipGetLastError();
+}
+// out = alpha_blend(GaussianBlur(frames, ksize), frames, masks) in one pass over the frames (gauss_blur_k<2, ..>)
+bool gauss_blend_fusable(const uint8_t* frames, const uint8_t* masks, const uint8_t* out, int w, int ksize) {
+  return ksize >= 3 && ksize <= 2 * kGMaxR + 1 && (ksize & 1) && frames != out && gauss_words(frames, masks, out, w);
+}
+hipError_t launch_gauss_blend(const uint8_t* frames, const uint8_t* masks, uint8_t* out, int w, int h, int ksize, int n, hipStream_t s) {
+  GaussCoef gc;
+  const int opts = gauss_opts(frames, w);
+  if (!gauss_coefficients(ksize, &gc, (opts & 1) ? (-(ksize / 2)) & 3 : 0) || !gauss_blend_fusable(frames, masks, out, w, ksize)) return hipErrorInvalidValue;
+  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
+    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
+    gauss_launch<2>(dim3((w + kGTW - 1) / kGTW, (h + kGTH - 1) / kGTH, nn), s, frames + (size_t)n0 * w * h * 3, out + (size_t)n0 * w * h * 3, masks + (size_t)n0 * w * h, w, h, gc, opts);
   }
   return hipGetLastError();
 }

@@ -488,6 +488,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
   store_partials(s_red, fa + d.part_B_off + (long)t_ * 16);
 
   // 2. 16 expanded channels at a time: x = act(pw_b(B)) → depthwise 3x3/s2 → c0
+  //    (requesting group g + 1's 1x1 tile while group g runs — 8 more registers, 5 instead of 6 waves per SIMD or 16 B of scratch at a cap of 6 — measured SLOWER:
+  //     45.4 → 51.3 us at 256 VGA streams, 170 → 187 us for mlkit / HD, profiles/r03af)
   const int C = d.dw.C, ngrp = (C + 15) >> 4, quad = lane & 3, px = lane >> 2;
   for (int grp = 0; grp < ngrp && !(d.dbg_skip & 2); grp++) {
     load_wtile(wr, w, d.pw_b, 16 * grp, li, g);

@@ -528,6 +528,35 @@ def main():
                               "note": "bsx_step_batch_yuyv: composite written as YUYV (2 B/px instead of 3), no separate packing pass"}
         del d_yuyv, a
 
+    # `-p bgblur:25` without `-b` (deepseg.cc:652-661): background = GaussianBlur of the stream's own frame.  One pass (BSX_STEP_BGBLUR: blur tile → blend out of LDS)
+    # against the two-call form (bsx_gaussian_blur_bgr into a per-stream background, then bsx_step_batch)
+    if rank == 0 and world == 1 and not args.no_extra_configs and W % 4 == 0:
+        mg, d_frames, d_out = res["mg"], res["d_frames"], res["d_out"]
+        d_two = torch.empty_like(d_out)
+        d_blur = torch.empty_like(d_frames)
+
+        def two_call():
+            mg.gaussian_blur(d_frames, 25, out=d_blur)
+            mg.step(d_frames, d_blur, d_two)
+
+        def one_pass():
+            mg.step_ex(d_frames, None, d_out, bgblur=25)
+
+        def timed(fn, iters=max(3, args.steps // 4)):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t1) / iters
+        ms_two, ms_one = timed(two_call), timed(one_pass)
+        result["bgblur_step"] = {"ksize": 25, "ms_per_step": round(ms_one, 4), "value": round(B / (ms_one * 1e-3), 1), "unit": "frames/s",
+                                 "two_call_ms_per_step": round(ms_two, 4), "speedup": round(ms_two / ms_one, 3),
+                                 "note": "bsx_step_batch_ex(BSX_STEP_BGBLUR(25)): blur + blend in one pass over the frames vs bsx_gaussian_blur_bgr + bsx_step_batch"}
+        del d_two, d_blur
+
     # the blend kernel with ONE BACKGROUND PER STREAM (animated backgrounds): nothing of its 10 B/px comes out of L2, unlike the shared
     # 0.9 MB picture of the default job whose roofline_blend line is flattered by cache hits (its PMC traffic is below the algorithmic bytes)
     if rank == 0 and world == 1 and not args.no_extra_configs and not args.per_stream_bg:

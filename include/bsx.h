@@ -149,6 +149,12 @@ int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_
  * Nothing later depends on it: every frame's mask is rebuilt from the model-resolution temporal state, which advances as usual; bsx_masks_device() then keeps
  * the last mask a call WITHOUT this flag stored.  For main loops that only need the composite (app/deepseg.cc:661 uses the mask for nothing else unless -d -d). */
 #define BSX_STEP_NO_MASK 8u
+/* BSX_STEP_BGBLUR(ksize): the background of every stream is cv::GaussianBlur(its own camera frame, Size(ksize, ksize), 0) — `-p bgblur:<ksize>` without `-b`,
+ * the reference's default way to run (app/deepseg.cc:652-661).  d_bg is ignored (may be NULL).  The blur and the alpha blend are ONE pass over the frames: each
+ * tile of the blurred frame is composited while it is still in LDS, so the blurred image is never written or read back and the frame is read once, not twice.
+ * Bit-identical to bsx_gaussian_blur_bgr into a per-stream background + bsx_step_batch_ex(flags) with bg_frame_stride = one frame; that two-call sequence is what
+ * runs, on a context-owned scratch background, when the single pass does not apply (YUYV / flip flags, width % 4 != 0, unaligned buffers, ksize 1).  ksize odd, 1..31. */
+#define BSX_STEP_BGBLUR(ksize) (((unsigned)(ksize) & 255u) << 8)
 int bsx_step_batch_ex(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                       uint8_t* d_out, int n, void* stream, unsigned flags);
 

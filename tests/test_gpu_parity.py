@@ -713,6 +713,43 @@ def test_step_with_flips_folded_into_the_blend(bs, oracle, key, res):
     mg_b.close()
 
 
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA), ("full", (1280, 720)), ("lite", (322, 242))])
+def test_step_with_own_blur_as_background(bs, oracle, key, res):
+    """BSX_STEP_BGBLUR(ksize): `-p bgblur:<n>` without `-b` (app/deepseg.cc:652-661) in one pass over the frames — the blurred tile is composited out of LDS.
+    Bit-identical to bsx_gaussian_blur_bgr into a per-stream background + bsx_step_batch, on the four flip-test geometries (the last one, width % 4 != 0,
+    takes the two-pass form inside the library), for three kernel sizes, with flags that force the two-pass form, and against the oracle's blur + blend."""
+    import torch
+    from backscrub_amd import synth
+    W, H = res
+    n = 3
+    mg_a = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    mg_b = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    out_a = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    out_b = torch.empty_like(out_a)
+    for t, ksize in enumerate((25, 3, 31, 25)):
+        frames = _dev(np.stack([synth.frame(W, H, i, t) for i in range(n)]))
+        mg_a.step(frames, mg_a.gaussian_blur(frames, ksize), out_a)
+        mg_b.step_ex(frames, None, out_b, bgblur=ksize)
+        assert torch.equal(out_a, out_b), "t=%d ksize=%d: %d bytes differ" % (t, ksize, int((out_a != out_b).sum()))
+        assert torch.equal(mg_a.masks(), mg_b.masks())
+    f0 = frames[0].cpu().numpy()
+    assert np.array_equal(out_b[0].cpu().numpy(), oracle.alpha_blend(oracle.gaussian_blur(f0, 25), f0, mg_b.masks()[0].cpu().numpy()))
+    # flags that the single pass does not serve: same bytes through the library's own two-pass form
+    mg_a.step_ex(frames, mg_a.gaussian_blur(frames, 7), out_a, flip_h=True)
+    mg_b.step_ex(frames, None, out_b, flip_h=True, bgblur=7)
+    assert torch.equal(out_a, out_b)
+    mg_a.step(frames, frames, out_a)                                     # ksize 1: the blur is the frame itself
+    mg_b.step_ex(frames, None, out_b, bgblur=1)
+    assert torch.equal(out_a, out_b) and torch.equal(out_b, frames)
+    for bad in (4, 33):
+        with pytest.raises(bs.BsxError):
+            mg_b.step_ex(frames, None, out_b, bgblur=bad)
+    with pytest.raises(bs.BsxError):
+        mg_b.step_ex(frames, None, frames, bgblur=5)                     # in place: the blur reads neighbours the composite would overwrite
+    mg_a.close()
+    mg_b.close()
+
+
 @pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA)])
 def test_step_without_storing_the_mask(bs, key, res):
     """BSX_STEP_NO_MASK: the same composite bytes as bsx_step_batch, the temporal state advances identically (the next frames agree too), and the
