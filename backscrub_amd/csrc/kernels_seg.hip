@@ -2,13 +2,13 @@
 //
 // Every kernel: grid = (tiles per frame, frames), 256 lanes = 4 waves per workgroup, several workgroups per CU.  A workgroup
 // owns one tile of its segment's OUTPUT pixels and recomputes the halo its depthwise 3x3 needs; intermediate tensors of the
-// tile live in LDS as dense [pixel][16] rows (conflict-free for both access patterns used here: the quad-transposed MFMA
+// tile live in LDS as dense [pixel][16] rows (conflict-free for both access patterns used here: the MFMA
 // epilogue stores and the (pixel, channel-quad) lanes of the depthwise phases), never in HBM.
 //
 // 1x1 convolutions and the 3x3 stem run on v_mfma_f32_16x16x4_f32 — exact f32 FMA chains, so the results stay within
 // float rounding of the reference order (measured against the oracle: < 1e-5 relative on the logits).  Operand maps as
-// in kernels_frame.hip: A lane (li, g) = x[pixel li][k = 4g..4g+3]; B lane = w[k][channel li]; D is transposed inside lane
-// quads (mfma_tile.hpp) so that a lane ends up with 4 consecutive channels of ONE pixel: 16-byte stores everywhere.
+// in kernels_frame.hip, operands swapped: A lane (li, g) = w[k][channel li]; B lane = x[pixel li][k = 4g..4g+3]; D lane = channels 4g..4g+3 of pixel li —
+// 4 consecutive channels of ONE pixel (acc_quad): 16-byte stores everywhere.
 //
 // Reference operators covered (file:line into /root/reference): Interpreter::Invoke() lib/libbackscrub.cc:307 — CONV_2D,
 // DEPTHWISE_CONV_2D, RESIZE_BILINEAR (half-pixel), MUL/ADD gates, AVERAGE_POOL_2D (as partial sums), FULLY_CONNECTED /
@@ -76,13 +76,18 @@ __device__ __forceinline__ float sg_act(float v, int act) {
   return __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
 }
 
+// The weights are the A operand of every MFMA here (rows = output channels) and the activations the B operand (columns = pixels): the accumulator of lane
+// (li, g) is then D[channels 4g..4g+3][pixel li] — four consecutive channels of ONE pixel, the 16-byte unit every store, bias and residual in these kernels
+// works in — without the 4x4 transpose inside lane quads (12 selects + 4 DPP moves per tile) the pixel-major operand order needed.  Same products, same
+// accumulation order over k: bit-identical values.
+__device__ __forceinline__ float4 acc_quad(const f4acc acc) { return make_float4(acc[0], acc[1], acc[2], acc[3]); }
 // one 16-pixel x 16-channel tile of a 1x1 convolution with Cin = 16: 4 MFMAs
 __device__ __forceinline__ f4acc mma16(const float4 a, const float (&wr)[4]) {
   f4acc acc = {0.f, 0.f, 0.f, 0.f};
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wr[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wr[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wr[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wr[3], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], a.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1], a.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2], a.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], a.w, acc, 0, 0, 0);
   return acc;
 }
 // B-operand registers of the [16][cout_pad] block at output channels n0..n0+15: lane (li, g) holds w[4g + r][n0 + li]
@@ -163,19 +168,22 @@ __device__ __forceinline__ void seg_gate(const SegGate& gt, const float* __restr
 }
 
 // ---- per-tile partial sums of a 16-channel tensor → partials[tile][16] -------------------------------------------------------
-// Lanes hold float4 partial sums of their channel quad.  MODE 0: MFMA-epilogue lanes (lane (g, li): channel quad li >> 2, the four
-// lanes li & 3 differ in pixel); MODE 1: depthwise lanes (lane = 4 * pixel + quad inside a 16-lane DPP row).  Two DPP steps leave
-// 16 partial float4 per wave; they meet in s_red[16 slots][16 channels] and the first 16 lanes of the workgroup finish the sum.
+// Lanes hold float4 partial sums of their channel quad.  MODE 0: MFMA-epilogue lanes (lane (g, li): channel quad g, the 16 lanes of
+// the row differ in pixel); MODE 1: depthwise lanes (lane = 4 * pixel + quad inside a 16-lane DPP row).  DPP row shifts leave
+// the partial float4s of a wave; they meet in s_red[16 slots][16 channels] and the first 16 lanes of the workgroup finish the sum.
 template <int SHR>
 __device__ __forceinline__ float dpp_row_shr(float v) {        // lane i <- lane i - SHR inside its row of 16 (0 where there is none)
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SHR, 0xf, 0xf, true));
 }
 template <int MODE>
 __device__ __forceinline__ void wave_reduce16(float4 v, float* s_red, int wave, int lane) {
-  if (MODE == 0) {
-    v.x += dpp_quad(v.x, 1); v.y += dpp_quad(v.y, 1); v.z += dpp_quad(v.z, 1); v.w += dpp_quad(v.w, 1);
-    v.x += dpp_quad(v.x, 2); v.y += dpp_quad(v.y, 2); v.z += dpp_quad(v.z, 2); v.w += dpp_quad(v.w, 2);
-    if ((lane & 3) == 0) st4(s_red + (wave * 4 + (lane >> 4)) * 16 + (lane & 12), v);          // slot (wave, g), channels 4 * (li >> 2)
+  if (MODE == 0) {                                                   // MFMA-epilogue lanes: row g of 16 lanes = 16 pixels of channel quad g
+    v.x += dpp_row_shr<1>(v.x); v.y += dpp_row_shr<1>(v.y); v.z += dpp_row_shr<1>(v.z); v.w += dpp_row_shr<1>(v.w);
+    v.x += dpp_row_shr<2>(v.x); v.y += dpp_row_shr<2>(v.y); v.z += dpp_row_shr<2>(v.z); v.w += dpp_row_shr<2>(v.w);
+    v.x += dpp_row_shr<4>(v.x); v.y += dpp_row_shr<4>(v.y); v.z += dpp_row_shr<4>(v.z); v.w += dpp_row_shr<4>(v.w);
+    v.x += dpp_row_shr<8>(v.x); v.y += dpp_row_shr<8>(v.y); v.z += dpp_row_shr<8>(v.z); v.w += dpp_row_shr<8>(v.w);
+    const int li = lane & 15;                                        // lane 15 of the row holds its sum → slot 4 * wave; lanes 12..14 zero the wave's other three slots
+    if (li >= 12) st4(s_red + (wave * 4 + (15 - li)) * 16 + 4 * (lane >> 4), li == 15 ? v : f4zero());
   } else {
     v.x += dpp_row_shr<4>(v.x); v.y += dpp_row_shr<4>(v.y); v.z += dpp_row_shr<4>(v.z); v.w += dpp_row_shr<4>(v.w);
     v.x += dpp_row_shr<8>(v.x); v.y += dpp_row_shr<8>(v.y); v.z += dpp_row_shr<8>(v.z); v.w += dpp_row_shr<8>(v.w);
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   float* x_t = in_t;
   float* A_out = fa + d.a_off;                                      // uniform bases + 32-bit lane offsets (global_load/store saddr forms)
   float* b0_out = fa + d.b0_off;
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
 
   // 1. input tile (zero outside the image: SAME padding of the stem): wave = rows, lane = row elements; every load of the lane is
   //    in flight before its first LDS store
@@ -332,13 +340,13 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   const float4 bias_s = ld4(w + d.stem.b_off + cq4);
   const Clamp cl_stem = clamp_of(d.stem.act), cl_pw = clamp_of(d.pw.act), cl_dw = clamp_of(d.dw.act);
   const int ntile = AR * ctiles;
-  const int xe = 4 * g + q;                                        // column of the pixel this lane owns after the quad transpose
+  const int xe = li;                                        // column of the pixel this lane owns after the quad transpose
   __syncthreads();
 
   // 2. stem on the A region, two tiles per iteration: their MFMA chains (7 dependent instructions each) interleave
   float4 sumA = f4zero();
   auto stem_epilogue = [&](const f4acc acc, const RowTile rt) {
-    float4 v = quad_transpose(acc, q);
+    float4 v = acc_quad(acc);
     const int x2 = 16 * rt.ct + xe, gy = ar0 + rt.row, gx = ac0 + x2;
     if (x2 < AC) {
       v = f4add(v, bias_s);
@@ -362,8 +370,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
     f4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s7 = 0; s7 < 7; s7++) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[s7], ws[s7], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[s7], ws[s7], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[s7], av0[s7], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[s7], av1[s7], acc1, 0, 0, 0);
     }
     stem_epilogue(acc0, r0t);
     if (two) stem_epilogue(acc1, r1t);
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 
   // 3. x = act(pw(A)) on the same region; zero outside the image (SAME padding of the depthwise); two tiles per iteration
   auto pw_epilogue = [&](const f4acc acc, const RowTile rt) {
-    float4 v = quad_transpose(acc, q);
+    float4 v = acc_quad(acc);
     const int x2 = 16 * rt.ct + xe, gy = ar0 + rt.row, gx = ac0 + x2;
     if (x2 < AC) {
       const bool inside = gy >= 0 && gy < d.H1 && gx >= 0 && gx < d.W1;
@@ -389,10 +397,10 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
     const float4 a0 = ld4(a_t + (r0t.row * RW + min(16 * r0t.ct + li, AC - 1)) * 16 + 4 * g);
     const float4 a1 = ld4(a_t + (r1t.row * RW + min(16 * r1t.ct + li, AC - 1)) * 16 + 4 * g);
     f4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wr[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wr[0], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wr[1], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wr[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wr[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wr[2], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wr[3], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wr[3], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], a0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], a1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1], a0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1], a1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2], a0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2], a1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], a0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], a1.w, acc1, 0, 0, 0);
     pw_epilogue(acc0, r0t);
     if (two) pw_epilogue(acc1, r1t);
   }
@@ -438,8 +446,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
   const float* b0_in = fa + d.b0_off;
   float* B_out = fa + d.B_off;
   float* c0_out = fa + d.c0_off;
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
-  const int ntile = BR * ctiles, xe = 4 * g + q;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
+  const int ntile = BR * ctiles, xe = li;
   // all of this wave's b0 operands are requested before the gate prologue (one memory round trip for the whole workgroup)
   constexpr int kB0 = 6;                                            // planner: ceil(BR * ctiles / 4) <= 6
   float4 b0v[kB0];
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
     float4 a = b0v[j];
     a = make_float4(__fmul_rn(a.x, sv.x), __fmul_rn(a.y, sv.y), __fmul_rn(a.z, sv.z), __fmul_rn(a.w, sv.w));
     const f4acc acc = mma16(a, wr);
-    float4 v = quad_transpose(acc, q);
+    float4 v = acc_quad(acc);
     const int x2 = 16 * rt.ct + xe, hy = br0 + rt.row, hx = bc0 + x2;
     if (x2 < BC) {
       v = clamp4(f4add(v, bias_a), cl_a);
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
       const RowTile rt = row_tile(t, ctiles, d.m_ct);
       const int bx = min(16 * rt.ct + li, BC - 1);
       const f4acc acc = mma16(ld4(B_t + (rt.row * RW + bx) * 16 + 4 * g), wr);
-      float4 v = quad_transpose(acc, q);
+      float4 v = acc_quad(acc);
       const int x2 = 16 * rt.ct + xe, hy = br0 + rt.row, hx = bc0 + x2;
       if (x2 < BC) {
         const bool inside = hy >= 0 && hy < d.H2 && hx >= 0 && hx < d.W2;
@@ -573,21 +581,21 @@ __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ ski
 }
 __device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* l_t, int H, int W, int HL, int WL, bool half_pixel, bool align, const float* s_gate,
                                               const SegConvW& pw, const float* __restrict__ w, int r0, int c0, int ZH, int ZC, float* z_t) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
   float wr[4];
   load_wtile(wr, w, pw, 0, li, g);
   const float4 bias = ld4(w + pw.b_off + cq4);
   const float4 gv = ld4(s_gate + 4 * g);
   const Clamp cl = clamp_of(pw.act);
   const float hs = up_scale(HL, H, align), wsc = up_scale(WL, W, align);
-  // column constants of this lane: operand side (pixel li) and epilogue side (pixel 4g + q)
+  // column constants of this lane: operand and epilogue side are the same pixel li
   const int ix = c0 - 1 + li;
   int x0, x1;
   float dx;
   up_axis(min(max(ix, 0), W - 1), wsc, half_pixel, WL, &x0, &x1, &dx);
   const int xo0 = (x0 - pre.lx0) * kLoStride + 4 * g, xo1 = (x1 - pre.lx0) * kLoStride + 4 * g;
-  const int xe = 4 * g + q, hx = c0 - 1 + xe;
-  const bool ecol_in = xe < ZC && hx >= 0 && hx < W;
+  const int xe = li;
+  const bool ecol_in = xe < ZC && ix >= 0 && ix < W;
 #pragma unroll
   for (int j = 0; j < kGatedRows; j++) {
     const int zy = wave + 4 * j, iy = r0 - 1 + zy;
@@ -607,7 +615,7 @@ __device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* 
     a.z = fmaf(sk.z, gv.z, fmaf(td.z, w11, fmaf(tc.z, w01, fmaf(tb.z, w10, ta.z * w00))));
     a.w = fmaf(sk.w, gv.w, fmaf(td.w, w11, fmaf(tc.w, w01, fmaf(tb.w, w10, ta.w * w00))));
     const f4acc acc = mma16(a, wr);
-    float4 v = quad_transpose(acc, q);
+    float4 v = acc_quad(acc);
     v = (ecol_in && row_in) ? clamp4(f4add(v, bias), cl) : f4zero();
     if (xe < ZC) st4(z_t + (zy * 16 + xe) * 16 + cq4, v);
   }
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
   float* t_t = z_t + ZH * 256;                                      // [TR][16][16]
   float* l_t = t_t + d.TR * 256;                                    // staged window of lo2
   float* lo_out = fa + d.lo_off;
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, q = li & 3, cq4 = li & ~3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
   const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
   if (tid < 16) seg_smem[kScrGate + tid] = fa[d.g_off + tid];
   __syncthreads();
@@ -650,10 +658,10 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
   const float4 bias2 = ld4(w + d.pw2.b_off + cq4);
   __syncthreads();
   float4 sum = f4zero();
-  const int xe = 4 * g + q;
+  const int xe = li;
   for (int py = wave; py < d.TR && r0 + py < d.H2; py += 4) {
     const f4acc acc = mma16(ld4(t_t + (py * 16 + min(li, d.TC - 1)) * 16 + 4 * g), wr);
-    float4 v = quad_transpose(acc, q);
+    float4 v = acc_quad(acc);
     if (xe < d.TC && c0 + xe < d.W2) {
       v = clamp4(f4add(v, bias2), cl_2);
       stg4<H16>(lo_out, (unsigned)(((r0 + py) * d.W2 + c0 + xe) * 16 + cq4), v);
