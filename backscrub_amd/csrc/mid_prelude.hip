@@ -98,20 +98,6 @@ template <int CTRL> __device__ __forceinline__ float dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRor4 = 0x124, kRor8 = 0x128, kHalfMirror = 0x141;
-__device__ __forceinline__ float dpp_self(float v, bool x2) {      // lane ^ 1 / lane ^ 2 inside a quad, old value = own
-  const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, x2 ? __builtin_amdgcn_update_dpp(i, i, kQuadXor2, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(i, i, kQuadXor1, 0xf, 0xf, true));
-}
-// 4x4 transpose inside each quad of adjacent lanes (mfma_tile.hpp): lane (g, li) ends with row 4g + (li & 3), columns 4 (li >> 2) .. +3
-__device__ __forceinline__ f4v quad_transpose(const f4v acc, int q) {
-  const bool odd = q & 1, hi = q & 2;
-  const float rx = dpp_self(odd ? acc[0] : acc[1], false), ry = dpp_self(odd ? acc[2] : acc[3], false);
-  const float t0 = odd ? rx : acc[0], t1 = odd ? acc[1] : rx, t2 = odd ? ry : acc[2], t3 = odd ? acc[3] : ry;
-  const float r0 = dpp_self(hi ? t0 : t2, true), r1 = dpp_self(hi ? t1 : t3, true);
-  f4v r;
-  if (hi) { r[0] = r0; r[1] = r1; r[2] = t2; r[3] = t3; } else { r[0] = t0; r[1] = t1; r[2] = r0; r[3] = r1; }
-  return r;
-}
 // float4 per lane → wave total of component (lane & 3) in every lane (kernels_frame.hip: wave_total_scatter)
 __device__ __forceinline__ float wave_total_scatter(f4v a, int lane) {
   const bool b0 = lane & 1, b1 = lane & 2;
@@ -207,23 +193,24 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
     f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NJ; j += 2) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j][0], acc0, 0, 0, 0);
-      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1 < NJ ? j + 1 : j].x, b[j + 1 < NJ ? j + 1 : j][0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j][1], acc0, 0, 0, 0);
-      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1 < NJ ? j + 1 : j].y, b[j + 1 < NJ ? j + 1 : j][1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j][2], acc0, 0, 0, 0);
-      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1 < NJ ? j + 1 : j].z, b[j + 1 < NJ ? j + 1 : j][2], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j][3], acc0, 0, 0, 0);
-      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1 < NJ ? j + 1 : j].w, b[j + 1 < NJ ? j + 1 : j][3], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][0], a[j].x, acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j + 1 < NJ ? j + 1 : j][0], a[j + 1 < NJ ? j + 1 : j].x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][1], a[j].y, acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j + 1 < NJ ? j + 1 : j][1], a[j + 1 < NJ ? j + 1 : j].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][2], a[j].z, acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j + 1 < NJ ? j + 1 : j][2], a[j + 1 < NJ ? j + 1 : j].z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][3], a[j].w, acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j + 1 < NJ ? j + 1 : j][3], a[j + 1 < NJ ? j + 1 : j].w, acc1, 0, 0, 0);
     }
     if constexpr (TM > 0) {
 #pragma unroll
-      for (int r = 0; r < TM; r++) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[r], tb[r], acc1, 0, 0, 0);
+      for (int r = 0; r < TM; r++) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tb[r], ta[r], acc1, 0, 0, 0);
     }
     const f4v acc = acc0 + acc1;
-    // epilogue: lane owns pixel m0 + 4 g + (li & 3), channels n0 + 4 (li >> 2) .. +3 → one 16-byte bias load, residual load, store
-    const int q = li & 3, c0 = n0 + (li & ~3), pix = m0 + 4 * g + q;
-    f4v v = quad_transpose(acc, q);
+    // epilogue: the weights are the MFMA's A operand (rows = output channels), the activations its B operand (columns = pixels), so the accumulator of lane
+    // (li, g) IS channels n0 + 4 g .. +3 of pixel m0 + li → one 16-byte bias load, residual load, store, and no 4x4 transpose inside lane quads
+    const int c0 = n0 + 4 * g, pix = m0 + li;
+    f4v v = acc;
     if ((T::COUT % 16 == 0 || c0 < T::COUT) && (P % 16 == 0 || pix < P)) {
       v = act4<T::ACT>(v + *(const lds_v4*)(bl + c0));
       if constexpr (T::R_SP != SP_NONE) v += ld4<T::R_SP>(L + T::R_OFF, A + T::R_OFF, pix * T::R_ST + c0);
