@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __r
 // (sample_linear, the tap order and roundings of prep_bilateral_k): bit-identical, and the stage-0 tests read its output.  Tile sizes are chosen per model so
 // that the tiles cover the canvas without a sliver (257 = 9 x 29, not 8 x 32 + 1).
 constexpr int kPfS = 36;                    // LDS row stride of the tile (TW <= 32)
-template <int OUT>
+template <int OUT, bool LINEAR>             // LINEAR: tab.mode == 0 (cv::resize INTER_LINEAR proper — the other modes are a copy and the exact 2x2 area average)
 __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restrict__ frames, int W, int H, Rect4 roi, float* __restrict__ input, uint32_t* __restrict__ input_u8,
                                                         int inW, int inH, Rect4 q, ResizeTab tab, BilateralParams bp, int TW, int TH, int ntx, int nty, int n_frames) {
   __shared__ float lut[768];
@@ -178,8 +178,69 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
   const int SW = TW + 2 * kCanvasPad, total = SW * (TH + 2 * kCanvasPad);
   const uint8_t* src = frames + n * (long)W * H * 3 + ((long)roi.y * W + roi.x) * 3;
   const unsigned msw = 0xFFFFFFFFu / (unsigned)SW + 1u;                    // i / SW for i < 2^16
+  constexpr int kItems = (kPfS * kPfS + kThreads - 1) / kThreads;
+  if constexpr (LINEAR) {
+    // INTER_LINEAR: everything that depends only on the tile COLUMN (reflected canvas x → source byte offset, coefficient pair, where the two taps sit inside the
+    // 8 bytes loaded) or only on the tile ROW (source row offsets, coefficient pair) is worked out once per column / row by the first lanes and kept in LDS; an item
+    // is then two table reads, four loads and arithmetic.  Two dependent memory round trips per LANE (tables, then all of its <= kItems samples at once) instead of
+    // two per SAMPLE — in the per-sample form (sample_linear inside `if (inside)`) the compiler waits for each sample before it starts the next.
+    // 8 source bytes [offc, offc + 8) cover both taps: offc = min(3 sx, row_bytes - 8) never reads past the image row; the taps are bytes s0.. and s1.. of them
+    // (s1 = s0 + 3, or s0 where cv::resize clamps the second tap onto the first), pulled out by v_perm_b32 with per-column selectors.  Same integers as sample_linear.
+    __shared__ int4 colT[kPfS], rowT[kPfS];                                // {offc | -1, a0 | a1 << 16, sel0, sel1}, {o0 | -1, o1, b0, b1}
+    const int rowlim = (W - roi.x) * 3, SHt = TH + 2 * kCanvasPad;
+    if (tid < SW) {
+      const int dx = reflect101(tx0 + tid - kCanvasPad, inW) - q.x;
+      int4 e = make_int4(-1, 0, 0, 0);
+      if (dx >= 0 && dx < q.w) {
+        const int sx = tab.xofs[dx], same = sx + 1 > tab.sw - 1, offb = sx * 3, offc = max(min(offb, rowlim - 8), 0), s0 = offb - offc, s1 = same ? s0 : s0 + 3;
+        const int a0 = tab.xa[2 * dx], a1 = tab.xa[2 * dx + 1];
+        e = make_int4(offc, (a0 & 0xffff) | (a1 << 16), 0x0c000000 | ((s0 + 2) << 16) | ((s0 + 1) << 8) | s0, 0x0c000000 | ((s1 + 2) << 16) | ((s1 + 1) << 8) | s1);
+      }
+      colT[tid] = e;
+    } else if (tid >= 64 && tid < 64 + SHt) {
+      const int ly = tid - 64, dy = reflect101(ty0 + ly - kCanvasPad, inH) - q.y;
+      int4 e = make_int4(-1, 0, 0, 0);
+      if (dy >= 0 && dy < q.h) {
+        const int sy = tab.yofs[dy], sy0 = min(max(sy, 0), tab.sh - 1), sy1 = min(max(sy + 1, 0), tab.sh - 1);
+        e = make_int4(sy0 * W * 3, sy1 * W * 3, tab.ya[2 * dy], tab.ya[2 * dy + 1]);
+      }
+      rowT[ly] = e;
+    }
+    __syncthreads();
+    uint32_t lo0[kItems], hi0[kItems], lo1[kItems], hi1[kItems];
 #pragma unroll
-  for (int k = 0; k < (kPfS * kPfS + kThreads - 1) / kThreads; k++) {
+    for (int k = 0; k < kItems; k++) {                                     // every load of the lane is requested here
+      const int i = min(tid + k * kThreads, total - 1), ly = (int)__umulhi((unsigned)i, msw), lx = i - ly * SW;
+      const int co = max(colT[lx].x, 0), o0 = max(rowT[ly].x, 0), o1 = rowT[ly].y;
+      struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
+      const uint8_t* p0 = src + (unsigned)(o0 + co);
+      const uint8_t* p1 = src + (unsigned)(o1 + co);
+      lo0[k] = reinterpret_cast<const U4*>(p0)->v; hi0[k] = reinterpret_cast<const U4*>(p0 + 4)->v;
+      lo1[k] = reinterpret_cast<const U4*>(p1)->v; hi1[k] = reinterpret_cast<const U4*>(p1 + 4)->v;
+    }
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+      const int i = tid + k * kThreads;
+      if (i < total) {
+        const int ly = (int)__umulhi((unsigned)i, msw), lx = i - ly * SW;
+        const int4 c = colT[lx], r = rowT[ly];
+        const int a0 = (short)(c.y & 0xffff), a1 = c.y >> 16, b0 = r.z, b1 = r.w;
+        const uint32_t t00 = __builtin_amdgcn_perm(hi0[k], lo0[k], (uint32_t)c.z), t01 = __builtin_amdgcn_perm(hi0[k], lo0[k], (uint32_t)c.w);   // row 0: tap 0 / tap 1 as B | G << 8 | R << 16
+        const uint32_t t10 = __builtin_amdgcn_perm(hi1[k], lo1[k], (uint32_t)c.z), t11 = __builtin_amdgcn_perm(hi1[k], lo1[k], (uint32_t)c.w);   // row 1
+        uint32_t v = 0;                                                    // the model canvas outside in_roi (the bars) is 0
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          const int h0 = (int)((t00 >> (8 * ch)) & 255u) * a0 + (int)((t01 >> (8 * ch)) & 255u) * a1;
+          const int h1 = (int)((t10 >> (8 * ch)) & 255u) * a0 + (int)((t11 >> (8 * ch)) & 255u) * a1;
+          const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          v |= (uint32_t)o << (8 * (2 - ch));                              // BGR2RGB
+        }
+        tile[ly * kPfS + lx] = (c.x >= 0 && r.x >= 0) ? v : 0u;
+      }
+    }
+  } else
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
     const int i = tid + k * kThreads;
     if (i < total) {
       const int ly = (int)__umulhi((unsigned)i, msw), lx = i - ly * SW;
@@ -821,9 +882,10 @@ hipError_t launch_prep_fused(const uint8_t* frames, int W, int H, Rect4 roi, flo
     const uint8_t* fr = frames + (size_t)n0 * W * H * 3;
     float* f = input ? input + (size_t)n0 * per_frame * 3 : nullptr;
     uint32_t* u = input_u8 ? input_u8 + (size_t)n0 * per_frame : nullptr;
-    if (f && u) prep_fused_k<3><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0);
-    else if (u) prep_fused_k<2><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0);
-    else prep_fused_k<1><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0);
+#define BSX_PF(O, L) prep_fused_k<O, L><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0)
+    if (tab.mode == 0) { if (f && u) BSX_PF(3, true); else if (u) BSX_PF(2, true); else BSX_PF(1, true); }
+    else { if (f && u) BSX_PF(3, false); else if (u) BSX_PF(2, false); else BSX_PF(1, false); }
+#undef BSX_PF
   }
   return hipGetLastError();
 }

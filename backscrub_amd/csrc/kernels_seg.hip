@@ -283,16 +283,20 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   //    in flight before its first LDS store
   if (d.dbg_skip & 8) { /* timing: no input tile */ } else
   if (U8IN) {                                                       // lane = pixel of the row (IC <= 63): one dword = three input values
+    // (addresses clamped into the image and the load unconditional: under `if (inside)` every row became an exec-masked region with its own s_waitcnt vmcnt(0) and
+    //  a dozen register copies to merge the paths — five serialised memory round trips where this has five loads in flight; outside pixels are zeroed below.
+    //  Measured: seg_head 55.5 -> 51.5 us lite, 249 -> 226 mlkit / HD.  The same rewrite of the k2 / k3 / tail prefetches, whose loads were already in flight,
+    //  measured 1-3 % slower — more loads issued — and was not kept: profiles/r03aj)
     const uint32_t* src = reinterpret_cast<const uint32_t*>(net_in) + (size_t)f * (size_t)(d.H0 * d.W0);
     const bool colok = lane < IC && ic0 + lane >= 0 && ic0 + lane < d.W0;
+    const int gxc = min(max(ic0 + lane, 0), d.W0 - 1);
     uint32_t v[5];
     bool ok[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
       const int row = wave + 4 * j, gy = ir0 + row;
       ok[j] = row < IR && gy >= 0 && gy < d.H0 && colok;
-      v[j] = 0u;
-      if (ok[j]) v[j] = src[(unsigned)(gy * d.W0 + ic0 + lane)];
+      v[j] = src[(unsigned)(min(max(gy, 0), d.H0 - 1) * d.W0 + gxc)];
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) {
