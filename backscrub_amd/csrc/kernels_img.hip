@@ -258,36 +258,45 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
   __syncthreads();
   const int lx = tid & 31, x = tx0 + lx;
   if (lx >= TW || x >= inW) return;
-#pragma unroll 2
-  for (int it = 0; it < kBilPix; it++) {
-    const int ly = (tid >> 5) + 8 * it, y = ty0 + ly;
-    if (ly >= TH || y >= inH) return;
-    const unsigned p = (unsigned)(y * inW + x);
-    const uint32_t* row[5];
-#pragma unroll
-    for (int d = 0; d < 5; d++) row[d] = tile + (ly + d) * kPfS + (lx + kCanvasPad);     // tile rows ly-2 .. ly+2 (canvas rows y-2 .. y+2) at column x
-    const uint32_t c0 = row[2][0];
-    float sr = 0.f, sg = 0.f, sb = 0.f, ws = 0.f;
+  // two pixels of the lane (rows ly and ly + 8) per pass, their sums in the two halves of packed registers: v_pk_mul_f32 / v_pk_add_f32 do both pixels' multiply
+  // (add) of a channel in one instruction — 9 instead of 13 VALU instructions per pixel and tap, the same IEEE operations in the same order (no contraction).
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  static_assert(kBilPix % 2 == 0, "pixel pairs");
+#pragma unroll 1
+  for (int it = 0; it < kBilPix; it += 2) {
+    const int lyA = (tid >> 5) + 8 * it, lyB = lyA + 8;                   // row B may lie outside the tile: it reads rows < kPfS of the LDS tile and is not stored
+    if (lyA >= TH || ty0 + lyA >= inH) return;
+    const uint32_t* ta = tile + (lyA + kCanvasPad) * kPfS + (lx + kCanvasPad);      // the centre pixel; tap (dy, dx) at ta[dy * kPfS + dx]
+    const uint32_t* tb = ta + 8 * kPfS;
+    const uint32_t cA0 = ta[0], cB0 = tb[0];
+    f2 sr = {0.f, 0.f}, sg = {0.f, 0.f}, sb = {0.f, 0.f}, ws = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 13; k++) {
-      const uint32_t c = row[kTapY[k] + 2][kTapX[k]];
-      const float w = __fmul_rn(bp.space_w[k], lut[__builtin_amdgcn_sad_u8(c, c0, 0u)]);
-      const float rr = (float)(c & 255), gg = (float)((c >> 8) & 255), bb = (float)((c >> 16) & 255);
-      sr = __fadd_rn(sr, __fmul_rn(rr, w));
-      sg = __fadd_rn(sg, __fmul_rn(gg, w));
-      sb = __fadd_rn(sb, __fmul_rn(bb, w));
-      ws = __fadd_rn(ws, w);
+      const uint32_t cA = ta[kTapY[k] * kPfS + kTapX[k]], cB = tb[kTapY[k] * kPfS + kTapX[k]];
+      f2 w = {lut[__builtin_amdgcn_sad_u8(cA, cA0, 0u)], lut[__builtin_amdgcn_sad_u8(cB, cB0, 0u)]};
+      w = w * (f2)(bp.space_w[k]);
+      const f2 rr = {(float)(cA & 255), (float)(cB & 255)}, gg = {(float)((cA >> 8) & 255), (float)((cB >> 8) & 255)}, bb = {(float)((cA >> 16) & 255), (float)((cB >> 16) & 255)};
+      sr = sr + rr * w;
+      sg = sg + gg * w;
+      sb = sb + bb * w;
+      ws = ws + w;
     }
-    ws = __fdiv_rn(1.f, ws);
-    int qr = __float2int_rn(__fmul_rn(sr, ws)), qg = __float2int_rn(__fmul_rn(sg, ws)), qb = __float2int_rn(__fmul_rn(sb, ws));
-    qr = min(max(qr, 0), 255); qg = min(max(qg, 0), 255); qb = min(max(qb, 0), 255);
-    if (OUT & 1) {
-      float* o = input + (n * (long)inW * inH + p) * 3;
-      o[0] = __fadd_rn(__fmul_rn((float)qr, bp.scale), bp.offset);
-      o[1] = __fadd_rn(__fmul_rn((float)qg, bp.scale), bp.offset);
-      o[2] = __fadd_rn(__fmul_rn((float)qb, bp.scale), bp.offset);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int y = ty0 + lyA + 8 * h;
+      if (h == 1 && (lyB >= TH || y >= inH)) break;
+      const unsigned p = (unsigned)(y * inW + x);
+      const float wi = __fdiv_rn(1.f, ws[h]);
+      int qr = __float2int_rn(__fmul_rn(sr[h], wi)), qg = __float2int_rn(__fmul_rn(sg[h], wi)), qb = __float2int_rn(__fmul_rn(sb[h], wi));
+      qr = min(max(qr, 0), 255); qg = min(max(qg, 0), 255); qb = min(max(qb, 0), 255);
+      if (OUT & 1) {
+        float* o = input + (n * (long)inW * inH + p) * 3;
+        o[0] = __fadd_rn(__fmul_rn((float)qr, bp.scale), bp.offset);
+        o[1] = __fadd_rn(__fmul_rn((float)qg, bp.scale), bp.offset);
+        o[2] = __fadd_rn(__fmul_rn((float)qb, bp.scale), bp.offset);
+      }
+      if (OUT & 2) input_u8[n * (long)inW * inH + p] = (uint32_t)qr | ((uint32_t)qg << 8) | ((uint32_t)qb << 16);
     }
-    if (OUT & 2) input_u8[n * (long)inW * inH + p] = (uint32_t)qr | ((uint32_t)qg << 8) | ((uint32_t)qb << 16);
   }
 }
 
