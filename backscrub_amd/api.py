@@ -72,6 +72,7 @@ SYMBOLS = [
     ("bsx_live_get_output_mask", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("bsx_live_timings", C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     ("bsx_gaussian_blur_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("bsx_debug_gauss_coeffs", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("bsx_flip_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_debug_buffer", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("bsx_debug_run_stage", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -468,6 +469,15 @@ def model_kernel_source(path: str) -> str:
     if n < 0:
         raise BsxError(buf.value.decode(errors="replace"))
     return buf.value.decode() if n > 0 else ""
+
+
+def gauss_coeff_words(ksize: int, shift: int = 0):
+    """(c4 [4][9] u32, c2 [2][17] u32): the coefficient words gauss_blur_k multiplies with (host only, no GPU) — bsx_debug_gauss_coeffs"""
+    c4 = np.zeros((4, 9), np.uint32)
+    c2 = np.zeros((2, 17), np.uint32)
+    _check(lib().bsx_debug_gauss_coeffs(int(ksize), int(shift), c4.ctypes.data_as(C.POINTER(C.c_uint32)), c2.ctypes.data_as(C.POINTER(C.c_uint32))), None,
+           "bsx_debug_gauss_coeffs")
+    return c4, c2
 
 
 def model_describe(path: str) -> str:

@@ -898,6 +898,10 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   return j;
 }
 
+int bsx_debug_gauss_coeffs(int ksize, int shift, uint32_t* c4, uint32_t* c2) {
+  return (c4 && c2 && gauss_coeff_words(ksize, shift, c4, c2)) ? BSX_OK : BSX_EINVAL;
+}
+
 int bsx_debug_program_timeline(bsx_ctx* c, int n, unsigned long long* ticks, int cap, void* stream) {
   if (!c || !ticks || n <= 0 || n > c->n_streams) return BSX_EINVAL;
   DeviceGuard guard(c->device);

@@ -108,6 +108,7 @@ hipError_t launch_yuyv_to_bgr(const uint8_t* yuyv, uint8_t* bgr, int w, int h, i
 hipError_t launch_flip_bgr(const uint8_t* src, uint8_t* dst, int w, int h, int code, int n, hipStream_t s);
 // cv::GaussianBlur(Size(ksize, ksize), sigma 0) of packed BGR u8 images (dst != src), ksize odd <= 31.  deepseg.cc:657-658 (-p bgblur:N)
 hipError_t launch_gauss_blur(const uint8_t* src, uint8_t* dst, int w, int h, int ksize, int n, hipStream_t s);
+bool gauss_coeff_words(int ksize, int shift, uint32_t* c4 /* [4][9] */, uint32_t* c2 /* [2][17] */);   // host: the tables launch_gauss_* pass to the kernel
 // blur + alpha blend of the frames over their own blur (deepseg.cc:652-661 without -b), the blurred image never stored; fusable = 4-byte aligned images, w % 4 == 0
 bool gauss_blend_fusable(const uint8_t* frames, const uint8_t* masks, const uint8_t* out, int w, int ksize);
 hipError_t launch_gauss_blend(const uint8_t* frames, const uint8_t* masks, uint8_t* out, int w, int h, int ksize, int n, hipStream_t s);

@@ -13,6 +13,7 @@
 //   yuyv_k               deepseg.cc:87-106        convert_rgb_to_yuyv
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "kernels.hpp"
 #include "mfma_tile.hpp"
 
@@ -1198,6 +1199,13 @@ bool gauss_coefficients(int n, GaussCoef* gc, int sh) {
     for (int i = 0; i < n; i++) gc->c4[j][(i + j + sh) >> 2] |= c[i] << (8 * ((i + j + sh) & 3));
   for (int h = 0; h < 2; h++)
     for (int i = 0; i < n; i++) gc->c2[h][(i + h) >> 1] |= c[i] << (16 * ((i + h) & 1));
+  return true;
+}
+bool gauss_coeff_words(int ksize, int shift, uint32_t* c4, uint32_t* c2) {
+  GaussCoef gc;
+  if (shift < 0 || shift > 3 || ksize + shift > 32 || !gauss_coefficients(ksize, &gc, shift)) return false;
+  memcpy(c4, gc.c4, sizeof(gc.c4));
+  memcpy(c2, gc.c2, sizeof(gc.c2));
   return true;
 }
 static bool gauss_words(const void* a, const void* b, const void* c, int w) {      // whole-dword output groups: 4 pixels = 12 bytes at 4-byte aligned addresses

@@ -225,6 +225,11 @@ long bsx_debug_tensor_of(bsx_ctx* ctx, int tensor_idx, int stream_idx, float* h_
  * Returns the number of micro-ops (cap must be >= that + 1), 0 if the program path is off, negative on error. */
 int bsx_debug_program_timeline(bsx_ctx* ctx, int n, unsigned long long* ticks, int cap, void* stream);
 
+/* Host only, no GPU: the coefficient words gauss_blur_k multiplies with for cv::GaussianBlur(ksize, sigma 0) on 8-bit images (app/deepseg.cc:657-658) when its LDS
+ * planes start `shift` (0..3) pixels left of the tile — c4[4][9]: the u8 taps packed 4 per word, delayed by j + shift bytes for output phase j; c2[2][17]: the same taps
+ * as u16 pairs delayed by h halves.  The parity tests check them against the oracle's taps (the kernels' arithmetic is only as right as these tables).  Returns 0 or BSX_EINVAL. */
+int bsx_debug_gauss_coeffs(int ksize, int shift, uint32_t* c4 /* 36 */, uint32_t* c2 /* 34 */);
+
 /* Parse a .tflite file and build the fused plan WITHOUT touching a GPU; writes a text description
  * ("ops=<n> nodes=<n> steps=<n> macs=<per frame> arena_floats=<per stream>" then one line per launch)
  * into buf (NUL-terminated, truncated to cap).  Returns 0, or BSX_EMODEL with the reason in buf. */

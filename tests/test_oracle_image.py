@@ -254,3 +254,37 @@ def test_gaussian_blur_restatement(oracle, n):
         if n > 7:
             assert np.abs(f - got).max() <= 3.0     # 8-bit coefficients (sum 256 or 257) on a pure-noise image
     assert got[0, 0].min() == 255
+
+
+@pytest.mark.parametrize("n", list(range(3, 32, 2)))
+def test_gauss_kernel_coefficient_words_are_the_oracle_taps_delayed(oracle, n):
+    """gauss_blur_k never realigns its data: the 4 neighbouring outputs of a horizontal item (2 of a vertical item) multiply the SAME aligned words with the tap sequence
+    delayed by 0..3 bytes (0..1 halves), plus `shift` more bytes when the LDS planes start left of the tile (4-pixel staging).  The words the launcher hands to the
+    kernel (bsx_debug_gauss_coeffs, host only) must therefore be exactly the oracle's taps at those delays and zero everywhere else — for every kernel size and shift,
+    and inside the word counts the kernel templates read (NT = ceil((n + 3 + shift) / 4) bytes-words, 2 NT - 1 half-words)."""
+    import backscrub_amd.api as api
+    taps = oracle.gaussian_coeffs(n).astype(np.int64)
+    assert 240 <= taps.sum() <= 257 and (taps <= 255).all()              # per-tap rounding: the sum drifts from 256 (252 at ksize 29); the kernel needs <= 257
+    for shift in range(4):
+        if n + shift > 32:
+            with pytest.raises(api.BsxError):
+                api.gauss_coeff_words(n, shift)
+            continue
+        c4, c2 = api.gauss_coeff_words(n, shift)
+        nt = (n + 3 + shift + 3) // 4
+        assert 2 <= nt <= 9
+        for j in range(4):
+            b = c4[j].view(np.uint8).astype(np.int64)                     # little endian: byte k of the sequence = tap k - (j + shift)
+            want = np.zeros(36, np.int64)
+            want[j + shift: j + shift + n] = taps
+            assert np.array_equal(b, want), "ksize %d shift %d phase %d" % (n, shift, j)
+            assert not b[4 * nt:].any()                                    # nothing beyond the words the horizontal pass reads
+        for h in range(2):
+            w = c2[h].view(np.uint16).astype(np.int64)
+            want = np.zeros(34, np.int64)
+            want[h: h + n] = taps
+            assert np.array_equal(w, want), "ksize %d half-phase %d" % (n, h)
+            assert not w[2 * (2 * nt - 1):].any()                          # nothing beyond the words the vertical pass reads
+    for bad in (0, 2, 4, 33):
+        with pytest.raises(api.BsxError):
+            api.gauss_coeff_words(bad, 0)
