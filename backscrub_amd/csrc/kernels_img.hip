@@ -893,7 +893,7 @@ hipError_t launch_prep_fused(const uint8_t* frames, int W, int H, Rect4 roi, flo
     float* f = input ? input + (size_t)n0 * per_frame * 3 : nullptr;
     uint32_t* u = input_u8 ? input_u8 + (size_t)n0 * per_frame : nullptr;
 #define BSX_PF(O, L) prep_fused_k<O, L><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0)
-    if (tab.mode == 0) { if (f && u) BSX_PF(3, true); else if (u) BSX_PF(2, true); else BSX_PF(1, true); }
+    if (tab.mode == 0 && (W - roi.x) * 3 >= 8) { if (f && u) BSX_PF(3, true); else if (u) BSX_PF(2, true); else BSX_PF(1, true); }   // (the 8-byte tap window needs an 8-byte row)
     else { if (f && u) BSX_PF(3, false); else if (u) BSX_PF(2, false); else BSX_PF(1, false); }
 #undef BSX_PF
   }
