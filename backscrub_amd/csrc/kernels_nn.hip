@@ -1675,9 +1675,12 @@ __global__ __launch_bounds__(kThreads) void resize_px_k(const float* __restrict_
 // Same interpolation arithmetic (interp / bilerp) and the same first-maximum-wins scan as the unfused kernels.
 // -------------------------------------------------------------------------------------
 constexpr int kFusedTW = 64, kFusedTH = 16, kFusedMaxSrc = 160;    // source pixels per tile (rows x cols), C <= kResizePxMaxC
-template <bool PERSON_ONLY>      // true: only "is the first maximum the person class?" is formed (two running maxima), not the argmax itself
-__global__ __launch_bounds__(kThreads) void resize_argmax_iir_k(const float* __restrict__ x, uint8_t* __restrict__ ofinal, int H, int W, int C, int OH, int OW,
-                                                               float hs, float ws, int half_pixel, int person, int ntx, int nty, int n_frames) {
+template <bool PERSON_ONLY, int CC = 0, int PC = -1>      // PERSON_ONLY: only "is the first maximum the person class?" is formed (two running maxima), not the argmax itself;
+                                                          // CC / PC: class count and person class as compile-time constants (the scan then resolves per class: one v_max each)
+__global__ __launch_bounds__(kThreads) void resize_argmax_iir_k(const float* __restrict__ x, uint8_t* __restrict__ ofinal, int H, int W, int C_, int OH, int OW,
+                                                               float hs, float ws, int half_pixel, int person_, int ntx, int nty, int n_frames) {
+  const int C = CC > 0 ? CC : C_;
+  int person = CC > 0 ? PC : person_;
   __shared__ float src[kFusedMaxSrc * kResizePxMaxC];
   unsigned f_, t_;
   xcd_frame_tile((unsigned)(ntx * nty), (unsigned)n_frames, &f_, &t_);      // a frame's tiles on one XCD: the 91 KB logits tensor is fetched into ONE L2 (PMC: 2.7x over-fetch in the plain order)
@@ -1736,11 +1739,13 @@ __global__ __launch_bounds__(kThreads) void resize_argmax_iir_k(const float* __r
       const f2v wy0 = {omdy, omdy}, wy1 = {dy, dy}, wx0 = {omdx, omdx}, wx1 = {dx, dx};
 #pragma unroll
       for (int q = 0; q < 6; q++) {
+        if (CC > 0 && 4 * q >= CC) break;
         const f4v v00 = *reinterpret_cast<const f4v*>(p00 + 4 * q), v10 = *reinterpret_cast<const f4v*>(p10 + 4 * q);
         const f4v v01 = *reinterpret_cast<const f4v*>(p01 + 4 * q), v11 = *reinterpret_cast<const f4v*>(p11 + 4 * q);
-        float r4[4];
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
+          if (CC > 0 && 4 * q + 2 * h >= CC) break;                      // padding classes of the last quad: never looked at
           const f2v a = (f2v{v00[2 * h], v00[2 * h + 1]} * wy0) * wx0, bb = (f2v{v10[2 * h], v10[2 * h + 1]} * wy1) * wx0;
           const f2v c2 = (f2v{v01[2 * h], v01[2 * h + 1]} * wy0) * wx1, d = (f2v{v11[2 * h], v11[2 * h + 1]} * wy1) * wx1;
           const f2v sum = ((a + bb) + c2) + d;
@@ -1831,7 +1836,8 @@ hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofi
   static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
   const int nf = xcd_on ? n : 0;
   const int person = 15;                                           // lib/libbackscrub.cc:330 (pascal VOC class 15)
-  if (!generic && st.Cin <= 24 && person < st.Cin) resize_argmax_iir_k<true><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person, ntx, nty, nf);
+  if (!generic && st.Cin == 21 && person == 15) resize_argmax_iir_k<true, 21, 15><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person, ntx, nty, nf);   // DeepLab / PASCAL VOC
+  else if (!generic && st.Cin <= 24 && person < st.Cin) resize_argmax_iir_k<true><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person, ntx, nty, nf);
   else resize_argmax_iir_k<false><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, generic ? -1 - person : person, ntx, nty, nf);
   return hipGetLastError();
 }
