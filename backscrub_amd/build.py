@@ -19,7 +19,7 @@ SOURCES = ["tflite_model.cpp", "plan.cpp", "gen_mid.cpp", "rtc.cpp", "media.cpp"
 HEADERS = ["mid_prelude.hip", "gen_mid.hpp", "rtc.hpp", "media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", os.path.join("..", "..", "include", "bsx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]      # only the BSX_API entry points of include/bsx.h are exported
 
 
 def _stale(target, deps):
@@ -67,8 +67,8 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("libbsx build failed")
-    if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz", "-lpthread", "-lhiprtc", "-ldl"]
+    if force or procs or _stale(LIB, objs + [os.path.join(CSRC, "libbsx.map")]):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,--version-script=" + os.path.join(CSRC, "libbsx.map"), "-o", LIB] + objs + ["-lz", "-lpthread", "-lhiprtc", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -615,7 +615,14 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
     BSX_HIP(c, launch_gauss_blur(d_frames, c->d_bgblur_scratch, c->width, c->height, bgblur, n, pick(c, stream)));
     return step_impl(c, d_frames, c->d_bgblur_scratch, fb, d_out, n, stream, flags & 15u);
   }
-  const bool fuse = !c->onmask && !c->no_mask_blend_fusion && (!yuyv || ((uintptr_t)d_out & 3) == 0) &&
+  // Aliasing (bsx.h): the reference flips `raw` in place (app/deepseg.cc:667-673), so a caller following it passes d_out == d_frames.  The fused tile kernel reads a
+  // frame pixel at (x, y) and stores the flipped (or YUYV-packed: 2 B/px) result at ANOTHER address, which a different tile may not have read yet — with overlapping
+  // buffers those forms take the unfused sequence (composite into the context's scratch first).  A plain composite in place (same address read, then written, by the
+  // same lane) is fine; partially overlapping buffers are refused.
+  const size_t in_bytes = (size_t)n * c->width * c->height * 3, out_bytes = (size_t)n * c->width * c->height * (yuyv ? 2 : 3);
+  const bool overlap = d_out < d_frames + in_bytes && d_frames < d_out + out_bytes;
+  if (overlap && !yuyv && !flip && d_out != d_frames) return BSX_EINVAL;
+  const bool fuse = !c->onmask && !c->no_mask_blend_fusion && (!yuyv || ((uintptr_t)d_out & 3) == 0) && !(overlap && (yuyv || flip)) &&
                     mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, yuyv ? d_frames : d_out);
   if (!fuse) {
     int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
@@ -639,27 +646,34 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
   // process (prep → network → decode), then mask-upscale+blur and alpha blend of each tile in ONE launch
   hipStream_t s = pick(c, stream);
   int rc;
-  if (c->lanes > 1 && n >= 16 * c->lanes && !c->onprep && !c->oninfer && !c->keep_logits) {
-    const int K = c->lanes, per = (n + K - 1) / K;
+  // (the per-launch path's arena is batch-major: a lane's compact arena is laid out for `per` streams starting at stream f0, so the LAST lane ends at
+  //  K * per streams — lanes are only taken when that still fits the allocation, e.g. not for n = n_streams = 66, K = 4: 4 * 17 = 68)
+  const int lane_per = (n + c->lanes - 1) / std::max(c->lanes, 1);
+  if (c->lanes > 1 && n >= 16 * c->lanes && !c->onprep && !c->oninfer && !c->keep_logits && (c->use_program || c->lanes * lane_per <= c->n_streams)) {
+    const int K = c->lanes, per = lane_per;
     const bool fd = infer_decodes(c);
     const size_t fb = (size_t)c->width * c->height * 3, ob = (size_t)c->width * c->height * (yuyv ? 2 : 3), sm = (size_t)c->outW * c->outH;
     BSX_HIP(c, hipEventRecord(c->ev_fork, s));
-    for (int k = 0; k < K; k++) {
+    int lane_rc = BSX_OK;
+    for (int k = 0; k < K && lane_rc == BSX_OK; k++) {
       const int f0 = k * per, nb = std::min(per, n - f0);
       if (nb <= 0) break;
       hipStream_t ls = k == 0 ? s : c->lane_stream[k];
-      if (k > 0) BSX_HIP(c, hipStreamWaitEvent(ls, c->ev_fork, 0));
+      if (k > 0 && hipStreamWaitEvent(ls, c->ev_fork, 0) != hipSuccess) { lane_rc = BSX_EDEVICE; break; }
       {
         LaneView view(c, f0, per);
-        if ((rc = run_prep(c, d_frames + (size_t)f0 * fb, nb, ls))) return rc;
-        if ((rc = run_infer(c, nb, ls, !fd, f0))) return rc;
-        if (!fd && (rc = run_decode(c, nb, ls, f0))) return rc;
+        lane_rc = run_prep(c, d_frames + (size_t)f0 * fb, nb, ls);
+        if (!lane_rc) lane_rc = run_infer(c, nb, ls, !fd, f0);
+        if (!lane_rc && !fd) lane_rc = run_decode(c, nb, ls, f0);
       }
-      BSX_HIP(c, launch_mask_blend(c->d_ofinal + (size_t)f0 * sm, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks + (size_t)f0 * c->width * c->height, c->width, c->height,
-                                   c->roi, d_bg + (size_t)f0 * bg_frame_stride, bg_frame_stride, d_frames + (size_t)f0 * fb, d_out + (size_t)f0 * ob, nb, ls, (int)flags));
-      if (k > 0) { BSX_HIP(c, hipEventRecord(c->ev_join[k], ls)); BSX_HIP(c, hipStreamWaitEvent(s, c->ev_join[k], 0)); }
+      if (!lane_rc && launch_mask_blend(c->d_ofinal + (size_t)f0 * sm, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks + (size_t)f0 * c->width * c->height, c->width, c->height,
+                                        c->roi, d_bg + (size_t)f0 * bg_frame_stride, bg_frame_stride, d_frames + (size_t)f0 * fb, d_out + (size_t)f0 * ob, nb, ls, (int)flags) != hipSuccess)
+        lane_rc = BSX_EDEVICE;
+      // forked lanes are ALWAYS joined, also after an error: the caller's stream must not be left with work in flight on streams it cannot see
+      if (k > 0 && (hipEventRecord(c->ev_join[k], ls) != hipSuccess || hipStreamWaitEvent(s, c->ev_join[k], 0) != hipSuccess)) lane_rc = lane_rc ? lane_rc : BSX_EDEVICE;
     }
-    return BSX_OK;
+    if (lane_rc == BSX_EDEVICE && c->last_error.empty()) c->last_error = "error: HIP failure while enqueuing a lane of the step\n";
+    return lane_rc;
   }
   if ((rc = run_prep(c, d_frames, n, s))) return rc;
   if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }
@@ -976,8 +990,14 @@ int bsx_model_precompile(const char* model_path, const char* arch, char* msg, si
 
 const char* bsx_plan_describe(bsx_ctx* c) { return c ? c->plan_text.c_str() : ""; }
 
+// BSX_ACT16 stores the arena tensors of the segmented networks as packed halves at their own strides: reading them back as f32 would return garbage without an
+// error, so the inspection entry points refuse arena tensors in that mode (network input / output keep their f32 buffers).
+static bool debug_tensor_readable(const bsx_ctx* c, int t) { return !c->act16 || t == c->plan.input || t == c->plan.output; }
+
 long bsx_debug_tensor_of(bsx_ctx* c, int t, int stream_idx, float* h_out, long cap) {
   if (!c || t < 0 || t >= (int)c->graph.tensors.size() || c->plan.tensor_off[t] < 0 || stream_idx < 0 || stream_idx >= c->n_streams) return BSX_EINVAL;
+  if (h_out && cap < 0) return BSX_EINVAL;
+  if (!debug_tensor_readable(c, t)) { c->last_error = "bsx_debug_tensor: arena tensors are stored as f16 under BSX_ACT16 and are not readable through this entry"; return BSX_EINVAL; }
   DeviceGuard guard(c->device);
   const long n = (long)c->graph.tensors[t].elems();
   if (!h_out) return n;
@@ -991,6 +1011,8 @@ long bsx_debug_tensor_of(bsx_ctx* c, int t, int stream_idx, float* h_out, long c
 
 long bsx_debug_tensor(bsx_ctx* c, int t, float* h_out, long cap) {
   if (!c || t < 0 || t >= (int)c->graph.tensors.size() || c->plan.tensor_off[t] < 0) return BSX_EINVAL;
+  if (h_out && cap < 0) return BSX_EINVAL;
+  if (!debug_tensor_readable(c, t)) { c->last_error = "bsx_debug_tensor: arena tensors are stored as f16 under BSX_ACT16 and are not readable through this entry"; return BSX_EINVAL; }
   DeviceGuard guard(c->device);
   long n = (long)c->graph.tensors[t].elems();
   if (!h_out) return n;

@@ -21,15 +21,25 @@ const char kPrelude[] =
 
 struct Out {
   std::string s;
-  void f(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+  void f(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {       // never truncates: a cut line could swallow the statement after it
     char buf[2048];
-    va_list ap;
+    va_list ap, ap2;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_copy(ap2, ap);
+    const int need = vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    s += buf;
+    if (need >= 0 && (size_t)need < sizeof buf) s.append(buf, (size_t)need);
+    else if (need >= 0) { std::string big((size_t)need + 1, '\0'); vsnprintf(&big[0], big.size(), fmt, ap2); big.resize((size_t)need); s += big; }
+    va_end(ap2);
   }
 };
+
+// an op label as a one-line comment: no line breaks, nothing that could close or continue a comment
+std::string comment_safe(const std::string& in) {
+  std::string o;
+  for (char ch : in.substr(0, 200)) o += (ch == '\n' || ch == '\r' || ch == '\\' || (unsigned char)ch < 32) ? ' ' : ch;
+  return o;
+}
 
 int sp_of(const Loc& l) { return l.space == kLocNone ? 0 : (l.space == kLocLds ? 1 : 2); }      // SP_NONE / SP_LDS / SP_GLB
 bool plain(const Loc& l) { return l.space == kLocNone || l.space == kLocLds || l.space == kLocGlobal; }   // no network input / output buffers in a middle program
@@ -79,6 +89,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
     const MicroOp& d = P[j + 1];
     if (!(a.kind == (int)StepKind::PwConv && a.mfma && !a.gemv && a.stage_floats > 0 && a.out.space == kLocGlobal && a.res.space == kLocNone) || !dw_chunked(d)) return false;
     if (d.in0.off != a.out.off || d.Cin != a.Cout || d.band_rows % 16 || a.cout_pad < a.Cout) return false;
+    for (long e : plan.program_ext_offs) if (e == a.out.off) return false;           // a segment kernel reads this tensor after the program: it must exist in the arena
     for (int q = j + 2; q < n; q++) {                               // the expanded tensor has no other reader (until its arena slot is written again: slots are re-used)
       for (const Loc* l : {&P[q].in0, &P[q].in1, &P[q].in2, &P[q].res, &P[q].scale}) if (l->space == kLocGlobal && l->off == a.out.off) return false;
       for (int c = 0; c < P[q].n_cat; c++) if (P[q].cat[c].space == kLocGlobal && P[q].cat[c].off == a.out.off) return false;
@@ -100,9 +111,9 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
     const MicroOp& m = P[i];
     for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.scale, &m.out}) if (!plain(*l)) return fail("operand in the network input / output buffer");
     if (fine && i > 0 && i <= 64) k.f("  FINE_END(%d);\n", i - 1);
-    k.f("  // ---- P%d %s\n", i, i < (int)plan.program_labels.size() ? plan.program_labels[i].c_str() : "");
     if (fine) k.f("  f_a = __builtin_readcyclecounter();\n");
     k.f("  op_barrier();\n  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[%d] = __builtin_amdgcn_s_memrealtime();\n", i);
+    k.f("  // ---- P%d %s\n", i, i < (int)plan.program_labels.size() ? comment_safe(plan.program_labels[i]).c_str() : "");      // label AFTER the barrier it belongs to
     if (fine) k.f("  f_b = __builtin_readcyclecounter();\n");
     const bool fed_by_prev = i > 0 && pw_feeds_dw(i - 1);            // this depthwise computes its input chunks itself: op i + 1's weight DMA waits for the last one
     if (i + 1 < n && !fed_by_prev) stage_of(i + 1, k);
@@ -131,7 +142,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
     };
     if (early(i + 1)) fc_loads(i + 1);
     if (m.kind == (int)StepKind::PwConv && m.mfma && !m.gemv) {
-      if (m.Cin % 4 || m.cout_pad % 16 || m.stage_floats <= 0) return fail("pw: channel counts / unstaged weights");
+      if (m.Cin % 4 || m.Cout % 4 || m.cout_pad % 16 || m.stage_floats <= 0) return fail("pw: channel counts / unstaged weights");   // op_pw stores 16-byte channel quads
       if (m.scale.space != kLocNone && m.scale.space != kLocLds) return fail("pw: scale vector outside LDS");
       o.f("struct Op%d {\n  static constexpr int P = %d, CIN = %d, COUT = %d, CPAD = %d, ACT = %d;\n", i, m.OH * m.OW, m.Cin, m.Cout, m.cout_pad, m.act);
       loc(o, "X", m.in0); loc(o, "Y", m.out); loc(o, "R", m.res); loc(o, "D", m.in2);

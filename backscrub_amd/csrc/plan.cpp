@@ -114,6 +114,8 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
   plan->program_labels.clear();
   plan->program_blocks.clear();
   plan->program_check.clear();
+  plan->program_ext_offs.clear();
+  for (int t : ext) if (t >= 0 && plan->tensor_off[t] >= 0) plan->program_ext_offs.push_back(plan->tensor_off[t]);
   const int NS = (int)steps.size();
   const int NT = (int)g.tensors.size();
   std::vector<int> last(NT, -1);

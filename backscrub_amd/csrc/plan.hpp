@@ -146,6 +146,7 @@ struct Plan {
   int program_lds_floats = 0;         // dynamic LDS the program needs (scratch included)
   int program_scratch_floats = 0;     // reduction scratch at the bottom of the LDS block: kLdsScratchFloats, or 64 when no micro-op of the lowering uses it
   int program_lds_tensors = 0, program_global_tensors = 0;
+  std::vector<long> program_ext_offs; // arena offsets of the tensors that cross the program's boundary (read or written by a segment kernel): never elided by the generator
   // every LDS reservation of the program: [off, off+len) floats, alive for steps [from, until] (tensors, weight slots,
   // band workspaces) — checked for overlap by verify_program_lds() at the end of the lowering and by the tests
   struct LdsBlock { int off, len, from, until; std::string what; };

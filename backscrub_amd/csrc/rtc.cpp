@@ -30,6 +30,17 @@ bool writable_dir(const std::string& d) {
   return access(d.c_str(), W_OK | X_OK) == 0;
 }
 
+// A cached code object is LOADED AND RUN on the GPU and its name is computable by anyone (the generated source is deterministic), so a directory the library picks
+// by itself must be one nobody else can write to: a real directory (not a symlink), owned by this user, no group / world write bit.  Created 0700 when missing.
+bool private_dir(const std::string& d) {
+  struct stat st;
+  if (lstat(d.c_str(), &st) != 0) {
+    if (mkdir(d.c_str(), 0700) != 0 || lstat(d.c_str(), &st) != 0) return false;
+  }
+  if (!S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 022) != 0) return false;
+  return access(d.c_str(), W_OK | X_OK) == 0;
+}
+
 std::string lib_dir() {
   Dl_info info;
   if (dladdr(reinterpret_cast<const void*>(&rtc_cache_dir), &info) && info.dli_fname) {
@@ -44,13 +55,18 @@ std::mutex g_mu;
 
 }  // namespace
 
+// BSX_KERNEL_CACHE (the user's explicit choice) → <library directory>/kcache → $XDG_CACHE_HOME/bsx_kcache → ~/.cache/bsx_kcache → /tmp/bsx_kcache_<uid>; every
+// directory but the first must pass private_dir().  "" = no usable directory: the cache is off and every context compiles its kernel.
 std::string rtc_cache_dir() {
   if (const char* e = getenv("BSX_KERNEL_CACHE")) { if (*e && writable_dir(e)) return e; }
   const std::string d = lib_dir() + "/kcache";
-  if (writable_dir(d)) return d;
+  if (private_dir(d)) return d;
+  if (const char* x = getenv("XDG_CACHE_HOME")) { if (*x == '/' && private_dir(std::string(x) + "/bsx_kcache")) return std::string(x) + "/bsx_kcache"; }
+  if (const char* h = getenv("HOME")) {
+    if (*h == '/') { const std::string c = std::string(h) + "/.cache"; (void)mkdir(c.c_str(), 0700); if (private_dir(c + "/bsx_kcache")) return c + "/bsx_kcache"; }
+  }
   const std::string t = "/tmp/bsx_kcache_" + std::to_string((long)getuid());
-  writable_dir(t);
-  return t;
+  return private_dir(t) ? t : std::string();
 }
 
 bool rtc_build(const std::string& source, const std::string& arch_in, std::vector<char>* code, std::string* log, bool* cached) {
@@ -59,10 +75,12 @@ bool rtc_build(const std::string& source, const std::string& arch_in, std::vecto
   int rtc_major = 0, rtc_minor = 0;
   hiprtcVersion(&rtc_major, &rtc_minor);
   const std::string opts_key = arch + "|O3|no-contract|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
-  const std::string path = rtc_cache_dir() + "/" + digest(opts_key + "\n" + source) + ".hsaco";
+  const std::string dir = rtc_cache_dir();
+  const bool cache_on = !dir.empty() && !getenv("BSX_KERNEL_CACHE_OFF");
+  const std::string path = dir + "/" + digest(opts_key + "\n" + source) + ".hsaco";
   if (cached) *cached = false;
   std::lock_guard<std::mutex> lock(g_mu);
-  if (!getenv("BSX_KERNEL_CACHE_OFF")) {
+  if (cache_on) {
     std::ifstream f(path, std::ios::binary);
     if (f) {
       code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
@@ -83,7 +101,7 @@ bool rtc_build(const std::string& source, const std::string& arch_in, std::vecto
   code->assign(cs, '\0');
   hiprtcGetCode(prog, code->data());
   hiprtcDestroyProgram(&prog);
-  if (!getenv("BSX_KERNEL_CACHE_OFF")) {                          // write to a temporary name, then rename: concurrent contexts / ranks never see half a file
+  if (cache_on) {                                                 // write to a temporary name, then rename: concurrent contexts / ranks never see half a file
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
     std::ofstream o(tmp, std::ios::binary);
     if (o) {

@@ -1,9 +1,15 @@
 """Multi-GPU plumbing: streams are independent (per-stream state only, lib/libbackscrub.cc:46-48),
 so the job shards contiguous blocks of streams across ranks with NO data-path collective.  The one
 collective is the all-reduce of the throughput counters {frames (sum), elapsed (max), checksum (sum)}
-— RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  SURVEY.md §8(e)."""
+— RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  SURVEY.md §8(e).
+
+`Collective` is what bench.py talks to: one process group that carries BOTH backends ("cpu:gloo,cuda:nccl"), a probe that
+proves RCCL works by actually all-reducing a device tensor (→ `ranks_seen`), and — if RCCL cannot be brought up on this node —
+a labelled fall-back to the same counter reduction over gloo, so that a broken fabric library costs the report a label, not the
+measurement."""
 from __future__ import annotations
 
+import datetime
 import os
 
 
@@ -30,3 +36,82 @@ def reduce_counters(frames: float, elapsed: float, checksum: int, device=None):
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return s[0].item(), m[0].item(), int(s[1].item()) % (1 << 40)
+
+
+class Collective:
+    """The job's only communication: barriers around the timed region and the counter reduction after it.
+
+    gpu=True : group "cpu:gloo,cuda:nccl"; the probe all-reduces a ones tensor ON THE GPU (RCCL) — `ranks_seen` is its result, so the JSON
+               line says how many ranks RCCL really connected; every rank then agrees (over gloo) whether all probes succeeded; if any failed the
+               job continues on CPU tensors over gloo and `backend` says why.
+    gpu=False: plain gloo (CPU tests, `bench.py --selftest-dist`)."""
+
+    def __init__(self, gpu: bool, timeout_s: int = 600):
+        self.rank, self.world, self.local_rank = env_rank_world()
+        self.backend, self.note, self.ranks_seen, self.device = "none", "", 1, None
+        if self.world == 1:
+            return
+        import torch
+        import torch.distributed as dist
+        to = datetime.timedelta(seconds=timeout_s)
+        if not gpu:
+            dist.init_process_group("gloo", timeout=to)
+            self.backend, self.device = "gloo", torch.device("cpu")
+        else:
+            dist.init_process_group("cpu:gloo,cuda:nccl", timeout=to)          # RCCL communicators are created lazily, by the probe below
+            ok, why = 1, ""
+            try:
+                t = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", self.local_rank))
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+                if int(t.item()) != self.world:
+                    ok, why = 0, "RCCL all-reduce of ones returned %r on rank %d" % (t.item(), self.rank)
+            except Exception as e:  # noqa: BLE001 — any RCCL bring-up failure (IPC handles, missing fabric, version skew)
+                ok, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)                         # CPU tensor → gloo: every rank takes the same branch
+            if int(flag.item()) == 1:
+                self.backend, self.device = "nccl (RCCL)", torch.device("cuda", self.local_rank)
+            else:
+                self.backend, self.device = "gloo (fallback)", torch.device("cpu")
+                self.note = why or "RCCL probe failed on another rank"
+        ones = torch.ones(1, dtype=torch.float64, device=self.device)
+        dist.all_reduce(ones)
+        self.ranks_seen = int(ones.item())
+
+    def barrier(self):
+        if self.world == 1:
+            return
+        import torch
+        import torch.distributed as dist
+        t = torch.zeros(1, dtype=torch.float64, device=self.device)
+        dist.all_reduce(t)
+        t.item()                                                                # the reduction has completed on this rank
+
+    def reduce(self, frames: float, elapsed: float, checksum: int):
+        return reduce_counters(frames, elapsed, checksum, device=self.device)
+
+    def gather(self, value: float):
+        """→ [value of rank 0, value of rank 1, …] on every rank."""
+        if self.world == 1:
+            return [float(value)]
+        import torch
+        import torch.distributed as dist
+        mine = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine)
+        return [float(o.item()) for o in out]
+
+    def describe(self):
+        d = {"backend": self.backend, "ranks_seen": self.ranks_seen, "world_size": self.world}
+        if self.note:
+            d["note"] = self.note
+        return d
+
+    def close(self):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        if dist.is_initialized():
+            self.barrier()
+            dist.destroy_process_group()

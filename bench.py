@@ -44,6 +44,48 @@ PMC_NAMES = {"frame_program": ("bsx_mid", "frame_program_k"), "blend": "blend16_
              "seg_head": "seg_head_k", "seg_k2": "seg_k2_k", "seg_k3": "seg_k3_k", "seg_tail": "seg_tail_k", "seg_tail+decode": "seg_tail_k", "seg_gate": "seg_gate_k"}
 
 
+def cpu_description():
+    """CPU model string + socket / core counts of this box ("core count and CPU model stated")."""
+    model, sockets, cores = "unknown", set(), os.cpu_count() or 1
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                sockets.add(line.split(":", 1)[1].strip())
+    except OSError:
+        pass
+    return {"model": model, "sockets": max(len(sockets), 1), "logical_cpus": cores}
+
+
+def csrc_digest():
+    """Content hash of the kernel sources (backscrub_amd/csrc): what ties the committed PMC passes to the kernels that are timed.  A content hash, not a git
+    tree id — the GPU box receives a snapshot without .git.  tools/merge_pmc.py stamps profiles/pmc_latest.json with the same function."""
+    import hashlib
+    d = os.path.join(ROOT, "backscrub_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".cpp", ".hpp")):
+            h.update(fn.encode() + b"\0")
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pipe_of(model_name, launch_name):
+    """(pipe label, peak TFLOP/s of USEFUL flops) of the arithmetic pipe a launch issues on — the denominator a flops fraction may be quoted against.
+    DeepLab's 1x1 convolutions (GEMM launches `conv#N`, and the expand half of the fused `conv#N+dw#M` launches) run on v_mfma_f32_16x16x32_f16 with the
+    3-term split product (f32-grade): the f16 pipe does 3 MFMAs per useful MAC → 2500 / 3; BSX_F16_GEMM=fast/fast16: 1 term; =off: the f32 pipe.
+    Meet / MLKit kernels use v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s); depthwise / resize / argmax work is f32 VALU (157.3)."""
+    if "deeplab" in model_name and launch_name.startswith("conv#") and not launch_name.startswith("conv#0+"):     # conv#0+dw#1+conv#2 = dl_head0_k: 3x3 stem on the f32 MFMA
+        mode = os.environ.get("BSX_F16_GEMM", "")
+        if mode == "off":
+            return "f32 MFMA (v_mfma_f32_16x16x4_f32)", FP32_PEAK_TFLOPS
+        if mode in ("fast", "fast16"):
+            return "f16 MFMA (v_mfma_f32_16x16x32_f16), 1 term", F16_PEAK_TFLOPS
+        return "f16 MFMA (v_mfma_f32_16x16x32_f16), 3-term split product: useful peak = dense f16 peak / 3", round(F16_PEAK_TFLOPS / 3.0, 1)
+    return "f32 MFMA / VALU", FP32_PEAK_TFLOPS
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,7 +99,10 @@ def parse():
     ap.add_argument("--model", default="lite", help="lite|full|mlkit|deeplab or a .tflite path")
     ap.add_argument("--per-stream-bg", action="store_true", help="every stream composites over its own background frame instead of one shared image")
     ap.add_argument("--bg-ring", action="store_true", help="animated background: every step uploads the next frame of a pinned 36-frame 480x360 ring (H2D) and resizes it on the GPU (grab_background), inside the timed region")
-    ap.add_argument("--host-io", action="store_true", help="also measure the step with per-step H2D of the frames and D2H of the composite (pinned host buffers); reported as host_io, never as value")
+    ap.add_argument("--host-io", action="store_true", help="measure the with-H2D/D2H variant (per-step upload of the frames and download of the composites through pinned host buffers) over steps/2 "
+                    "steps instead of the default line's 4; reported as host_io, never as value")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the host_io leg")
+    ap.add_argument("--second-device-check", action="store_true", help="(internal, run by `--gpus N` as a subprocess of rank 0) one context on a device other than 0, checked against device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` / `single_stream` legs (N = 1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -124,14 +169,40 @@ def parity_sample(model_path, width, height, frames, bg, gpu_masks, gpu_out, nee
     return out
 
 
+def usable_cpus():
+    """How many CPUs this process can really run on: the scheduler affinity mask AND the cgroup CPU quota (cpu.max / cfs_quota_us) — a container on a
+    256-thread host is often given a fraction of it, while os.cpu_count() still says 256 (round 3's all-core leg: 7.6x of one thread on "256 threads")."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
 def cpu_baseline(model_path, width, height, target_s):
-    """Time the CPU oracle port on a bounded sample: all host cores (the `value`), plus the 1-thread and 2-thread legs SURVEY §8(d) asks
-    for (2 = the reference's default `threads`, app/deepseg.cc:362).  The port parallelises with OpenMP ACROSS streams (one stream per thread);
-    the reference's threads are TFLite intra-op threads of ONE stream — a scalar port has no intra-op parallelism, so the t-thread leg is the
-    throughput of t cores running t streams."""
+    """Time the CPU oracle port on a bounded sample: a thread sweep 1, 2 (the reference's default `threads`, app/deepseg.cc:362), then doubling up to the CPUs
+    this process can use (usable_cpus: affinity and cgroup quota, not os.cpu_count()); `value` = the best leg, `cores` = its thread count.  The port parallelises
+    with OpenMP ACROSS streams (one stream — one context, created and first-touched by the thread that runs it — per thread); the reference's threads are TFLite
+    intra-op threads of ONE stream — a scalar port has no intra-op parallelism, so the t-thread leg is the throughput of t cores running t streams."""
     from backscrub_amd import synth
     from oracle import oracle_py
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    affinity, quota = usable_cpus()
+    top = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
     bg = synth.background(width, height)
 
     def leg(threads, budget_s):
@@ -142,16 +213,23 @@ def cpu_baseline(model_path, width, height, target_s):
         sec, stages, _ = oracle_py.baseline_run(model_path, frames, bg, iters, threads)
         return threads * iters / sec, iters, sec, stages
 
-    legs = []
-    for t in sorted({1, min(2, cores)}):
-        fps, iters, sec, _ = leg(t, max(1.5, 0.15 * target_s))
-        legs.append({"threads": t, "value": round(fps, 2), "unit": "frames/s", "sample": "%d stream(s) x %d frames, %.1f s" % (t, iters, sec)})
-    fps, iters, sec, stages = leg(cores, 0.7 * target_s)
-    legs.append({"threads": cores, "value": round(fps, 2), "unit": "frames/s", "sample": "%d streams x %d frames, %.1f s" % (cores, iters, sec)})
+    counts = sorted({1, min(2, top), top} | {t for t in (4, 8, 16, 32, 64, 128, 256) if t < top})
+    if affinity > top:
+        counts.append(affinity)              # one leg beyond the quota, to show that it is the quota (not the port) that caps the scaling
+    legs, best = [], None
+    share = target_s / (len(counts) + 1.0)
+    for t in counts:
+        fps, iters, sec, stages = leg(t, max(1.0, share * (2.0 if t == top else 1.0)))
+        legs.append({"threads": t, "value": round(fps, 2), "unit": "frames/s", "fps_per_thread": round(fps / t, 2),
+                     "sample": "%d stream(s) x %d frames, %.1f s" % (t, iters, sec)})
+        if best is None or fps > best[0]:
+            best = (fps, t, iters, sec, stages)
+    fps, t, iters, sec, stages = best
     tot = sum(stages) or 1.0
-    return {"value": round(fps, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d streams x %d frames of %dx%d through oracle/libbs_oracle_fast.so (-O3 -mavx2 -mfma, OpenMP over streams), %.1f s"
-                      % (cores, iters, width, height, sec),
+    return {"value": round(fps, 2), "unit": "frames/s", "cores": t, "kind": "port",
+            "sample": "%d streams x %d frames of %dx%d through oracle/libbs_oracle_fast.so (-O3 -mavx2 -mfma, OpenMP over streams, one context per thread), %.1f s; "
+                      "best of the thread sweep in `legs`" % (t, iters, width, height, sec),
+            "host": {**cpu_description(), "affinity_cpus": affinity, "cgroup_cpu_quota": quota, "logical_cpus": logical},
             "legs": legs,
             "stage_share": {k: round(v / tot, 3) for k, v in zip(("prep", "infer", "mask", "blend"), stages)}}
 
@@ -167,6 +245,8 @@ def load_pmc(B, W, H, model_name):
         for e in pj.get("workloads", [pj]):
             wl = e.get("workload", {})
             if (wl.get("batch"), wl.get("width"), wl.get("height"), wl.get("model")) == (B, W, H, model_name):
+                e = dict(e)
+                e["csrc_digest"] = pj.get("csrc_digest")          # the kernel sources the passes were collected on (tools/merge_pmc.py)
                 return e
     except Exception:
         pass
@@ -196,31 +276,46 @@ def traffic_of(pmc, launch_index, n_launches, name):
     return None, None
 
 
-def roofline_of(s, pmc, mode_dtype, launch_index=-1, n_launches=0):
+def roofline_of(s, pmc, model_name, launch_index=-1, n_launches=0):
     """achieved = ALGORITHMIC bytes (or flops) of the launch / its mean hipEvent duration; traffic = HBM bytes per launch from
     the committed rocprofv3 PMC passes: (2*FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 counts
-    128-B reads at 64 B)."""
+    128-B reads at 64 B).  The wall is chosen against the pipe the kernel ISSUES on (pipe_of): a launch is "mfma"-bound only if its arithmetic
+    intensity exceeds that pipe's ridge; below it the line is HBM bytes.  `frac_counted_traffic` = the counted HBM bytes over the same duration —
+    what really crosses HBM (algorithmic bytes that hit L2, e.g. a shared background image, are not in it)."""
     traffic, kern = traffic_of(pmc, launch_index, n_launches, s["name"]) if pmc else (None, None)
-    src = {"traffic_source": "committed rocprofv3 --pmc passes (profiles/pmc_latest.json, round %s), not measured in this run" % pmc.get("round", "?")} if traffic is not None else {}
+    src = {}
+    if traffic is not None:
+        stale = pmc.get("csrc_digest") != csrc_digest()
+        src = {"traffic_source": "committed rocprofv3 --pmc passes (profiles/pmc_latest.json, round %s), not measured in this run" % pmc.get("round", "?"),
+               "traffic_stale": bool(stale)}
+        if stale:
+            src["traffic_stale_note"] = "backscrub_amd/csrc changed since the passes were collected (digest %s then, %s now)" % (pmc.get("csrc_digest"), csrc_digest())
     if kern:
         src["traffic_kernel"] = kern
-    peak_tf = F16_PEAK_TFLOPS if mode_dtype == "f16" else FP32_PEAK_TFLOPS
+    pipe, peak_tf = pipe_of(model_name, s["name"])
+    counted = {"frac_counted_traffic": round(traffic / (s["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} if traffic and s["avg_ms"] > 0 else {}
     if s["flops"] > 0 and s["flops"] / max(s["bytes"], 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
         a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
-        return {"kernel": s["name"], "bound": "mfma", "achieved": round(a, 3), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(a / peak_tf, 4),
-                "traffic": traffic, **src, "avg_ms": round(s["avg_ms"], 4), "algorithmic_flops_per_launch": int(s["flops"]),
+        return {"kernel": s["name"], "bound": "mfma", "pipe": pipe, "achieved": round(a, 3), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(a / peak_tf, 4),
+                "traffic": traffic, **src, **counted, "avg_ms": round(s["avg_ms"], 4), "algorithmic_flops_per_launch": int(s["flops"]),
                 "algorithmic_bytes_per_launch": int(s["bytes"])}
-    return {"kernel": s["name"], "bound": "hbm", "achieved": round(s["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, **src, "avg_ms": round(s["avg_ms"], 4),
-            "algorithmic_bytes_per_launch": int(s["bytes"])}
+    out = {"kernel": s["name"], "bound": "hbm", "achieved": round(s["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, **src, **counted, "avg_ms": round(s["avg_ms"], 4),
+           "algorithmic_bytes_per_launch": int(s["bytes"])}
+    if s["flops"] > 0:
+        a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
+        out.update({"algorithmic_flops_per_launch": int(s["flops"]), "flops_pipe": pipe, "flops_frac_of_pipe": round(a / peak_tf, 4),
+                    "intensity_flop_per_byte": round(s["flops"] / max(s["bytes"], 1), 1), "ridge_flop_per_byte": round(peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9), 1)})
+    return out
 
 
-def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stream_bg=False, bg_ring=False, profile_iters=5, dump_launches="", ramp_s=0.0):
+def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stream_bg=False, bg_ring=False, profile_iters=5, dump_launches="", ramp_s=0.0, coll=None,
+            profile=True):
     """Run one configuration on this rank's GPU.  Returns a dict with the timed result and (rank 0) the per-launch profile and
-    the samples the parity leg needs."""
+    the samples the parity leg needs.  `coll` (backscrub_amd.dist.Collective) carries the barriers around the timed region and the one
+    reduction of the job; None = this rank alone (N = 1, and rank 0's solo reference run at N > 1)."""
     import numpy as np
     import torch
-    import torch.distributed as dist
 
     import backscrub_amd
     from backscrub_amd import synth
@@ -265,9 +360,9 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
             mg.step(d_frames, d_bg, d_out)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
+        if coll is not None:
+            coll.barrier()
 
     if ramp_s > 0:                        # clock ramp (untimed, before the W warmup steps): sustained work until the GPU is out of its idle state
         t_r = time.perf_counter()
@@ -285,11 +380,16 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
     elapsed = time.perf_counter() - t0
 
     checksum = int(d_out[:, ::16, ::16].to(torch.int64).sum().item())
-    total_frames, max_elapsed, checksum_all = reduce_counters(B * steps, elapsed, checksum, device="cuda")   # the only collective of the job
+    if coll is not None:                   # the only collective of the job: {frames Σ, elapsed max, checksum Σ} + the per-rank rates for the report
+        total_frames, max_elapsed, checksum_all = coll.reduce(B * steps, elapsed, checksum)
+        rank_fps = coll.gather(B * steps / elapsed)
+    else:
+        total_frames, max_elapsed, checksum_all = reduce_counters(B * steps, elapsed, checksum)
+        rank_fps = [B * steps / elapsed]
     res = {"model_path": model_path, "model_name": model_name, "weights": weights, "B": B, "W": W, "H": H, "photo": photo,
-           "fps": total_frames / max_elapsed, "ms_per_step": 1e3 * max_elapsed / steps, "checksum": checksum_all, "mg": mg,
+           "fps": total_frames / max_elapsed, "ms_per_step": 1e3 * max_elapsed / steps, "checksum": checksum_all, "mg": mg, "rank_fps": rank_fps,
            "d_frames": d_frames, "d_bg": d_bg, "d_out": d_out, "host": host, "bg_host": bg_host}
-    if rank == 0:
+    if rank == 0 and profile:
         k = 4
         if ring is not None:                 # parity needs ONE known background: re-run the last step over the still image
             mg.step(d_frames, d_bg, d_out)
@@ -349,23 +449,34 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
     return res
 
 
-def summarize(res, pmc, mode_dtype="f32"):
+def summarize(res, pmc):
     """→ the JSON fragment of one measured configuration (rank 0)."""
     stats, extra = res["stats"], res["extra"]
     dom = max(stats, key=lambda s: s["avg_ms"])
     blend = dict((extra or [s for s in stats if s["name"] in ("blend", "mask_blend")])[0], name="blend")
     n_l = len(stats)
     out = {"value": round(res["fps"], 1), "unit": "frames/s", "ms_per_step": round(res["ms_per_step"], 4),
-           "roofline": roofline_of(dom, pmc, mode_dtype, stats.index(dom), n_l), "roofline_blend": roofline_of(blend, pmc, mode_dtype)}
+           "roofline": roofline_of(dom, pmc, res["model_name"], stats.index(dom), n_l), "roofline_blend": roofline_of(blend, pmc, res["model_name"])}
     if extra:
         out["roofline_blend"]["note"] = "bsx_composite_batch kernel timed stand-alone; inside the step the blend is fused with mask upscale+blur (mask_blend)"
-    if res["net_launches"] > 1:              # per-launch network (DeepLab): the whole network as one roofline line as well
-        a = res["net_flops"] / (res["net_ms"] * 1e-3) / 1e12
+    if res["net_launches"] > 1:              # the network launches together, against BOTH walls: useful flops over the pipe they issue on, and bytes over HBM
+        ms = res["net_ms"] * 1e-3
         net_traffic = [traffic_of(pmc, i, n_l, s_["name"])[0] for i, s_ in enumerate(stats) if s_ in res["net"]] if pmc and len(pmc.get("step_launches") or []) else []
-        out["roofline_network"] = {"kernel": "network (%d launches)" % res["net_launches"], "bound": "mfma", "achieved": round(a, 3), "peak": FP32_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(a / FP32_PEAK_TFLOPS, 4),
-                                   "traffic": int(sum(net_traffic)) if net_traffic and all(t is not None for t in net_traffic) else None,
-                                   "avg_ms": round(res["net_ms"], 4)}
+        traffic = int(sum(net_traffic)) if net_traffic and all(t is not None for t in net_traffic) else None
+        # pipe time: every launch's flops at the peak of ITS pipe (DeepLab: GEMM launches on the split-f16 pipe, the rest f32)
+        pipe_s = sum(s_["flops"] / (pipe_of(res["model_name"], s_["name"])[1] * 1e12) for s_ in res["net"])
+        alg_bytes = sum(s_["bytes"] for s_ in res["net"])
+        f_pipe = pipe_s / ms
+        f_alg = alg_bytes / ms / 1e9 / HBM_PEAK_GBS
+        f_cnt = traffic / ms / 1e9 / HBM_PEAK_GBS if traffic else None
+        hbm_side = max(f_alg, f_cnt or 0.0)
+        out["roofline_network"] = {"kernel": "network (%d launches)" % res["net_launches"], "bound": "hbm" if hbm_side >= f_pipe else "mfma",
+                                   "frac": round(max(hbm_side, f_pipe), 4),
+                                   "flops_TFLOPs": round(res["net_flops"] / ms / 1e12, 3), "frac_of_issuing_pipes": round(f_pipe, 4),
+                                   "algorithmic_GBps": round(alg_bytes / ms / 1e9, 1), "frac_hbm_algorithmic": round(f_alg, 4),
+                                   "counted_GBps": round(traffic / ms / 1e9, 1) if traffic else None, "frac_hbm_counted_traffic": round(f_cnt, 4) if f_cnt else None,
+                                   "peak_hbm_GBps": HBM_PEAK_GBS, "traffic": traffic, "avg_ms": round(res["net_ms"], 4),
+                                   "note": "frac_of_issuing_pipes = sum over launches of useful flops / the peak of the pipe that launch issues on (pipe_of), over the measured time"}
     if res.get("composite_only") is not None:
         out["composite_only"] = res["composite_only"]
     if res.get("full_batch") is not None:
@@ -409,32 +520,138 @@ def single_stream_latency(model_key, W, H, calls):
             "fps_at_p50": round(1e3 / ts[len(ts) // 2], 1)}
 
 
+def multi_gpu_sections(coll, main, c4, solo1, solo4, world):
+    """The N > 1 part of the line (rank 0): what RCCL really connected, the per-rank rates behind `value`, the north-star job's per-GPU slice
+    (BASELINE configs[4]: 8192 x 1280x720 segm_full streams over 8 GPUs = 1024 per GPU, weak-scaled to N) and both against rank 0 running the
+    same work ALONE on this box a moment earlier (the other ranks waiting at a barrier) — the driver computes its own efficiency from separate runs;
+    this one is same-box, same-minute.  `main` / `c4`: {"fps", "ms_per_step", "rank_fps"}; solo*: frames/s or None."""
+    def leg(r, solo, what):
+        fps = r["rank_fps"]
+        d = {"workload": what, "value": round(r["fps"], 1), "unit": "frames/s", "ms_per_step": round(r["ms_per_step"], 4),
+             "per_rank_fps": [round(v, 1) for v in fps], "per_rank_fps_min": round(min(fps), 1), "per_rank_fps_max": round(max(fps), 1)}
+        if solo:
+            d["rank0_alone_fps"] = round(solo, 1)
+            d["efficiency_vs_rank0_alone"] = round(r["fps"] / (world * solo), 4)
+        return d
+    out = {"collective": coll.describe(), "ranks_seen": coll.ranks_seen,
+           "configs1": leg(main, solo1, "BASELINE configs[1] per GPU: %d x %dx%d, %s" % (main["B"], main["W"], main["H"], main["model_name"]))}
+    if c4 is not None:
+        out["configs4"] = leg(c4, solo4, "BASELINE configs[4]: %d x %dx%d %s streams sharded as contiguous blocks of %d per GPU over %d GPU(s), no data-path collective"
+                              % (c4["B"] * world, c4["W"], c4["H"], c4["model_name"], c4["B"], world))
+        out["configs4"]["streams_total"] = c4["B"] * world
+    return out
+
+
 def selftest_dist(args):
-    """CPU plumbing check of the multi-process path (tests/test_dist_gloo.py): same launch, rendezvous and counter reduction as
-    the GPU run, gloo instead of RCCL, no GPU work."""
-    import torch.distributed as dist
-    from backscrub_amd.dist import reduce_counters, shard_streams
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    if world > 1:
-        dist.init_process_group("gloo")
+    """CPU plumbing check of the multi-process path (tests/test_dist_gloo.py): the same launch, rendezvous, Collective (gloo instead of RCCL),
+    barriers, counter reduction, per-rank gather and JSON assembly (multi_gpu_sections) as the GPU run — the GPU work replaced by made-up timings."""
+    from backscrub_amd.dist import Collective, shard_streams
+    coll = Collective(gpu=False)
+    world, rank = coll.world, coll.rank
+
+    def fake(B, W, H, name, steps, ms):                   # what measure() does around its timed region, with a rank-dependent made-up duration
+        coll.barrier()
+        elapsed = steps * ms * 1e-3 * (1.0 + 0.25 * rank)
+        coll.barrier()
+        frames, max_elapsed, checksum = coll.reduce(B * steps, elapsed, 1000 + rank)
+        return {"B": B, "W": W, "H": H, "model_name": name, "fps": frames / max_elapsed, "ms_per_step": 1e3 * max_elapsed / steps,
+                "rank_fps": coll.gather(B * steps / elapsed), "frames": frames, "elapsed_max": max_elapsed, "checksum": checksum}
     a, b = shard_streams(args.batch * world, world, rank)
-    frames, elapsed, checksum = reduce_counters((b - a) * args.steps, 1.0 + 0.25 * rank, 1000 + rank)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    main = fake(b - a, args.width, args.height, NAMES["lite"], args.steps, 1.0)
+    c4 = fake(1024, 1280, 720, NAMES["full"], max(3, args.steps // 4), 4.0)
+    line = None
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "selftest": "dist", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "frames": frames,
-                          "elapsed_max": elapsed, "checksum": checksum, "value": frames / elapsed, "unit": "frames/s", "scaling": "weak"}), flush=True)
+        line = {"metric": METRIC, "selftest": "dist", "value": main["fps"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": main["ms_per_step"], "higher_is_better": True, "scaling": "weak", "frames": main["frames"], "elapsed_max": main["elapsed_max"],
+                "checksum": main["checksum"], "host": cpu_description()}
+        line.update(multi_gpu_sections(coll, main, c4, main["rank_fps"][0], c4["rank_fps"][0], world))
+    coll.close()
+    if rank == 0:
+        if not args.no_cpu_baseline:                      # kept at world > 1 (rank 0, after the other ranks have left)
+            try:
+                path, _, _ = resolve_model(args.model)
+                line["cpu_baseline"] = cpu_baseline(path, args.width, args.height, args.cpu_seconds)
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+
+
+def second_device_check():
+    """`bench.py --second-device-check` (a subprocess of rank 0 at N > 1, so that a fault cannot take the measurement down): the code path with device != 0 —
+    per-device kernel attributes, hipRTC module load, hipGraph capture of the host path, every entry point's device guard — executed on real hardware the first
+    time two devices are visible.  One context on the LAST visible device and one on device 0, same frames: masks, composites and the single-frame host path
+    must be byte-identical, and the caller's current device must be untouched."""
+    import numpy as np
+    import torch
+
+    import backscrub_amd
+    from backscrub_amd import synth
+    ndev = backscrub_amd.lib().bsx_device_count()
+    if ndev < 2:
+        print(json.dumps({"ran": False, "why": "%d visible device(s)" % ndev}))
+        return
+    out = {"ran": True, "devices": [0, ndev - 1], "models": {}}
+    ok_all = True
+    W, H, n = 640, 480, 4
+    frames = np.stack([synth.frame(W, H, s, 0) for s in range(n)])
+    bg = synth.background(W, H)
+    torch.cuda.set_device(0)
+    for key in ("lite", "deeplab"):
+        path, name, _ = resolve_model(key)
+        got = {}
+        for dev in (0, ndev - 1):
+            mg = backscrub_amd.MaskGen(path, W, H, n_streams=n, device=dev)
+            with torch.cuda.device(dev):
+                d = torch.from_numpy(frames).cuda()
+                d_bg = torch.from_numpy(bg).cuda()
+                o = torch.empty_like(d)
+                for _ in range(3):
+                    mg.step(d, d_bg, o)
+                torch.cuda.synchronize()
+                masks, comp = mg.masks().cpu().numpy(), o.cpu().numpy()
+            restored = torch.cuda.current_device() == 0
+            hm = np.empty((H, W), np.uint8)
+            mg.reset()
+            torch.cuda.synchronize(dev)
+            for _ in range(3):
+                mg.process_host(frames[1], 1, hm)          # the drop-in path (hipGraph capture + replay) on that device
+            got[dev] = (masks, comp, hm.copy(), restored and torch.cuda.current_device() == 0)
+            mg.close()
+        a_, b_ = got[0], got[ndev - 1]
+        res = {"masks_identical": bool(np.array_equal(a_[0], b_[0])), "composites_identical": bool(np.array_equal(a_[1], b_[1])),
+               "host_path_identical": bool(np.array_equal(a_[2], b_[2])), "host_path_equals_batch_path": bool(np.array_equal(b_[2], b_[0][1])),
+               "callers_device_restored": bool(a_[3] and b_[3]), "person_fraction": round(float((b_[0] < 128).mean()), 4)}
+        ok_all = ok_all and all(v for k, v in res.items() if k != "person_fraction")
+        out["models"][name] = res
+    out["ok"] = ok_all
+    print(json.dumps(out))
+
+
+def run_second_device_check():
+    import subprocess
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                "TORCHELASTIC_RUN_ID", "ROLE_RANK", "ROLE_WORLD_SIZE")}
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--second-device-check"], env=env, capture_output=True, text=True, timeout=240)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"ran": True, "ok": False, "returncode": p.returncode, "stderr_tail": p.stderr[-600:]}
+    except Exception as e:  # noqa: BLE001
+        return {"ran": True, "ok": False, "error": repr(e)}
 
 
 def main():
     args = parse()
+    if args.second_device_check:
+        return second_device_check()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                     # does not return
     if args.selftest_dist:
         return selftest_dist(args)
     import torch
-    import torch.distributed as dist
+
+    from backscrub_amd.dist import Collective
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -444,12 +661,51 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+    coll = Collective(gpu=True) if world > 1 else None        # RCCL over xGMI, probed; labelled gloo fall-back if RCCL cannot be brought up
 
     W, H, B = args.width, args.height, args.batch
+    default_job = (args.model, W, H, B) == ("lite", 640, 480, 256) and not args.per_stream_bg and not args.bg_ring
+    solo1 = solo4 = None
+    if coll is not None:
+        # rank 0 ALONE first (the others wait at the barrier): the N = 1 reference of this box, minutes — not runs — apart from the N-rank number
+        if rank == 0:
+            r1 = measure(args.model, W, H, B, args.steps, args.warmup, 0, 1, local_rank, ramp_s=args.ramp_seconds, per_stream_bg=args.per_stream_bg, bg_ring=args.bg_ring,
+                         profile=False)
+            solo1 = r1["fps"]
+            release(r1)
+        coll.barrier()
     res = measure(args.model, W, H, B, args.steps, args.warmup, rank, world, local_rank, ramp_s=args.ramp_seconds, per_stream_bg=args.per_stream_bg, bg_ring=args.bg_ring,
-                  profile_iters=args.profile_iters, dump_launches=args.dump_launches)
+                  profile_iters=args.profile_iters, dump_launches=args.dump_launches, coll=coll)
+    multi = None
+    c4_frag = c4_samples = None
+    if coll is not None:
+        main_leg = {k: res[k] for k in ("B", "W", "H", "model_name", "fps", "ms_per_step", "rank_fps")}
+        c4 = None
+        if default_job and not args.no_extra_configs:
+            # the north-star job's per-GPU slice on EVERY rank: BASELINE configs[4] = 8192 x HD segm_full streams / 8 GPUs = 1024 per GPU
+            n4 = max(3, args.steps // 4)
+            kw4 = dict(model_key="full", W=1280, H=720, B=1024)
+            try:
+                if rank == 0:
+                    r4s = measure(steps=n4, warmup=2, rank=0, world=1, local_rank=local_rank, profile=False, **kw4)
+                    solo4 = r4s["fps"]
+                    release(r4s)
+                coll.barrier()
+                r4 = measure(steps=n4, warmup=2, rank=rank, world=world, local_rank=local_rank, profile_iters=2, coll=coll, **kw4)
+                c4 = {k: r4[k] for k in ("B", "W", "H", "model_name", "fps", "ms_per_step", "rank_fps")}
+                if rank == 0:
+                    c4_frag = summarize(r4, load_pmc(1024, 1280, 720, r4["model_name"]))
+                    c4_samples = (r4["model_path"], r4["host"][:2].copy(), r4["bg_host"], r4["masks_k"], r4["out_k"], r4["photo"])
+                release(r4)
+            except Exception as e:  # noqa: BLE001 — every rank takes the same path: the exception classes here are allocation / model errors, identical on all ranks
+                c4 = None
+                if rank == 0:
+                    c4_frag = {"error": repr(e)}
+        if rank == 0:
+            multi = multi_gpu_sections(coll, main_leg, c4, solo1, solo4, world)
+            if c4_frag is not None and "configs4" in multi:
+                multi["configs4"].update({k: v for k, v in c4_frag.items() if k in ("roofline", "stage_ms", "top_launches", "full_batch_twin_streams", "error")})
+        coll.close()                                          # ranks > 0 are done; rank 0 goes on alone (parity, CPU baseline, the device check)
     result = None
     if rank == 0:
         import backscrub_amd
@@ -462,14 +718,16 @@ def main():
                                    "mask IoU vs the CPU oracle: cpu_baseline.parity_sample" % (B, W, H, res["model_name"]),
                        "streams_per_gpu": B, "frame": "%dx%d" % (W, H), "network": res["model_name"], "sharding": "streams/%d GPUs, no data-path collective" % world,
                        "library": mode},
-            "checksum": res["checksum"],
+            "checksum": res["checksum"], "host": cpu_description(),
         }
         result.update({k: v for k, v in summarize(res, load_pmc(B, W, H, res["model_name"])).items() if k not in ("value", "unit", "ms_per_step")})
+        if multi is not None:
+            result.update(multi)
 
     # PCIe-inclusive variant: every step uploads its frames and downloads its composites through pinned buffers.
     # Copies run on their own HIP streams with double-buffered device frames / composites, so the upload of step t+1 and the
     # download of step t-1 overlap the compute of step t (the per-stream mask state keeps the compute steps in order).
-    if rank == 0 and args.host_io:
+    if rank == 0 and world == 1 and not args.no_host_io:
         from backscrub_amd import synth
         mg, d_frames, d_bg, d_out = res["mg"], res["d_frames"], res["d_bg"], res["d_out"]
         h_in = torch.from_numpy(synth.frames(B, W, H, distinct=16)).pin_memory()
@@ -498,11 +756,11 @@ def main():
             torch.cuda.synchronize()
 
         run(2)
-        io_steps = max(4, args.steps // 2)
+        io_steps = max(4, args.steps // 2) if args.host_io else 4      # the default line carries a 4-step leg (device-resident AND with-H2D/D2H variants)
         t1 = time.perf_counter()
         run(io_steps)
         dt = time.perf_counter() - t1
-        result["host_io"] = {"value": round(B * io_steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / io_steps, 3),
+        result["host_io"] = {"value": round(B * io_steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / io_steps, 3), "steps": io_steps,
                              "note": "same step + H2D of %d frames and D2H of %d composites per step (pinned buffers, copy streams overlapped with "
                                      "compute, double-buffered); %.1f GB/s each way" % (B, B, B * W * H * 3 / (dt / io_steps) / 1e9)}
         del bufs, h_in, h_out
@@ -585,7 +843,12 @@ def main():
     release(res)
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world > 1:
+            result["second_device_check"] = run_second_device_check()
+            if c4_samples is not None and not args.no_cpu_baseline and "configs4" in result:
+                mp_, fr_, bg_, mk_, out_, photo_ = c4_samples
+                result["configs4"]["parity_sample"] = parity_sample(mp_, 1280, 720, fr_, bg_, mk_, out_, need_person=photo_)
+        if not args.no_cpu_baseline:                        # kept at N > 1: rank 0, after the other ranks have left (their GPUs idle, the host cores free)
             try:
                 result["cpu_baseline"] = cpu_baseline(main_samples[0], W, H, args.cpu_seconds)
                 if not args.per_stream_bg:
@@ -593,7 +856,6 @@ def main():
                     result["cpu_baseline"]["parity_sample"] = parity_sample(mp_, W, H, fr_, bg_, mk_, out_, need_person=photo_)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
-        default_job = (args.model, W, H, B) == ("lite", 640, 480, 256) and not args.per_stream_bg and not args.bg_ring
         if world == 1 and default_job and not args.no_extra_configs:
             # the other single-GPU BASELINE configurations, same protocol with fewer steps (they are 3-70x longer per step)
             extra_cfgs = [
@@ -666,9 +928,6 @@ def main():
             except Exception as e:
                 result["single_stream"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -41,6 +41,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the entry points below are its ONLY exported symbols (tests/test_cabi.py checks `nm -D`), so
+ * linking it into an application adds nothing but `bsx_*` to that application's symbol namespace. */
+#ifndef BSX_API
+#define BSX_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -77,64 +83,64 @@ typedef struct bsx_info {
 } bsx_info;
 
 /* "bsx <ver> (HIP gfx950)"; static storage. */
-const char* bsx_version(void);
+BSX_API const char* bsx_version(void);
 
 /* Number of visible HIP devices (0 if none / runtime missing). */
-int bsx_device_count(void);
+BSX_API int bsx_device_count(void);
 
 /* Create a mask generator for `n_streams` independent camera streams of width x height BGR
  * frames on HIP device `device`.  `threads` is accepted for signature parity with
  * bs_maskgen_new (intra-op CPU threads there) and recorded only.  Callbacks may be NULL.
  * 1 <= n_streams <= 65535 (the stream index rides in a grid dimension).
  * Returns NULL on failure after reporting through ondebug (or stderr), like the reference. */
-bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t height,
+BSX_API bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t height,
                  int n_streams, int device,
                  bsx_debug_fn ondebug, bsx_stage_fn onprep, bsx_stage_fn oninfer, bsx_stage_fn onmask,
                  void* caller_ctx);
 
 /* NULL-safe. */
-void bsx_delete(bsx_ctx* ctx);
+BSX_API void bsx_delete(bsx_ctx* ctx);
 
-int bsx_get_info(const bsx_ctx* ctx, bsx_info* out);
+BSX_API int bsx_get_info(const bsx_ctx* ctx, bsx_info* out);
 
 /* Last error text for this context (or the global one if ctx==NULL); static/ctx storage. */
-const char* bsx_last_error(const bsx_ctx* ctx);
+BSX_API const char* bsx_last_error(const bsx_ctx* ctx);
 
 /* Reset the per-stream temporal state (`ofinal` → 0, `mask` → 255) of all streams. */
-int bsx_reset(bsx_ctx* ctx, void* stream);
+BSX_API int bsx_reset(bsx_ctx* ctx, void* stream);
 
 /* Drop-in single-frame path.  h_bgr: height rows of width*3 bytes, `bgr_stride` bytes apart
  * (CV_8UC3 cv::Mat data/step).  h_mask: height rows of width bytes, `mask_stride` apart;
  * receives the full-frame mask (255 = background).  Uses stream slot `stream_idx`.
  * Synchronous: returns after the mask is in h_mask. */
-int bsx_process_host(bsx_ctx* ctx, int stream_idx, const uint8_t* h_bgr, size_t bgr_stride,
+BSX_API int bsx_process_host(bsx_ctx* ctx, int stream_idx, const uint8_t* h_bgr, size_t bgr_stride,
                      uint8_t* h_mask, size_t mask_stride);
 
 /* Batched device path: frames [n][height][width][3] u8 contiguous (n <= n_streams; frame i
  * belongs to stream i).  Updates each stream's temporal state and its persistent full-frame
  * mask.  If d_masks != NULL the masks are also copied there ([n][height][width]).
  * Asynchronous on `stream` unless callbacks are set (each callback needs a stream sync). */
-int bsx_process_batch(bsx_ctx* ctx, const uint8_t* d_frames, int n, uint8_t* d_masks, void* stream);
+BSX_API int bsx_process_batch(bsx_ctx* ctx, const uint8_t* d_frames, int n, uint8_t* d_masks, void* stream);
 
 /* Device pointer of the persistent masks [n_streams][height][width] (valid until bsx_delete;
  * contents valid after the process call that produced them has completed on its stream) —
  * the analogue of `mask = ctx.mask` aliasing the lib-owned buffer (lib/libbackscrub.cc:374). */
-uint8_t* bsx_masks_device(bsx_ctx* ctx);
+BSX_API uint8_t* bsx_masks_device(bsx_ctx* ctx);
 
 /* out = (bg*m + frame*(255-m))/255 per byte (C truncating divide).  d_bg is one
  * [height][width][3] image shared by all frames when bg_frame_stride == 0, else frame i uses
  * d_bg + i*bg_frame_stride.  d_masks == NULL means "use the context's persistent masks". */
-int bsx_composite_batch(bsx_ctx* ctx, const uint8_t* d_bg, size_t bg_frame_stride,
+BSX_API int bsx_composite_batch(bsx_ctx* ctx, const uint8_t* d_bg, size_t bg_frame_stride,
                         const uint8_t* d_frames, const uint8_t* d_masks, uint8_t* d_out, int n, void* stream);
 
 /* bsx_process_batch followed by bsx_composite_batch on the same stream. */
-int bsx_step_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
+BSX_API int bsx_step_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                    uint8_t* d_out, int n, void* stream);
 
 /* The same main-loop iteration with the composite leaving as YUYV 4:2:2 [n][height][width][2] (bytes Y0 V Y1 U): convert_rgb_to_yuyv
  * (app/deepseg.cc:87-106, applied at :681 right after alpha_blend) runs in the blend's epilogue — 2 B/px written instead of 3, and no separate
  * pass over the composite — for callers that feed a V4L2 YUYV sink.  Bit-identical to bsx_step_batch followed by bsx_bgr_to_yuyv.  width even. */
-int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
+BSX_API int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                         uint8_t* d_out_yuyv, int n, void* stream);
 
 /* The same iteration with the post steps of the main loop that sit between alpha_blend and the device write folded into WHERE the blend stores
@@ -142,6 +148,10 @@ int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_
  * a lane composites go to the mirrored column group in reverse order, the row to the mirrored row — no extra pass over the frame) and / or
  * BSX_STEP_YUYV (convert_rgb_to_yuyv of the — flipped — composite, as bsx_step_batch_yuyv).  flags = 0 is bsx_step_batch.  The persistent masks
  * are those of the unflipped camera frame, as in the reference.  Bit-identical to bsx_step_batch + bsx_flip_bgr [+ bsx_bgr_to_yuyv]. */
+/* Aliasing: d_out == d_frames (the reference flips and composites `raw` in place, app/deepseg.cc:661-673) is allowed for every flag combination — with a flip or
+ * YUYV flag and overlapping buffers the library composites into its own scratch first (the fused kernel would store to addresses another tile has not read
+ * yet), so in-place costs one extra pass there; a plain composite runs in place at full speed.  Buffers that overlap PARTIALLY return BSX_EINVAL, and so does
+ * BSX_STEP_BGBLUR with d_out == d_frames (every output pixel needs a neighbourhood of input pixels). */
 #define BSX_STEP_YUYV 1u
 #define BSX_STEP_FLIP_H 2u
 #define BSX_STEP_FLIP_V 4u
@@ -155,44 +165,44 @@ int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_
  * Bit-identical to bsx_gaussian_blur_bgr into a per-stream background + bsx_step_batch_ex(flags) with bg_frame_stride = one frame; that two-call sequence is what
  * runs, on a context-owned scratch background, when the single pass does not apply (YUYV / flip flags, width % 4 != 0, unaligned buffers, ksize 1).  ksize odd, 1..31. */
 #define BSX_STEP_BGBLUR(ksize) (((unsigned)(ksize) & 255u) << 8)
-int bsx_step_batch_ex(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
+BSX_API int bsx_step_batch_ex(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                       uint8_t* d_out, int n, void* stream, unsigned flags);
 
 /* cv::resize(src, dst, Size(dw,dh)) with INTER_LINEAR on packed BGR u8 (device pointers, n images). */
-int bsx_resize_bgr(bsx_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream);
+BSX_API int bsx_resize_bgr(bsx_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream);
 
 /* BGR u8 [n][h][w][3] -> YUYV 4:2:2 [n][h][w][2] exactly as convert_rgb_to_yuyv (byte order Y0 V Y1 U). */
-int bsx_bgr_to_yuyv(bsx_ctx* ctx, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, int h, int n, void* stream);
+BSX_API int bsx_bgr_to_yuyv(bsx_ctx* ctx, const uint8_t* d_bgr, uint8_t* d_yuyv, int w, int h, int n, void* stream);
 
 /* YUYV 4:2:2 (bytes Y0 U Y1 V) [n][h][w][2] -> BGR u8 [n][h][w][3], exactly cv::cvtColor(COLOR_YUV2BGR_YUYV): the conversion
  * cv::VideoCapture applies to raw camera frames for the reference (app/deepseg.cc:553, :725).  Lets a caller upload 2 B/px. */
-int bsx_yuyv_to_bgr(bsx_ctx* ctx, const uint8_t* d_yuyv, uint8_t* d_bgr, int w, int h, int n, void* stream);
+BSX_API int bsx_yuyv_to_bgr(bsx_ctx* ctx, const uint8_t* d_yuyv, uint8_t* d_bgr, int w, int h, int n, void* stream);
 
 /* cv::flip(src, dst, code) on packed BGR u8 [n][h][w][3] (device pointers, dst != src): code 0 flips around the x axis
  * (-v / flipVertical), code > 0 around the y axis (-h / flipHorizontal), code < 0 both (app/deepseg.cc:667-673). */
-int bsx_flip_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int code, void* stream);
+BSX_API int bsx_flip_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int code, void* stream);
 
 /* cv::GaussianBlur(src, dst, Size(ksize, ksize), 0) on packed BGR u8 [n][h][w][3] (device pointers, dst != src), BORDER_REFLECT_101,
  * OpenCV's 8-bit fixed-point coefficients; ksize odd, 1 <= ksize <= 31 (the reference's default strength is 25, app/deepseg.cc:429).
  * The "blur my own room" mode of the reference = this on the camera frames, then bsx_step_batch with bg_frame_stride = one frame. */
-int bsx_gaussian_blur_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int ksize, void* stream);
+BSX_API int bsx_gaussian_blur_bgr(bsx_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n, int ksize, void* stream);
 
 /* ---- background source (app/background.cc) ----
  * load_background(): a still image or an animation (GIF87a/89a, 8-bit non-interlaced PNG, binary PPM decoded in this library; other
  * formats through bsx_background_from_frames with frames the caller decoded).  The frames live on the context's GPU; an animation gets
  * the FPS-paced reader thread of background.cc:29-104 (advances one frame per 1/fps, wraps to 0 at the end).  NULL on error. */
 typedef struct bsx_background bsx_background;
-bsx_background* bsx_background_load(bsx_ctx* ctx, const char* path, int debug);
-bsx_background* bsx_background_from_frames(bsx_ctx* ctx, const uint8_t* h_bgr, int width, int height, int n_frames, double fps, int debug);
-void bsx_background_free(bsx_background* bg);
-int bsx_background_info(const bsx_background* bg, int* width, int* height, int* n_frames, double* fps, int* is_video);
+BSX_API bsx_background* bsx_background_load(bsx_ctx* ctx, const char* path, int debug);
+BSX_API bsx_background* bsx_background_from_frames(bsx_ctx* ctx, const uint8_t* h_bgr, int width, int height, int n_frames, double fps, int debug);
+BSX_API void bsx_background_free(bsx_background* bg);
+BSX_API int bsx_background_info(const bsx_background* bg, int* width, int* height, int* n_frames, double* fps, int* is_video);
 /* grab_background(): the current frame resized (cv::resize INTER_LINEAR) to width x height into d_bgr_out [height][width][3].
  * Returns the frame number or -1 on error: 1 for a still image; for an animation the reference's count of pictures read since the last rewind, i.e.
  * picture c (= floor(t * fps) mod n, t since the background was created: real-time playback, looping at the end) is reported as c + 1. */
-int bsx_background_grab(bsx_background* bg, int width, int height, uint8_t* d_bgr_out, void* stream);
+BSX_API int bsx_background_grab(bsx_background* bg, int width, int height, uint8_t* d_bgr_out, void* stream);
 /* host-only decode of the same formats (no GPU): frames → malloc'ed [n][h][w][3] BGR; returns n (> 0) or a negative BSX_E* code */
-int bsx_media_decode(const char* path, int* width, int* height, double* fps, uint8_t** h_bgr, char* errbuf, size_t errcap);
-void bsx_media_free(uint8_t* h_bgr);
+BSX_API int bsx_media_decode(const char* path, int* width, int* height, double* fps, uint8_t** h_bgr, char* errbuf, size_t errcap);
+BSX_API void bsx_media_free(uint8_t* h_bgr);
 
 /* ---- live single-camera mode: class CalcMask (app/deepseg.cc:159-286) ----
  * set_input_frame clones the frame into pinned memory and enqueues upload + mask pipeline (stream slot 0) + mask download on a private HIP
@@ -200,48 +210,48 @@ void bsx_media_free(uint8_t* h_bgr);
  * get_output_mask polls the completion events: it copies the newest finished mask (returns 1) or leaves h_mask untouched (0).
  * timings: how long the queue sat idle before the last submission / upload + pipeline + download of the last mask handed out (HIP events). */
 typedef struct bsx_live bsx_live;
-bsx_live* bsx_live_new(bsx_ctx* ctx);
-void bsx_live_delete(bsx_live* live);
-int bsx_live_set_input_frame(bsx_live* live, const uint8_t* h_bgr, size_t bgr_stride);
-int bsx_live_get_output_mask(bsx_live* live, uint8_t* h_mask, size_t mask_stride);
-int bsx_live_timings(const bsx_live* live, long* waitns, long* loopns);
+BSX_API bsx_live* bsx_live_new(bsx_ctx* ctx);
+BSX_API void bsx_live_delete(bsx_live* live);
+BSX_API int bsx_live_set_input_frame(bsx_live* live, const uint8_t* h_bgr, size_t bgr_stride);
+BSX_API int bsx_live_get_output_mask(bsx_live* live, uint8_t* h_mask, size_t mask_stride);
+BSX_API int bsx_live_timings(const bsx_live* live, long* waitns, long* loopns);
 
 /* ---- introspection used by the parity tests and the bench (stage-by-stage checks) ---- */
 /* Device pointer + element count of: 0 = model input tensor [n_streams][in_h][in_w][in_c] f32,
  * 1 = model output tensor f32, 2 = ofinal u8 [n_streams][out_h][out_w], 3 = masks u8. */
-int bsx_debug_buffer(bsx_ctx* ctx, int which, void** d_ptr, size_t* bytes);
+BSX_API int bsx_debug_buffer(bsx_ctx* ctx, int which, void** d_ptr, size_t* bytes);
 /* Run single stages on the current buffers (n streams): 0 = prep, 1 = infer, 2 = decode+IIR, 3 = upscale+blur. */
-int bsx_debug_run_stage(bsx_ctx* ctx, int stage, const uint8_t* d_frames, int n, void* stream);
+BSX_API int bsx_debug_run_stage(bsx_ctx* ctx, int stage, const uint8_t* d_frames, int n, void* stream);
 /* Per-launch description of the fused plan, one line per GPU launch; returned string is owned by ctx. */
-const char* bsx_plan_describe(bsx_ctx* ctx);
+BSX_API const char* bsx_plan_describe(bsx_ctx* ctx);
 /* Copy out the value of graph tensor `tensor_idx` for stream 0 after an infer (only tensors that survive
  * fusion are available); returns element count or negative error.  h_out may be NULL to query the size. */
-long bsx_debug_tensor(bsx_ctx* ctx, int tensor_idx, float* h_out, long cap);
+BSX_API long bsx_debug_tensor(bsx_ctx* ctx, int tensor_idx, float* h_out, long cap);
 /* The same for stream `stream_idx` of the last batch (full-batch parity tests: every stream against its twin). */
-long bsx_debug_tensor_of(bsx_ctx* ctx, int tensor_idx, int stream_idx, float* h_out, long cap);
+BSX_API long bsx_debug_tensor_of(bsx_ctx* ctx, int tensor_idx, int stream_idx, float* h_out, long cap);
 
 /* Per-frame-program timeline: runs the network once for n streams and returns, for workgroup 0, the wall-clock
  * (100 MHz constant-rate counter) ticks at the start of every micro-op plus one final tick; ticks[i+1]-ticks[i] = op i.
  * Returns the number of micro-ops (cap must be >= that + 1), 0 if the program path is off, negative on error. */
-int bsx_debug_program_timeline(bsx_ctx* ctx, int n, unsigned long long* ticks, int cap, void* stream);
+BSX_API int bsx_debug_program_timeline(bsx_ctx* ctx, int n, unsigned long long* ticks, int cap, void* stream);
 
 /* Host only, no GPU: the coefficient words gauss_blur_k multiplies with for cv::GaussianBlur(ksize, sigma 0) on 8-bit images (app/deepseg.cc:657-658) when its LDS
  * planes start `shift` (0..3) pixels left of the tile — c4[4][9]: the u8 taps packed 4 per word, delayed by j + shift bytes for output phase j; c2[2][17]: the same taps
  * as u16 pairs delayed by h halves.  The parity tests check them against the oracle's taps (the kernels' arithmetic is only as right as these tables).  Returns 0 or BSX_EINVAL. */
-int bsx_debug_gauss_coeffs(int ksize, int shift, uint32_t* c4 /* 36 */, uint32_t* c2 /* 34 */);
+BSX_API int bsx_debug_gauss_coeffs(int ksize, int shift, uint32_t* c4 /* 36 */, uint32_t* c2 /* 34 */);
 
 /* Parse a .tflite file and build the fused plan WITHOUT touching a GPU; writes a text description
  * ("ops=<n> nodes=<n> steps=<n> macs=<per frame> arena_floats=<per stream>" then one line per launch)
  * into buf (NUL-terminated, truncated to cap).  Returns 0, or BSX_EMODEL with the reason in buf. */
-int bsx_model_describe(const char* model_path, char* buf, size_t cap);
+BSX_API int bsx_model_describe(const char* model_path, char* buf, size_t cap);
 /* Host only, no GPU: build the plan of `model_path`, emit the kernel specialised to that graph (the per-frame program of the Meet / MLKit
  * family as straight-line code: csrc/gen_mid.cpp) and compile it with hipRTC for `arch` (NULL = "gfx950") into the code-object cache, so
  * that bsx_new on the GPU box only loads it.  This replaces what InterpreterBuilder / AllocateTensors do when the reference creates its
  * context (lib/libbackscrub.cc:205-217).  msg receives "compiled" / "cached" / why the graph stays interpreted.  Returns 0, or BSX_EMODEL. */
-int bsx_model_precompile(const char* model_path, const char* arch, char* msg, size_t cap);
+BSX_API int bsx_model_precompile(const char* model_path, const char* arch, char* msg, size_t cap);
 /* The generated source itself (tests, inspection): returns its length (without NUL), copies at most cap - 1 bytes; 0 when the graph has no
  * specialised form (reason in buf), negative on a model error. */
-long bsx_model_kernel_source(const char* model_path, char* buf, size_t cap);
+BSX_API long bsx_model_kernel_source(const char* model_path, char* buf, size_t cap);
 
 /* ---- measurement ---- */
 typedef struct bsx_launch_stat {
@@ -255,7 +265,7 @@ typedef struct bsx_launch_stat {
  * `iters` times, bracketing EVERY launch with hipEvents on `stream`, and writes one record per
  * launch (in launch order) into out[0..cap).  Returns the number of launches, or a negative error.
  * The temporal state advances exactly as `iters` calls of bsx_step_batch would. */
-int bsx_profile_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out,
+BSX_API int bsx_profile_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out,
                       int n, int iters, bsx_launch_stat* out, int cap, void* stream);
 
 #ifdef __cplusplus

@@ -927,15 +927,19 @@ void bso_ctx_post(void* h) { ctx_post(*(OCtx*)h); }
 // Returns elapsed seconds (wall) or <0 on error; stage_s[4] = prep, infer, post, blend seconds (summed over threads).
 double bso_baseline_run(const char* model_path, int width, int height, int n_streams, int iters, int threads,
                         const uint8_t* frames, const uint8_t* bg, uint8_t* out, double* stage_s) {
+  // one context per stream, created (and therefore first-touched: its tensors land on the NUMA node of the core that uses them) by the thread that runs it
   std::vector<OCtx*> ctxs(n_streams, nullptr);
-  for (int s = 0; s < n_streams; s++) { ctxs[s] = ctx_new(model_path, width, height); if (!ctxs[s]) return -1.0; }
   size_t fsz = (size_t)width * height * 3;
   double st[4] = {0, 0, 0, 0};
 #ifdef _OPENMP
   if (threads > 0) omp_set_num_threads(threads);
 #endif
+  int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+  for (int s = 0; s < n_streams; s++) { ctxs[s] = ctx_new(model_path, width, height); if (!ctxs[s]) bad++; }
+  if (bad) { for (auto* c : ctxs) delete c; return -1.0; }
   auto t0 = std::chrono::steady_clock::now();
-#pragma omp parallel for schedule(dynamic) reduction(+ : st[:4])
+#pragma omp parallel for schedule(static) reduction(+ : st[:4])
   for (int s = 0; s < n_streams; s++) {
     OCtx& c = *ctxs[s];
     std::vector<uint8_t> local(out ? 0 : fsz);

@@ -37,13 +37,47 @@ def test_a_fresh_bench_line_has_the_contract_fields():
     r_ = d["roofline"]
     assert r_["bound"] in ("hbm", "mfma") and r_["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-3 and (r_["traffic"] is None or r_["traffic"] > 0)
-    assert r_["traffic"] is None or "traffic_source" in r_                             # counters come from a committed profile: the line must say so
+    assert r_["traffic"] is None or ("traffic_source" in r_ and isinstance(r_["traffic_stale"], bool))   # counters come from a committed profile: the line says so, and whether the kernels changed since
+    assert r_["traffic"] is None or 0 < r_["frac_counted_traffic"] <= 1.0             # the counted-bytes figure next to the algorithmic one
+    assert d["host"]["model"] and d["host"]["logical_cpus"] >= 1                       # CPU model and core count stated
+    h = d["host_io"]                                                                   # the with-H2D/D2H variant is in the default line
+    assert h["value"] > 0 and h["steps"] >= 4 and h["value"] <= d["value"] * 1.05
     for t in d["top_launches"]:
         assert t["GBps"] <= 8000.0, "%s: %s GB/s is above the HBM peak — its byte model is wrong" % (t["name"], t["GBps"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
     assert [l["threads"] for l in c["legs"]][:2] == [1, 2] and all(l["value"] > 0 for l in c["legs"])
+    assert c["value"] == max(l["value"] for l in c["legs"]) and c["cores"] in [l["threads"] for l in c["legs"]] and c["host"]["model"]
     p = c["parity_sample"]
     assert p["mask_iou_min"] >= 0.999 and p["composite_max_abs_diff"] <= 1
     fb = d["full_batch_twin_streams"]                                                  # every stream of the batch was compared with its scene twin on the GPU
     assert fb["streams"] == 256 and fb["groups_compared_with_group_0"] == 15 and fb["all_identical"] is True
+
+
+def test_roofline_denominators_name_the_pipe_the_kernel_issues_on():
+    """DeepLab's fused expand + depthwise issues v_mfma_f32_16x16x32_f16 (3-term split) — priced against the f32 matrix peak it looked
+    mfma-bound at 0.56; against its own pipe (2500 / 3 TFLOP/s useful, ridge 104 FLOP/B) a 38 FLOP/B launch is HBM-bound."""
+    sys.path.insert(0, ROOT)
+    import bench
+    s = {"name": "conv#50+dw#51", "avg_ms": 1.059, "bytes": 2.46e9, "flops": 93.8e9, "GBps": 2.46e9 / 1.059e-3 / 1e9}
+    r = bench.roofline_of(s, {}, "deeplabv3_257_mv_gpu.tflite")
+    assert r["bound"] == "hbm" and abs(r["frac"] - 0.29) < 0.01 and r["ridge_flop_per_byte"] > 100 and r["flops_frac_of_pipe"] < 0.15
+    assert bench.pipe_of("deeplabv3_257_mv_gpu.tflite", "conv#0+dw#1+conv#2")[1] == bench.FP32_PEAK_TFLOPS       # the stem kernel is f32 MFMA
+    assert bench.pipe_of("segm_lite_v681.tflite", "seg_head")[1] == bench.FP32_PEAK_TFLOPS
+    os.environ["BSX_F16_GEMM"] = "off"
+    try:
+        assert bench.pipe_of("deeplabv3_257_mv_gpu.tflite", "conv#60")[1] == bench.FP32_PEAK_TFLOPS
+    finally:
+        os.environ.pop("BSX_F16_GEMM")
+    # an HBM-bound byte kernel with a stale / fresh PMC stamp
+    pmc = {"round": "rXX", "csrc_digest": "0" * 16, "kernels": {"mask_tile_k<true>": {"FETCH_SIZE_KiB": 130430, "WRITE_SIZE_KiB": 304700, "kernel": "mask_tile_k<true>"}}}
+    m = {"name": "mask_blend", "avg_ms": 0.1389, "bytes": 789577728.0, "flops": 0.0, "GBps": 789577728.0 / 0.1389e-3 / 1e9}
+    r = bench.roofline_of(m, pmc, "segm_lite_v681.tflite")
+    assert r["traffic_stale"] is True and 0.5 < r["frac_counted_traffic"] < r["frac"]
+    pmc["csrc_digest"] = bench.csrc_digest()
+    assert bench.roofline_of(m, pmc, "segm_lite_v681.tflite")["traffic_stale"] is False
+
+
+def test_committed_pmc_file_is_stamped():
+    pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    assert "csrc_digest" in pj and len(pj["csrc_digest"]) == 16

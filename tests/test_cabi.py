@@ -68,3 +68,17 @@ def test_process_host_rejects_a_bad_mask_out_before_reaching_c(built):
         with pytest.raises(api.BsxError, match="mask_out"):
             mg.process_host(frame, 0, bad)
     assert api.bs_maskgen_process(mg, frame, np.zeros((4, 7), np.uint8)) is False
+
+
+def test_library_exports_only_the_c_abi(built):
+    """A drop-in library gets linked into someone else's application: its dynamic symbol table is include/bsx.h and nothing else — no internal bsx::… C++
+    symbols, no un-prefixed C helpers (round 3 leaked `step_impl` and 42 mangled names), no weak libstdc++ instantiations (-fvisibility=hidden + csrc/libbsx.map)."""
+    import re
+    import subprocess
+    lib = os.path.join(ROOT, "backscrub_amd", "libbsx.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert names and all(n.startswith("bsx_") for n in names), [n for n in names if not n.startswith("bsx_")][:10]
+    hdr = open(os.path.join(ROOT, "include", "bsx.h")).read()
+    declared = set(re.findall(r"^BSX_API [^;(]*?\b(bsx_\w+)\(", hdr, re.M))
+    assert declared == set(names), (sorted(declared - set(names)), sorted(set(names) - declared))

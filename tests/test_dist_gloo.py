@@ -48,6 +48,46 @@ def test_counter_allreduce_world2():
         assert frames == 5130.0 and elapsed == 1.5 and checksum == 2001
 
 
+def _coll_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from backscrub_amd.dist import Collective
+    c = Collective(gpu=False)
+    c.barrier()
+    got = (c.describe(), c.reduce(10 * (rank + 1), 1.0 + rank, 7), c.gather(100.0 + rank))
+    c.close()
+    q.put((rank, got))
+
+
+def test_collective_object_world2():
+    """backscrub_amd.dist.Collective — what bench.py holds at N > 1 — on gloo: probe (ranks_seen), barrier, reduce, gather, close."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_coll_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        desc, red, gat = res[r]
+        assert desc == {"backend": "gloo", "ranks_seen": 2, "world_size": 2}
+        assert red == (30.0, 2.0, 14) and gat == [100.0, 101.0]
+
+
+def test_collective_is_a_no_op_for_one_rank():
+    from backscrub_amd.dist import Collective
+    env = {k: os.environ.pop(k) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK") if k in os.environ}
+    try:
+        c = Collective(gpu=True)          # world 1: nothing is initialised, no GPU is touched
+        c.barrier()
+        assert c.ranks_seen == 1 and c.reduce(5, 2.0, 7) == (5.0, 2.0, 7) and c.gather(3.0) == [3.0]
+        c.close()
+    finally:
+        os.environ.update(env)
+
+
 def test_reduce_counters_without_group():
     assert reduce_counters(5, 2.0, 7) == (5.0, 2.0, 7)
 
@@ -60,11 +100,20 @@ def test_bench_self_launches_its_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-dist", "--batch", "8", "--steps", "5"],
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-dist", "--batch", "8", "--steps", "5", "--cpu-seconds", "2"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["frames"] == 80.0 and d["elapsed_max"] == 1.25 and d["checksum"] == 2001
+    assert d["n_gpus"] == 2 and d["frames"] == 80.0 and abs(d["elapsed_max"] - 0.00625) < 1e-9 and d["checksum"] == 2001
     assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"]
+    # the N > 1 shape of the line (bench.multi_gpu_sections, shared with the GPU run): what the collective really connected, per-rank rates,
+    # the north-star job's slice on every rank, both against rank 0 alone, and the CPU baseline kept
+    assert d["ranks_seen"] == 2 and d["collective"] == {"backend": "gloo", "ranks_seen": 2, "world_size": 2}
+    c1, c4 = d["configs1"], d["configs4"]
+    assert len(c1["per_rank_fps"]) == 2 and c1["per_rank_fps_min"] == min(c1["per_rank_fps"]) and c1["per_rank_fps_max"] == max(c1["per_rank_fps"])
+    assert abs(c1["value"] - d["value"]) < 1e-6 and abs(c1["efficiency_vs_rank0_alone"] - 0.8) < 1e-9       # rank 1 is 25 % slower by construction; time = max over ranks
+    assert c4["streams_total"] == 2048 and "segm_full_v679" in c4["workload"] and "1280x720" in c4["workload"] and len(c4["per_rank_fps"]) == 2
+    assert abs(c4["value"] - 2 * 1024 * 1e3 / c4["ms_per_step"]) / c4["value"] < 1e-6
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["host"]["model"] and d["host"]["logical_cpus"] >= 1

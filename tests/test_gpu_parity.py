@@ -713,6 +713,45 @@ def test_step_with_flips_folded_into_the_blend(bs, oracle, key, res):
     mg_b.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA)])
+def test_step_in_place_like_the_reference(bs, oracle, key, res):
+    """The reference flips and composites `raw` IN PLACE (app/deepseg.cc:661-673): d_out == d_frames.  Round 3's fused kernel stored the flipped composite to
+    addresses another tile had not read yet (advisor, medium).  Every flag combination must give the bytes of the out-of-place call; partial overlap is refused."""
+    import torch
+    from backscrub_amd import synth
+    W, H = res
+    n = 3
+    mg_a = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    mg_b = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    bg = _dev(synth.random_u8((n, H, W, 3), 79))
+    want = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    t = 0
+    for fh, fv in ((False, False), (True, False), (False, True), (True, True)):
+        frames = _dev(np.stack([synth.frame(W, H, i, t) for i in range(n)]))
+        t += 1
+        inplace = frames.clone()
+        mg_a.step_ex(frames, bg, want, flip_h=fh, flip_v=fv)
+        mg_b.step_ex(inplace, bg, inplace, flip_h=fh, flip_v=fv)
+        assert torch.equal(inplace, want), "in place, flip_h=%s flip_v=%s: %d bytes differ" % (fh, fv, int((inplace != want).sum()))
+        assert torch.equal(mg_a.masks(), mg_b.masks())
+    # YUYV in place: 2 B/px written over the 3 B/px frames
+    frames = _dev(np.stack([synth.frame(W, H, i, t) for i in range(n)]))
+    buf = frames.clone()
+    want2 = torch.empty((n, H, W, 2), dtype=torch.uint8, device="cuda")
+    mg_a.step_ex(frames, bg, want2, yuyv=True, flip_h=True)
+    out_view = buf.view(-1)[: n * H * W * 2].view(n, H, W, 2)
+    mg_b.step_ex(buf, bg, out_view, yuyv=True, flip_h=True)
+    assert torch.equal(out_view, want2)
+    # partial overlap: refused
+    big = torch.empty((n + 1, H, W, 3), dtype=torch.uint8, device="cuda")
+    shifted = big.view(-1)[W * 3 * 8: W * 3 * 8 + n * H * W * 3].view(n, H, W, 3)
+    with pytest.raises(bs.BsxError):
+        mg_b.step_ex(big[:n], bg, shifted)
+    mg_a.close()
+    mg_b.close()
+
+
 @pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA), ("full", (1280, 720)), ("lite", (322, 242))])
 def test_step_with_own_blur_as_background(bs, oracle, key, res):
     """BSX_STEP_BGBLUR(ksize): `-p bgblur:<n>` without `-b` (app/deepseg.cc:652-661) in one pass over the frames — the blurred tile is composited out of LDS.

@@ -8,6 +8,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
 
 
 def main():
@@ -21,7 +23,9 @@ def main():
         wl.append(e)
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of `bench.py --steps 5 --warmup 2` per workload, round %s; "
                    "traffic bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section); produced by "
-                   "tools/profile_config.sh + tools/merge_pmc.py" % tag, "workloads": wl}
+                   "tools/profile_config.sh + tools/merge_pmc.py" % tag, "workloads": wl,
+           # what ties the passes to the kernels: bench.py compares this with the tree it runs from and prints traffic_stale when they differ
+           "csrc_digest": bench.csrc_digest(), "csrc_digest_note": "sha256[:16] over backscrub_amd/csrc/*.{hip,cpp,hpp} (bench.csrc_digest) of the tree the passes ran on"}
     for dst in (os.path.join(ROOT, "profiles", "pmc_latest.json"), os.path.join(ROOT, "gpurun_out", "pmc_latest.json")):
         with open(dst, "w") as f:
             json.dump(out, f, indent=1)
