@@ -59,6 +59,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
   const bool fine = getenv("BSX_RTC_FINE") != nullptr;
   Out o;
   o.s.reserve(sizeof kPrelude + 64 * 1024);
+  if (getenv("BSX_RTC_EXP_MFMA")) o.s += "#define BSXM_EXP_MFMA_QUARTER 1   // timing experiment: WRONG RESULTS (mid_prelude.hip op_pw)\n";
   o.s += kPrelude;
   o.f("\nnamespace bsxm {\n");
   std::string body;

@@ -191,6 +191,16 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
       }
     }
     f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#if defined(BSXM_EXP_MFMA_QUARTER)
+    // TIMING EXPERIMENT ONLY (BSX_RTC_EXP_MFMA=1, results are wrong): one of every four MFMAs of the K loop, every load / scale / epilogue unchanged — an UPPER bound on
+    // what a split-f16 v_mfma_f32_16x16x32_f16 form of this op (3 f16 MFMAs where 8 f32 ones are, plus the operand split) could gain
+#pragma unroll
+    for (int j = 0; j < NJ; j += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][0] + b[j][1] + b[j][2] + b[j][3], a[j].x + a[j].y + a[j].z + a[j].w, acc0, 0, 0, 0);
+      if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j + 1 < NJ ? j + 1 : j][0] + b[j + 1 < NJ ? j + 1 : j][1] + b[j + 1 < NJ ? j + 1 : j][2] + b[j + 1 < NJ ? j + 1 : j][3],
+                                                                  a[j + 1 < NJ ? j + 1 : j].x + a[j + 1 < NJ ? j + 1 : j].y + a[j + 1 < NJ ? j + 1 : j].z + a[j + 1 < NJ ? j + 1 : j].w, acc1, 0, 0, 0);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < NJ; j += 2) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][0], a[j].x, acc0, 0, 0, 0);
@@ -202,6 +212,7 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][3], a[j].w, acc0, 0, 0, 0);
       if (j + 1 < NJ) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j + 1 < NJ ? j + 1 : j][3], a[j + 1 < NJ ? j + 1 : j].w, acc1, 0, 0, 0);
     }
+#endif
     if constexpr (TM > 0) {
 #pragma unroll
       for (int r = 0; r < TM; r++) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tb[r], ta[r], acc1, 0, 0, 0);

@@ -660,8 +660,13 @@ def main():
         sys.exit("--gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists)")
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev                                     # more ranks than GPUs (e.g. `--gpus 2` on a 1-GPU box): ranks share devices round-robin — a plumbing run,
+    local_rank = local_rank % n_dev                            # labelled `gpu_sharing` in the line; RCCL needs one GPU per rank, so the counters then travel over gloo
     torch.cuda.set_device(local_rank)
-    coll = Collective(gpu=True) if world > 1 else None        # RCCL over xGMI, probed; labelled gloo fall-back if RCCL cannot be brought up
+    coll = Collective(gpu=not shared) if world > 1 else None   # RCCL over xGMI, probed; labelled gloo fall-back if RCCL cannot be brought up
+    if coll is not None and shared:
+        coll.backend, coll.note = "gloo (ranks share GPUs)", "%d ranks on %d visible GPU(s): RCCL requires one GPU per rank" % (world, n_dev)
 
     W, H, B = args.width, args.height, args.batch
     default_job = (args.model, W, H, B) == ("lite", 640, 480, 256) and not args.per_stream_bg and not args.bg_ring
@@ -723,6 +728,8 @@ def main():
         result.update({k: v for k, v in summarize(res, load_pmc(B, W, H, res["model_name"])).items() if k not in ("value", "unit", "ms_per_step")})
         if multi is not None:
             result.update(multi)
+            if shared:
+                result["gpu_sharing"] = "%d ranks on %d GPU(s): throughput numbers of this line are a plumbing run, not a scaling measurement" % (world, n_dev)
 
     # PCIe-inclusive variant: every step uploads its frames and downloads its composites through pinned buffers.
     # Copies run on their own HIP streams with double-buffered device frames / composites, so the upload of step t+1 and the

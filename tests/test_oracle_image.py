@@ -288,3 +288,37 @@ def test_gauss_kernel_coefficient_words_are_the_oracle_taps_delayed(oracle, n):
     for bad in (0, 2, 4, 33):
         with pytest.raises(api.BsxError):
             api.gauss_coeff_words(bad, 0)
+
+
+def test_bilateral_rounding_tie_audit(oracle):
+    """Decision-margin audit of the bilateral's final rounding (OpenCV absent: unpinned).  out = cvRound(sum * (1 / wsum)) in f32; an OpenCV build that contracts the
+    accumulation into FMAs (or sums in another order) moves `sum` by a few ulp, which changes the 8-bit result only where sum / wsum sits within a few ulp of x.5.
+    Count those values on the canvases the models really see (photo fixture + synthetic scene, resized as prep does): the upper bound on network-input bytes that can
+    differ by 1 LSB from the real reference.  Recorded in DESIGN.md §2."""
+    from backscrub_amd import synth
+    from tools import make_photo_fixture
+    lut = np.exp(np.arange(768, dtype=np.float64) ** 2 * (-0.5 / 100.0 ** 2)).astype(np.float32)
+    taps = [(i, j) for i in range(-2, 3) for j in range(-2, 3) if np.sqrt(i * i + j * j) <= 2]
+    report = {}
+    for name, frame in (("photo", make_photo_fixture.load_frames()[0]), ("synthetic", synth.frame(640, 480, 0, 0))):
+        for tag, (dw, dh), roi in (("mlkit 256x256", (256, 256), (80, 0, 480, 480)), ("meet-lite 128x96", (128, 96), (0, 0, 640, 480))):
+            x0, y0, w, h = roi
+            img = oracle.resize_linear(np.ascontiguousarray(frame[y0:y0 + h, x0:x0 + w]), dw, dh)[..., ::-1].copy()      # BGR2RGB
+            p = np.pad(img, ((2, 2), (2, 2), (0, 0)), mode="reflect").astype(np.int32)
+            c = img.astype(np.int32)
+            acc = np.zeros(img.shape, np.float32)
+            ws = np.zeros(img.shape[:2], np.float32)
+            for i, j in taps:
+                nb = p[2 + i:2 + i + dh, 2 + j:2 + j + dw]
+                wgt = np.float32(np.exp((i * i + j * j) * (-0.5 / 100.0 ** 2))) * lut[np.abs(nb - c).sum(-1)]
+                acc = acc + nb.astype(np.float32) * wgt[..., None]
+                ws = ws + wgt
+            v = acc * (np.float32(1) / ws)[..., None]
+            assert np.array_equal(np.rint(v).astype(np.uint8), oracle.bilateral(img))
+            frac = np.abs(v - np.floor(v) - np.float32(0.5))
+            ulp = np.spacing(np.maximum(v, np.float32(1)).astype(np.float32))
+            near = int((frac <= 4 * ulp).sum())                  # 13 accumulations: an FMA / reordered build stays within ~4 ulp of this one
+            report["%s, %s" % (name, tag)] = (near, int(v.size))
+    print("bilateral tie audit (values within 4 ulp of x.5 / all values):", report)
+    for near, total in report.values():
+        assert near <= 2e-4 * total
