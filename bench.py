@@ -309,6 +309,23 @@ def roofline_of(s, pmc, model_name, launch_index=-1, n_launches=0):
     return out
 
 
+def finish_counters(coll, frames, elapsed, checksum):
+    """The job's one reduction, shared by measure() and the CPU self-test: {frames Σ, elapsed max, checksum Σ} + every rank's own rate.  coll=None = THIS RANK ALONE
+    (N = 1, or rank 0's solo reference run while the other ranks wait at a barrier): nothing collective may be touched then — an all-reduce entered by one rank
+    only would pair up with the waiting ranks' barrier (round 4, found by `bench.py --gpus 2` on one GPU: it hung)."""
+    if coll is None:
+        return float(frames), float(elapsed), int(checksum) % (1 << 40), [frames / elapsed]
+    total, max_elapsed, checksum_all = coll.reduce(frames, elapsed, checksum)
+    return total, max_elapsed, checksum_all, coll.gather(frames / elapsed)
+
+
+def solo_reference(coll, rank, fn):
+    """rank 0 runs fn() ALONE — fn must not touch the collective (coll=None inside) — while the other ranks wait; → fn()'s value on rank 0, None elsewhere"""
+    v = fn() if rank == 0 else None
+    coll.barrier()
+    return v
+
+
 def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stream_bg=False, bg_ring=False, profile_iters=5, dump_launches="", ramp_s=0.0, coll=None,
             profile=True):
     """Run one configuration on this rank's GPU.  Returns a dict with the timed result and (rank 0) the per-launch profile and
@@ -319,7 +336,6 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
 
     import backscrub_amd
     from backscrub_amd import synth
-    from backscrub_amd.dist import reduce_counters
 
     model_path, model_name, weights = resolve_model(model_key)
     mg = backscrub_amd.MaskGen(model_path, W, H, n_streams=B, device=local_rank)
@@ -380,12 +396,7 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
     elapsed = time.perf_counter() - t0
 
     checksum = int(d_out[:, ::16, ::16].to(torch.int64).sum().item())
-    if coll is not None:                   # the only collective of the job: {frames Σ, elapsed max, checksum Σ} + the per-rank rates for the report
-        total_frames, max_elapsed, checksum_all = coll.reduce(B * steps, elapsed, checksum)
-        rank_fps = coll.gather(B * steps / elapsed)
-    else:
-        total_frames, max_elapsed, checksum_all = reduce_counters(B * steps, elapsed, checksum)
-        rank_fps = [B * steps / elapsed]
+    total_frames, max_elapsed, checksum_all, rank_fps = finish_counters(coll, B * steps, elapsed, checksum)     # the only collective of the job
     res = {"model_path": model_path, "model_name": model_name, "weights": weights, "B": B, "W": W, "H": H, "photo": photo,
            "fps": total_frames / max_elapsed, "ms_per_step": 1e3 * max_elapsed / steps, "checksum": checksum_all, "mg": mg, "rank_fps": rank_fps,
            "d_frames": d_frames, "d_bg": d_bg, "d_out": d_out, "host": host, "bg_host": bg_host}
@@ -549,22 +560,28 @@ def selftest_dist(args):
     coll = Collective(gpu=False)
     world, rank = coll.world, coll.rank
 
-    def fake(B, W, H, name, steps, ms):                   # what measure() does around its timed region, with a rank-dependent made-up duration
-        coll.barrier()
+    def fake(B, W, H, name, steps, ms, c):                # what measure() does around its timed region, with a rank-dependent made-up duration
+        if c is not None:
+            c.barrier()
         elapsed = steps * ms * 1e-3 * (1.0 + 0.25 * rank)
-        coll.barrier()
-        frames, max_elapsed, checksum = coll.reduce(B * steps, elapsed, 1000 + rank)
+        if c is not None:
+            c.barrier()
+        frames, max_elapsed, checksum, rank_fps = finish_counters(c, B * steps, elapsed, 1000 + rank)
         return {"B": B, "W": W, "H": H, "model_name": name, "fps": frames / max_elapsed, "ms_per_step": 1e3 * max_elapsed / steps,
-                "rank_fps": coll.gather(B * steps / elapsed), "frames": frames, "elapsed_max": max_elapsed, "checksum": checksum}
+                "rank_fps": rank_fps, "frames": frames, "elapsed_max": max_elapsed, "checksum": checksum}
     a, b = shard_streams(args.batch * world, world, rank)
-    main = fake(b - a, args.width, args.height, NAMES["lite"], args.steps, 1.0)
-    c4 = fake(1024, 1280, 720, NAMES["full"], max(3, args.steps // 4), 4.0)
+    n4 = max(3, args.steps // 4)
+    # the same order of solo runs, barriers and collectives as main()
+    solo1 = solo_reference(coll, rank, lambda: fake(b - a, args.width, args.height, NAMES["lite"], args.steps, 1.0, None)["fps"]) if world > 1 else None
+    main = fake(b - a, args.width, args.height, NAMES["lite"], args.steps, 1.0, coll)
+    solo4 = solo_reference(coll, rank, lambda: fake(1024, 1280, 720, NAMES["full"], n4, 4.0, None)["fps"]) if world > 1 else None
+    c4 = fake(1024, 1280, 720, NAMES["full"], n4, 4.0, coll)
     line = None
     if rank == 0:
         line = {"metric": METRIC, "selftest": "dist", "value": main["fps"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": main["ms_per_step"], "higher_is_better": True, "scaling": "weak", "frames": main["frames"], "elapsed_max": main["elapsed_max"],
                 "checksum": main["checksum"], "host": cpu_description()}
-        line.update(multi_gpu_sections(coll, main, c4, main["rank_fps"][0], c4["rank_fps"][0], world))
+        line.update(multi_gpu_sections(coll, main, c4, solo1, solo4, world))
     coll.close()
     if rank == 0:
         if not args.no_cpu_baseline:                      # kept at world > 1 (rank 0, after the other ranks have left)
@@ -673,12 +690,13 @@ def main():
     solo1 = solo4 = None
     if coll is not None:
         # rank 0 ALONE first (the others wait at the barrier): the N = 1 reference of this box, minutes — not runs — apart from the N-rank number
-        if rank == 0:
+        def solo_main():
             r1 = measure(args.model, W, H, B, args.steps, args.warmup, 0, 1, local_rank, ramp_s=args.ramp_seconds, per_stream_bg=args.per_stream_bg, bg_ring=args.bg_ring,
                          profile=False)
-            solo1 = r1["fps"]
+            fps = r1["fps"]
             release(r1)
-        coll.barrier()
+            return fps
+        solo1 = solo_reference(coll, rank, solo_main)
     res = measure(args.model, W, H, B, args.steps, args.warmup, rank, world, local_rank, ramp_s=args.ramp_seconds, per_stream_bg=args.per_stream_bg, bg_ring=args.bg_ring,
                   profile_iters=args.profile_iters, dump_launches=args.dump_launches, coll=coll)
     multi = None
@@ -691,11 +709,12 @@ def main():
             n4 = max(3, args.steps // 4)
             kw4 = dict(model_key="full", W=1280, H=720, B=1024)
             try:
-                if rank == 0:
+                def solo_c4():
                     r4s = measure(steps=n4, warmup=2, rank=0, world=1, local_rank=local_rank, profile=False, **kw4)
-                    solo4 = r4s["fps"]
+                    fps = r4s["fps"]
                     release(r4s)
-                coll.barrier()
+                    return fps
+                solo4 = solo_reference(coll, rank, solo_c4)
                 r4 = measure(steps=n4, warmup=2, rank=rank, world=world, local_rank=local_rank, profile_iters=2, coll=coll, **kw4)
                 c4 = {k: r4[k] for k in ("B", "W", "H", "model_name", "fps", "ms_per_step", "rank_fps")}
                 if rank == 0:
