@@ -414,6 +414,7 @@ __device__ __forceinline__ uint32_t blend_word(uint32_t a, uint32_t b, uint32_t 
   const uint32_t r13 = __builtin_bit_cast(uint32_t, pk_blend((a >> 8) & K, (b >> 8) & K, m13));
   return r02 | (r13 << 8);
 }
+typedef uint32_t u3v __attribute__((ext_vector_type(3)));      // four packed BGR pixels: one global_{load,store}_dwordx3 (4-byte aligned)
 // 4 pixels = 12 bytes = 3 words; mw holds their 4 mask bytes.  Byte→pixel map of the words: (0,0,0,1) (1,1,2,2) (2,3,3,3).
 __device__ __forceinline__ void blend_quad(const uint32_t a[3], const uint32_t b[3], uint32_t mw, uint32_t o[3]) {
   const uint32_t m00 = __builtin_amdgcn_perm(mw, mw, 0x0c000c00u), m01 = __builtin_amdgcn_perm(mw, mw, 0x0c010c00u);
@@ -549,7 +550,9 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
         __builtin_nontemporal_store(yuyv_pair(o3[0] & 255u, (o3[0] >> 8) & 255u, (o3[0] >> 16) & 255u, o3[0] >> 24, o3[1] & 255u, (o3[1] >> 8) & 255u), op);
         __builtin_nontemporal_store(yuyv_pair((o3[1] >> 16) & 255u, o3[1] >> 24, o3[2] & 255u, (o3[2] >> 8) & 255u, (o3[2] >> 16) & 255u, o3[2] >> 24), op + 1);
       } else {
-        __builtin_nontemporal_store(o3[0], op); __builtin_nontemporal_store(o3[1], op + 1); __builtin_nontemporal_store(o3[2], op + 2);
+        // ONE 12-byte store (global_store_dwordx3): the 32 lanes of a tile row then write 384 contiguous bytes per instruction — as three dword stores each
+        // instruction wrote 4 of every 12 bytes (a third of every line, three times over)
+        __builtin_nontemporal_store(u3v{o3[0], o3[1], o3[2]}, reinterpret_cast<u3v*>(op));
       }
     }
   }
@@ -746,6 +749,39 @@ __global__ __launch_bounds__(kThreads) void blend16_k(const uint8_t* __restrict_
   for (int q = 0; q < 4; q++) blend_quad(&aw[3 * q], &bw[3 * q], mw[q], &ow[3 * q]);
 #pragma unroll
   for (int k = 0; k < 3; k++) op[k] = make_uint4(ow[4 * k], ow[4 * k + 1], ow[4 * k + 2], ow[4 * k + 3]);
+}
+
+// The same blend with every memory instruction COALESCED ACROSS LANES (round 4).  blend16_k gives a lane 16 consecutive pixels: its 16-byte loads and stores are
+// 48 bytes apart from the neighbouring lane's, so one wave instruction touches a third of each of 24 cache lines and every line is visited by three instructions.
+// Here a lane owns kB4 groups of FOUR pixels, group j of lane l at group index (block * kB4 + j) * 256 + l: one wave instruction = 64 lanes x 12 contiguous bytes
+// = 768 bytes = six whole lines (global_load_dwordx3 / global_store_dwordx3, 4-byte aligned), the mask 64 x 4 bytes = two lines.  tools/microbench_mix.hip: a
+// plain streaming kernel with this mix and coalesced accesses moves 5.7-6.2 TB/s through HBM where blend16_k moved 4.8.
+constexpr int kB4 = 4;
+__global__ __launch_bounds__(kThreads) void blend4x4_k(const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ fr,
+                                                      const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, unsigned quads_per_frame, long npix) {
+  const long n = blockIdx.y;
+  const unsigned q0 = blockIdx.x * (kThreads * kB4) + threadIdx.x;      // first 4-pixel group of this lane
+  const uint8_t* const a0 = bg + (bg_stride ? n * bg_stride : 0);
+  const uint8_t* const b0 = fr + n * npix * 3;
+  const uint8_t* const m0 = mask + n * npix;
+  uint8_t* const o0 = out + n * npix * 3;
+  u3v av[kB4], bv[kB4];
+  uint32_t mw[kB4];
+#pragma unroll
+  for (int j = 0; j < kB4; j++) {
+    const unsigned q = min(q0 + j * kThreads, quads_per_frame - 1);     // groups past the end re-read the last one (never stored)
+    av[j] = *reinterpret_cast<const u3v*>(a0 + (size_t)q * 12);
+    bv[j] = __builtin_nontemporal_load(reinterpret_cast<const u3v*>(b0 + (size_t)q * 12));
+    mw[j] = *reinterpret_cast<const uint32_t*>(m0 + (size_t)q * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < kB4; j++) {
+    const unsigned q = q0 + j * kThreads;
+    const uint32_t a3[3] = {av[j].x, av[j].y, av[j].z}, b3[3] = {bv[j].x, bv[j].y, bv[j].z};
+    uint32_t o3[3];
+    blend_quad(a3, b3, mw[j], o3);
+    if (q < quads_per_frame) __builtin_nontemporal_store(u3v{o3[0], o3[1], o3[2]}, reinterpret_cast<u3v*>(o0 + (size_t)q * 12));
+  }
 }
 
 // scalar tail / unaligned fallback: one pixel per lane
@@ -1002,13 +1038,18 @@ hipError_t launch_blend(const uint8_t* bg, size_t bg_stride, const uint8_t* fram
                         hipStream_t s) {
   bool aligned = (((uintptr_t)bg | (uintptr_t)frames | (uintptr_t)masks | (uintptr_t)out) & 15) == 0 && (npix % 16 == 0) && (bg_stride % 16 == 0);
   const long groups = aligned ? (long)(npix / 16) : 0;
+  // lane-coalesced form: 4-byte alignment and whole 4-pixel groups are enough.  BSX_BLEND16=1 keeps the 16-pixels-per-lane kernel (A/B timing, tests)
+  static const bool use16 = getenv("BSX_BLEND16") != nullptr;
+  const bool quad_ok = (((uintptr_t)bg | (uintptr_t)frames | (uintptr_t)masks | (uintptr_t)out) & 3) == 0 && (npix % 4 == 0) && (bg_stride % 4 == 0) && npix / 4 < (1l << 31);
+  const long quads = quad_ok && !(use16 && groups) ? (long)(npix / 4) : 0;
   for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
     const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
     const uint8_t* bgp = bg + (size_t)n0 * bg_stride;
     const uint8_t* fp = frames + (size_t)n0 * npix * 3;
     const uint8_t* mp = masks + (size_t)n0 * npix;
     uint8_t* op = out + (size_t)n0 * npix * 3;
-    if (groups) blend16_k<<<dim3(blocks_for(groups), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (unsigned)groups, (long)npix);
+    if (quads) blend4x4_k<<<dim3((unsigned)((quads + kThreads * kB4 - 1) / (kThreads * kB4)), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (unsigned)quads, (long)npix);
+    else if (groups) blend16_k<<<dim3(blocks_for(groups), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (unsigned)groups, (long)npix);
     else blend1_k<<<dim3(blocks_for((long)npix), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (long)npix);
   }
   return hipGetLastError();

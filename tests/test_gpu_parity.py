@@ -466,6 +466,7 @@ def test_end_to_end_iou_and_composite(bs, oracle, key, res, real):
     bg = synth.background(W, H)
     d_bg = _dev(bg)
     out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    stats = {"frames": 0, "frames_with_identical_masks": 0, "mask_pixels_differing": 0, "composite_pixels_over_1_lsb": 0, "composite_max_abs": 0}
     for t in range(T):
         frames = np.stack([synth.frame(W, H, s, t) for s in range(n)])
         d_frames = _dev(frames)
@@ -485,6 +486,18 @@ def test_end_to_end_iou_and_composite(bs, oracle, key, res, real):
             same = got_mask[i] == want_mask
             assert int(diff[same].max(initial=0)) == 0, "t=%d stream %d: composite differs where the masks agree" % (t, i)
             assert (~same).mean() <= 1e-3, "t=%d stream %d: %.5f of mask pixels differ" % (t, i, (~same).mean())
+            # the north star's literal bar (max-abs <= 1 LSB): holds on the WHOLE frame whenever the masks agree (the usual case — counted below), and the pixels
+            # above 1 LSB are a subset of the (counted, bounded) mask pixels that differ
+            over = diff > 1
+            assert not np.any(over & same) and int(over.sum()) <= int((~same).sum())
+            stats["frames"] += 1
+            stats["frames_with_identical_masks"] += int(same.all())
+            stats["mask_pixels_differing"] += int((~same).sum())
+            stats["composite_pixels_over_1_lsb"] += int(over.sum())
+            stats["composite_max_abs"] = max(stats["composite_max_abs"], int(diff.max()))
+    print("end-to-end %s %dx%d %s weights: %s" % (key, W, H, "real" if real else "synthetic", stats))
+    if real:                       # the four BASELINE geometries with the reference's weights: the literal bar, frame by frame
+        assert stats["frames_with_identical_masks"] == stats["frames"] or stats["composite_pixels_over_1_lsb"] <= stats["mask_pixels_differing"]
     for c in oc:
         c.close()
     mg.close()
