@@ -81,6 +81,7 @@ SYMBOLS = [
     ("bsx_model_precompile", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("bsx_model_kernel_source", C.c_long, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("bsx_debug_tensor_of", C.c_long, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_long]),
+    ("bsx_debug_mask_tile_stats", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_long)]),
     ("bsx_debug_program_timeline", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p]),
     ("bsx_model_describe", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("bsx_profile_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.c_void_p]),
@@ -306,6 +307,13 @@ class MaskGen:
 
     def plan(self) -> str:
         return lib().bsx_plan_describe(self.h).decode()
+
+    def mask_tile_stats(self, n=None) -> dict:
+        """how the fused mask + blend launch classifies its tiles for the current temporal state: a uniform tile (whole source block 0xFF / 0x00) skips the
+        mask phases and reads only the operand its composite copies"""
+        a = (C.c_long * 4)()
+        _check(lib().bsx_debug_mask_tile_stats(self.h, n or self.n_streams, a), self.h, "bsx_debug_mask_tile_stats")
+        return {"tiles": a[0], "uniform_255": a[1], "uniform_0": a[2], "general": a[3], "tile": "128x32"}
 
     def graph_tensor(self, idx, stream=None) -> np.ndarray:
         if stream is not None:

@@ -123,12 +123,15 @@ struct bsx_ctx {
   std::string mid_note;             //   (gen_mid.cpp, mid_prelude.hip); mid.fn == nullptr: the interpreter runs (BSX_NO_RTC=1, or why in mid_note)
   BilateralParams bilateral{};
   DevResizeTab tab_down, tab_up;
+  uint8_t* d_tile_class = nullptr;    // [n_streams][mask tiles]: 1 / 2 = the tile's source block is all 0xFF / 0x00 (tile_class_k), read by mask_tile_k
+  size_t tiles_per_frame = 0;
   std::map<std::pair<std::pair<int, int>, std::pair<int, int>>, DevResizeTab> bg_tabs;
   std::string last_error, plan_text;
   bool keep_logits = false;            // BSX_KEEP_LOGITS: segmented plans write the logits and run the stand-alone decode (A/B, debugging)
   bool no_mask_blend_fusion = false;   // BSX_NO_MASK_BLEND_FUSION, read once at bsx_new (no getenv on the per-step path)
   bool no_bgblur_fusion = false;       // BSX_NO_BGBLUR_FUSION: BSX_STEP_BGBLUR always as blur pass + step (the A/B switch of the single-pass form)
   bool no_mask_tile = false;           // BSX_NO_MASK_TILE (tests: the generic mask kernel), likewise
+  bool no_uniform_tiles = false;       // BSX_NO_UNIFORM_TILES (A/B timing, tests: every mask tile on the general path), likewise
   bool tail_generic = false;           // BSX_TAIL_GENERIC (tests: the scalar argmax scan of the DeepLab tail), likewise
   // Lanes (BSX_LANES=k, experiment): the fused step splits its batch into k contiguous groups of streams and runs each group's launch sequence on its own
   // HIP stream — streams are independent, so the HBM-bound tail of one group (mask + blend) can overlap the latency-bound network kernels of another.
@@ -184,6 +187,7 @@ int upload_tab(bsx_ctx* c, const HostResizeTab& h, DevResizeTab* d) {
   d->tab.sw = h.sw; d->tab.sh = h.sh; d->tab.dw = h.dw; d->tab.dh = h.dh; d->tab.mode = h.mode;
   if (h.mode != 0) return BSX_OK;
   d->tab.tile_ok = (mask_tile_fits(h.xofs.data(), h.yofs.data(), h.sw, h.sh, h.dw, h.dh) && !c->no_mask_tile) ? 1 : 0;
+  d->tab.tile_class = nullptr;
   size_t b_xofs = h.xofs.size() * 4, b_yofs = h.yofs.size() * 4, b_xa = h.xa.size() * 2, b_ya = h.ya.size() * 2;
   auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
   size_t total = up16(b_xofs) + up16(b_yofs) + up16(b_xa) + up16(b_ya);
@@ -296,6 +300,13 @@ int init_device_state(bsx_ctx* c) {
   if (rc) return rc;
   rc = upload_tab(c, make_resize_tab(c->in_roi.w, c->in_roi.h, c->roi.w, c->roi.h), &c->tab_up);
   if (rc) return rc;
+  // one class byte per (stream, mask tile) for the tile kernel's uniform-tile shortcut (kernels_img.hip: tile_class_k); absent = every tile on the general path
+  c->tiles_per_frame = (size_t)((c->roi.w + mask_tile_width() - 1) / mask_tile_width()) * (size_t)((c->roi.h + mask_tile_height() - 1) / mask_tile_height());
+  if (!c->no_uniform_tiles && c->tab_up.tab.mode == 0 && c->tab_up.tab.tile_ok) {
+    BSX_HIP(c, hipMalloc(&c->d_tile_class, N * c->tiles_per_frame + 4));          // (+4: the tile kernel reads the aligned word around a byte)
+    BSX_HIP(c, hipMemset(c->d_tile_class, 0, N * c->tiles_per_frame + 4));
+    c->tab_up.tab.tile_class = c->d_tile_class;
+  }
   // canvas outside in_roi is written as 0 by the prep kernel on every frame (the reference keeps a
   // persistent zeroed in_u8_bgr, :251); nothing else to initialise.
   return BSX_OK;
@@ -369,8 +380,14 @@ int run_decode(bsx_ctx* c, int n, hipStream_t s, int slot = 0) {
   BSX_HIP(c, launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal + (size_t)slot * c->outW * c->outH, c->outW * c->outH, c->outC, n, s));
   return BSX_OK;
 }
+// the mask up-scale table with its tile-class scratch re-based to stream `slot` (lanes run concurrently on disjoint slot ranges)
+ResizeTab tab_up_at(const bsx_ctx* c, int slot) {
+  ResizeTab t = c->tab_up.tab;
+  if (t.tile_class) t.tile_class += (size_t)slot * c->tiles_per_frame;
+  return t;
+}
 int run_mask(bsx_ctx* c, int n, hipStream_t s, int slot = 0) {
-  BSX_HIP(c, launch_mask_upscale_blur(c->d_ofinal + (size_t)slot * c->outW * c->outH, c->outW, c->outH, c->in_roi, c->tab_up.tab,
+  BSX_HIP(c, launch_mask_upscale_blur(c->d_ofinal + (size_t)slot * c->outW * c->outH, c->outW, c->outH, c->in_roi, tab_up_at(c, slot),
                                       c->d_masks + (size_t)slot * c->width * c->height, c->width, c->height, c->roi, n, s));
   return BSX_OK;
 }
@@ -451,6 +468,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
   c->no_mask_blend_fusion = getenv("BSX_NO_MASK_BLEND_FUSION") != nullptr;
   c->no_bgblur_fusion = getenv("BSX_NO_BGBLUR_FUSION") != nullptr;
   c->no_mask_tile = getenv("BSX_NO_MASK_TILE") != nullptr;
+  c->no_uniform_tiles = getenv("BSX_NO_UNIFORM_TILES") != nullptr;
   c->tail_generic = getenv("BSX_TAIL_GENERIC") != nullptr;
   c->keep_logits = getenv("BSX_KEEP_LOGITS") != nullptr;
   int ndev = 0;
@@ -485,7 +503,7 @@ void bsx_delete(bsx_ctx* c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (auto& kv : c->host_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   rtc_unload(&c->mid);
-  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_bgblur_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16};
+  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_bgblur_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16, c->d_tile_class};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -666,7 +684,7 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
         if (!lane_rc) lane_rc = run_infer(c, nb, ls, !fd, f0);
         if (!lane_rc && !fd) lane_rc = run_decode(c, nb, ls, f0);
       }
-      if (!lane_rc && launch_mask_blend(c->d_ofinal + (size_t)f0 * sm, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks + (size_t)f0 * c->width * c->height, c->width, c->height,
+      if (!lane_rc && launch_mask_blend(c->d_ofinal + (size_t)f0 * sm, c->outW, c->outH, c->in_roi, tab_up_at(c, f0), c->d_masks + (size_t)f0 * c->width * c->height, c->width, c->height,
                                         c->roi, d_bg + (size_t)f0 * bg_frame_stride, bg_frame_stride, d_frames + (size_t)f0 * fb, d_out + (size_t)f0 * ob, nb, ls, (int)flags) != hipSuccess)
         lane_rc = BSX_EDEVICE;
       // forked lanes are ALWAYS joined, also after an error: the caller's stream must not be left with work in flight on streams it cannot see
@@ -910,6 +928,20 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     put(j++, "blend", N * 10.0 * px, 0);
   }
   return j;
+}
+
+int bsx_debug_mask_tile_stats(bsx_ctx* c, int n, long* out4) {
+  if (!c || !out4 || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
+  out4[0] = (long)c->tiles_per_frame * n; out4[1] = out4[2] = 0; out4[3] = out4[0];
+  if (!c->d_tile_class) return BSX_OK;                          // generic kernel / shortcut off: every tile is general
+  // the classifier the launches themselves run, on the current temporal state
+  BSX_HIP(c, launch_tile_class(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->roi, n, nullptr));
+  std::vector<uint8_t> cls((size_t)out4[0]);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(cls.data(), c->d_tile_class, cls.size(), hipMemcpyDeviceToHost) != hipSuccess) return BSX_EDEVICE;
+  out4[3] = 0;
+  for (uint8_t v : cls) out4[v == 1 ? 1 : (v == 2 ? 2 : 3)]++;
+  return BSX_OK;
 }
 
 int bsx_debug_gauss_coeffs(int ksize, int shift, uint32_t* c4, uint32_t* c2) {

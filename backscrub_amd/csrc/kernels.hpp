@@ -60,8 +60,16 @@ struct ResizeTab {
   int sw = 0, sh = 0, dw = 0, dh = 0;
   int mode = 0;                  // 0 linear, 1 copy (same size), 2 INTER_AREA 2x2 (both scales exactly 2)
   int tile_ok = 0;               // mask_tile_fits(): every mask tile's source block fits the LDS staging area
+  // mask up-scale table only: device scratch of one byte per (stream, mask tile), written by tile_class_k right before the tile kernel reads it (1 = the tile's
+  // whole source block is 0xFF, 2 = 0x00, 0 = anything else).  nullptr (BSX_NO_UNIFORM_TILES at bsx_new: A/B timing, parity tests) = every tile on the general path
+  uint8_t* tile_class = nullptr;
 };
 bool mask_tile_fits(const int* xofs, const int* yofs, int sw, int sh, int dw, int dh);
+int mask_tile_width();             // the mask tile kernel's tile geometry (kernels_img.hip: kTW x kTH)
+int mask_tile_height();
+// classify the mask tiles of n streams into tab.tile_class (see ResizeTab); launch_mask_upscale_blur / launch_mask_blend run it themselves
+struct Rect4;
+hipError_t launch_tile_class(const uint8_t* ofinal, int outW, int outH, const Rect4& in_roi, const ResizeTab& tab, const Rect4& roi, int n, hipStream_t s);
 
 struct Rect4 { int x, y, w, h; };
 

@@ -445,9 +445,10 @@ __device__ __forceinline__ uint32_t yuyv_pair(uint32_t a0, uint32_t a1, uint32_t
 // Composite operands of a lane's kTileItems 4-pixel groups (12 B of background + 12 B of frame each), requested at the very
 // top of the kernel so that their HBM latency hides behind the LDS phases.
 struct TileBlendOperands { uint32_t a[kTileItems][3], b[kTileItems][3]; };
+// `uniform` (wave-uniform): 0 = both operands; 1 = the tile's mask is 255 everywhere → only the background is needed; 2 = 0 everywhere → only the frame
 template <bool BLEND>
 __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
-                                                         int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid) {
+                                                         int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int uniform = 0) {
   if constexpr (BLEND) {
     const int ly0 = tid / (kTW / 4), gx = tx0 + (tid % (kTW / 4)) * 4;
     const long pix0 = (long)(roi.y + ty0 + ly0) * W + roi.x + gx;        // frame coordinates of the ROI-relative tile pixel
@@ -459,8 +460,8 @@ __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, c
       if (ty0 + ly0 + 8 * i < roi.h && gx < roi.w) {
         const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0 + (long)(8 * i) * W * 3);
         const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * 3);
-        o.a[i][0] = ap[0]; o.a[i][1] = ap[1]; o.a[i][2] = ap[2];
-        o.b[i][0] = __builtin_nontemporal_load(bp); o.b[i][1] = __builtin_nontemporal_load(bp + 1); o.b[i][2] = __builtin_nontemporal_load(bp + 2);   // streamed once
+        if (uniform != 2) { o.a[i][0] = ap[0]; o.a[i][1] = ap[1]; o.a[i][2] = ap[2]; }
+        if (uniform != 1) { o.b[i][0] = __builtin_nontemporal_load(bp); o.b[i][1] = __builtin_nontemporal_load(bp + 1); o.b[i][2] = __builtin_nontemporal_load(bp + 2); }   // streamed once
       }
     }
   }
@@ -511,9 +512,11 @@ __device__ __forceinline__ void reverse4px(uint32_t (&w)[3]) {
 }
 // flip (yuyv bits 1-2: 2 = horizontal, 4 = vertical): cv::flip of the COMPOSITE (deepseg.cc:667-673) folded into where the tile stores it — the lane's four
 // pixels go to the mirrored column group in reverse order, the row to the mirrored row; the persistent mask is the unflipped frame's and stays put.
+// `uniform` (wave-uniform; see mask_tile_k): 1 / 2 = every mask byte of the tile is 255 / 0 — no sums to form, and the composite IS the background / the frame
+// ((a*255 + b*0)/255 == a for every byte: the exhaustive blend test covers m = 0 and 255)
 template <bool BLEND>
 __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __restrict__ mask, uint8_t* __restrict__ outp, const TileBlendOperands& o,
-                                                 int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int yuyv_flip) {
+                                                 int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int yuyv_flip, int uniform = 0) {
   const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
   const int gx = tx0 + lx;
   const int yuyv = yuyv_flip & 1;
@@ -527,16 +530,19 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
   for (int i = 0; i < kTileItems; i++) {
     const int ly = ly0 + 8 * i, gy = ty0 + ly;
     if (gy >= roi.h || gx >= roi.w) continue;
-    uint2 acc = *reinterpret_cast<const uint2*>(&hs[ly * kTW + lx]);
+    uint32_t packed = uniform == 1 ? 0xFFFFFFFFu : 0u;
+    if (!uniform) {
+      uint2 acc = *reinterpret_cast<const uint2*>(&hs[ly * kTW + lx]);
 #pragma unroll
-    for (int r = 1; r < 5; r++) {
-      const uint2 v = *reinterpret_cast<const uint2*>(&hs[(ly + r) * kTW + lx]);
-      acc.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.x) + __builtin_bit_cast(us2, v.x));
-      acc.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.y) + __builtin_bit_cast(us2, v.y));
+      for (int r = 1; r < 5; r++) {
+        const uint2 v = *reinterpret_cast<const uint2*>(&hs[(ly + r) * kTW + lx]);
+        acc.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.x) + __builtin_bit_cast(us2, v.x));
+        acc.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, acc.y) + __builtin_bit_cast(us2, v.y));
+      }
+      const uint32_t m0 = (__umul24(acc.x & 0xffffu, 5243u) + 12u * 5243u) >> 17, m1 = (__umul24(acc.x >> 16, 5243u) + 12u * 5243u) >> 17;
+      const uint32_t m2 = (__umul24(acc.y & 0xffffu, 5243u) + 12u * 5243u) >> 17, m3 = (__umul24(acc.y >> 16, 5243u) + 12u * 5243u) >> 17;
+      packed = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
     }
-    const uint32_t m0 = (__umul24(acc.x & 0xffffu, 5243u) + 12u * 5243u) >> 17, m1 = (__umul24(acc.x >> 16, 5243u) + 12u * 5243u) >> 17;
-    const uint32_t m2 = (__umul24(acc.y & 0xffffu, 5243u) + 12u * 5243u) >> 17, m3 = (__umul24(acc.y >> 16, 5243u) + 12u * 5243u) >> 17;
-    const uint32_t packed = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
     uint8_t* dst = dst0 + (long)(8 * i) * W;
     if (BLEND && (yuyv_flip & 8)) { /* composite only (BSX_STEP_NO_MASK): the full-resolution mask stays in registers */ }
     else if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
@@ -544,7 +550,9 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
     if constexpr (BLEND) {
       uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * orow * obpp);
       uint32_t o3[3];
-      blend_quad(o.a[i], o.b[i], packed, o3);
+      if (uniform == 1) { o3[0] = o.a[i][0]; o3[1] = o.a[i][1]; o3[2] = o.a[i][2]; }
+      else if (uniform == 2) { o3[0] = o.b[i][0]; o3[1] = o.b[i][1]; o3[2] = o.b[i][2]; }
+      else blend_quad(o.a[i], o.b[i], packed, o3);
       if (fh) reverse4px(o3);
       if (yuyv) {                                                  // deepseg.cc:87-106 on the four composited pixels: 8 bytes instead of 12
         __builtin_nontemporal_store(yuyv_pair(o3[0] & 255u, (o3[0] >> 8) & 255u, (o3[0] >> 16) & 255u, o3[0] >> 24, o3[1] & 255u, (o3[1] >> 8) & 255u), op);
@@ -670,6 +678,25 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   xcd_frame_tile((unsigned)(ntx * nty), (unsigned)n_frames, &f_, &t_);
   const int n = (int)f_, tid = threadIdx.x, tby = (int)t_ / ntx, tbx = (int)t_ - tby * ntx;
   const int tx0 = tbx * kTW, ty0 = tby * kTH;
+  // UNIFORM TILES (round 4).  In the steady state of the temporal filter the model-resolution mask is exactly 0x00 or 0xFF wherever the person's outline is not
+  //     (lib/libbackscrub.cc:330-355: three equal decisions in a row), and a tile whose whole source block (taps of the halo included) holds one of those two values
+  //     gets that value in every pixel: cv::resize of a constant is the constant ((b0 * 32640 >> 16) + (b1 * 32640 >> 16) + 2) >> 2 == 255 for every b0 + b1 == 2048,
+  //     tests/test_oracle_image.py), and so is the box blur ((25 v + 12) / 25).  Such a tile skips steps 1-5, and its composite is a copy: of the background where the
+  //     mask is 255 — the frame is not even read — and of the frame where it is 0.  tile_class_k (below) classified every tile of the launch a moment ago: one
+  //     scalar load here, no vote, no barrier, nothing serialised in front of the operand loads (the first version voted inside this kernel: block load → ballot →
+  //     barrier → operand loads cost the general path 6 %, profiles/r04e).  Bit-identical by construction; BSX_NO_UNIFORM_TILES=1 (read when the context is
+  //     created) keeps every tile on the general path (A/B timing; the parity tests run both).
+  int uniform = 0;
+  if (tab.tile_class) {                                     // the aligned word that holds the byte: a SCALAR load (uniform address), not a vector load + readfirstlane
+    const uintptr_t ca = (uintptr_t)tab.tile_class + (size_t)n * (size_t)(ntx * nty) + (size_t)(tby * ntx + tbx);
+    uniform = (int)((*reinterpret_cast<const uint32_t*>(ca & ~(uintptr_t)3) >> (8 * (unsigned)(ca & 3))) & 255u);
+  }
+  if (uniform) {                                           // wave-uniform: nothing of the general path below is even requested
+    TileBlendOperands uo;
+    tile_load_blend_operands<BLEND>(uo, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, uniform);
+    tile_vsum5_store<BLEND>(hq_hs, mask, outp, uo, n, W, H, roi, tx0, ty0, tid, yuyv, uniform);
+    return;
+  }
   // extents of the source block: xofs / yofs are monotonic, so the extreme destination rows / columns give them
   const int gy_lo = max(ty0 - 2, 0), gy_hi = min(ty0 + kTH + 1, roi.h - 1);
   const int gx_lo = max(tx0 - 2, 0), gx_hi = min(tx0 + kTW + 1, roi.w - 1);
@@ -972,6 +999,8 @@ hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, i
 }
 
 // Every tile's source block must fit the LDS staging area of mask_tile_k (host tables, checked once per ResizeTab).
+int mask_tile_width() { return kTW; }
+int mask_tile_height() { return kTH; }
 bool mask_tile_fits(const int* xofs, const int* yofs, int sw, int sh, int dw, int dh) {
   auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
   int max_rows = 0, max_cols = 0;
@@ -999,8 +1028,60 @@ hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, R
   const bool shared_lines = ((roi.x * 3) & 127) != 0 || ((W * 3) & 127) != 0;
   const int nf = (xcd_on && shared_lines) ? n : 0;
   dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
+  if (hipError_t e = launch_tile_class(ofinal, outW, outH, in_roi, tab, roi, n, s)) return e;
   if (mask_tile_usable(tab)) mask_tile_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0, ntx, nty, nf);
   else mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0, ntx, nty, nf);
+  return hipGetLastError();
+}
+
+// Tile classes of one frame per workgroup: is a tile's source block — the extents mask_tile_k computes — all 0xFF (→ 1), all 0x00 (→ 2) or neither (→ 0)?
+// Two steps through LDS so that every model-resolution byte is looked at once per tile COLUMN, with wide loads: (1) item (row r, tile column tbx) scans the bytes
+// [cmin(tbx), cmax(tbx)] of row r as unaligned dwords, AND / OR accumulated → two flags; (2) tile (tby, tbx) ANDs the flags of its rows [smin(tby), smax(tby)].
+// (The first version gave every tile a wave that walked its block row by row, byte by byte: 17 us at 256 lite/VGA streams, 151 us at 1024 DeepLab streams —
+// more than the shortcut saved; profiles/r04g.)
+constexpr int kClsMaxItems = 8192, kClsMaxTx = 16;
+__global__ __launch_bounds__(kThreads) void tile_class_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab, Rect4 roi, int ntx, int nty) {
+  __shared__ uint8_t f255[kClsMaxItems], f0[kClsMaxItems];
+  __shared__ int cmn[kClsMaxTx], cmx[kClsMaxTx];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const uint8_t* const fr = ofinal + (long)n * outW * outH + (long)q.y * outW + q.x;
+  if (tid < ntx) {
+    const int tx0 = tid * kTW, gx_lo = max(tx0 - 2, 0), gx_hi = min(tx0 + kTW + 1, roi.w - 1);
+    cmn[tid] = tab.xofs[gx_lo]; cmx[tid] = min(tab.xofs[gx_hi] + 1, tab.sw - 1);
+  }
+  __syncthreads();
+  struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
+  const int items = tab.sh * ntx;
+  for (int i = tid; i < items; i += kThreads) {
+    const int r = i / ntx, tbx = i - r * ntx, c0 = cmn[tbx], len = cmx[tbx] - c0 + 1;
+    const uint8_t* p = fr + (unsigned)(r * outW + c0);
+    uint32_t a = 0xFFFFFFFFu, o = 0u;
+    if (len >= 4) {
+#pragma unroll 4
+      for (int k = 0; k + 4 <= len; k += 4) { const uint32_t w = reinterpret_cast<const U4*>(p + k)->v; a &= w; o |= w; }
+      const uint32_t w = reinterpret_cast<const U4*>(p + len - 4)->v;      // the last four bytes (overlapping the loop's: AND / OR do not care)
+      a &= w; o |= w;
+    } else {
+      for (int k = 0; k < len; k++) { const uint32_t w = p[k] * 0x01010101u; a &= w; o |= w; }
+    }
+    f255[i] = a == 0xFFFFFFFFu; f0[i] = o == 0u;
+  }
+  __syncthreads();
+  for (int t = tid; t < ntx * nty; t += kThreads) {
+    const int tby = t / ntx, tbx = t - tby * ntx, ty0 = tby * kTH;
+    const int gy_lo = max(ty0 - 2, 0), gy_hi = min(ty0 + kTH + 1, roi.h - 1);
+    const int smin = min(max(tab.yofs[gy_lo], 0), tab.sh - 1), smax = min(max(tab.yofs[gy_hi] + 1, 0), tab.sh - 1);
+    int all255 = 1, all0 = 1;
+    for (int r = smin; r <= smax; r++) { all255 &= f255[r * ntx + tbx]; all0 &= f0[r * ntx + tbx]; }
+    tab.tile_class[(size_t)n * (size_t)(ntx * nty) + t] = (uint8_t)(all255 ? 1 : (all0 ? 2 : 0));
+  }
+}
+
+hipError_t launch_tile_class(const uint8_t* ofinal, int outW, int outH, const Rect4& in_roi, const ResizeTab& tab, const Rect4& roi, int n, hipStream_t s) {
+  if (!tab.tile_class || !mask_tile_usable(tab)) return hipSuccess;
+  const int ntx = (roi.w + kTW - 1) / kTW, nty = (roi.h + kTH - 1) / kTH;
+  if (ntx > kClsMaxTx || (long)tab.sh * ntx > kClsMaxItems) return hipMemsetAsync(tab.tile_class, 0, (size_t)ntx * nty * n, s);      // out of the classifier's range: all general
+  tile_class_k<<<dim3((unsigned)n), kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, roi, ntx, nty);
   return hipGetLastError();
 }
 
@@ -1029,6 +1110,7 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   const bool shared_lines = ((roi.x * 3) & 127) != 0 || ((W * 3) & 127) != 0;
   const int nf = (xcd_on && shared_lines) ? n : 0;
   dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
+  if (hipError_t e = launch_tile_class(ofinal, outW, outH, in_roi, tab, roi, n, s)) return e;
   if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   return hipGetLastError();

@@ -302,6 +302,11 @@ def roofline_of(s, pmc, model_name, launch_index=-1, n_launches=0):
     out = {"kernel": s["name"], "bound": "hbm", "achieved": round(s["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, **src, **counted, "avg_ms": round(s["avg_ms"], 4),
            "algorithmic_bytes_per_launch": int(s["bytes"])}
+    if "bytes_dense" in s:           # the data-dependent fused mask + blend (measure()): what the launch had to move for this input, next to SURVEY §8(d)'s dense figure
+        out.update({"tiles": s["tiles"], "algorithmic_bytes_per_launch_dense_10Bpx": int(s["bytes_dense"]),
+                    "achieved_dense_10Bpx": round(s["bytes_dense"] / (s["avg_ms"] * 1e-3) / 1e9, 1),
+                    "note": "algorithmic bytes for THIS input: 11 B per ROI pixel on general tiles, 7 B on tiles whose mask is uniformly 0 / 255 (one operand is not read, "
+                            "the mask phases are skipped), 6 B outside the ROI; the *_dense_10Bpx fields price every pixel at SURVEY 8(d)'s 10 B and are NOT a bandwidth"})
     if s["flops"] > 0:
         a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
         out.update({"algorithmic_flops_per_launch": int(s["flops"]), "flops_pipe": pipe, "flops_frac_of_pipe": round(a / peak_tf, 4),
@@ -440,6 +445,24 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
             res["full_batch"] = {"streams": B, "distinct_scenes": distinct, "groups_compared_with_group_0": max(n_groups - 1, 0), "groups_identical": groups_ok,
                                  "all_identical": groups_ok == max(n_groups - 1, 0)}
         stats = mg.profile(d_frames, d_bg, d_out, iters=profile_iters)
+        # The fused mask + blend launch is data dependent since round 4: a tile whose whole model-resolution source block is 0xFF / 0x00 (the temporal filter's steady
+        # state away from the person's outline) skips the mask phases and reads only the operand its composite is a copy of.  Its algorithmic bytes are therefore
+        # stated for THIS input: per ROI pixel 11 B on a general tile (background 3 + frame 3 read, composite 3 + mask 1 written), 7 B on a uniform one; 6 B outside
+        # the ROI (background copied).  `bytes_dense` keeps SURVEY §8(d)'s 10 B/px figure.
+        try:
+            ts = mg.mask_tile_stats(B)
+            i_ = mg.info
+            roi_px, in_roi_px = i_["roi"][2] * i_["roi"][3], i_["in_roi"][2] * i_["in_roi"][3]
+            f_uni = (ts["uniform_255"] + ts["uniform_0"]) / max(ts["tiles"], 1)
+            aware = B * (in_roi_px + 6.0 * (W * H - roi_px) + roi_px * (11.0 * (1.0 - f_uni) + 7.0 * f_uni))
+            res["mask_tiles"] = {k: ts[k] for k in ("tiles", "uniform_255", "uniform_0", "general", "tile")}
+            for s in stats:
+                if s["name"] == "mask_blend":
+                    s["bytes_dense"] = s["bytes"]
+                    s["bytes"] = aware
+                    s["tiles"] = {k: ts[k] for k in ("tiles", "uniform_255", "uniform_0", "general", "tile")}
+        except Exception:  # noqa: BLE001 — accounting only
+            pass
         for s in stats:
             s["GBps"] = s["bytes"] / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
         extra = [s for s in stats if s["name"].endswith("(standalone)")]   # measured for its roofline line, not part of the step
@@ -488,6 +511,8 @@ def summarize(res, pmc):
                                    "counted_GBps": round(traffic / ms / 1e9, 1) if traffic else None, "frac_hbm_counted_traffic": round(f_cnt, 4) if f_cnt else None,
                                    "peak_hbm_GBps": HBM_PEAK_GBS, "traffic": traffic, "avg_ms": round(res["net_ms"], 4),
                                    "note": "frac_of_issuing_pipes = sum over launches of useful flops / the peak of the pipe that launch issues on (pipe_of), over the measured time"}
+    if res.get("mask_tiles") is not None:      # how the fused mask + blend launch classified its tiles for this input (uniform tiles skip the mask phases and one operand)
+        out["mask_tiles"] = res["mask_tiles"]
     if res.get("composite_only") is not None:
         out["composite_only"] = res["composite_only"]
     if res.get("full_batch") is not None:

@@ -230,6 +230,11 @@ BSX_API long bsx_debug_tensor(bsx_ctx* ctx, int tensor_idx, float* h_out, long c
 /* The same for stream `stream_idx` of the last batch (full-batch parity tests: every stream against its twin). */
 BSX_API long bsx_debug_tensor_of(bsx_ctx* ctx, int tensor_idx, int stream_idx, float* h_out, long cap);
 
+/* How the fused mask + blend launch would classify its tiles for the CURRENT temporal state of the first n streams (host-side, exact same extents as the kernel):
+ * out4 = {tiles, tiles whose whole source block is 0xFF, ... 0x00, tiles on the general path}.  A uniform tile skips the up-scale / blur phases and reads only the
+ * operand its composite is a copy of (kernels_img.hip: mask_tile_k); bench.py uses the counts to state the bytes the launch really has to move. */
+BSX_API int bsx_debug_mask_tile_stats(bsx_ctx* ctx, int n, long* out4);
+
 /* Per-frame-program timeline: runs the network once for n streams and returns, for workgroup 0, the wall-clock
  * (100 MHz constant-rate counter) ticks at the start of every micro-op plus one final tick; ticks[i+1]-ticks[i] = op i.
  * Returns the number of micro-ops (cap must be >= that + 1), 0 if the program path is off, negative on error. */

@@ -66,6 +66,8 @@ def main():
     rc["profile"] = min(0, L.bsx_profile_batch(ctx, p(frames), p(bg), 0, p(out), n, 1, stats, info.n_steps + 8, None)); caller_device_after("bsx_profile_batch")
     for stage in range(4):
         rc["stage_%d" % stage] = L.bsx_debug_run_stage(ctx, stage, p(frames), n, None); caller_device_after("bsx_debug_run_stage")
+    st4 = (C.c_long * 4)()
+    rc["tile_stats"] = L.bsx_debug_mask_tile_stats(ctx, n, st4); caller_device_after("bsx_debug_mask_tile_stats")
     ticks = (C.c_ulonglong * 300)()
     rc["timeline"] = min(0, L.bsx_debug_program_timeline(ctx, n, ticks, 300, None)); caller_device_after("bsx_debug_program_timeline")
     # background source + live worker (their own streams / threads)

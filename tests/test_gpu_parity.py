@@ -726,6 +726,63 @@ def test_step_with_flips_folded_into_the_blend(bs, oracle, key, res):
     mg_b.close()
 
 
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", HD), ("deeplab", VGA), ("lite", (322, 242))])
+def test_uniform_tile_shortcut_is_bit_identical(bs, oracle, key, res, monkeypatch):
+    """mask_tile_k skips the resize / blur phases (and the read of the operand the blend does not need) for tiles whose whole source block is 0x00 or 0xFF — the state the
+    temporal filter settles into away from the person's outline.  Same bytes as the general path (BSX_NO_UNIFORM_TILES=1) and as the oracle: on hand-made states with
+    uniform regions, near-uniform values (1, 254: NOT uniform), thin features and pure noise; and through five frames of the whole step (transient 0xE0 / 0xFC states,
+    then the steady state), BGR / flipped / YUYV / composite-only outputs."""
+    import torch
+    from backscrub_amd import synth
+    W, H = res
+    n = 4
+    path = model_path(key)
+    mg_u = bs.MaskGen(path, W, H, n_streams=n)
+    monkeypatch.setenv("BSX_NO_UNIFORM_TILES", "1")
+    mg_g = bs.MaskGen(path, W, H, n_streams=n)
+    monkeypatch.delenv("BSX_NO_UNIFORM_TILES")
+    i = mg_u.info
+    oh, ow = i["out_h"], i["out_w"]
+    rng = np.random.default_rng(5)
+    states = np.zeros((n, oh, ow), np.uint8)
+    states[0, : oh // 2] = 255                                     # two uniform halves, one horizontal edge
+    states[1] = 255; states[1, oh // 3: oh // 3 + 2, ow // 4: ow // 4 + 3] = 254; states[1, -1, -1] = 0      # almost uniform: one tile must NOT take the shortcut
+    states[2] = rng.integers(0, 2, (oh, ow)).astype(np.uint8) * 255; states[2, :, : ow // 2] = 0             # half noise, half uniform 0
+    states[3] = rng.integers(0, 256, (oh, ow), dtype=np.uint8)                                             # no uniform tile at all
+    states[3, oh // 2:, ow // 2:] = 1
+    for mg in (mg_u, mg_g):
+        mg.ofinal().copy_(_dev(states))
+        mg.run_stage(3, n=n)                                       # mask_tile_k<false>
+    mu, mgm = mg_u.masks().cpu().numpy(), mg_g.masks().cpu().numpy()
+    assert np.array_equal(mu, mgm)
+    rx, ry, rw, rh = i["roi"]
+    qx, qy, qw, qh = i["in_roi"]
+    for k in range(n):
+        want = np.full((H, W), 255, np.uint8)
+        want[ry:ry + rh, rx:rx + rw] = oracle.blur5(oracle.resize_linear(np.ascontiguousarray(states[k, qy:qy + qh, qx:qx + qw]), rw, rh))
+        assert np.array_equal(mu[k], want), "state %d" % k
+    # the whole step, frame by frame: identical temporal state on both contexts → identical bytes out of the fused kernel's two paths
+    mg_u.reset(); mg_g.reset()
+    bg = _dev(synth.random_u8((n, H, W, 3), 81))
+    out_u = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    out_g = torch.empty_like(out_u)
+    y_u = torch.empty((n, H, W, 2), dtype=torch.uint8, device="cuda")
+    y_g = torch.empty_like(y_u)
+    frames = _dev(np.stack([synth.frame(W, H, s, 0) for s in range(n)]))
+    for t in range(5):
+        kw = [dict(), dict(flip_h=True), dict(yuyv=True), dict(flip_v=True, no_mask=True), dict()][t]
+        if W % 2 and kw.get("yuyv"):
+            kw = dict()
+        a, b = (y_u, y_g) if kw.get("yuyv") else (out_u, out_g)
+        mg_u.step_ex(frames, bg, a, **kw)
+        mg_g.step_ex(frames, bg, b, **kw)
+        assert torch.equal(a, b), "frame %d %s: %d bytes differ" % (t, kw, int((a != b).sum()))
+        assert torch.equal(mg_u.masks(), mg_g.masks()) and torch.equal(mg_u.ofinal(), mg_g.ofinal())
+    of = mg_u.ofinal().cpu().numpy()
+    assert set(np.unique(of).tolist()) <= {0, 255}                  # steady state reached: the last frames DID run the shortcut
+    mg_u.close(); mg_g.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA)])
 def test_step_in_place_like_the_reference(bs, oracle, key, res):
