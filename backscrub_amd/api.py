@@ -56,6 +56,7 @@ SYMBOLS = [
     ("bsx_step_batch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_step_batch_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     ("bsx_step_batch_ex", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_uint]),
+    ("bsx_step_batch_pipelined", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_uint]),
     ("bsx_resize_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_bgr_to_yuyv", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("bsx_yuyv_to_bgr", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -194,6 +195,24 @@ class MaskGen:
         _check(lib().bsx_step_batch_ex(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr() if bg is not None else None), stride,
                                        C.c_void_p(out.data_ptr()), n, _stream_ptr(), flags), self.h, "bsx_step_batch_ex")
         return out
+
+    def step_pipelined(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False, no_mask=False):
+        """throughput mode (bsx_step_batch_pipelined): enqueue the mask pipeline of THIS batch and, concurrently, the composite of the batch handed over by
+        the previous call (the reference's CalcMask worker next to its blend loop, app/deepseg.cc:159-285).  `out` — and masks() — hold THIS batch's results
+        once the NEXT call (or flush_pipelined()) has completed; frames / bg / out must stay untouched until then.  Bit-identical to step_ex per batch."""
+        n = self._n(frames)
+        want = (self.height, self.width, 2 if yuyv else 3)
+        if out.dim() != 4 or tuple(out.shape[1:]) != want or out.shape[0] < n or not out.is_contiguous() or not out.is_cuda or out.dtype != _torch().uint8:
+            raise BsxError("out must be a contiguous cuda uint8 tensor [>=%d,%d,%d,%d]" % ((n,) + want))
+        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0)
+        _check(lib().bsx_step_batch_pipelined(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride, C.c_void_p(out.data_ptr()), n, _stream_ptr(), flags),
+               self.h, "bsx_step_batch_pipelined")
+        return out
+
+    def flush_pipelined(self):
+        """composite the batch still pending in the two-deep pipeline (on the current stream)"""
+        _check(lib().bsx_step_batch_pipelined(self.h, None, None, 0, None, 0, _stream_ptr(), 0), self.h, "bsx_step_batch_pipelined(flush)")
 
     def profile(self, frames, bg, out, iters=5):
         """per-launch hipEvent timings of the whole per-batch sequence → list of dicts"""

@@ -138,6 +138,14 @@ struct bsx_ctx {
   int lanes = 1;
   hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  // Two-deep pipeline (bsx_step_batch_pipelined): the composite of the batch handed over by the PREVIOUS call (mask up-scale + blur + alpha blend: HBM-bound) runs
+  // on comp_stream while the caller's stream runs the mask pipeline of THIS call's batch (prep → network: latency-bound) — the batch-level form of the reference's
+  // CalcMask worker thread next to its capture / blend loop (app/deepseg.cc:159-285, 634-661).  The one shared object is the model-resolution temporal state:
+  // the kernel that advances it (tail / argmax tail / decode) waits for ev_pcomp first (state_write_fence).
+  struct PendingComposite { bool active = false; const uint8_t* frames = nullptr; const uint8_t* bg = nullptr; size_t bg_stride = 0; uint8_t* out = nullptr; int n = 0; unsigned flags = 0; } pend;
+  hipStream_t comp_stream = nullptr;
+  hipEvent_t ev_pfork = nullptr, ev_pcomp = nullptr;
+  hipEvent_t wait_before_state = nullptr;   // consumed by the next launch that writes d_ofinal
   bool act16 = false;                  // BSX_ACT16=1: 16-bit activation STORAGE for the segmented Meet / MLKit networks (g1) — opt-in, IoU-gated; needs the specialised middle kernel
 
   // stream-0 view of a graph tensor (network input/output have dedicated buffers; intermediates are batch-major in
@@ -347,6 +355,15 @@ hipError_t launch_program(bsx_ctx* c, int n, hipStream_t s, unsigned long long* 
   return launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out, c->d_weights, n, s,
                               timeline);
 }
+// bsx_step_batch_pipelined: the launch that advances the temporal state (d_ofinal) waits until the composite of the previous batch — which reads that state on
+// comp_stream — has finished.  Called right in front of every such launch; a no-op outside a pipelined call.
+int state_write_fence(bsx_ctx* c, hipStream_t s) {
+  if (!c->wait_before_state) return BSX_OK;
+  hipEvent_t ev = c->wait_before_state;
+  c->wait_before_state = nullptr;
+  BSX_HIP(c, hipStreamWaitEvent(s, ev, 0));
+  return BSX_OK;
+}
 bool infer_decodes(const bsx_ctx* c) { return (c->use_program && c->plan.seg.on && !c->keep_logits) || argmax_tail(c); }
 int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0) {
   if (c->use_program && c->plan.seg.on) {
@@ -357,6 +374,7 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
     BSX_HIP(c, launch_program(c, n, s));
     BSX_HIP(c, launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
     if (sp.tail.pre_gate_off >= 0) BSX_HIP(c, launch_seg_gate(sp.tail.gate, c->d_arena, pf, c->d_weights, sp.tail.pre_gate_off, n, s));
+    if (!logits) { const int frc = state_write_fence(c, s); if (frc) return frc; }       // the decoding tail reads and writes d_ofinal
     BSX_HIP(c, launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal + (size_t)slot * c->outW * c->outH, c->d_weights, logits, n, s, c->act16));
     return BSX_OK;
   }
@@ -370,6 +388,7 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
     BSX_HIP(c, launch_step(c->plan.steps[i], c->plan, c->d_arena, c->d_net_in, c->d_net_out, c->d_weights, n, c->n_streams, s, c->d_weights16, c->f16_terms, c->in_u8 ? c->d_net_in_u8 : nullptr, c->norm_scale, c->norm_offset));
   if (fused_tail) {
     const Step& last = c->plan.steps.back();
+    { const int frc = state_write_fence(c, s); if (frc) return frc; }
     BSX_HIP(c, launch_resize_argmax_iir(last, c->d_arena + (size_t)c->plan.tensor_off[last.in0] * (size_t)c->n_streams,
                                         c->d_ofinal + (size_t)slot * c->outW * c->outH, n, s, c->tail_generic));
   }
@@ -377,6 +396,7 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
 }
 // `slot` = first state slot (stream index) of the batch: frame i uses ofinal / mask slot `slot + i`
 int run_decode(bsx_ctx* c, int n, hipStream_t s, int slot = 0) {
+  { const int frc = state_write_fence(c, s); if (frc) return frc; }
   BSX_HIP(c, launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal + (size_t)slot * c->outW * c->outH, c->outW * c->outH, c->outC, n, s));
   return BSX_OK;
 }
@@ -509,6 +529,9 @@ void bsx_delete(bsx_ctx* c) {
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   for (int k = 1; k < 4; k++) { if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->comp_stream) { (void)hipStreamSynchronize(c->comp_stream); (void)hipStreamDestroy(c->comp_stream); }
+  if (c->ev_pfork) (void)hipEventDestroy(c->ev_pfork);
+  if (c->ev_pcomp) (void)hipEventDestroy(c->ev_pcomp);
   delete c;
 }
 
@@ -531,6 +554,7 @@ int bsx_reset(bsx_ctx* c, void* stream) {
   DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   const size_t N = (size_t)c->n_streams;
+  c->pend.active = false;                                          // a composite still pending in the two-deep pipeline is dropped with the state it belongs to
   BSX_HIP(c, hipMemsetAsync(c->d_ofinal, 0, N * c->outW * c->outH, s));
   BSX_HIP(c, hipMemsetAsync(c->d_masks, 255, N * c->width * c->height, s));
   return BSX_OK;
@@ -540,6 +564,7 @@ uint8_t* bsx_masks_device(bsx_ctx* c) { return c ? c->d_masks : nullptr; }
 
 int bsx_process_batch(bsx_ctx* c, const uint8_t* d_frames, int n, uint8_t* d_masks, void* stream) {
   if (!c || !d_frames || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  if (c->pend.active) { c->last_error = "error: a pipelined composite is pending (flush with bsx_step_batch_pipelined(ctx, NULL, ...) first)\n"; return BSX_EINVAL; }
   DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   int rc;
@@ -551,6 +576,7 @@ int bsx_process_batch(bsx_ctx* c, const uint8_t* d_frames, int n, uint8_t* d_mas
 int bsx_process_host(bsx_ctx* c, int stream_idx, const uint8_t* h_bgr, size_t bgr_stride, uint8_t* h_mask, size_t mask_stride) {
   if (!c || !h_bgr || !h_mask || stream_idx < 0 || stream_idx >= c->n_streams) return BSX_EINVAL;
   if (bgr_stride < (size_t)c->width * 3 || mask_stride < (size_t)c->width) return BSX_ESIZE;
+  if (c->pend.active) { c->last_error = "error: a pipelined composite is pending (flush with bsx_step_batch_pipelined(ctx, NULL, ...) first)\n"; return BSX_EINVAL; }
   DeviceGuard guard(c->device);
   hipStream_t s = c->own_stream;
   const size_t fbytes = (size_t)c->width * c->height * 3;
@@ -616,6 +642,7 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
   const int bgblur = (int)((flags >> 8) & 255u);                // BSX_STEP_BGBLUR(ksize): background = blur of the stream's own frame, d_bg unused
   if (!c || !d_frames || (!d_bg && !bgblur) || !d_out || n <= 0 || n > c->n_streams || (flags & ~(15u | 0xFF00u))) return BSX_EINVAL;
   if (bgblur && (bgblur > 31 || !(bgblur & 1) || d_frames == d_out)) return BSX_EINVAL;
+  if (c->pend.active) { c->last_error = "error: a pipelined composite is pending (flush with bsx_step_batch_pipelined(ctx, NULL, ...) first)\n"; return BSX_EINVAL; }
   const int yuyv = (int)(flags & BSX_STEP_YUYV);
   const unsigned flip = flags & (BSX_STEP_FLIP_H | BSX_STEP_FLIP_V);
   if (yuyv && (c->width & 1)) return BSX_EINVAL;                // 4:2:2 pairs pixels horizontally
@@ -713,6 +740,80 @@ int bsx_step_batch_yuyv(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg
 }
 int bsx_step_batch_ex(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, unsigned flags) {
   return step_impl(c, d_frames, d_bg, bg_frame_stride, d_out, n, stream, flags);
+}
+
+// ---- two-deep pipeline: mask pipeline of batch k  ||  composite of batch k - 1 ------------------------------------------------------------------
+// The reference overlaps exactly these two halves of its main loop: CalcMask::run() segments on a worker thread (app/deepseg.cc:182-216) while the capture loop
+// blends and writes (:634-681).  Here both halves are GPU work of one context: the composite (HBM-bound: mask tiles + alpha blend) of the batch handed over
+// by the previous call goes to comp_stream, the mask pipeline (latency-bound network kernels) of this call's batch to the caller's stream, and the only shared
+// object — the model-resolution temporal state — is protected by ev_pcomp in front of the launch that advances it.  Unlike the reference's loop, which blends a
+// frame with whatever mask is newest, every frame is composited with ITS OWN mask: results are bit-identical to bsx_step_batch_ex, one call later.
+namespace {
+int pipelined_objects(bsx_ctx* c) {
+  if (c->comp_stream) return BSX_OK;
+  // the composite fills the gaps of the network kernels, not the other way round: lowest priority the device offers (BSX_PIPE_PRIO=0: default priority)
+  int lo = 0, hi = 0;
+  const char* pe = getenv("BSX_PIPE_PRIO");
+  if (!(pe && atoi(pe) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+    BSX_HIP(c, hipStreamCreateWithPriority(&c->comp_stream, hipStreamNonBlocking, lo));
+  } else {
+    BSX_HIP(c, hipStreamCreateWithFlags(&c->comp_stream, hipStreamNonBlocking));
+  }
+  BSX_HIP(c, hipEventCreateWithFlags(&c->ev_pfork, hipEventDisableTiming));
+  BSX_HIP(c, hipEventCreateWithFlags(&c->ev_pcomp, hipEventDisableTiming));
+  return BSX_OK;
+}
+int composite_pending(bsx_ctx* c, hipStream_t s) {
+  const bsx_ctx::PendingComposite& p = c->pend;
+  BSX_HIP(c, launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, p.bg, p.bg_stride, p.frames, p.out, p.n, s,
+                               (int)p.flags));
+  return BSX_OK;
+}
+}  // namespace
+
+int bsx_step_batch_pipelined(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, unsigned flags) {
+  if (!c) return BSX_EINVAL;
+  DeviceGuard guard(c->device);
+  hipStream_t s = pick(c, stream);
+  if (!d_frames) {                                                  // flush: the composite of the last batch, on the caller's stream
+    if (!c->pend.active) return BSX_OK;
+    const int rc = composite_pending(c, s);
+    c->pend.active = false;
+    return rc;
+  }
+  if (!d_bg || !d_out || n <= 0 || n > c->n_streams || (flags & ~15u)) return BSX_EINVAL;
+  const int yuyv = (int)(flags & BSX_STEP_YUYV);
+  if (yuyv && (c->width & 1)) return BSX_EINVAL;
+  // the pipeline exists for the fused tile kernel only; out(k) is written while frames(k + 1) are read, so the buffers of a call must not overlap at all
+  const size_t in_bytes = (size_t)n * c->width * c->height * 3, out_bytes = (size_t)n * c->width * c->height * (yuyv ? 2 : 3);
+  const bool overlap = d_out < d_frames + in_bytes && d_frames < d_out + out_bytes;
+  const bool fuse = !c->onprep && !c->oninfer && !c->onmask && !c->no_mask_blend_fusion && !overlap && (!yuyv || ((uintptr_t)d_out & 3) == 0) &&
+                    mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, yuyv ? d_frames : d_out);
+  if (!fuse) { c->last_error = "error: bsx_step_batch_pipelined needs the fused mask + blend geometry, no stage callbacks and non-overlapping buffers\n"; return BSX_EINVAL; }
+  int rc = pipelined_objects(c);
+  if (rc) return rc;
+  bool forked = false;
+  if (c->pend.active) {
+    BSX_HIP(c, hipEventRecord(c->ev_pfork, s));                    // behind everything the caller's stream holds, i.e. behind the network of the pending batch
+    BSX_HIP(c, hipStreamWaitEvent(c->comp_stream, c->ev_pfork, 0));
+    rc = composite_pending(c, c->comp_stream);
+    // forked work is ALWAYS joined, also after an error: the caller's stream must not be left with work in flight on a stream it cannot see
+    if (hipEventRecord(c->ev_pcomp, c->comp_stream) != hipSuccess) rc = rc ? rc : BSX_EDEVICE;
+    c->pend.active = false;
+    forked = true;
+    if (!rc) c->wait_before_state = c->ev_pcomp;
+  }
+  if (!rc) rc = run_prep(c, d_frames, n, s);
+  const bool fused_decode = infer_decodes(c);
+  if (!rc) rc = run_infer(c, n, s, !fused_decode, 0);
+  if (!rc && !fused_decode) rc = run_decode(c, n, s);
+  if (forked && (c->wait_before_state || rc)) {                     // fence not consumed (error on the way): join here
+    c->wait_before_state = nullptr;
+    if (hipStreamWaitEvent(s, c->ev_pcomp, 0) != hipSuccess) rc = rc ? rc : BSX_EDEVICE;
+  }
+  if (rc) return rc;
+  c->pend.active = true; c->pend.frames = d_frames; c->pend.bg = d_bg; c->pend.bg_stride = bg_frame_stride; c->pend.out = d_out; c->pend.n = n; c->pend.flags = flags;
+  return BSX_OK;
 }
 
 int bsx_resize_bgr(bsx_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream) {

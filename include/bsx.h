@@ -18,6 +18,7 @@
  *   bsx_step_batch         one main-loop iteration        app/deepseg.cc:634-661
  *   bsx_step_batch_yuyv    … with convert_rgb_to_yuyv fused app/deepseg.cc:634-681
  *   bsx_step_batch_ex      … with cv::flip (and YUYV) fused  app/deepseg.cc:667-681
+ *   bsx_step_batch_pipelined  … with the CalcMask worker's overlap of segmentation and blending  app/deepseg.cc:159-285, 634-661
  *                          (set_input_frame → mask → alpha_blend), batched
  *   bsx_resize_bgr         grab_background() cv::resize   app/background.cc:178-194
  *   bsx_bgr_to_yuyv        convert_rgb_to_yuyv()          app/deepseg.cc:87-106
@@ -167,6 +168,20 @@ BSX_API int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uin
 #define BSX_STEP_BGBLUR(ksize) (((unsigned)(ksize) & 255u) << 8)
 BSX_API int bsx_step_batch_ex(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                       uint8_t* d_out, int n, void* stream, unsigned flags);
+
+/* Throughput mode — the same main-loop iteration as a TWO-DEEP PIPELINE.  The reference runs its two halves concurrently: CalcMask::run() segments on a
+ * worker thread (app/deepseg.cc:182-216) while the capture loop blends and writes (:634-681).  Call k enqueues the mask pipeline (prep → network → decode /
+ * temporal filter) of batch k on `stream` and, concurrently on a context-owned low-priority stream, the mask up-scale + blur + composite of batch k - 1 — the
+ * HBM-bound half fills the gaps of the latency-bound half instead of waiting behind it.  Every frame is still composited with ITS OWN mask (the reference's
+ * loop blends with whatever mask is newest): outputs, persistent masks and temporal state are bit-identical to bsx_step_batch_ex(flags), one call later.
+ *   - d_out(k) and bsx_masks_device() hold batch k's results once call k + 1 (or the flush) has completed on `stream`;
+ *   - d_frames(k), d_bg(k) and d_out(k) must stay valid and unmodified until then; d_out must not overlap d_frames;
+ *   - d_frames == NULL flushes: the pending composite runs on `stream` (all other arguments ignored); bsx_reset drops it;
+ *   - flags: BSX_STEP_YUYV | BSX_STEP_FLIP_H | BSX_STEP_FLIP_V | BSX_STEP_NO_MASK (no BSX_STEP_BGBLUR); the geometry must be the fused tile kernel's
+ *     (width, roi.x, roi.w multiples of 4, 4-byte aligned buffers) and no stage callback may be set — otherwise BSX_EINVAL, as does every other entry point
+ *     that advances the temporal state while a composite is pending. */
+BSX_API int bsx_step_batch_pipelined(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
+                             uint8_t* d_out, int n, void* stream, unsigned flags);
 
 /* cv::resize(src, dst, Size(dw,dh)) with INTER_LINEAR on packed BGR u8 (device pointers, n images). */
 BSX_API int bsx_resize_bgr(bsx_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n, void* stream);

@@ -52,6 +52,10 @@ def main():
     rc["step_flip"] = L.bsx_step_batch_ex(ctx, p(frames), p(bg), 0, p(out), n, None, 2 | 4); caller_device_after("bsx_step_batch_ex(flip)")
     rc["step_inplace_flip"] = L.bsx_step_batch_ex(ctx, p(frames), p(bg), 0, p(frames), n, None, 2); caller_device_after("bsx_step_batch_ex(in place)")
     rc["step_bgblur"] = L.bsx_step_batch_ex(ctx, p(frames), None, 0, p(out), n, None, 25 << 8); caller_device_after("bsx_step_batch_ex(bgblur)")
+    for i in range(3):                       # two-deep pipeline: the first call only enqueues, the next ones fork the composite onto the context's own stream
+        rc["step_pipelined_%d" % i] = L.bsx_step_batch_pipelined(ctx, p(frames), p(bg), 0, p(out), n, None, 0); caller_device_after("bsx_step_batch_pipelined")
+    rc["step_while_pending_refused"] = 0 if L.bsx_step_batch(ctx, p(frames), p(bg), 0, p(out), n, None) == -1 else -1; caller_device_after("bsx_step_batch(pending)")
+    rc["step_pipelined_flush"] = L.bsx_step_batch_pipelined(ctx, None, None, 0, None, 0, None, 0); caller_device_after("bsx_step_batch_pipelined(flush)")
     rc["composite"] = L.bsx_composite_batch(ctx, p(bg), 0, p(frames), None, p(out), n, None); caller_device_after("bsx_composite_batch")
     mask = np.zeros((H, W), np.uint8)
     for i in range(3):                       # first call captures the slot's hipGraph, the next ones replay it

@@ -79,6 +79,8 @@ hipError_t hipMemset(void* d, int v, size_t n) { use("hipMemset", d); memset(d, 
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) { use("hipMemsetAsync", d); use("hipMemsetAsync", st); memset(d, v, n); logf("hipMemsetAsync", "affine"); return hipSuccess; }
 
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)handle(); own(*s); logf("hipStreamCreateWithFlags", "affine"); return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)handle(); own(*s); logf("hipStreamCreateWithPriority", "affine"); return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; logf("hipDeviceGetStreamPriorityRange", "affine"); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { use("hipStreamDestroy", s); disown(s); free(s); logf("hipStreamDestroy", "affine"); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { use("hipStreamSynchronize", s); logf("hipStreamSynchronize", "affine"); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { use("hipStreamWaitEvent", s); use("hipStreamWaitEvent", e); logf("hipStreamWaitEvent", "affine"); return hipSuccess; }

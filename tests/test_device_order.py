@@ -52,7 +52,7 @@ def test_context_on_device_1_never_touches_device_0(stub, tmp_path, key, res):
     affine = [l for l in lines if l[0] == "affine"]
     assert len(affine) > 100                                             # the run really went through the interposer
     apis = {l[1] for l in affine}
-    for must in ("hipMalloc", "hipLaunchKernel", "hipFuncSetAttribute", "hipStreamCreateWithFlags", "hipGraphLaunch", "hipStreamBeginCapture", "hipEventRecord", "hipMemcpy2DAsync"):
+    for must in ("hipMalloc", "hipLaunchKernel", "hipFuncSetAttribute", "hipStreamCreateWithFlags", "hipStreamCreateWithPriority", "hipStreamWaitEvent", "hipGraphLaunch", "hipStreamBeginCapture", "hipEventRecord", "hipMemcpy2DAsync"):
         assert must in apis, "%s never reached: the driver does not cover that path" % must
     if key != "deeplab":
         assert d["specialised"] and "hipModuleLoadData" in apis and "hipModuleLaunchKernel" in apis       # the hipRTC kernel, loaded and launched on device 1

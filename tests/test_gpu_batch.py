@@ -167,3 +167,53 @@ def test_context_on_a_second_device(bs, oracle):
         oc.close()
         assert _iou(masks[i], want) >= 0.999
     mg.close()
+
+
+@pytest.mark.parametrize("key,res,n,flags", [("lite", VGA, 64, {}), ("lite", VGA, 24, {"yuyv": True, "flip_h": True}), ("mlkit", HD, 16, {}), ("mlkit", HD, 8, {"no_mask": True, "flip_v": True}),
+                                             ("full", HD, 16, {}), ("deeplab", VGA, 8, {})])
+def test_pipelined_step_is_bit_identical_one_call_later(bs, key, res, n, flags):
+    """bsx_step_batch_pipelined (mask pipeline of batch k on the caller's stream || composite of batch k - 1 on the context's stream): composites, persistent
+    masks and temporal state are those of bsx_step_batch_ex, delivered one call later — over T steps of moving scenes, with two alternating frame buffers
+    (the pending batch's frames must stay untouched), on a side stream of the caller as well as on the default stream."""
+    from backscrub_amd import synth
+    W, H = res
+    T = 5
+    path = model_path(key)
+    bg = torch.from_numpy(synth.background(W, H)).cuda()
+    seq = [torch.from_numpy(np.stack([synth.frame(W, H, s % 7, t) for s in range(n)])).cuda() for t in range(T)]
+    oc = 2 if flags.get("yuyv") else 3
+    ref = bs.MaskGen(path, W, H, n_streams=n)
+    want, want_masks = [], []
+    for t in range(T):
+        o = torch.empty((n, H, W, oc), dtype=torch.uint8, device="cuda")
+        ref.step_ex(seq[t], bg, o, **flags)
+        want.append(o)
+        want_masks.append(ref.masks()[:n].clone())
+    want_state = ref.ofinal().clone()
+    ref.close()
+    for use_side_stream in (False, True):
+        mg = bs.MaskGen(path, W, H, n_streams=n)
+        outs = [torch.zeros((n, H, W, oc), dtype=torch.uint8, device="cuda") for _ in range(T)]
+        stream = torch.cuda.Stream() if use_side_stream else torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for t in range(T):
+                mg.step_pipelined(seq[t], bg, outs[t], **flags)
+                if t >= 1:                                   # batch t - 1 is complete in stream order once call t has been enqueued
+                    assert torch.equal(outs[t - 1], want[t - 1]), "composite of batch %d (side stream: %s)" % (t - 1, use_side_stream)
+                    if not flags.get("no_mask"):
+                        assert torch.equal(mg.masks()[:n], want_masks[t - 1]), "masks of batch %d" % (t - 1)
+            # the synchronous entry points refuse to advance the state under a pending composite
+            with pytest.raises(bs.BsxError):
+                mg.step(seq[0], bg, torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda"))
+            mg.flush_pipelined()
+            assert torch.equal(outs[T - 1], want[T - 1])
+            if not flags.get("no_mask"):
+                assert torch.equal(mg.masks()[:n], want_masks[T - 1])
+            assert torch.equal(mg.ofinal(), want_state)
+            mg.flush_pipelined()                             # nothing pending: a no-op
+            # and the context is an ordinary one again
+            o = torch.empty((n, H, W, oc), dtype=torch.uint8, device="cuda")
+            mg.step_ex(seq[0], bg, o, **flags)
+        torch.cuda.synchronize()
+        mg.close()
