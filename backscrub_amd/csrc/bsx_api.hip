@@ -146,6 +146,8 @@ struct bsx_ctx {
   hipStream_t comp_stream = nullptr;
   hipEvent_t ev_pfork = nullptr, ev_pcomp = nullptr;
   hipEvent_t wait_before_state = nullptr;   // consumed by the next launch that writes d_ofinal
+  int pipe_wgs = 0;                         // BSX_PIPE_WGS (read at bsx_new, experiment): workgroups per CU the pipelined composite may hold (occupancy cap by an LDS pad; 0 = no cap,
+                                            // the default: every cap measured slower — the tile kernel needs its waves, profiles/r04l)
   bool act16 = false;                  // BSX_ACT16=1: 16-bit activation STORAGE for the segmented Meet / MLKit networks (g1) — opt-in, IoU-gated; needs the specialised middle kernel
 
   // stream-0 view of a graph tensor (network input/output have dedicated buffers; intermediates are batch-major in
@@ -266,6 +268,7 @@ int init_device_state(bsx_ctx* c) {
   } else {
     BSX_HIP(c, nn_prepare());                 // per-launch path: the fused kernels' dynamic-LDS limits on this device
   }
+  if (const char* l = getenv("BSX_PIPE_WGS")) c->pipe_wgs = std::min(8, std::max(0, atoi(l)));
   if (const char* l = getenv("BSX_LANES")) c->lanes = std::min(4, std::max(1, atoi(l)));
   if (c->lanes > 1) {
     BSX_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -426,6 +429,22 @@ int process_impl(bsx_ctx* c, const uint8_t* d_frames, int n, int slot, hipStream
 
 }  // namespace
 
+namespace {
+// workgroup barriers one launch of the specialised middle kernel executes per frame: one in front of every micro-op, the ones inside squeeze-excite ops (pool | FC | FC)
+// and between the channel chunks of staged depthwise ops — counted in the generated source itself (gen_mid.cpp), so the line cannot drift from the kernel
+std::string mid_barrier_line(const Plan& p, bool act16) {
+  std::string why;
+  const std::string src = generate_mid_source(p, &why, act16);
+  if (src.empty()) return "specialised middle kernel: none (" + why + ")\n";
+  const size_t k0 = src.find("extern \"C\" __global__");
+  auto count = [&](const char* pat) { size_t n = 0; for (size_t q = src.find(pat, k0); q != std::string::npos; q = src.find(pat, q + 1)) n++; return n; };
+  const size_t ob = count("op_barrier();"), sy = count("__syncthreads();");
+  char line[256];
+  snprintf(line, sizeof line, "specialised middle kernel: %zu micro-ops, %zu workgroup barriers per launch (%zu between ops + %zu inside ops)\n", p.program.size(), ob + sy, ob, sy);
+  return line;
+}
+}  // namespace
+
 extern "C" {
 
 const char* bsx_version(void) { return "bsx 0.1 (HIP gfx950, f32 NHWC)"; }
@@ -505,6 +524,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     c->plan_text += line;
     if (c->use_program) c->plan_text += "program execution: " + c->mid_note + "\n";
     if (c->use_program && c->plan.seg.on) c->plan_text += c->plan.seg_text;
+    if (c->use_program && c->mid.fn) c->plan_text += mid_barrier_line(c->plan, c->act16);
     for (size_t i = 0; i < c->plan.program_labels.size(); i++) { c->plan_text += "P" + std::to_string(i) + " " + c->plan.program_labels[i] + "\n"; }
   }
   return c.release();
@@ -763,10 +783,13 @@ int pipelined_objects(bsx_ctx* c) {
   BSX_HIP(c, hipEventCreateWithFlags(&c->ev_pcomp, hipEventDisableTiming));
   return BSX_OK;
 }
-int composite_pending(bsx_ctx* c, hipStream_t s) {
+int composite_pending(bsx_ctx* c, hipStream_t s, bool concurrent) {
   const bsx_ctx::PendingComposite& p = c->pend;
+  // next to the network kernels the composite holds at most pipe_wgs workgroups per CU (an unused LDS pad: static 16.7 KB + pad <= 64 KB, i.e. >= 2 per CU)
+  int pad = 0;
+  if (concurrent && c->pipe_wgs > 0) pad = std::max(0, std::min(47 * 1024, (160 * 1024 / c->pipe_wgs - 17 * 1024) & ~255));
   BSX_HIP(c, launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, p.bg, p.bg_stride, p.frames, p.out, p.n, s,
-                               (int)p.flags));
+                               (int)p.flags, pad));
   return BSX_OK;
 }
 }  // namespace
@@ -777,7 +800,7 @@ int bsx_step_batch_pipelined(bsx_ctx* c, const uint8_t* d_frames, const uint8_t*
   hipStream_t s = pick(c, stream);
   if (!d_frames) {                                                  // flush: the composite of the last batch, on the caller's stream
     if (!c->pend.active) return BSX_OK;
-    const int rc = composite_pending(c, s);
+    const int rc = composite_pending(c, s, false);
     c->pend.active = false;
     return rc;
   }
@@ -796,7 +819,7 @@ int bsx_step_batch_pipelined(bsx_ctx* c, const uint8_t* d_frames, const uint8_t*
   if (c->pend.active) {
     BSX_HIP(c, hipEventRecord(c->ev_pfork, s));                    // behind everything the caller's stream holds, i.e. behind the network of the pending batch
     BSX_HIP(c, hipStreamWaitEvent(c->comp_stream, c->ev_pfork, 0));
-    rc = composite_pending(c, c->comp_stream);
+    rc = composite_pending(c, c->comp_stream, true);
     // forked work is ALWAYS joined, also after an error: the caller's stream must not be left with work in flight on a stream it cannot see
     if (hipEventRecord(c->ev_pcomp, c->comp_stream) != hipSuccess) rc = rc ? rc : BSX_EDEVICE;
     c->pend.active = false;
@@ -1083,6 +1106,8 @@ int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
              p.program_lds_floats, p.program_lds_tensors, p.program_global_tensors, p.program_blocks.size(), p.program_check.c_str());
     out += head;
     for (size_t i = 0; i < p.program_labels.size(); i++) out += "P" + std::to_string(i) + " " + p.program_labels[i] + "\n";
+    if (p.seg.on) out += p.seg_text;
+    if (!p.program.empty()) out += mid_barrier_line(p, false);
   }
   } catch (const std::exception& e) { out = std::string("exception while reading the model: ") + e.what(); rc = BSX_EMODEL; }
   catch (...) { out = "unknown exception while reading the model"; rc = BSX_EMODEL; }

@@ -102,7 +102,7 @@ hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, R
 // pixels outside the ROI — mask 255 forever — get the background copied)
 bool mask_blend_fusable(int W, int H, Rect4 roi, const uint8_t* bg, size_t bg_stride, const uint8_t* frames, const uint8_t* out);
 hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
-                             const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s, int yuyv = 0);
+                             const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s, int yuyv = 0, int lds_pad = 0);
 // alpha blend.  deepseg.cc:108-134
 hipError_t launch_blend(const uint8_t* bg, size_t bg_stride, const uint8_t* frames, const uint8_t* masks, uint8_t* out, size_t npix,
                         int n, hipStream_t s);

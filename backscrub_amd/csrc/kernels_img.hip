@@ -1091,7 +1091,10 @@ bool mask_blend_fusable(int W, int H, Rect4 roi, const uint8_t* bg, size_t bg_st
 }
 
 hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
-                             const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s, int yuyv) {
+                             const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s, int yuyv, int lds_pad) {
+  // lds_pad (bytes of dynamic LDS nobody uses): an OCCUPANCY CAP for the two-deep pipeline (bsx_step_batch_pipelined) — left alone this HBM-bound launch takes every wave
+  // slot of every CU and the latency-bound network kernels of the other stream run on what is left (seg_head 2.65x slower, profiles/r04k); with the pad only
+  // 160 KB / (static + pad) workgroups fit a CU
   // outside the ROI the persistent mask is 255 forever (libbackscrub.cc:248-249), i.e. the composite there IS the background
   // ((a*255 + b*0)/255 == a): those strips are copied, the ROI is composited by the mask tiles
   // `yuyv`: bit 0 = YUYV output, bits 1-2 = horizontal / vertical flip of the composite, bit 3 = do not store the full-resolution mask (bsx.h: BSX_STEP_*)
@@ -1100,7 +1103,7 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   else if ((yuyv & 1) && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
     outside_roi_yuyv_k<<<dim3(blocks_for((long)(W / 2) * H), n), kThreads, 0, s>>>(bg, (long)bg_stride, reinterpret_cast<uint32_t*>(out), W, H, roi);
   else if (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H)
-    outside_roi_copy_k<<<dim3(blocks_for((long)(H - roi.h) * (W * 3 / 4) + (long)roi.h * ((W - roi.w) * 3 / 4)), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H,
+    outside_roi_copy_k<<<dim3(blocks_for((long)(H - roi.h) * (W * 3 / 4) + (long)roi.h * ((W - roi.w) * 3 / 4)), n), kThreads, (size_t)lds_pad, s>>>(bg, (long)bg_stride, out, W, H,
                                                                                                                                  roi);
   const int ntx = (roi.w + kTW - 1) / kTW, nty = (roi.h + kTH - 1) / kTH;
   if ((unsigned long long)ntx * nty * (unsigned long long)n >= (1ull << 31)) return hipErrorInvalidValue;
@@ -1111,7 +1114,7 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   const int nf = (xcd_on && shared_lines) ? n : 0;
   dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
   if (hipError_t e = launch_tile_class(ofinal, outW, outH, in_roi, tab, roi, n, s)) return e;
-  if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
+  if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   return hipGetLastError();
 }
