@@ -1102,12 +1102,14 @@ int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
     snprintf(head, sizeof head, "ops=%d nodes=%d steps=%d macs=%.0f arena_floats=%zu\n", g.n_file_ops, (int)g.nodes.size(), (int)p.steps.size(),
              p.macs_per_frame, p.arena_floats_per_stream);
     out = head + p.describe();
-    snprintf(head, sizeof head, "program micro-ops=%zu lds_floats=%d lds_tensors=%d hbm_tensors=%d lds_blocks=%zu lds_check=%s\n", p.program.size(),
-             p.program_lds_floats, p.program_lds_tensors, p.program_global_tensors, p.program_blocks.size(), p.program_check.c_str());
+    snprintf(head, sizeof head, "program micro-ops=%zu lds_floats=%d lds_tensors=%d hbm_tensors=%d arena_bytes_per_frame=%ld placement_policy=%u lds_blocks=%zu lds_check=%s\n", p.program.size(),
+             p.program_lds_floats, p.program_lds_tensors, p.program_global_tensors, p.program_arena_bytes, p.program_policy, p.program_blocks.size(), p.program_check.c_str());
     out += head;
     for (size_t i = 0; i < p.program_labels.size(); i++) out += "P" + std::to_string(i) + " " + p.program_labels[i] + "\n";
     if (p.seg.on) out += p.seg_text;
     if (!p.program.empty()) out += mid_barrier_line(p, false);
+    if (getenv("BSX_PLAN_BLOCKS"))           // debugging: the LDS reservations of the program (float offset, length, first / last step, owner)
+      for (const auto& b : p.program_blocks) { snprintf(head, sizeof head, "block off=%d len=%d steps=[%d,%d] %s\n", b.off, b.len, b.from, b.until, b.what.c_str()); out += head; }
   }
   } catch (const std::exception& e) { out = std::string("exception while reading the model: ") + e.what(); rc = BSX_EMODEL; }
   catch (...) { out = "unknown exception while reading the model"; rc = BSX_EMODEL; }

@@ -47,6 +47,44 @@ bool plain(const Loc& l) { return l.space == kLocNone || l.space == kLocLds || l
 
 }  // namespace
 
+
+// depthwise ops the strip body covers, and those among them that run chunk by chunk through an LDS workspace the planner reserved (input in the arena)
+static bool dw_geom_ok(const MicroOp& d) { return d.strip && d.dh == 1 && d.dw == 1 && d.kh == d.kw && (d.kh == 3 || d.kh == 5) && d.sh == d.sw && (d.sh == 1 || d.sh == 2) && d.Cin % 4 == 0; }
+bool mid_dw_chunked(const MicroOp& d) {
+  return d.kind == (int)StepKind::DwConv && dw_geom_ok(d) && d.in0.space == kLocGlobal && d.band_rows > 0 && d.Cin % d.band_rows == 0 && d.res.space == kLocNone &&
+         !getenv("BSX_RTC_NO_DW_STAGE");
+}
+// 1x1 → depthwise without the tensor in between (see generate_mid_source): is op j a 1x1 whose arena output is only read by the chunked depthwise j + 1, with every
+// LDS region the 1x1 still needs disjoint from what the depthwise places?  Shared with the planner's cost model (plan.cpp: program_arena_bytes) — an elided tensor
+// costs no arena bytes.
+bool mid_pw_feeds_dw(const Plan& plan, int j) {
+  const std::vector<MicroOp>& P = plan.program;
+  const int n = (int)P.size();
+  auto disjoint = [](long a0, long a1, long b0, long b1) { return a1 <= b0 || b1 <= a0; };
+  if (getenv("BSX_RTC_NO_PWDW") || j < 0 || j + 1 >= n) return false;
+  const MicroOp& a = P[j];
+  const MicroOp& d = P[j + 1];
+  if (!(a.kind == (int)StepKind::PwConv && a.mfma && !a.gemv && a.stage_floats > 0 && a.out.space == kLocGlobal && a.res.space == kLocNone) || !mid_dw_chunked(d)) return false;
+  if (d.in0.off != a.out.off || d.Cin != a.Cout || d.band_rows % 16 || a.cout_pad < a.Cout) return false;
+  for (long e : plan.program_ext_offs) if (e == a.out.off) return false;           // a segment kernel reads this tensor after the program: it must exist in the arena
+  for (int q = j + 2; q < n; q++) {                               // the expanded tensor has no other reader (until its arena slot is written again: slots are re-used)
+    for (const Loc* l : {&P[q].in0, &P[q].in1, &P[q].in2, &P[q].res, &P[q].scale}) if (l->space == kLocGlobal && l->off == a.out.off) return false;
+    for (int c = 0; c < P[q].n_cat; c++) if (P[q].cat[c].space == kLocGlobal && P[q].cat[c].off == a.out.off) return false;
+    if (P[q].out.space == kLocGlobal && P[q].out.off == a.out.off) break;
+  }
+  const long pin = (long)a.H * a.W, ws0 = d.ws_off, ws1 = ws0 + (long)d.H * d.W * (d.band_rows + 4);
+  std::vector<std::pair<long, long>> keep, placed;
+  keep.push_back({a.w_lds, a.w_lds + a.stage_floats});                                   // the 1x1's staged weights
+  if (a.in0.space == kLocLds) keep.push_back({a.in0.off, a.in0.off + pin * a.in0.stride});
+  if (a.in2.space == kLocLds) keep.push_back({a.in2.off, a.in2.off + pin * a.in2.stride});
+  if (a.scale.space == kLocLds) keep.push_back({a.scale.off, a.scale.off + a.Cin});
+  placed.push_back({ws0, ws1});
+  if (d.stage_floats > 0) placed.push_back({d.w_lds, d.w_lds + d.stage_floats});
+  if (d.out.space == kLocLds) placed.push_back({d.out.off, d.out.off + (long)d.OH * d.OW * d.out.stride});
+  for (auto& kq : keep) for (auto& pq : placed) if (!disjoint(kq.first, kq.second, pq.first, pq.second)) return false;
+  return true;
+}
+
 std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) {
   // address space of an ACTIVATION tensor operand: arena tensors are packed halves in the 16-bit storage mode (mid_prelude.hip: SP_GLB16)
   auto asp = [&](const Loc& l) { const int sp = sp_of(l); return (sp == 2 && act16) ? 3 : sp; };
@@ -80,34 +118,9 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
   // of being written to the arena by op j and loaded back by op j + 1.  Op j then emits nothing but its barrier.  The regions the 1x1 needs while op j + 1 runs
   // (its input if that is in LDS, its staged weights) were planned to live until op j only: the fusion is taken only where they are disjoint from everything op j + 1
   // places (workspace, depthwise weights, depthwise output), and the DMA of op j + 2's weights — normally issued at the top of op j + 1 — waits for the last chunk.
-  auto dw_geom_ok = [&](const MicroOp& d) { return d.strip && d.dh == 1 && d.dw == 1 && d.kh == d.kw && (d.kh == 3 || d.kh == 5) && d.sh == d.sw && (d.sh == 1 || d.sh == 2) && d.Cin % 4 == 0; };
-  auto dw_chunked = [&](const MicroOp& d) { return d.kind == (int)StepKind::DwConv && dw_geom_ok(d) && d.in0.space == kLocGlobal && d.band_rows > 0 && d.Cin % d.band_rows == 0 &&
-                                                    d.res.space == kLocNone && !getenv("BSX_RTC_NO_DW_STAGE"); };
-  auto disjoint = [](long a0, long a1, long b0, long b1) { return a1 <= b0 || b1 <= a0; };
-  auto pw_feeds_dw = [&](int j) {
-    if (fine || getenv("BSX_RTC_NO_PWDW") || j < 0 || j + 1 >= n) return false;
-    const MicroOp& a = P[j];
-    const MicroOp& d = P[j + 1];
-    if (!(a.kind == (int)StepKind::PwConv && a.mfma && !a.gemv && a.stage_floats > 0 && a.out.space == kLocGlobal && a.res.space == kLocNone) || !dw_chunked(d)) return false;
-    if (d.in0.off != a.out.off || d.Cin != a.Cout || d.band_rows % 16 || a.cout_pad < a.Cout) return false;
-    for (long e : plan.program_ext_offs) if (e == a.out.off) return false;           // a segment kernel reads this tensor after the program: it must exist in the arena
-    for (int q = j + 2; q < n; q++) {                               // the expanded tensor has no other reader (until its arena slot is written again: slots are re-used)
-      for (const Loc* l : {&P[q].in0, &P[q].in1, &P[q].in2, &P[q].res, &P[q].scale}) if (l->space == kLocGlobal && l->off == a.out.off) return false;
-      for (int c = 0; c < P[q].n_cat; c++) if (P[q].cat[c].space == kLocGlobal && P[q].cat[c].off == a.out.off) return false;
-      if (P[q].out.space == kLocGlobal && P[q].out.off == a.out.off) break;
-    }
-    const long pin = (long)a.H * a.W, ws0 = d.ws_off, ws1 = ws0 + (long)d.H * d.W * (d.band_rows + 4);
-    std::vector<std::pair<long, long>> keep, placed;
-    keep.push_back({a.w_lds, a.w_lds + a.stage_floats});                                   // the 1x1's staged weights
-    if (a.in0.space == kLocLds) keep.push_back({a.in0.off, a.in0.off + pin * a.in0.stride});
-    if (a.in2.space == kLocLds) keep.push_back({a.in2.off, a.in2.off + pin * a.in2.stride});
-    if (a.scale.space == kLocLds) keep.push_back({a.scale.off, a.scale.off + a.Cin});
-    placed.push_back({ws0, ws1});
-    if (d.stage_floats > 0) placed.push_back({d.w_lds, d.w_lds + d.stage_floats});
-    if (d.out.space == kLocLds) placed.push_back({d.out.off, d.out.off + (long)d.OH * d.OW * d.out.stride});
-    for (auto& kq : keep) for (auto& pq : placed) if (!disjoint(kq.first, kq.second, pq.first, pq.second)) return false;
-    return true;
-  };
+  auto dw_chunked = [&](const MicroOp& d) { return mid_dw_chunked(d); };
+  (void)dw_chunked;
+  auto pw_feeds_dw = [&](int j) { return !fine && mid_pw_feeds_dw(plan, j); };
   for (int i = 0; i < n; i++) {
     const MicroOp& m = P[i];
     for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.scale, &m.out}) if (!plain(*l)) return fail("operand in the network input / output buffer");

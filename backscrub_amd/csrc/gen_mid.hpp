@@ -12,4 +12,8 @@ namespace bsx {
 // (the segment kernels either side are launched with h16 = true to match).
 std::string generate_mid_source(const Plan& plan, std::string* why, bool act16 = false);
 
+// which ops of plan.program the generator fuses / chunks (shared with the planner's cost model, plan.cpp)
+bool mid_dw_chunked(const MicroOp& d);
+bool mid_pw_feeds_dw(const Plan& plan, int j);
+
 }  // namespace bsx

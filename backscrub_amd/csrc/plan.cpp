@@ -1,5 +1,6 @@
 // plan.cpp — graph → fused step list + weight packing + activation arena layout.
 #include "plan.hpp"
+#include "gen_mid.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -108,7 +109,8 @@ std::string Plan::describe() const {
 // program's boundary (produced or consumed by a segment kernel) — they live at their arena offset, never in LDS.
 // `part_n[t]` > 0 marks tensor t of a pooling step as "already pooled per tile": [part_n][C] partial sums at tensor_off[t].
 static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<Step>& steps, const std::vector<int>& ext, const std::map<int, int>& part_n,
-                                const std::map<int, int>& part_hw, const int scratch) {
+                                const std::map<int, int>& part_hw, const int scratch, const unsigned policy = 0) {
+  const bool long_to_hbm = (policy & 1u) != 0, elide_expand = (policy & 2u) != 0, small_top = (policy & 4u) != 0;
   plan->program.clear();
   plan->program_scratch_floats = scratch;
   plan->program_labels.clear();
@@ -130,6 +132,22 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
   }
   last[g.output] = NS + 1;
   for (int t : ext) if (t >= 0) last[t] = NS + 1;          // consumed after the program ends
+  // Policy `elide_expand` (see place()): steps whose output is never materialised because the depthwise of the next step computes it chunk by chunk.  Decided up front,
+  // from sizes alone, because the fused form runs the 1x1 INSIDE the next step: its staged weights and its LDS operands must stay alive one step longer.
+  auto padded = [&](int t) { const TensorInfo& ti = g.tensors[t]; const int C = ti.dims[3], P = ti.dims[1] * ti.dims[2]; return (P * (C + (((C / 4) % 2 == 0) ? 4 : 8)) + 3) / 4 * 4; };
+  std::vector<char> elide(NS, 0);
+  if (elide_expand)
+    for (int s = 0; s + 1 < NS; s++) {
+      const Step& a = steps[s];
+      const Step& d = steps[s + 1];
+      if (!(a.kind == StepKind::PwConv && a.residual < 0 && a.out >= 0 && last[a.out] == s + 1 && d.kind == StepKind::DwConv && d.in0 == a.out && d.residual < 0 && d.dh == 1 && d.dw == 1)) continue;
+      if (a.out == g.output || std::find(ext.begin(), ext.end(), a.out) != ext.end() || g.tensors[a.out].dims[3] % 32) continue;
+      const int P = g.tensors[a.out].dims[1] * g.tensors[a.out].dims[2], need = padded(a.out), need_o = padded(d.out), ws = (P * 36 + 3) / 4 * 4, room = kLdsTotalFloats - scratch - 2 * kLdsMaxStageFloats;
+      if (need + need_o > room && need_o + ws <= room) {
+        elide[s] = 1;
+        for (int t : {a.in0, a.in2, a.in_scale}) if (t >= 0) last[t] = std::max(last[t], s + 1);
+      }
+    }
   const bool no_lds = getenv("BSX_PROGRAM_NO_LDS") != nullptr;  // debugging: every tensor in the HBM arena
   std::vector<Loc> loc(NT);
   struct Blk { int off, len, until; };
@@ -137,9 +155,9 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
   // ---- reserved zone for the long-lived tensors (see place()): stacked from the top of the block, at most a quarter of it
   std::map<int, int> reserved_at;
   int reserved = 0;
+  std::vector<int> firstdef(NT, -1);
+  for (int s = 0; s < NS; s++) if (steps[s].out >= 0 && firstdef[steps[s].out] < 0) firstdef[steps[s].out] = s;
   if (!getenv("BSX_PLAN_NO_TOPDOWN")) {
-    std::vector<int> firstdef(NT, -1);
-    for (int s = 0; s < NS; s++) if (steps[s].out >= 0 && firstdef[steps[s].out] < 0) firstdef[steps[s].out] = s;
     for (int t = 0; t < NT; t++) {
       if (firstdef[t] < 0 || last[t] - firstdef[t] <= 8 || t == g.input || t == g.output) continue;
       if (std::find(ext.begin(), ext.end(), t) != ext.end()) continue;
@@ -167,6 +185,17 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
     // a tensor that would leave no room for the weight slots of the ops around it turns those ops into their slow unstaged
     // forms (MLKit's 16x16x128 tensors are 132 KB): such a tensor goes to HBM instead
     if (need > kLdsTotalFloats - scratch - 2 * kLdsMaxStageFloats && !getenv("BSX_PLAN_NO_SLOT_RESERVE")) lds_ok = false;
+    // Policy `long_to_hbm`: a LONG-LIVED tensor (a skip connection: alive across more than 8 steps) that is too large for the reserved zone would sit in the
+    // general area for its whole life and push every large short-lived tensor of the levels below it into the arena (segm_full: the 72 KB level-3 skip keeps the
+    // 76 KB depthwise outputs of all three level-4 blocks in HBM).  It is written once and read twice: it goes to the arena instead, and the short-lived tensors,
+    // which are written and read back-to-back by latency-bound ops, get the LDS.  build_frame_program keeps whichever policy moves fewer arena bytes.
+    if (long_to_hbm && lds_ok && reserved_at.find(t) == reserved_at.end() && firstdef[t] >= 0 && last[t] - firstdef[t] > 8 && P > 1 &&
+        std::find(ext.begin(), ext.end(), t) == ext.end()) lds_ok = false;
+    // Policy `elide_expand`: the output of a 1x1 that only the depthwise of the NEXT step reads need not exist at all — with its "home" in the arena the generator
+    // computes it chunk by chunk straight into the depthwise's LDS workspace (gen_mid.cpp: mid_pw_feeds_dw).  Taken where the expanded tensor and the depthwise's
+    // output cannot both be LDS-resident: first-fit would give the LDS to the expanded tensor (it comes first) and send the depthwise output — read twice more, by
+    // the squeeze-excite pool and the project 1x1 — to the arena (segm_full's three 9x16x128 blocks).
+    if (lds_ok && s >= 0 && s < NS && elide[s] && steps[s].out == t) lds_ok = false;
     if (lds_ok) {
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
@@ -177,7 +206,18 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       // HBM although 110 KB were free).
       auto rz = reserved_at.find(t);
       if (rz != reserved_at.end()) pos = rz->second;
-      else
+      else if (small_top && need <= kLdsTotalFloats / 6) {
+        // Policy `small_top`: small tensors (block inputs / residuals: <= 1/6 of the block) allocate from the TOP like the weight slots, so that they do not end up
+        // in the middle of the block — above whatever large tensor was alive when they were placed — and split the space the next large tensor needs
+        // (segm_full: the 20 KB block input at 57 KB kept the 76 KB depthwise output out of a block with 80 KB free)
+        pos = cap + 1;
+        int hi = cap;
+        for (int k = (int)live.size() - 1; k >= -1; k--) {
+          const int lo = k >= 0 ? live[k].off + live[k].len : scratch;
+          if (hi - lo >= need) { pos = hi - need; break; }
+          if (k >= 0) hi = std::min(hi, live[k].off);
+        }
+      } else
       for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
       if (rz != reserved_at.end() || pos + need <= cap) {
         l.space = kLocLds; l.off = pos; l.stride = stride;
@@ -274,8 +314,9 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
         for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
       }
       if (pos + need <= cap) {
-        slot[s2] = pos; live.push_back({pos, need, s2}); high = std::max(high, pos + need);
-        plan->program_blocks.push_back({pos, need, s, s2, "weights of step " + std::to_string(s2)});
+        const int until = elide[s2] ? s2 + 1 : s2;          // an elided 1x1 runs inside the depthwise of the next step
+        slot[s2] = pos; live.push_back({pos, need, until}); high = std::max(high, pos + need);
+        plan->program_blocks.push_back({pos, need, s, until, "weights of step " + std::to_string(s2)});
       }
       else stage[s2] = 0;                       // no room: the op falls back to its unstaged form
     }
@@ -449,14 +490,47 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
 // The reduction scratch at the bottom of the LDS block (frame_program.hpp: kLdsScratchFloats, 8 KB) is used by the single-pixel GEMV form and by the
 // fused decoder tail only.  A lowering that contains neither (every FC folded into a squeeze-excite op: the middle of a segmented plan) is
 // repeated with 256 bytes of scratch — segm_lite's 6x10x96 tensor missed LDS by 1.2 KB.
+// bytes of arena (HBM / L2) operands one frame's program touches: every use of a tensor that is not in LDS, read or written
+static long program_arena_bytes(const Plan& plan) {
+  long b = 0;
+  const int n = (int)plan.program.size();
+  for (int i = 0; i < n; i++) {
+    const MicroOp& m = plan.program[i];
+    const bool out_elided = mid_pw_feeds_dw(plan, i), in_elided = i > 0 && mid_pw_feeds_dw(plan, i - 1);     // the tensor between a fused 1x1 → depthwise pair never exists
+    for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.out}) {
+      if (l->space != kLocGlobal || (l == &m.out && out_elided) || (l == &m.in0 && in_elided)) continue;
+      b += 4L * l->elems;
+    }
+    for (int c = 0; c < m.n_cat; c++) if (m.cat[c].space == kLocGlobal && m.cat_parts[c] == 0) b += 4L * m.cat[c].elems;
+  }
+  return b;
+}
 static void build_frame_program(const Graph& g, Plan* plan, const std::vector<Step>& steps, const std::vector<int>& ext = {},
                                 const std::map<int, int>& part_n = {}, const std::map<int, int>& part_hw = {}) {
-  lower_frame_program(g, plan, steps, ext, part_n, part_hw, kLdsScratchFloats);
-  if (plan->program.empty() || getenv("BSX_PLAN_FULL_SCRATCH")) return;
-  for (const MicroOp& m : plan->program)
-    if ((m.kind == (int)StepKind::PwConv && m.gemv) || m.kind == kMicroTail || m.kind == (int)StepKind::Conv) return;
-  lower_frame_program(g, plan, steps, ext, part_n, part_hw, 64);
-  if (plan->program.empty()) lower_frame_program(g, plan, steps, ext, part_n, part_hw, kLdsScratchFloats);
+  auto lower = [&](unsigned policy) {
+    lower_frame_program(g, plan, steps, ext, part_n, part_hw, kLdsScratchFloats, policy);
+    if (plan->program.empty() || getenv("BSX_PLAN_FULL_SCRATCH")) return;
+    for (const MicroOp& m : plan->program)
+      if ((m.kind == (int)StepKind::PwConv && m.gemv) || m.kind == kMicroTail || m.kind == (int)StepKind::Conv) return;
+    lower_frame_program(g, plan, steps, ext, part_n, part_hw, 64, policy);
+    if (plan->program.empty()) lower_frame_program(g, plan, steps, ext, part_n, part_hw, kLdsScratchFloats, policy);
+  };
+  // The placement is greedy (program order, first fit); which tensors SHOULD lose the LDS is a policy question with three independent answers (lower_frame_program:
+  // bit 0 long-lived tensors to the arena, bit 1 expanded tensors elided, bit 2 small tensors from the top).  All eight combinations are lowered — microseconds on the
+  // host — and the one whose program touches the fewest arena bytes per frame is kept; ties keep the lowest policy number (0 = the round-3 planner).
+  // BSX_PLAN_POLICY=<0..7> forces one (A/B timing).
+  if (const char* force = getenv("BSX_PLAN_POLICY")) { plan->program_policy = (unsigned)atoi(force) & 7u; lower(plan->program_policy); plan->program_arena_bytes = program_arena_bytes(*plan); return; }
+  unsigned best = 0;
+  long best_b = -1;
+  for (unsigned pol = 0; pol < 8; pol++) {
+    lower(pol);
+    if (plan->program.empty()) continue;
+    const long b = program_arena_bytes(*plan);
+    if (best_b < 0 || b < best_b) { best_b = b; best = pol; }
+  }
+  lower(best);
+  plan->program_policy = best;
+  plan->program_arena_bytes = program_arena_bytes(*plan);
 }
 
 // Independent check of the lowering: no two LDS reservations that are alive at the same step may share a float, every block

@@ -154,6 +154,8 @@ struct Plan {
   std::string program_check;            // "ok" or the first violation found
   // spatially-parallel segment kernels around the program (segments.hpp); when seg.on, `program` is only the MIDDLE of the network
   SegPlan seg;
+  unsigned program_policy = 0;          // the placement policy build_frame_program kept (bit 0 long-lived tensors to the arena, bit 1 expanded tensors elided, bit 2 small tensors top-down)
+  long program_arena_bytes = 0;         // arena (HBM / L2) bytes one frame's program touches: every use of an operand that is not LDS-resident
   std::string seg_text;                 // one line per segment kernel (tiles, LDS) for bsx_plan_describe
   std::string describe() const;
 };
