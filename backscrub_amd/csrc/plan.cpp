@@ -142,7 +142,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       const Step& d = steps[s + 1];
       if (!(a.kind == StepKind::PwConv && a.residual < 0 && a.out >= 0 && last[a.out] == s + 1 && d.kind == StepKind::DwConv && d.in0 == a.out && d.residual < 0 && d.dh == 1 && d.dw == 1)) continue;
       if (a.out == g.output || std::find(ext.begin(), ext.end(), a.out) != ext.end() || g.tensors[a.out].dims[3] % 32) continue;
-      const int P = g.tensors[a.out].dims[1] * g.tensors[a.out].dims[2], need = padded(a.out), need_o = padded(d.out), ws = (P * 36 + 3) / 4 * 4, room = kLdsTotalFloats - scratch - 2 * kLdsMaxStageFloats;
+      const int P = g.tensors[a.out].dims[1] * g.tensors[a.out].dims[2], need = padded(a.out), need_o = padded(d.out), ws = (P * 20 + 3) / 4 * 4 /* the 16-channel chunk */, room = kLdsTotalFloats - scratch - 2 * kLdsMaxStageFloats;
       if (need + need_o > room && need_o + ws <= room) {
         elide[s] = 1;
         for (int t : {a.in0, a.in2, a.in_scale}) if (t >= 0) last[t] = std::max(last[t], s + 1);
