@@ -271,10 +271,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, ar0 = 2 * r0 - d.dw_pt, ac0 = 2 * c0 - d.dw_pl, RW = d.rw, ctiles = RW >> 4;
   const int IR = 2 * AR + 1, IC = 2 * AC + 1, ir0 = 2 * ar0 - d.stem_pt, ic0 = 2 * ac0 - d.stem_pl, rowf = IC * 3;
   float* fa = arena + (size_t)f * (size_t)per_frame;
-  float* in_t = seg_smem + kScrFloats;                              // [IR][IC * 3]; later x_t = act(pw(A)) [AR][RW][16]
-  const int r1 = max(IR * rowf, AR * RW * 16);
-  float* a_t = in_t + ((r1 + 3) & ~3);                              // [AR][RW][16]
-  float* x_t = in_t;
+  float* in_t = seg_smem + kScrFloats;                              // [IR][IC * 3]
+  float* a_t = in_t + ((IR * rowf + 3) & ~3);                       // x = act(pw(stem)) [AR][AC][16]: rows of AC pixels, not of RW = 16 ceil(AC / 16) — the MFMA tiles
+                                                                    // round the COMPUTE up to 16 pixels, the storage need not (5 workgroups per CU instead of 4 at a 4 x 13 tile)
   float* A_out = fa + d.a_off;                                      // uniform bases + 32-bit lane offsets (global_load/store saddr forms)
   float* b0_out = fa + d.b0_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
@@ -347,20 +346,40 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   const int xe = li;                                        // column of the pixel this lane owns after the quad transpose
   __syncthreads();
 
-  // 2. stem on the A region, two tiles per iteration: their MFMA chains (7 dependent instructions each) interleave
+  // 2 + 3. stem on the A region and x = act(pw(A)) on the same pixels, two tiles per iteration (their MFMA chains interleave).  With the weights as the MFMA's A
+  //    operand the stem's accumulator lane (li, g) holds channels 4 g .. 4 g + 3 of pixel li — EXACTLY the B operand the 1x1's four MFMAs want from that lane: the
+  //    activated stem output goes from the accumulator registers straight into them (round 4).  Until then it made a round trip through an LDS tile of its own
+  //    ([AR][RW][16]: 18 KB written, a barrier, 18 KB read) and the 1x1 was a second loop over the tiles; the same values enter the same instructions, so the results
+  //    are the same bits.  x lands where that tile was (a_t's region: in_t is still being read by the other waves' stem tiles); zero outside the image = SAME padding
+  //    of the depthwise.
+  float* x_f = a_t;
+  float wr[4];
+  load_wtile(wr, w, d.pw, 0, li, g);
+  const float4 bias_p = ld4(w + d.pw.b_off + cq4);
   float4 sumA = f4zero();
-  auto stem_epilogue = [&](const f4acc acc, const RowTile rt) {
+  auto stem_pw_epilogue = [&](const f4acc acc, const RowTile rt) {
     float4 v = acc_quad(acc);
     const int x2 = 16 * rt.ct + xe, gy = ar0 + rt.row, gx = ac0 + x2;
+    v = f4add(v, bias_s);
+    v = STEM_HSWISH ? hswish4(v) : clamp4(v, cl_stem);
+    // (lanes past the tile's last column hold the stem of column AC - 1, as the clamped read of the two-loop form did; their results are dropped below)
+    f4acc pa = {0.f, 0.f, 0.f, 0.f};
+    if (!(d.dbg_skip & 2)) {
+      pa = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], v.x, pa, 0, 0, 0);
+      pa = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1], v.y, pa, 0, 0, 0);
+      pa = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2], v.z, pa, 0, 0, 0);
+      pa = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], v.w, pa, 0, 0, 0);
+    }
     if (x2 < AC) {
-      v = f4add(v, bias_s);
-      v = STEM_HSWISH ? hswish4(v) : clamp4(v, cl_stem);
-      st4(a_t + (rt.row * RW + x2) * 16 + cq4, v);
       const bool row_owned = gy >= max(2 * r0, 0) && gy < min(2 * r0 + 2 * d.TR, d.H1);          // scalar
       if (row_owned && gx >= 2 * c0 && gx < min(2 * c0 + 2 * d.TC, d.W1)) {                      // each A pixel is stored by exactly one tile
         stg4<H16>(A_out, (unsigned)((gy * d.W1 + gx) * 16 + cq4), v);
         sumA = f4add(sumA, v);
       }
+      float4 xv = acc_quad(pa);
+      const bool inside = gy >= 0 && gy < d.H1 && gx >= 0 && gx < d.W1;
+      xv = inside ? clamp4(f4add(xv, bias_p), cl_pw) : f4zero();
+      st4(x_f + (rt.row * AC + x2) * 16 + cq4, xv);
     }
   };
   for (int t = wave; t < ntile && !(d.dbg_skip & 1); t += 8) {
@@ -377,36 +396,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[s7], av0[s7], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[s7], av1[s7], acc1, 0, 0, 0);
     }
-    stem_epilogue(acc0, r0t);
-    if (two) stem_epilogue(acc1, r1t);
-  }
-  float wr[4];
-  load_wtile(wr, w, d.pw, 0, li, g);
-  const float4 bias_p = ld4(w + d.pw.b_off + cq4);
-  __syncthreads();
-
-  // 3. x = act(pw(A)) on the same region; zero outside the image (SAME padding of the depthwise); two tiles per iteration
-  auto pw_epilogue = [&](const f4acc acc, const RowTile rt) {
-    float4 v = acc_quad(acc);
-    const int x2 = 16 * rt.ct + xe, gy = ar0 + rt.row, gx = ac0 + x2;
-    if (x2 < AC) {
-      const bool inside = gy >= 0 && gy < d.H1 && gx >= 0 && gx < d.W1;
-      v = inside ? clamp4(f4add(v, bias_p), cl_pw) : f4zero();
-      st4(x_t + (rt.row * RW + x2) * 16 + cq4, v);
-    }
-  };
-  for (int t = wave; t < ntile && !(d.dbg_skip & 2); t += 8) {
-    const bool two = t + 4 < ntile;
-    const RowTile r0t = row_tile(t, ctiles, d.m_ct), r1t = row_tile(two ? t + 4 : t, ctiles, d.m_ct);
-    const float4 a0 = ld4(a_t + (r0t.row * RW + min(16 * r0t.ct + li, AC - 1)) * 16 + 4 * g);
-    const float4 a1 = ld4(a_t + (r1t.row * RW + min(16 * r1t.ct + li, AC - 1)) * 16 + 4 * g);
-    f4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], a0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], a1.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1], a0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[1], a1.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2], a0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[2], a1.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], a0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[3], a1.w, acc1, 0, 0, 0);
-    pw_epilogue(acc0, r0t);
-    if (two) pw_epilogue(acc1, r1t);
+    stem_pw_epilogue(acc0, r0t);
+    if (two) stem_pw_epilogue(acc1, r1t);
   }
   const int quad = lane & 3, px = lane >> 2;                        // depthwise lanes: (pixel of the row, channel quad)
   f4v wd[9];
@@ -420,7 +411,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   for (int py = wave; py < d.TR && !(d.dbg_skip & 4); py += 4) {
     if (r0 + py >= d.H2) break;
     if (px < d.TC && c0 + px < d.W2) {
-      const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
+      const float4 v = clamp4(tof4(dw3x3<2>(x_f, AC, py, px, quad, wd) + bias_d), cl_dw);
       stg4<H16>(b0_out, (unsigned)(((r0 + py) * d.W2 + c0 + px) * 16 + 4 * quad), v);
       sumB = f4add(sumB, v);
     }

@@ -98,9 +98,8 @@ constexpr int kSegScratchFloats = 640;   // gate vector / means / hidden / parti
 constexpr int kSegGateStageFloats = 512 + 2 * (32 * 32 + 32);   // gate prologue staging (aliases the first tile region)
 inline int seg_row_width(int cols) { return (cols + 15) / 16 * 16; }
 inline int seg_head_lds_floats(const SegHead& d) {
-  const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, IR = 2 * AR + 1, IC = 2 * AC + 1, RW = seg_row_width(AC);
-  const int a = IR * IC * 3, b = AR * RW * 16, r1 = a > b ? a : b;
-  return kSegScratchFloats + ((r1 + 3) & ~3) + AR * RW * 16;
+  const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, IR = 2 * AR + 1, IC = 2 * AC + 1;
+  return kSegScratchFloats + ((IR * IC * 3 + 3) & ~3) + AR * AC * 16;      // input window + x = act(pw(stem)) (the stem output itself stays in registers: seg_head_k)
 }
 inline int seg_k2_lds_floats(const SegK2& d) { const int v = 2 * (2 * d.TR + 1) * seg_row_width(2 * d.TC + 1) * 16; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats); }
 constexpr int kSegLoTileFloats = 12 * 16 * 20;   // staged window of the low-resolution tensor a k3 / tail tile interpolates from: <= 12 rows x 16 columns x 20 floats
