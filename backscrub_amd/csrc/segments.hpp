@@ -21,6 +21,8 @@
 // Plain PODs shared by the planner (plan.cpp) and the device code (kernels_seg.hip); passed to the kernels BY VALUE
 // (kernarg → SGPRs: no descriptor fetches on the critical path).
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 
 namespace bsx {
@@ -74,6 +76,7 @@ struct SegK3 {
   long long skip_off = 0, lo2_off = 0, g_off = 0, lo_off = 0, part_lo_off = 0;
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
+  int lo_floats = 0;                                      // LDS floats of the staged low-resolution window: the largest any tile of THIS geometry needs (seg_lo_window_floats)
   int dbg_skip = 0;                                       // BSX_SEG_SKIP (timing experiments, results invalid): bit mask of phases this kernel skips
 };
 
@@ -89,11 +92,13 @@ struct SegTail {
   long long pre_gate_off = -1;                            // >= 0: the gate vector (16 floats per frame) was computed ONCE per frame by seg_gate_k and lives here in the arena
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
+  int lo_floats = 0;                                      // as SegK3::lo_floats
   int dbg_skip = 0;                                       // BSX_SEG_SKIP (timing experiments, results invalid): bit mask of phases this kernel skips
 };
 
 // LDS floats each kernel needs for the tile sizes in its descriptor (the planner picks the tiles against these; the kernels
 // carve the same regions)
+constexpr int kSegLoTileFloats = 12 * 16 * 20;   // staged window of the low-resolution tensor a k3 / tail tile interpolates from: <= 12 rows x 16 columns x 20 floats
 constexpr int kSegScratchFloats = 640;   // gate vector / means / hidden / partial-sum meeting points
 constexpr int kSegGateStageFloats = 512 + 2 * (32 * 32 + 32);   // gate prologue staging (aliases the first tile region)
 inline int seg_row_width(int cols) { return (cols + 15) / 16 * 16; }
@@ -102,9 +107,36 @@ inline int seg_head_lds_floats(const SegHead& d) {
   return kSegScratchFloats + ((IR * IC * 3 + 3) & ~3) + AR * AC * 16;      // input window + x = act(pw(stem)) (the stem output itself stays in registers: seg_head_k)
 }
 inline int seg_k2_lds_floats(const SegK2& d) { const int v = 2 * (2 * d.TR + 1) * seg_row_width(2 * d.TC + 1) * 16; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats); }
-constexpr int kSegLoTileFloats = 12 * 16 * 20;   // staged window of the low-resolution tensor a k3 / tail tile interpolates from: <= 12 rows x 16 columns x 20 floats
-inline int seg_k3_lds_floats(const SegK3& d) { return kSegScratchFloats + (d.TR + 2) * 256 + d.TR * 256 + kSegLoTileFloats; }
-inline int seg_tail_lds_floats(const SegTail& d) { const int v = (d.TR + 2) * 256; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats) + kSegLoTileFloats; }
+// The staged window of the low-resolution tensor a k3 / tail tile interpolates from ([LR][LC][20] floats) was reserved at its worst case (12 x 16 pixels = 15 KB) for
+// every geometry; a 2x up-sampling tile of 16 x 14 pixels reads 10 x 9.  The planner now walks the tiles of the actual geometry with the kernels' own index
+// arithmetic (up_axis, TFLite's clamping) and reserves the largest window + one row and one column of margin: k3 43.5 -> 33 KB (4 workgroups per CU instead
+// of 3), tail 35.5 -> 28 KB (5 instead of 4 where its registers allow).
+inline void seg_up_axis(int o, float scale, bool half_pixel, int in_size, int* lo, int* hi) {
+  const float v = half_pixel ? ((float)o + 0.5f) * scale + -0.5f : (float)o * scale;       // compiled with -ffp-contract=off: the two roundings of the device code
+  const float fl = std::floor(v);
+  *lo = std::max((int)fl, 0);
+  *hi = std::min((int)std::ceil(v), in_size - 1);
+}
+inline int seg_lo_window_floats(int H, int W, int HL, int WL, bool half_pixel, bool align, int TR, int TC, int tiles_y, int tiles_x) {
+  const float hs = (align && H > 1) ? (float)(HL - 1) / (float)(H - 1) : (float)HL / (float)H, ws = (align && W > 1) ? (float)(WL - 1) / (float)(W - 1) : (float)WL / (float)W;
+  int lr = 1, lc = 1, a, b, c, e;
+  for (int ty = 0; ty < tiles_y; ty++) {
+    const int r0 = ty * TR;
+    seg_up_axis(std::max(r0 - 1, 0), hs, half_pixel, HL, &a, &b);
+    seg_up_axis(std::min(r0 + TR, H - 1), hs, half_pixel, HL, &c, &e);
+    lr = std::max(lr, e - a + 1);
+  }
+  for (int tx = 0; tx < tiles_x; tx++) {
+    const int c0 = tx * TC;
+    seg_up_axis(std::max(c0 - 1, 0), ws, half_pixel, WL, &a, &b);
+    seg_up_axis(std::min(c0 + TC, W - 1), ws, half_pixel, WL, &c, &e);
+    lc = std::max(lc, e - a + 1);
+  }
+  const int need = (lr + 1) * (lc + 1) * 20;
+  return need < kSegLoTileFloats ? need : kSegLoTileFloats;
+}
+inline int seg_k3_lds_floats(const SegK3& d) { return kSegScratchFloats + (d.TR + 2) * 256 + d.TR * 256 + (d.lo_floats > 0 ? d.lo_floats : kSegLoTileFloats); }
+inline int seg_tail_lds_floats(const SegTail& d) { const int v = (d.TR + 2) * 256; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats) + (d.lo_floats > 0 ? d.lo_floats : kSegLoTileFloats); }
 
 struct SegPlan {
   bool on = false;
