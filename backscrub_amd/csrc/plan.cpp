@@ -668,7 +668,8 @@ static bool build_segments(Graph& g, Plan* plan) {
   // tile geometry (BSX_SEG_TILES="hTR,hTC,k2TR,k2TC,k3TR,k3TC,tTR,tTC" overrides the targets)
   // kernel limits: head TR <= 4, TC <= 15 (one depthwise row per wave, 2TC+1 <= 32 columns of 6 floats per input row lane chunk);
   // k2 TC <= 15; k3 / tail TC <= 14 (TC + 2 <= 16: one MFMA tile per halo-region row)
-  int tgt[8] = {4, 14, 4, 7, 16, 14, 16, 14};
+  int tgt[8] = {4, 14, 4, 7, 16, 14, 18, 14};       // (tail rows 16 -> 18, round 4: segm_full's 72 rows split into 4 x 18 instead of 5 x 15 — no padded rows, one halo pair fewer:
+                                                   //  tail 466 -> 414 us at 1024 HD streams, profiles/r04q; 48 and 128 rows still split into 16s)
   if (const char* e = getenv("BSX_SEG_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &tgt[0], &tgt[1], &tgt[2], &tgt[3], &tgt[4], &tgt[5], &tgt[6], &tgt[7]);
   auto split = [&](int extent, int target, int* tile, int* n) { *n = tiles_for(extent, std::max(1, target)); *tile = (extent + *n - 1) / *n; };
 

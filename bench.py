@@ -105,11 +105,15 @@ def parse():
     ap.add_argument("--second-device-check", action="store_true", help="(internal, run by `--gpus N` as a subprocess of rank 0) one context on a device other than 0, checked against device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` / `single_stream` legs (N = 1 only)")
+    ap.add_argument("--no-side-probes", action="store_true", help="skip the composite_only / pipelined probes that follow the timed region (profiling runs: their launches would mix into the per-kernel averages)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--profile-iters", type=int, default=5)
     ap.add_argument("--dump-launches", default="", help="write the per-launch hipEvent table to this file")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU plumbing test of the multi-process path (gloo): launch, rendezvous, counter all-reduce, JSON line — no GPU work")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.no_side_probes:
+        os.environ["BSX_BENCH_NO_SIDE_PROBES"] = "1"
+    return a
 
 
 def resolve_model(key):
@@ -423,7 +427,7 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
         res["out_k"] = d_out[:k].cpu().numpy()
         # the same step without STORING the full-resolution mask (BSX_STEP_NO_MASK: 6 instead of 7 HBM bytes per pixel in the last launch) — reported beside
         # `value`, never as it: the headline materialises the mask, as bs_maskgen_process does
-        if ring is None and not per_stream_bg:
+        if ring is None and not per_stream_bg and not os.environ.get("BSX_BENCH_NO_SIDE_PROBES"):
             probe = max(3, min(steps, 100))
             d_probe = torch.empty_like(d_out)
             for t in range(3):

@@ -6,7 +6,7 @@
 # Separate --pmc passes with --kernel-trace only (see the gpurun rules); FETCH_SIZE and WRITE_SIZE do not fit one pass (TCC slots).
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; NAME=$2; DESC=$3; shift 3
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-configs --profile-iters 1 --ramp-seconds 0 $@"
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-configs --no-side-probes --profile-iters 1 --ramp-seconds 0 $@"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_$NAME -o bench -- $B > $R/gpurun_out/prof_${TAG}_$NAME.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch_${TAG}_$NAME -o bench -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write_${TAG}_$NAME -o bench -- $B > /dev/null 2>&1

@@ -5,9 +5,9 @@
 # Summaries are then written by tools/rocpd_summary.py (here, so the box needs no second trip).
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-configs --profile-iters 2 --ramp-seconds 0"
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-configs --no-side-probes --profile-iters 2 --ramp-seconds 0"
 # kernel durations: the bench's own command line (clock ramp, 20 + 200 steps), so that the averages are the warmed-up kernels bench.py times live
-BS="python $R/bench.py --no-cpu-baseline --no-extra-configs --profile-iters 2 --ramp-seconds 1.0"
+BS="python $R/bench.py --no-cpu-baseline --no-extra-configs --no-side-probes --profile-iters 2 --ramp-seconds 1.0"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o bench -- $BS > $R/gpurun_out/prof_$TAG.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch_$TAG -o bench -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write_$TAG -o bench -- $B > /dev/null 2>&1
