@@ -6,6 +6,7 @@
 // Graphs with micro-ops the templates do not cover return an empty string: the interpreter (kernels_frame.hip) runs them.
 #include "gen_mid.hpp"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -51,7 +52,7 @@ bool plain(const Loc& l) { return l.space == kLocNone || l.space == kLocLds || l
 // depthwise ops the strip body covers, and those among them that run chunk by chunk through an LDS workspace the planner reserved (input in the arena)
 static bool dw_geom_ok(const MicroOp& d) { return d.strip && d.dh == 1 && d.dw == 1 && d.kh == d.kw && (d.kh == 3 || d.kh == 5) && d.sh == d.sw && (d.sh == 1 || d.sh == 2) && d.Cin % 4 == 0; }
 bool mid_dw_chunked(const MicroOp& d) {
-  return d.kind == (int)StepKind::DwConv && dw_geom_ok(d) && d.in0.space == kLocGlobal && d.band_rows > 0 && d.Cin % d.band_rows == 0 && d.res.space == kLocNone &&
+  return d.kind == (int)StepKind::DwConv && dw_geom_ok(d) && d.in0.space == kLocGlobal && d.band_rows > 0 && (d.Cin % d.band_rows) % 8 == 0 && d.res.space == kLocNone &&
          !getenv("BSX_RTC_NO_DW_STAGE");
 }
 // 1x1 → depthwise without the tensor in between (see generate_mid_source): is op j a 1x1 whose arena output is only read by the chunked depthwise j + 1, with every
@@ -175,13 +176,14 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
       if (!staged && (m.w_off > 0x7fffffffll || m.b_off > 0x7fffffffll)) return fail("dw: weight offset");
       // one traits struct per channel chunk: the whole layer (CK = C), or — input in the arena and an LDS workspace planned for it (plan.cpp) — chunks of
       // band_rows channels staged through the workspace by load_chunk
-      const bool chunked = m.in0.space == kLocGlobal && m.band_rows > 0 && m.Cin % m.band_rows == 0 && m.res.space == kLocNone && !getenv("BSX_RTC_NO_DW_STAGE");
-      const int CK = chunked ? m.band_rows : m.Cin, nch = m.Cin / CK;
+      const bool chunked = mid_dw_chunked(m);
+      const int CK = chunked ? m.band_rows : m.Cin, nch = (m.Cin + CK - 1) / CK;
       for (int c = 0; c < nch; c++) {
+        const int CKc = std::min(CK, m.Cin - c * CK);            // the last chunk may be ragged (88 channels = 5 x 16 + 8); the workspace keeps its CK + 4 row stride
         char name[32];
         if (chunked) snprintf(name, sizeof name, "Op%d_%d", i, c); else snprintf(name, sizeof name, "Op%d", i);
         o.f("struct %s {\n  static constexpr int K = %d, S = %d, H = %d, W = %d, OH = %d, OW = %d, PT = %d, PL = %d, C = %d, CW = %d, YC0 = %d, ACT = %d, V = %d, TX = %d;\n", name, K, S,
-            m.H, m.W, m.OH, m.OW, m.pt, m.pl, CK, m.Cin, c * CK, m.act, V, TX);
+            m.H, m.W, m.OH, m.OW, m.pt, m.pl, CKc, m.Cin, c * CK, m.act, V, TX);
         if (chunked) o.f("  static constexpr int X_SP = 1, X_OFF = %d, X_ST = %d;\n", m.ws_off, CK + 4); else loc(o, "X", m.in0);
         loc(o, "Y", m.out); loc(o, "R", m.res);
         if (staged) o.f("  static constexpr int W_SP = SP_LDS, W_OFF = %d, B_OFF = %d;\n};\n", m.w_lds + c * CK, m.w_lds + (int)(m.b_off - m.w_off) + c * CK);
@@ -194,11 +196,11 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
             loc(o, "X", a.in0); loc(o, "R", a.res); loc(o, "D", a.in2);
             o.f("  static constexpr int Y_SP = 1, Y_OFF = %d, Y_ST = %d;\n", m.ws_off, CK + 4);
             o.f("  static constexpr int S_OFF = %d, W_LDS = %d, B_LDS = %d;\n", a.scale.space == kLocLds ? a.scale.off : -1, a.w_lds, a.w_lds + (int)(a.b_off - a.w_off));
-            o.f("  static constexpr int N0 = %d, NCOLS = %d, YSUB = %d;\n  static constexpr bool NFAST = true;\n};\n", c * CK, CK, c * CK);
+            o.f("  static constexpr int N0 = %d, NCOLS = %d, YSUB = %d;\n  static constexpr bool NFAST = true;\n};\n", c * CK, (CKc + 15) / 16 * 16, c * CK);
             k.f("  op_pw<Op%d_%d>(L, A);\n  __syncthreads();\n", i - 1, c);
             if (c == nch - 1 && i + 1 < n) stage_of(i + 1, k);    // every wave is past the last 1x1 chunk: its weight slot is free for the next op's DMA only now
           } else
-            k.f("  load_chunk<%d, %d, %d, %d, %d, %d, %d>(L, A);\n  __syncthreads();\n", asp(m.in0), m.in0.off, m.H * m.W, m.in0.stride, CK, c * CK, m.ws_off);
+            k.f("  load_chunk<%d, %d, %d, %d, %d, %d, %d, %d>(L, A);\n  __syncthreads();\n", asp(m.in0), m.in0.off, m.H * m.W, m.in0.stride, CKc, c * CK, m.ws_off, CK + 4);
         }
         k.f("  op_dw<%s>(L, A, W);\n", name);
       }

@@ -233,7 +233,7 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
 // ---- channels [C0, C0 + CK) of an arena tensor [P][CFULL] → LDS workspace [P][CK + 4] (one coalesced pass: CK / 4 lanes read one pixel's 4 CK contiguous bytes) ----
 // A depthwise whose input lives in the arena reads every element ~10 times (K output rows x overlapping strips) through an L2 that 32 frames share; with the
 // chunk staged here each element leaves memory ONCE and the taps run from LDS.  All of a lane's loads are in flight before its first LDS store.
-template <int SP, int X_OFF, int P, int CFULL, int CK, int C0, int WS>
+template <int SP, int X_OFF, int P, int CFULL, int CK, int C0, int WS, int WST = CK + 4>      // WST: row stride of the workspace (the full chunk's CK + 4 also for a ragged last chunk)
 __device__ __forceinline__ void load_chunk(lds_f* L, const glb_f* A) {
   constexpr int Q = CK / 4, TOTAL = P * Q, IT = (TOTAL + kThreads - 1) / kThreads;
   f4v v[IT];
@@ -245,7 +245,7 @@ __device__ __forceinline__ void load_chunk(lds_f* L, const glb_f* A) {
 #pragma unroll
   for (int it = 0; it < IT; it++) {
     const int i = (int)threadIdx.x + it * kThreads, px = i / Q, q = i - px * Q;
-    if (i < TOTAL) *(lds_v4*)(L + WS + px * (CK + 4) + 4 * q) = v[it];
+    if (i < TOTAL) *(lds_v4*)(L + WS + px * WST + 4 * q) = v[it];
   }
 }
 

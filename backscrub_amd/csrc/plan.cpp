@@ -141,9 +141,9 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       const Step& a = steps[s];
       const Step& d = steps[s + 1];
       if (!(a.kind == StepKind::PwConv && a.residual < 0 && a.out >= 0 && last[a.out] == s + 1 && d.kind == StepKind::DwConv && d.in0 == a.out && d.residual < 0 && d.dh == 1 && d.dw == 1)) continue;
-      if (a.out == g.output || std::find(ext.begin(), ext.end(), a.out) != ext.end() || g.tensors[a.out].dims[3] % 32) continue;
+      if (a.out == g.output || std::find(ext.begin(), ext.end(), a.out) != ext.end() || g.tensors[a.out].dims[3] % 8 || a.cout_pad < (g.tensors[a.out].dims[3] + 15) / 16 * 16) continue;
       const int P = g.tensors[a.out].dims[1] * g.tensors[a.out].dims[2], need = padded(a.out), need_o = padded(d.out), ws = (P * 20 + 3) / 4 * 4 /* the 16-channel chunk */, room = kLdsTotalFloats - scratch - 2 * kLdsMaxStageFloats;
-      if (need + need_o > room && need_o + ws <= room) {
+      if (need + need_o > room && (need_o > room ? ws : need_o + ws) <= room) {     // (a depthwise output too large for LDS lives in the arena either way: then only the chunk workspace must fit)
         elide[s] = 1;
         for (int t : {a.in0, a.in2, a.in_scale}) if (t >= 0) last[t] = std::max(last[t], s + 1);
       }
@@ -401,7 +401,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
       for (int CK : {32, 16}) {                      // (8-channel chunks leave most lanes without an item and cost two barriers each: the arena form is faster)
-        if (st.Cin % CK || m.band_rows) continue;
+        if (m.band_rows || (st.Cin % CK) % 8) continue;        // whole chunks, or a ragged last one of whole 8-channel pieces (88 = 5 x 16 + 8: round 4)
         const int need = (st.H * st.W * (CK + 4) + 3) / 4 * 4;
         int pos = scratch;
         for (const Blk& b : live) { if (pos + need <= b.off) break; pos = std::max(pos, b.off + b.len); }
@@ -497,9 +497,11 @@ static long program_arena_bytes(const Plan& plan) {
   for (int i = 0; i < n; i++) {
     const MicroOp& m = plan.program[i];
     const bool out_elided = mid_pw_feeds_dw(plan, i), in_elided = i > 0 && mid_pw_feeds_dw(plan, i - 1);     // the tensor between a fused 1x1 → depthwise pair never exists
+    // a fused 1x1 runs once per channel chunk of the depthwise behind it: its arena operands are read that many times
+    const long reps = out_elided ? (plan.program[i + 1].Cin + plan.program[i + 1].band_rows - 1) / plan.program[i + 1].band_rows : 1;
     for (const Loc* l : {&m.in0, &m.in1, &m.in2, &m.res, &m.out}) {
       if (l->space != kLocGlobal || (l == &m.out && out_elided) || (l == &m.in0 && in_elided)) continue;
-      b += 4L * l->elems;
+      b += 4L * l->elems * (l == &m.out ? 1 : reps);
     }
     for (int c = 0; c < m.n_cat; c++) if (m.cat[c].space == kLocGlobal && m.cat_parts[c] == 0) b += 4L * m.cat[c].elems;
   }

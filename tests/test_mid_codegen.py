@@ -69,7 +69,7 @@ def test_arena_tensors_of_the_larger_graphs_are_staged_and_fused(api, monkeypatc
     """MLKit / segm_full keep their 16x16x{96,128} (9x16) level-4 tensors in the arena.  The generator then (a) stages the depthwise inputs through the LDS
     workspace the planner reserved, chunk by chunk, and (b) where the 1x1 in front is the only producer computes each chunk straight into that workspace, so the
     expanded tensor is never stored; (c) 1x1 convolutions that write to the arena walk N-tile fastest.  segm_lite keeps those tensors in LDS: nothing to stage."""
-    for key, fused in (("mlkit", 4), ("full", 3), ("lite", 0)):      # full (round 4): P5, P9, P13 — the placement search fuses the level-3 pair too and keeps the third level-4 block's 9x16x96 expanded tensor in LDS
+    for key, fused in (("mlkit", 4), ("full", 4), ("lite", 0)):      # full (round 4): P2, P5, P9, P13 — the placement search fuses both level-3 pairs (the 88-channel one in 16-channel chunks with a ragged last one) and keeps the third level-4 block's 9x16x96 expanded tensor in LDS
         src = api.model_kernel_source(model_path(key))
         assert len(re.findall(r"computed chunk by chunk inside P\d+", src)) == fused, key
         assert ("op_pw<Op8_0>" in src) == (fused > 0)
