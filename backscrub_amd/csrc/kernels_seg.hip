@@ -271,7 +271,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, ar0 = 2 * r0 - d.dw_pt, ac0 = 2 * c0 - d.dw_pl, RW = d.rw, ctiles = RW >> 4;
   const int IR = 2 * AR + 1, IC = 2 * AC + 1, ir0 = 2 * ar0 - d.stem_pt, ic0 = 2 * ac0 - d.stem_pl, rowf = IC * 3;
   float* fa = arena + (size_t)f * (size_t)per_frame;
-  float* in_t = seg_smem + kScrFloats;                              // [IR][IC * 3]
+  float* in_t = seg_smem;                                           // [IR][IC * 3]; no scratch block in front: the head has no gate prologue, and its partial-sum meeting
+                                                                    // points (s_red, 512 floats) reuse this window once the stem is done with it — 2.5 KB that put the 4 x 14 tile's
+                                                                    // workgroup exactly ON the 32 KB line (5 per CU only if the allocator wastes nothing)
   float* a_t = in_t + ((IR * rowf + 3) & ~3);                       // x = act(pw(stem)) [AR][AC][16]: rows of AC pixels, not of RW = 16 ceil(AC / 16) — the MFMA tiles
                                                                     // round the COMPUTE up to 16 pixels, the storage need not (5 workgroups per CU instead of 4 at a 4 x 13 tile)
   float* A_out = fa + d.a_off;                                      // uniform bases + 32-bit lane offsets (global_load/store saddr forms)
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
       sumB = f4add(sumB, v);
     }
   }
-  float* s_red = seg_smem + kScrRed;
+  float* s_red = in_t;                                              // (every wave is past the stem — the barrier in front of the depthwise — so the window is free)
   wave_reduce16<0>(sumA, s_red, wave, lane);
   wave_reduce16<1>(sumB, s_red + 256, wave, lane);
   __syncthreads();

@@ -104,7 +104,8 @@ constexpr int kSegGateStageFloats = 512 + 2 * (32 * 32 + 32);   // gate prologue
 inline int seg_row_width(int cols) { return (cols + 15) / 16 * 16; }
 inline int seg_head_lds_floats(const SegHead& d) {
   const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, IR = 2 * AR + 1, IC = 2 * AC + 1;
-  return kSegScratchFloats + ((IR * IC * 3 + 3) & ~3) + AR * AC * 16;      // input window + x = act(pw(stem)) (the stem output itself stays in registers: seg_head_k)
+  const int win = (IR * IC * 3 + 3) & ~3;                                  // input window (>= 512 floats: it doubles as the partial-sum meeting points at the end)
+  return (win > 512 ? win : 512) + AR * AC * 16;                           // + x = act(pw(stem)) (the stem output itself stays in registers: seg_head_k)
 }
 inline int seg_k2_lds_floats(const SegK2& d) { const int v = 2 * (2 * d.TR + 1) * seg_row_width(2 * d.TC + 1) * 16; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats); }
 // The staged window of the low-resolution tensor a k3 / tail tile interpolates from ([LR][LC][20] floats) was reserved at its worst case (12 x 16 pixels = 15 KB) for
