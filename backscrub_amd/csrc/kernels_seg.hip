@@ -541,7 +541,7 @@ constexpr int kLoStride = 20;           // floats per staged low-resolution pixe
 struct GatedPre { float4 s[kGatedRows]; int ly0, lx0, LC; };
 template <bool H16>
 __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ skip, const float* __restrict__ lo, int H, int W, int HL, int WL, bool half_pixel,
-                                                   bool align, int r0, int c0, int ZH, int ZC, float* l_t) {
+                                                   float hs, float wsc, int r0, int c0, int ZH, int ZC, float* l_t) {
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4;
   GatedPre pre;
   const int ix = c0 - 1 + li;
@@ -552,8 +552,9 @@ __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ ski
     pre.s[j] = f4zero();
     if (zy < ZH && iy >= 0 && iy < H && col_in) pre.s[j] = ldg4<H16>(skip, (unsigned)((iy * W + ix) * 16 + 4 * g));
   }
-  // low-resolution window: rows y0(first image row of the region) .. y1(last), columns likewise (monotone maps)
-  const float hs = up_scale(HL, H, align), wsc = up_scale(WL, W, align);
+  // low-resolution window: rows y0(first image row of the region) .. y1(last), columns likewise (monotone maps).  hs / wsc: the two up-sampling scales — launch constants the
+  // planner computes (SegK3 / SegTail::hs, ::ws: the same IEEE single-precision quotients); computed here they were four correctly-rounded divisions (both `align` forms of
+  // each axis) of ~11 instructions in front of the prefetch's first address, and four more in gated_compute
   int ly0, ly1, lx0, lx1, t0, t1;
   float fr;
   up_axis(max(r0 - 1, 0), hs, half_pixel, HL, &ly0, &t1, &fr);
@@ -576,7 +577,7 @@ __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ ski
   }
   return pre;
 }
-__device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* l_t, int H, int W, int HL, int WL, bool half_pixel, bool align, const float* s_gate,
+__device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* l_t, int H, int W, int HL, int WL, bool half_pixel, float hs, float wsc, const float* s_gate,
                                               const SegConvW& pw, const float* __restrict__ w, int r0, int c0, int ZH, int ZC, float* z_t) {
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
   float wr[4];
@@ -584,7 +585,6 @@ __device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* 
   const float4 bias = ld4(w + pw.b_off + cq4);
   const float4 gv = ld4(s_gate + 4 * g);
   const Clamp cl = clamp_of(pw.act);
-  const float hs = up_scale(HL, H, align), wsc = up_scale(WL, W, align);
   // column constants of this lane: operand and epilogue side are the same pixel li
   const int ix = c0 - 1 + li;
   int x0, x1;
@@ -633,10 +633,10 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
   float* l_t = t_t + d.TR * 256;                                    // staged window of lo2
   float* lo_out = fa + d.lo_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
-  const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
+  const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.hs, d.ws, r0, c0, ZH, ZC, l_t);
   if (tid < 16) seg_smem[kScrGate + tid] = fa[d.g_off + tid];
   __syncthreads();
-  gated_compute(pre, l_t, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw1, w, r0, c0, ZH, ZC, z_t);
+  gated_compute(pre, l_t, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.hs, d.ws, seg_smem + kScrGate, d.pw1, w, r0, c0, ZH, ZC, z_t);
   const int quad = lane & 3, px = lane >> 2;
   f4v wd[9];
 #pragma unroll
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
   const int fy = quad >> 1, fx = quad & 1, ix = c0 + px;
   // every global read of the workgroup is requested here, before the first wait: skip operands, the window of lo, the temporal
   // state bytes this lane will update, then (inside seg_gate) the pooled partial sums and the gate weights
-  const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo_off, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, r0, c0, ZH, ZC, l_t);
+  const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo_off, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.hs, d.ws, r0, c0, ZH, ZC, l_t);
   constexpr int kRowsB = 5;                                          // TR <= 18 → <= 5 tile rows per wave in phase B
   uint8_t prev[kRowsB];
   if (!LOGITS) {
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
     if (tid < 16) seg_smem[kScrGate + tid] = fa[d.pre_gate_off + tid];
     __syncthreads();
   } else seg_gate(d.gate, fa, w, seg_smem, z_t);
-  if (!(d.dbg_skip & 1)) gated_compute(pre, l_t, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.align_corners != 0, seg_smem + kScrGate, d.pw, w, r0, c0, ZH, ZC, z_t);
+  if (!(d.dbg_skip & 1)) gated_compute(pre, l_t, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.hs, d.ws, seg_smem + kScrGate, d.pw, w, r0, c0, ZH, ZC, z_t);
   if (d.dbg_skip & 2) return;
   f4v wd[9];
 #pragma unroll

@@ -694,6 +694,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   k3.H2 = kp1.OH; k3.W2 = kp1.OW; k3.HL = kr.H; k3.WL = kr.W; k3.half_pixel = kr.half_pixel; k3.align_corners = kr.align_corners;
   k3.pw1 = conv_w(kp1); k3.pw2 = conv_w(kp2); k3.dw = dw_w(kd);
   split(k3.H2, tgt[4], &k3.TR, &k3.tiles_y); split(k3.W2, tgt[5], &k3.TC, &k3.tiles_x);
+  k3.hs = seg_up_scale(k3.HL, k3.H2, k3.align_corners != 0); k3.ws = seg_up_scale(k3.WL, k3.W2, k3.align_corners != 0);
   if (!getenv("BSX_SEG_LO_WORST")) k3.lo_floats = seg_lo_window_floats(k3.H2, k3.W2, k3.HL, k3.WL, k3.half_pixel != 0, k3.align_corners != 0, k3.TR, k3.TC, k3.tiles_y, k3.tiles_x);
   k3.lds_floats = seg_k3_lds_floats(k3);
   if (k3.TC > 14 || k3.TR > 18) return seg_fail(32);
@@ -701,6 +702,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   tl.H1 = tpw.OH; tl.W1 = tpw.OW; tl.HL = tr.H; tl.WL = tr.W; tl.H0 = ttc.OH; tl.W0 = ttc.OW; tl.half_pixel = tr.half_pixel; tl.align_corners = tr.align_corners;
   tl.pw = conv_w(tpw); tl.dw = dw_w(tdw); tl.tc_w_off = (long long)ttc.w_off; tl.tc_b_off = (long long)ttc.b_off; tl.Co = ttc.Cout; tl.act3 = ttc.act;
   split(tl.H1, tgt[6], &tl.TR, &tl.tiles_y); split(tl.W1, tgt[7], &tl.TC, &tl.tiles_x);
+  tl.hs = seg_up_scale(tl.HL, tl.H1, tl.align_corners != 0); tl.ws = seg_up_scale(tl.WL, tl.W1, tl.align_corners != 0);
   if (!getenv("BSX_SEG_LO_WORST")) tl.lo_floats = seg_lo_window_floats(tl.H1, tl.W1, tl.HL, tl.WL, tl.half_pixel != 0, tl.align_corners != 0, tl.TR, tl.TC, tl.tiles_y, tl.tiles_x);
   tl.lds_floats = seg_tail_lds_floats(tl);
   if (tl.TC > 14 || tl.TR > 18) return seg_fail(33);

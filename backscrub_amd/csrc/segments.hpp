@@ -77,6 +77,7 @@ struct SegK3 {
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
   int lo_floats = 0;                                      // LDS floats of the staged low-resolution window: the largest any tile of THIS geometry needs (seg_lo_window_floats)
+  float hs = 0.f, ws = 0.f;                               // the two up-sampling scales ((float)in / out, or (in - 1) / (out - 1) with align_corners): launch constants, so the planner divides
   int dbg_skip = 0;                                       // BSX_SEG_SKIP (timing experiments, results invalid): bit mask of phases this kernel skips
 };
 
@@ -93,6 +94,7 @@ struct SegTail {
   int TR = 0, TC = 0, tiles_y = 0, tiles_x = 0;
   int lds_floats = 0;
   int lo_floats = 0;                                      // as SegK3::lo_floats
+  float hs = 0.f, ws = 0.f;                               // as SegK3::hs / ws
   int dbg_skip = 0;                                       // BSX_SEG_SKIP (timing experiments, results invalid): bit mask of phases this kernel skips
 };
 
@@ -118,8 +120,9 @@ inline void seg_up_axis(int o, float scale, bool half_pixel, int in_size, int* l
   *lo = std::max((int)fl, 0);
   *hi = std::min((int)std::ceil(v), in_size - 1);
 }
+inline float seg_up_scale(int in, int out, bool align) { return (align && out > 1) ? (float)(in - 1) / (float)(out - 1) : (float)in / (float)out; }
 inline int seg_lo_window_floats(int H, int W, int HL, int WL, bool half_pixel, bool align, int TR, int TC, int tiles_y, int tiles_x) {
-  const float hs = (align && H > 1) ? (float)(HL - 1) / (float)(H - 1) : (float)HL / (float)H, ws = (align && W > 1) ? (float)(WL - 1) / (float)(W - 1) : (float)WL / (float)W;
+  const float hs = seg_up_scale(HL, H, align), ws = seg_up_scale(WL, W, align);
   int lr = 1, lc = 1, a, b, c, e;
   for (int ty = 0; ty < tiles_y; ty++) {
     const int r0 = ty * TR;
