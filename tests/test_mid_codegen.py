@@ -102,3 +102,40 @@ def test_prelude_is_a_valid_translation_unit_on_its_own():
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-fsyntax-only", "-x", "hip",
                         os.path.join(here, "backscrub_amd", "csrc", "mid_prelude.hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_placement_search_keeps_the_cheapest_valid_plan(api, monkeypatch):
+    """plan.cpp: build_frame_program lowers the program under eight placement policies and keeps the one that touches the fewest arena bytes per frame.  For every
+    model and every forced policy the plan must pass the independent LDS check (no two live reservations overlap — also with the lifetimes an elided 1x1 extends),
+    the default must be the minimum over the forced ones (ties: the lowest policy number), segm_lite / MLKit must stay on the round-3 plan (policy 0, i.e. the
+    same kernels), and segm_full's search must really have paid: fewer arena tensors and < 60 % of policy 0's arena bytes."""
+    def facts(key):
+        line = [l for l in api.model_describe(model_path(key)).splitlines() if l.startswith("program ")][0]
+        f = dict(kv.split("=") for kv in line.split()[1:])
+        return int(f["arena_bytes_per_frame"]), int(f["placement_policy"]), int(f["hbm_tensors"]), f["lds_check"]
+    for key in ("lite", "mlkit", "full"):
+        forced = {}
+        for pol in range(8):
+            monkeypatch.setenv("BSX_PLAN_POLICY", str(pol))
+            b, p, n_hbm, chk = facts(key)
+            assert chk == "ok" and p == pol, (key, pol, chk)
+            forced[pol] = (b, n_hbm)
+        monkeypatch.delenv("BSX_PLAN_POLICY")
+        b, p, n_hbm, chk = facts(key)
+        best = min(v[0] for v in forced.values())
+        assert chk == "ok" and b == best and p == min(q for q, v in forced.items() if v[0] == best), (key, b, p, forced)
+        if key in ("lite", "mlkit"):
+            assert p == 0
+        else:
+            assert p != 0 and n_hbm < forced[0][1] and b < 0.6 * forced[0][0], (b, forced[0])
+
+
+def test_segment_lds_footprints_are_what_the_occupancy_story_says(api):
+    """DESIGN 5.1 (round 4): seg_head without a stem tile / scratch block (<= 30 KB: 5 workgroups per CU), k3 / tail with the low-resolution window sized for the geometry
+    (k3 <= 36 KB on segm_lite / segm_full: 4 per CU)."""
+    import re
+    for key, head_max, k3_max in (("lite", 30.0, 36.0), ("mlkit", 30.0, 46.0), ("full", 30.0, 36.0)):
+        d = api.model_describe(model_path(key))
+        kib = {m.group(1): float(m.group(2)) for m in re.finditer(r"segment (\w+)\s+tile \S+ \S+ tiles per frame, LDS ([\d.]+) KiB", d)}
+        assert set(kib) == {"head", "k2", "k3", "tail"}, kib
+        assert kib["head"] <= head_max and kib["k3"] <= k3_max and kib["tail"] <= 32.0, (key, kib)
