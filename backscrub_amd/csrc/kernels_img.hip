@@ -213,11 +213,10 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
     for (int k = 0; k < kItems; k++) {                                     // every load of the lane is requested here
       const int i = min(tid + k * kThreads, total - 1), ly = (int)__umulhi((unsigned)i, msw), lx = i - ly * SW;
       const int co = max(colT[lx].x, 0), o0 = max(rowT[ly].x, 0), o1 = rowT[ly].y;
-      struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
-      const uint8_t* p0 = src + (unsigned)(o0 + co);
-      const uint8_t* p1 = src + (unsigned)(o1 + co);
-      lo0[k] = reinterpret_cast<const U4*>(p0)->v; hi0[k] = reinterpret_cast<const U4*>(p0 + 4)->v;
-      lo1[k] = reinterpret_cast<const U4*>(p1)->v; hi1[k] = reinterpret_cast<const U4*>(p1 + 4)->v;
+      struct __attribute__((packed, aligned(1))) U8 { uint64_t v; };            // ONE 8-byte load per source row (byte-aligned: global_load_dwordx2), not two 4-byte ones
+      const uint64_t q0 = reinterpret_cast<const U8*>(src + (unsigned)(o0 + co))->v, q1 = reinterpret_cast<const U8*>(src + (unsigned)(o1 + co))->v;
+      lo0[k] = (uint32_t)q0; hi0[k] = (uint32_t)(q0 >> 32);
+      lo1[k] = (uint32_t)q1; hi1[k] = (uint32_t)(q1 >> 32);
     }
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
