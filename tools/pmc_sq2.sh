@@ -3,7 +3,7 @@
 # usage (on the GPU box): bash tools/pmc_sq2.sh <tag> [bench args]  → gpurun_out/pmc_sq2_<tag>.md
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs --profile-iters 1 --ramp-seconds 0 $@"
+B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs --no-side-probes --profile-iters 1 --ramp-seconds 0 $@"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace \
   -d $R/gpurun_out/pmc_sq2a_$TAG -o b -- $B > $R/gpurun_out/pmc_sq2_$TAG.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace \
