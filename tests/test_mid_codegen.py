@@ -7,7 +7,7 @@ import subprocess
 
 import pytest
 
-from conftest import MODEL_KEYS, model_path
+from conftest import MODEL_KEYS, ROOT, model_path
 
 HIPCC = "/opt/rocm/bin/hipcc"
 
@@ -139,3 +139,49 @@ def test_segment_lds_footprints_are_what_the_occupancy_story_says(api):
         kib = {m.group(1): float(m.group(2)) for m in re.finditer(r"segment (\w+)\s+tile \S+ \S+ tiles per frame, LDS ([\d.]+) KiB", d)}
         assert set(kib) == {"head", "k2", "k3", "tail"}, kib
         assert kib["head"] <= head_max and kib["k3"] <= k3_max and kib["tail"] <= 32.0, (key, kib)
+
+
+def test_low_resolution_window_reservation_covers_every_tile(tmp_path):
+    """segments.hpp: seg_lo_window_floats sizes the LDS window of the low-resolution tensor a k3 / tail tile interpolates from (round 4: the geometry's need, not a 15 KB worst
+    case).  An under-reservation would let one tile's staged window run into the next LDS region, so the host function (compiled here from the header itself, -ffp-contract=off
+    like the library) is held against a brute-force walk in float32 — every tile, every halo-region row and column, TFLite's index arithmetic — for the three models' geometries,
+    both resize conventions, and odd sizes / tile shapes the planner could pick for other models."""
+    import subprocess
+
+    import numpy as np
+    src = tmp_path / "lo.cpp"
+    src.write_text('#include <cstdio>\n#include <cstdlib>\n#include "segments.hpp"\nint main(int c, char** v) { int a[10]; for (int i = 0; i < 10; i++) a[i] = atoi(v[i + 1]);\n'
+                   '  printf("%d\\n", bsx::seg_lo_window_floats(a[0], a[1], a[2], a[3], a[4] != 0, a[5] != 0, a[6], a[7], a[8], a[9])); return 0; }\n')
+    exe = tmp_path / "lo"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(ROOT, "backscrub_amd", "csrc"), str(src), "-o", str(exe)])
+
+    def axis(o, scale, half_pixel, in_size):
+        f = np.float32
+        v = (f(o) + f(0.5)) * f(scale) + f(-0.5) if half_pixel else f(o) * f(scale)
+        return max(int(np.floor(v)), 0), min(int(np.ceil(v)), in_size - 1)
+
+    def brute(H, W, HL, WL, hp, al, TR, TC):
+        f = np.float32
+        hs = f(HL - 1) / f(H - 1) if (al and H > 1) else f(HL) / f(H)
+        ws = f(WL - 1) / f(W - 1) if (al and W > 1) else f(WL) / f(W)
+        ty_n, tx_n = -(-H // TR), -(-W // TC)
+        need = 0
+        for ty in range(ty_n):
+            rows = range(max(ty * TR - 1, 0), min(ty * TR + TR, H - 1) + 1)
+            lo_r = min(axis(r, hs, hp, HL)[0] for r in rows); hi_r = max(axis(r, hs, hp, HL)[1] for r in rows)
+            for tx in range(tx_n):
+                cols = range(max(tx * TC - 1, 0), min(tx * TC + TC, W - 1) + 1)
+                lo_c = min(axis(c_, ws, hp, WL)[0] for c_ in cols); hi_c = max(axis(c_, ws, hp, WL)[1] for c_ in cols)
+                need = max(need, (hi_r - lo_r + 1) * (hi_c - lo_c + 1) * 20)
+        return need, ty_n, tx_n
+
+    cases = [(48, 80, 24, 40, 16, 14), (24, 40, 12, 20, 12, 14),                 # segm_lite: tail, k3
+             (128, 128, 64, 64, 16, 13), (64, 64, 32, 32, 16, 13),               # MLKit
+             (72, 128, 36, 64, 18, 13), (36, 64, 18, 32, 12, 13),                # segm_full
+             (50, 70, 25, 35, 17, 11), (33, 47, 17, 24, 9, 14), (40, 40, 13, 13, 18, 14)]   # odd sizes, a 3x up-sampling
+    for H, W, HL, WL, TR, TC in cases:
+        for hp, al in ((1, 0), (0, 0), (0, 1)):
+            need, ty_n, tx_n = brute(H, W, HL, WL, bool(hp), bool(al), TR, TC)
+            got = int(subprocess.check_output([str(exe)] + [str(x) for x in (H, W, HL, WL, hp, al, TR, TC, ty_n, tx_n)]).decode())
+            assert got >= min(need, 12 * 16 * 20), ((H, W, HL, WL, hp, al, TR, TC), got, need)
+            assert got <= 12 * 16 * 20
