@@ -863,37 +863,6 @@ __global__ __launch_bounds__(kThreads) void outside_roi_copy_k(const uint8_t* __
   }
 }
 
-// The same copy without index divisions (round 4, after the SQ counters showed the word-indexed form at 86 % of its vector-ISSUE bound — a copy limited by its two
-// divisions per lane): grid = (16-byte chunks, image row, frame).  Rows outside the ROI's rows copy every chunk; ROI rows copy the chunks of the two side strips (lane i < nl:
-// left chunk i, else right chunk c_r0 + i - nl); a chunk that straddles a strip boundary (the boundaries are word- but not 16-byte-aligned: 840 B at the MLKit ROI) copies its
-// outside words one by one.  Needs whole chunks per row (W * 3 % 16 == 0, i.e. W % 16 == 0); other widths keep the kernel above.
-__global__ __launch_bounds__(kThreads) void outside_roi_copy16_k(const uint8_t* __restrict__ bg, long bg_stride, uint8_t* __restrict__ out, int W, int H, Rect4 roi, int full_rows) {
-  const unsigned y = blockIdx.y, i = blockIdx.x * kThreads + threadIdx.x;
-  const unsigned cpr = (unsigned)W * 3u / 16u, lo = (unsigned)roi.x * 3u, hi = (unsigned)(roi.x + roi.w) * 3u;       // chunks per row; byte range of the ROI inside a row
-  const bool roi_row = y >= (unsigned)roi.y && y < (unsigned)(roi.y + roi.h);
-  unsigned c = i;
-  if (roi_row) {
-    const unsigned nl = (lo + 15u) / 16u, c_r0 = hi / 16u;                   // left strip: chunks [0, nl); right strip: chunks [c_r0, cpr)
-    if (i >= nl) c = c_r0 + (i - nl);
-    if (c_r0 < nl && i >= nl) c++;                                           // (a ROI narrower than a chunk: one chunk holds both boundaries — it is in the left set already)
-  } else if (!full_rows) return;
-  if (c >= cpr) return;
-  const unsigned b0 = c * 16u;
-  const long n = blockIdx.z, off = ((long)y * W) * 3 + (long)b0;
-  const uint8_t* src = bg + (bg_stride ? n * bg_stride : 0) + off;
-  uint8_t* dst = out + n * (long)W * H * 3 + off;
-  if (!roi_row || b0 + 16u <= lo || b0 >= hi) {
-    struct __attribute__((packed, aligned(4))) W4 { uint32_t v[4]; };
-    *reinterpret_cast<W4*>(dst) = *reinterpret_cast<const W4*>(src);
-    return;
-  }
-#pragma unroll
-  for (unsigned k = 0; k < 4; k++) {
-    const unsigned wb = b0 + 4u * k;
-    if (wb < lo || wb >= hi) *reinterpret_cast<uint32_t*>(dst + 4 * k) = *reinterpret_cast<const uint32_t*>(src + 4 * k);
-  }
-}
-
 // ---- generic BGR resize -------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void resize_bgr_k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ResizeTab tab) {
   const unsigned p = blockIdx.x * kThreads + threadIdx.x;
@@ -1137,8 +1106,6 @@ bool mask_blend_fusable(int W, int H, Rect4 roi, const uint8_t* bg, size_t bg_st
          ((((uintptr_t)bg) | ((uintptr_t)frames) | ((uintptr_t)out)) & 3) == 0;
 }
 
-static bool getenv_once_no_copy16() { static const bool v = getenv("BSX_NO_COPY16") != nullptr; return v; }   // A/B timing, tests: the word-indexed copy kernel
-
 hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in_roi, ResizeTab tab, uint8_t* mask, int W, int H, Rect4 roi,
                              const uint8_t* bg, size_t bg_stride, const uint8_t* frames, uint8_t* out, int n, hipStream_t s, int yuyv, int lds_pad) {
   // lds_pad (bytes of dynamic LDS nobody uses): an OCCUPANCY CAP for the two-deep pipeline (bsx_step_batch_pipelined) — left alone this HBM-bound launch takes every wave
@@ -1151,12 +1118,6 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
     outside_roi_flip_k<<<dim3(blocks_for((long)(W / 4) * H), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H, roi, yuyv);
   else if ((yuyv & 1) && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
     outside_roi_yuyv_k<<<dim3(blocks_for((long)(W / 2) * H), n), kThreads, 0, s>>>(bg, (long)bg_stride, reinterpret_cast<uint32_t*>(out), W, H, roi);
-  else if ((roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H) && (W % 16) == 0 && H <= 65535 && n <= 65535 && !getenv_once_no_copy16()) {
-    const unsigned cpr = (unsigned)W * 3u / 16u, nl = ((unsigned)roi.x * 3u + 15u) / 16u, c_r0 = (unsigned)(roi.x + roi.w) * 3u / 16u;
-    const int full_rows = roi.h != H;
-    const unsigned lanes = full_rows ? cpr : std::min(cpr, nl + (cpr - c_r0) + 1u);      // rows outside the ROI's rows need every chunk of the row
-    outside_roi_copy16_k<<<dim3((lanes + kThreads - 1) / kThreads, (unsigned)H, (unsigned)n), kThreads, (size_t)lds_pad, s>>>(bg, (long)bg_stride, out, W, H, roi, full_rows);
-  }
   else if (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H)
     outside_roi_copy_k<<<dim3(blocks_for(((long)(H - roi.h) * (W * 3 / 4) + (long)roi.h * ((W - roi.w) * 3 / 4) + 3) / 4), n), kThreads, (size_t)lds_pad, s>>>(bg, (long)bg_stride, out, W, H,
                                                                                                                                  roi);
