@@ -56,6 +56,13 @@ def main():
         rc["step_pipelined_%d" % i] = L.bsx_step_batch_pipelined(ctx, p(frames), p(bg), 0, p(out), n, None, 0); caller_device_after("bsx_step_batch_pipelined")
     rc["step_while_pending_refused"] = 0 if L.bsx_step_batch(ctx, p(frames), p(bg), 0, p(out), n, None) == -1 else -1; caller_device_after("bsx_step_batch(pending)")
     rc["step_pipelined_flush"] = L.bsx_step_batch_pipelined(ctx, None, None, 0, None, 0, None, 0); caller_device_after("bsx_step_batch_pipelined(flush)")
+    # argument checks of the pipelined entry point (each must refuse with BSX_EINVAL = -1 and leave nothing pending)
+    rc["pipelined_refuses_bgblur"] = 0 if L.bsx_step_batch_pipelined(ctx, p(frames), p(bg), 0, p(out), n, None, 25 << 8) == -1 else -1
+    rc["pipelined_refuses_in_place"] = 0 if L.bsx_step_batch_pipelined(ctx, p(frames), p(bg), 0, p(frames), n, None, 0) == -1 else -1
+    rc["pipelined_refuses_too_many_streams"] = 0 if L.bsx_step_batch_pipelined(ctx, p(frames), p(bg), 0, p(out), n + 1, None, 0) == -1 else -1
+    rc["step_after_refusals"] = L.bsx_step_batch(ctx, p(frames), p(bg), 0, p(out), n, None); caller_device_after("bsx_step_batch(after refusals)")
+    rc["pipelined_then_reset_drops_pending"] = L.bsx_step_batch_pipelined(ctx, p(frames), p(bg), 0, p(out), n, None, 0) or L.bsx_reset(ctx, None) or L.bsx_step_batch(ctx, p(frames), p(bg), 0, p(out), n, None)
+    caller_device_after("bsx_reset(pending)")
     rc["composite"] = L.bsx_composite_batch(ctx, p(bg), 0, p(frames), None, p(out), n, None); caller_device_after("bsx_composite_batch")
     mask = np.zeros((H, W), np.uint8)
     for i in range(3):                       # first call captures the slot's hipGraph, the next ones replay it
