@@ -163,6 +163,14 @@ class MaskGen:
                                          C.c_void_p(out.data_ptr()), n, _stream_ptr()), self.h, "bsx_composite_batch")
         return out
 
+    def _bg(self, bg, n):
+        """background operand of a step: ONE image [H,W,3] shared by all streams or one per stream [>=n,H,W,3]; contiguous cuda uint8 on the frames' device"""
+        ok = (bg.dtype == _torch().uint8 and bg.is_cuda and bg.is_contiguous() and bg.dim() in (3, 4) and tuple(bg.shape[-3:]) == (self.height, self.width, 3)
+              and (bg.dim() == 3 or bg.shape[0] >= n) and bg.device.index == self.device)
+        if not ok:
+            raise BsxError("bg must be a contiguous cuda:%d uint8 tensor [%d,%d,3] or [>=%d,%d,%d,3]" % (self.device, self.height, self.width, n, self.height, self.width))
+        return 0 if bg.dim() == 3 else bg.stride(0)
+
     def step(self, frames, bg, out):
         n = self._n(frames)
         stride = 0 if bg.dim() == 3 else bg.stride(0)
@@ -204,15 +212,25 @@ class MaskGen:
         want = (self.height, self.width, 2 if yuyv else 3)
         if out.dim() != 4 or tuple(out.shape[1:]) != want or out.shape[0] < n or not out.is_contiguous() or not out.is_cuda or out.dtype != _torch().uint8:
             raise BsxError("out must be a contiguous cuda uint8 tensor [>=%d,%d,%d,%d]" % ((n,) + want))
-        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        stride = self._bg(bg, n)
         flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0)
         _check(lib().bsx_step_batch_pipelined(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride, C.c_void_p(out.data_ptr()), n, _stream_ptr(), flags),
                self.h, "bsx_step_batch_pipelined")
+        # the composite of THIS batch is enqueued by the NEXT call, on a stream torch's caching allocator knows nothing about: the three tensors stay referenced
+        # here until then (a caller that drops them would otherwise have their memory handed out again under the pending kernel)
+        self._pending = (frames, bg, out)
         return out
 
     def flush_pipelined(self):
         """composite the batch still pending in the two-deep pipeline (on the current stream)"""
         _check(lib().bsx_step_batch_pipelined(self.h, None, None, 0, None, 0, _stream_ptr(), 0), self.h, "bsx_step_batch_pipelined(flush)")
+        self._release_pending()
+
+    def _release_pending(self):
+        """drop the references step_pipelined holds: after a flush the composite that used them is ordered on the caller's own stream, after a reset it was dropped
+        with the state.  (Between calls k and k + 1 the references move on by themselves: call k + 1 orders the caller's stream behind composite k — the launch that
+        advances the temporal state waits for it — so memory freed after that call cannot be reused ahead of the composite.)"""
+        self._pending = None
 
     def profile(self, frames, bg, out, iters=5):
         """per-launch hipEvent timings of the whole per-batch sequence → list of dicts"""
@@ -245,6 +263,7 @@ class MaskGen:
 
     def reset(self):
         _check(lib().bsx_reset(self.h, _stream_ptr()), self.h, "bsx_reset")
+        self._release_pending()
 
     def resize_bgr(self, src, dw, dh):
         torch = _torch()

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbsx.so")
 SOURCES = ["tflite_model.cpp", "plan.cpp", "gen_mid.cpp", "rtc.cpp", "media.cpp", "jpeg.cpp", "live.cpp", "kernels_nn.hip", "kernels_img.hip", "kernels_frame.hip", "kernels_seg.hip", "bsx_api.hip"]
-HEADERS = ["mid_prelude.hip", "gen_mid.hpp", "rtc.hpp", "media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", os.path.join("..", "..", "include", "bsx.h")]
+HEADERS = ["mid_prelude.hip", "gen_mid.hpp", "rtc.hpp", "media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", "roctx_ranges.hpp", os.path.join("..", "..", "include", "bsx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]      # only the BSX_API entry points of include/bsx.h are exported

@@ -18,6 +18,7 @@
 #include "../../include/bsx.h"
 #include "gen_mid.hpp"
 #include "kernels.hpp"
+#include "roctx_ranges.hpp"
 #include "rtc.hpp"
 #include "plan.hpp"
 #include "tflite_model.hpp"
@@ -144,7 +145,8 @@ struct bsx_ctx {
   // the kernel that advances it (tail / argmax tail / decode) waits for ev_pcomp first (state_write_fence).
   struct PendingComposite { bool active = false; const uint8_t* frames = nullptr; const uint8_t* bg = nullptr; size_t bg_stride = 0; uint8_t* out = nullptr; int n = 0; unsigned flags = 0; } pend;
   hipStream_t comp_stream = nullptr;
-  hipEvent_t ev_pfork = nullptr, ev_pcomp = nullptr;
+  hipEvent_t ev_pdone = nullptr, ev_pcomp = nullptr;   // ev_pdone: end of the mask pipeline of the PENDING batch, recorded on the stream of the call that enqueued it — the composite
+                                                       // (and the next call's network) wait for THAT event, so a caller may alternate streams between calls
   hipEvent_t wait_before_state = nullptr;   // consumed by the next launch that writes d_ofinal
   int pipe_wgs = 0;                         // BSX_PIPE_WGS (read at bsx_new, experiment): workgroups per CU the pipelined composite may hold (occupancy cap by an LDS pad; 0 = no cap,
                                             // the default: every cap measured slower — the tile kernel needs its waves, profiles/r04l)
@@ -329,6 +331,7 @@ hipStream_t pick(bsx_ctx*, void* s) { return (hipStream_t)s; }
 
 // with_f32: also materialise the f32 input tensor when the stem reads the 8-bit form (the stage-debug entry: tests inspect the tensor)
 int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s, bool with_f32 = false) {
+  bsx_roctx::Range range("bsx:prep");
   float* f32 = (!c->in_u8 || with_f32) ? c->tensor_ptr(c->plan.input) : nullptr;
   uint32_t* u8 = c->in_u8 ? c->d_net_in_u8 : nullptr;
   if (!c->prep_split) {
@@ -369,6 +372,7 @@ int state_write_fence(bsx_ctx* c, hipStream_t s) {
 }
 bool infer_decodes(const bsx_ctx* c) { return (c->use_program && c->plan.seg.on && !c->keep_logits) || argmax_tail(c); }
 int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0) {
+  bsx_roctx::Range range("bsx:network");
   if (c->use_program && c->plan.seg.on) {
     const SegPlan& sp = c->plan.seg;
     const long pf = (long)c->plan.arena_floats_per_stream;
@@ -399,6 +403,7 @@ int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0
 }
 // `slot` = first state slot (stream index) of the batch: frame i uses ofinal / mask slot `slot + i`
 int run_decode(bsx_ctx* c, int n, hipStream_t s, int slot = 0) {
+  bsx_roctx::Range range("bsx:decode");
   { const int frc = state_write_fence(c, s); if (frc) return frc; }
   BSX_HIP(c, launch_decode(c->model_type, c->tensor_ptr(c->plan.output), c->d_ofinal + (size_t)slot * c->outW * c->outH, c->outW * c->outH, c->outC, n, s));
   return BSX_OK;
@@ -410,6 +415,7 @@ ResizeTab tab_up_at(const bsx_ctx* c, int slot) {
   return t;
 }
 int run_mask(bsx_ctx* c, int n, hipStream_t s, int slot = 0) {
+  bsx_roctx::Range range("bsx:mask");
   BSX_HIP(c, launch_mask_upscale_blur(c->d_ofinal + (size_t)slot * c->outW * c->outH, c->outW, c->outH, c->in_roi, tab_up_at(c, slot),
                                       c->d_masks + (size_t)slot * c->width * c->height, c->width, c->height, c->roi, n, s));
   return BSX_OK;
@@ -550,7 +556,7 @@ void bsx_delete(bsx_ctx* c) {
   for (int k = 1; k < 4; k++) { if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->comp_stream) { (void)hipStreamSynchronize(c->comp_stream); (void)hipStreamDestroy(c->comp_stream); }
-  if (c->ev_pfork) (void)hipEventDestroy(c->ev_pfork);
+  if (c->ev_pdone) (void)hipEventDestroy(c->ev_pdone);
   if (c->ev_pcomp) (void)hipEventDestroy(c->ev_pcomp);
   delete c;
 }
@@ -635,6 +641,7 @@ int bsx_composite_batch(bsx_ctx* c, const uint8_t* d_bg, size_t bg_frame_stride,
   if (!c || !d_bg || !d_frames || !d_out || n <= 0) return BSX_EINVAL;
   if (!d_masks) { if (n > c->n_streams) return BSX_EINVAL; d_masks = c->d_masks; }
   DeviceGuard guard(c->device);
+  bsx_roctx::Range range("bsx:blend");
   BSX_HIP(c, launch_blend(d_bg, bg_frame_stride, d_frames, d_masks, d_out, (size_t)c->width * c->height, n, pick(c, stream)));
   return BSX_OK;
 }
@@ -746,6 +753,7 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
   if ((rc = run_infer(c, n, s, !fused_decode, 0))) return rc;
   if (c->oninfer) { BSX_HIP(c, hipStreamSynchronize(s)); c->oninfer(c->caller_ctx); }
   if (!fused_decode && (rc = run_decode(c, n, s))) return rc;
+  bsx_roctx::Range range("bsx:mask+blend");
   BSX_HIP(c, launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, d_bg,
                                bg_frame_stride, d_frames, d_out, n, s, (int)flags));
   return BSX_OK;
@@ -779,7 +787,7 @@ int pipelined_objects(bsx_ctx* c) {
   } else {
     BSX_HIP(c, hipStreamCreateWithFlags(&c->comp_stream, hipStreamNonBlocking));
   }
-  BSX_HIP(c, hipEventCreateWithFlags(&c->ev_pfork, hipEventDisableTiming));
+  BSX_HIP(c, hipEventCreateWithFlags(&c->ev_pdone, hipEventDisableTiming));
   BSX_HIP(c, hipEventCreateWithFlags(&c->ev_pcomp, hipEventDisableTiming));
   return BSX_OK;
 }
@@ -788,6 +796,7 @@ int composite_pending(bsx_ctx* c, hipStream_t s, bool concurrent) {
   // next to the network kernels the composite holds at most pipe_wgs workgroups per CU (an unused LDS pad: static 16.7 KB + pad <= 64 KB, i.e. >= 2 per CU)
   int pad = 0;
   if (concurrent && c->pipe_wgs > 0) pad = std::max(0, std::min(47 * 1024, (160 * 1024 / c->pipe_wgs - 17 * 1024) & ~255));
+  bsx_roctx::Range range("bsx:mask+blend");
   BSX_HIP(c, launch_mask_blend(c->d_ofinal, c->outW, c->outH, c->in_roi, c->tab_up.tab, c->d_masks, c->width, c->height, c->roi, p.bg, p.bg_stride, p.frames, p.out, p.n, s,
                                (int)p.flags, pad));
   return BSX_OK;
@@ -800,6 +809,7 @@ int bsx_step_batch_pipelined(bsx_ctx* c, const uint8_t* d_frames, const uint8_t*
   hipStream_t s = pick(c, stream);
   if (!d_frames) {                                                  // flush: the composite of the last batch, on the caller's stream
     if (!c->pend.active) return BSX_OK;
+    BSX_HIP(c, hipStreamWaitEvent(s, c->ev_pdone, 0));               // the pending batch's network may have run on another stream than this call's
     const int rc = composite_pending(c, s, false);
     c->pend.active = false;
     return rc;
@@ -817,8 +827,8 @@ int bsx_step_batch_pipelined(bsx_ctx* c, const uint8_t* d_frames, const uint8_t*
   if (rc) return rc;
   bool forked = false;
   if (c->pend.active) {
-    BSX_HIP(c, hipEventRecord(c->ev_pfork, s));                    // behind everything the caller's stream holds, i.e. behind the network of the pending batch
-    BSX_HIP(c, hipStreamWaitEvent(c->comp_stream, c->ev_pfork, 0));
+    BSX_HIP(c, hipStreamWaitEvent(c->comp_stream, c->ev_pdone, 0)); // behind the network of the pending batch, whatever stream the call that enqueued it was given
+    BSX_HIP(c, hipStreamWaitEvent(s, c->ev_pdone, 0));              // this call's network reuses the arena of the previous one: same order if the caller changed streams
     rc = composite_pending(c, c->comp_stream, true);
     // forked work is ALWAYS joined, also after an error: the caller's stream must not be left with work in flight on a stream it cannot see
     if (hipEventRecord(c->ev_pcomp, c->comp_stream) != hipSuccess) rc = rc ? rc : BSX_EDEVICE;
@@ -835,6 +845,7 @@ int bsx_step_batch_pipelined(bsx_ctx* c, const uint8_t* d_frames, const uint8_t*
     if (hipStreamWaitEvent(s, c->ev_pcomp, 0) != hipSuccess) rc = rc ? rc : BSX_EDEVICE;
   }
   if (rc) return rc;
+  BSX_HIP(c, hipEventRecord(c->ev_pdone, s));
   c->pend.active = true; c->pend.frames = d_frames; c->pend.bg = d_bg; c->pend.bg_stride = bg_frame_stride; c->pend.out = d_out; c->pend.n = n; c->pend.flags = flags;
   return BSX_OK;
 }
@@ -897,6 +908,7 @@ int bsx_debug_buffer(bsx_ctx* c, int which, void** d_ptr, size_t* bytes) {
 
 int bsx_debug_run_stage(bsx_ctx* c, int stage, const uint8_t* d_frames, int n, void* stream) {
   if (!c || n <= 0 || n > c->n_streams) return BSX_EINVAL;
+  if (stage >= 1 && stage <= 3 && c->pend.active) { c->last_error = "error: a pipelined composite is pending (flush with bsx_step_batch_pipelined(ctx, NULL, ...) first)\n"; return BSX_EINVAL; }
   DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   switch (stage) {
@@ -911,6 +923,7 @@ int bsx_debug_run_stage(bsx_ctx* c, int stage, const uint8_t* d_frames, int n, v
 int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_stride, uint8_t* d_out, int n, int iters,
                       bsx_launch_stat* out, int cap, void* stream) {
   if (!c || !d_frames || !d_bg || !d_out || !out || n <= 0 || n > c->n_streams || iters <= 0) return BSX_EINVAL;
+  if (c->pend.active) { c->last_error = "error: a pipelined composite is pending (flush with bsx_step_batch_pipelined(ctx, NULL, ...) first)\n"; return BSX_EINVAL; }
   DeviceGuard guard(c->device);
   hipStream_t s = pick(c, stream);
   const bool seg = c->use_program && c->plan.seg.on;

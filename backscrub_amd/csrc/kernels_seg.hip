@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   float* in_t = seg_smem;                                           // [IR][IC * 3]; no scratch block in front: the head has no gate prologue, and its partial-sum meeting
                                                                     // points (s_red, 512 floats) reuse this window once the stem is done with it — 2.5 KB that put the 4 x 14 tile's
                                                                     // workgroup exactly ON the 32 KB line (5 per CU only if the allocator wastes nothing)
-  float* a_t = in_t + ((IR * rowf + 3) & ~3);                       // x = act(pw(stem)) [AR][AC][16]: rows of AC pixels, not of RW = 16 ceil(AC / 16) — the MFMA tiles
+  float* a_t = in_t + max(512, (IR * rowf + 3) & ~3);                      // x = act(pw(stem)) [AR][AC][16]: rows of AC pixels, not of RW = 16 ceil(AC / 16) — the MFMA tiles
                                                                     // round the COMPUTE up to 16 pixels, the storage need not (5 workgroups per CU instead of 4 at a 4 x 13 tile)
   float* A_out = fa + d.a_off;                                      // uniform bases + 32-bit lane offsets (global_load/store saddr forms)
   float* b0_out = fa + d.b0_off;

@@ -115,3 +115,60 @@ class Collective:
         if dist.is_initialized():
             self.barrier()
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# host-side placement: a rank's launch loop and its pinned staging buffers belong on the NUMA node its GPU hangs off
+# ---------------------------------------------------------------------------------------------------------------------------
+def parse_cpulist(text: str):
+    """'0-3,8,10-11' (sysfs cpulist) → [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(pci_bus_id: str, sysfs: str = "/sys"):
+    """(numa node, its CPUs) of the PCI device 'dddd:bb:dd.f' per sysfs; (None, []) when the platform does not say (numa_node = -1: one node, or a VM)"""
+    try:
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower(), "numa_node")).read().strip())
+        if node < 0:
+            return None, []
+        return node, parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")).read())
+    except (OSError, ValueError):
+        return None, []
+
+
+def bind_to_gpu_numa(local_rank, sysfs: str = "/sys", pci_bus_id: str | None = None, dry_run: bool = False):
+    """Restrict this process to the CPUs of the NUMA node of GPU `local_rank` (∩ its current affinity mask) — one rank per GPU on a two-socket node otherwise
+    runs half of its launch loops and pinned copies across the socket interconnect.  Returns a small record for the bench detail file; never raises:
+    a platform that does not expose the topology leaves the affinity alone.  local_rank=None / dry_run: only report."""
+    rec = {"bound": False}
+    try:
+        if pci_bus_id is None and local_rank is not None:
+            import torch
+            p = torch.cuda.get_device_properties(local_rank)
+            pci_bus_id = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        if pci_bus_id is None:
+            rec["why"] = "no device"
+            return rec
+        rec["pci"] = pci_bus_id
+        node, cpus = gpu_numa_cpus(pci_bus_id, sysfs)
+        if node is None or not cpus:
+            rec["why"] = "sysfs names no NUMA node for this device"
+            return rec
+        rec["node"] = node
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            rec["why"] = "node %d has no CPU inside this process's affinity mask" % node
+            return rec
+        rec["cpus"] = len(allowed)
+        if not dry_run:
+            os.sched_setaffinity(0, allowed)
+            rec["bound"] = True
+    except Exception as e:  # noqa: BLE001 — placement is an optimisation, never a failure
+        rec["why"] = "%s: %s" % (type(e).__name__, e)
+    return rec

@@ -9,21 +9,26 @@ launched that way by someone else it just reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 A "step" is one pass of the whole per-frame hot path over one batch of device-resident synthetic camera frames: ROI
 resize + BGR2RGB + bilateral + normalise, the segmentation network, decode + temporal IIR, mask upscale + 5x5 blur, alpha
-blend with the background (`bsx_step_batch`).  `value` = BASELINE.json configs[1]: batch of 256 640x480 frames,
-segm_lite_v681 (Google Meet 160x96).  Streams are independent, so N GPUs run N such batches (weak scaling, no data-path
-collective); the only RCCL traffic is the all-reduce of the throughput counters.
+blend with the background (`bsx_step_batch`; reference: lib/libbackscrub.cc:279-376 + app/deepseg.cc:108-134).
+`value` = BASELINE.json configs[1]: batch of 256 640x480 frames, segm_lite_v681 (Google Meet 160x96), on a MOVING scene:
+every step reads the next batch of a ring of RING time steps per stream (the person sways, the sensor noise is redrawn),
+as a camera delivers them.  Streams are independent, so N GPUs run N such batches (weak scaling, no data-path collective);
+the only RCCL traffic is the all-reduce of the throughput counters.
 
-Rank 0 prints ONE JSON line (contract in the task statement) that additionally carries
-  roofline / roofline_blend   dominant kernel and the blend kernel, hipEvent-timed per launch (bsx_profile_batch)
-  cpu_baseline                the CPU oracle port timed on this box's host cores (+ parity_sample: mask IoU vs the oracle)
-  configs                     (N = 1 only) the other single-GPU BASELINE configurations, measured the same way:
-                              configs[2] 256 x 1280x720 mlkit, configs[3] 1024 x 640x480 deeplab with a per-step H2D upload +
-                              GPU resize of an animated background frame, configs[4]'s per-GPU slice 1024 x 1280x720 segm_full
-  single_stream               latency of the drop-in path (bsx_process_host = what bs_maskgen_process forwards to)
+Rank 0 prints ONE COMPACT JSON line (< 6 KB: contract keys + roofline + cpu_baseline + one short entry per BASELINE
+config) and writes everything else — per-launch tables, every leg of the CPU thread sweeps, the opt-in modes, notes — to
+`bench_detail.json` next to this file (and under gpurun_out/ when that directory exists).  compact_line() is the only
+place the printed line is assembled; tests/test_bench_contract.py holds it to the size limit.
+
+`roofline.frac` has ONE definition everywhere: bytes of the launch that must cross HBM (algorithmic bytes for this input
+minus the reads of cache-resident data all streams share) / hipEvent duration / 8 TB/s.  SURVEY 8(d)'s dense 10 B/px
+figure is carried as `dense_10Bpx_GBps` and is never a fraction.
+
 The oracle is used only in the cpu_baseline / parity legs — never in the measured path.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import sys
@@ -36,12 +41,15 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP32_PEAK_TFLOPS = 157.3   # f32 vector/matrix peak
 F16_PEAK_TFLOPS = 2500.0   # dense f16 MFMA peak
+LINE_LIMIT = 6144          # bytes of the printed line (the driver keeps an 8 KB tail: round 4's 22 KB line was unparsable)
+RING = 4                   # time steps per stream of the moving scene
 METRIC = "composited frames/sec at 640×480 (batch), 1/2/4/8 MI355X + mask IoU vs CPU ref"
 NAMES = {"lite": "segm_lite_v681.tflite", "full": "segm_full_v679.tflite",
          "mlkit": "selfiesegmentation_mlkit-256x256-2021_01_19-v1215.f16.tflite", "deeplab": "deeplabv3_257_mv_gpu.tflite"}
 PMC_NAMES = {"frame_program": ("bsx_mid", "frame_program_k"), "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
              "mask_upscale_blur": "mask_tile_k<false>", "prep": "prep_fused_k", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k",
              "seg_head": "seg_head_k", "seg_k2": "seg_k2_k", "seg_k3": "seg_k3_k", "seg_tail": "seg_tail_k", "seg_tail+decode": "seg_tail_k", "seg_gate": "seg_gate_k"}
+IMAGE_LAUNCHES = {"prep_resize": "prep", "prep_bilateral": "prep", "prep": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend", "mask_blend": "blend"}
 
 
 def cpu_description():
@@ -92,11 +100,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ramp-seconds", type=float, default=2.0, help="untimed clock ramp before the warmup steps: the step is repeated for this long so that "
-                    "the GPU has left its idle power state (a step is ~0.6 ms: W = 20 of them do not; a cold box measured 380 k instead of 455 k frames/s)")
+                    "the GPU has left its idle power state (a step is ~0.4 ms: W = 20 of them do not; a cold box measured 380 k instead of 455 k frames/s)")
     ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--model", default="lite", help="lite|full|mlkit|deeplab or a .tflite path")
+    ap.add_argument("--static-scene", action="store_true", help="time the SAME batch of frames every step (rounds 1-4's protocol) instead of the moving scene")
     ap.add_argument("--per-stream-bg", action="store_true", help="every stream composites over its own background frame instead of one shared image")
     ap.add_argument("--bg-ring", action="store_true", help="animated background: every step uploads the next frame of a pinned 36-frame 480x360 ring (H2D) and resizes it on the GPU (grab_background), inside the timed region")
     ap.add_argument("--host-io", action="store_true", help="measure the with-H2D/D2H variant (per-step upload of the frames and download of the composites through pinned host buffers) over steps/2 "
@@ -104,15 +113,14 @@ def parse():
     ap.add_argument("--no-host-io", action="store_true", help="skip the host_io leg")
     ap.add_argument("--second-device-check", action="store_true", help="(internal, run by `--gpus N` as a subprocess of rank 0) one context on a device other than 0, checked against device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` / `single_stream` legs (N = 1 only)")
-    ap.add_argument("--no-side-probes", action="store_true", help="skip the composite_only / pipelined probes that follow the timed region (profiling runs: their launches would mix into the per-kernel averages)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
-    ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the other BASELINE configurations, the opt-in modes and the single-stream legs (N = 1 only)")
+    ap.add_argument("--no-side-probes", action="store_true", help="skip everything that follows the timed region of the main configuration except its per-launch profile (profiling runs: other launches would mix into the per-kernel averages)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample of the main configuration (the other configurations get a third of it each)")
+    ap.add_argument("--profile-iters", type=int, default=8, help="per-launch hipEvent passes (each over the next batch of the scene ring)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch hipEvent table to this file")
+    ap.add_argument("--detail", default="", help="where the full record goes (default: bench_detail.json next to bench.py, and gpurun_out/ when it exists)")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU plumbing test of the multi-process path (gloo): launch, rendezvous, counter all-reduce, JSON line — no GPU work")
     a = ap.parse_args()
-    if a.no_side_probes:
-        os.environ["BSX_BENCH_NO_SIDE_PROBES"] = "1"
     return a
 
 
@@ -145,30 +153,44 @@ def self_launch(args):
 # ------------------------------------------------------------------------------------------------------------------------------
 # CPU legs (test infrastructure: the oracle is the checker / the baseline, never the measured path)
 # ------------------------------------------------------------------------------------------------------------------------------
-def parity_sample(model_path, width, height, frames, bg, gpu_masks, gpu_out, need_person):
-    """The metric's "mask IoU vs CPU ref" on a small sample: the first streams of the measured job (constant frames, so both
-    sides are in the IIR steady state) against the CPU oracle."""
+def parity_sequence(model_path, width, height, seq):
+    """The metric's "mask IoU vs CPU ref" on a small sample.  `seq` (measure(): parity_run) holds, for the first k streams of the measured job, the frames of S
+    consecutive steps FROM A RESET CONTEXT and what the GPU produced at every one of them; the oracle runs the same sequence from its own zero state
+    (lib/libbackscrub.cc:330,339,355: the IIR carries three frames of history), so outline pixels are compared while they still hold 0xE0 / 0xFC transients."""
     import numpy as np
     from oracle import oracle_py
-    ious, max_abs, differing, fg = [], 0, 0, []
-    k = len(frames)
-    for i in range(k):
+    frames, masks, outs, bgs = seq["frames"], seq["masks"], seq["out"], seq["bg"]
+    S, k = len(frames), len(frames[0])
+
+    def one_stream(i):
+        ious, max_abs, differing, fg, transient = [], 0, 0, 0.0, 0
         ctx = oracle_py.Ctx(model_path, width, height)
-        for _ in range(4):                                   # 3 frames flush the IIR, the 4th is the steady state
-            want = ctx.process(frames[i])
+        bg = bgs[i] if bgs.ndim == 4 else bgs
+        for t in range(S):
+            want = ctx.process(frames[t][i])
+            fa, fb = masks[t][i] < 128, want < 128
+            union = np.logical_or(fa, fb).sum()
+            ious.append(1.0 if union == 0 else float(np.logical_and(fa, fb).sum() / union))
+            comp = oracle_py.alpha_blend(bg, frames[t][i], want)
+            d = np.abs(comp.astype(np.int16) - outs[t][i].astype(np.int16))
+            max_abs = max(max_abs, int(d.max()))
+            differing += int((d > 1).any(axis=-1).sum())
+            if t == S - 1:
+                fg = float(fb.mean())
+                transient = int(((want > 0) & (want < 255)).sum())
         ctx.close()
-        fa, fb = gpu_masks[i] < 128, want < 128
-        fg.append(float(fb.mean()))
-        union = np.logical_or(fa, fb).sum()
-        ious.append(1.0 if union == 0 else float(np.logical_and(fa, fb).sum() / union))
-        comp = oracle_py.alpha_blend(bg, frames[i], want)
-        d = np.abs(comp.astype(np.int16) - gpu_out[i].astype(np.int16))
-        max_abs = max(max_abs, int(d.max()))
-        differing += int((d > 1).any(axis=-1).sum())
-    out = {"streams": k, "mask_iou_min": round(min(ious), 6), "composite_max_abs_diff": max_abs,
-           "composite_pixels_off_by_more_than_1": differing, "pixels": k * width * height,
-           "oracle_person_fraction": [round(v, 4) for v in fg]}
-    if need_person and max(fg) < 0.05:
+        return ious, max_abs, differing, fg, transient
+
+    from concurrent.futures import ThreadPoolExecutor          # one oracle context per stream, the C calls release the GIL (DeepLab: ~1.5 s per frame)
+    with ThreadPoolExecutor(max_workers=k) as ex:
+        per = list(ex.map(one_stream, range(k)))
+    ious = [v for p_ in per for v in p_[0]]
+    max_abs, differing = max(p_[1] for p_ in per), sum(p_[2] for p_ in per)
+    fg, transient = [p_[3] for p_ in per], sum(p_[4] for p_ in per)
+    out = {"streams": k, "steps": S, "mask_iou_min": round(min(ious), 6), "composite_max_abs_diff": max_abs,
+           "composite_pixels_off_by_more_than_1": differing, "pixels": k * S * width * height,
+           "oracle_person_fraction": [round(v, 4) for v in fg], "oracle_mask_pixels_between_0_and_255_last_step": transient}
+    if seq.get("need_person") and max(fg) < 0.05:
         out["warning"] = "oracle masks contain no person: IoU is vacuous"
     return out
 
@@ -197,33 +219,34 @@ def usable_cpus():
     return n, quota
 
 
-def cpu_baseline(model_path, width, height, target_s):
+def cpu_baseline(model_path, width, height, target_s, short=False):
     """Time the CPU oracle port on a bounded sample: a thread sweep 1, 2 (the reference's default `threads`, app/deepseg.cc:362), then doubling up to the CPUs
-    this process can use (usable_cpus: affinity and cgroup quota, not os.cpu_count()); `value` = the best leg, `cores` = its thread count.  The port parallelises
-    with OpenMP ACROSS streams (one stream — one context, created and first-touched by the thread that runs it — per thread); the reference's threads are TFLite
-    intra-op threads of ONE stream — a scalar port has no intra-op parallelism, so the t-thread leg is the throughput of t cores running t streams."""
+    this process can use (usable_cpus: affinity and cgroup quota, not os.cpu_count()); `value` = the best leg, `cores` = its thread count.  short=True (the
+    configurations other than the headline): only 1, 2 and the quota.  The port parallelises with OpenMP ACROSS streams (one stream — one context, created and
+    first-touched by the thread that runs it — per thread); the reference's threads are TFLite intra-op threads of ONE stream — a scalar port has no intra-op
+    parallelism, so the t-thread leg is the throughput of t cores running t streams."""
     from backscrub_amd import synth
     from oracle import oracle_py
     logical = os.cpu_count() or 1
     affinity, quota = usable_cpus()
     top = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
     bg = synth.background(width, height)
+    scenes = synth.frames(4, width, height)
 
     def leg(threads, budget_s):
-        frames = synth.frames(threads, width, height, distinct=min(threads, 4))
-        oracle_py.baseline_run(model_path, frames, bg, 1, threads)                 # warm-up (page faults, thread pool)
-        sec, _, _ = oracle_py.baseline_run(model_path, frames, bg, 2, threads)     # calibration
-        iters = int(max(2, min(200, budget_s / max(sec / 2, 1e-3))))
+        frames = scenes[[i % 4 for i in range(threads)]]
+        sec, _, _ = oracle_py.baseline_run(model_path, frames, bg, 1, threads)     # warm-up (page faults, thread pool) = calibration
+        iters = int(max(2, min(200, budget_s / max(sec, 1e-3))))
         sec, stages, _ = oracle_py.baseline_run(model_path, frames, bg, iters, threads)
         return threads * iters / sec, iters, sec, stages
 
-    counts = sorted({1, min(2, top), top} | {t for t in (4, 8, 16, 32, 64, 128, 256) if t < top})
-    if affinity > top:
+    counts = sorted({1, min(2, top), top} | (set() if short else {t for t in (4, 8, 16, 32, 64, 128, 256) if t < top}))
+    if affinity > top and not short:
         counts.append(affinity)              # one leg beyond the quota, to show that it is the quota (not the port) that caps the scaling
     legs, best = [], None
     share = target_s / (len(counts) + 1.0)
     for t in counts:
-        fps, iters, sec, stages = leg(t, max(1.0, share * (2.0 if t == top else 1.0)))
+        fps, iters, sec, stages = leg(t, max(0.5, share * (2.0 if t == top else 1.0)))
         legs.append({"threads": t, "value": round(fps, 2), "unit": "frames/s", "fps_per_thread": round(fps / t, 2),
                      "sample": "%d stream(s) x %d frames, %.1f s" % (t, iters, sec)})
         if best is None or fps > best[0]:
@@ -239,11 +262,11 @@ def cpu_baseline(model_path, width, height, target_s):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-# one measured configuration
+# roofline accounting
 # ------------------------------------------------------------------------------------------------------------------------------
 def load_pmc(B, W, H, model_name):
     """HBM-traffic counters of this workload from the COMMITTED rocprofv3 passes (profiles/pmc_latest.json: one entry per workload,
-    tools/profile_config.sh) — not measured in this run; the line says so in `traffic_source`."""
+    tools/profile_config.sh) — not measured in this run; the detail record says so in `traffic_source`."""
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         for e in pj.get("workloads", [pj]):
@@ -280,12 +303,18 @@ def traffic_of(pmc, launch_index, n_launches, name):
     return None, None
 
 
+def hbm_bytes_of(s):
+    """bytes of one launch that must cross HBM: its algorithmic bytes for this input minus the reads of cache-resident data every stream shares
+    (ONE background image for all B streams: 0.9 MB at VGA — L2 / MALL hits by construction)"""
+    return float(s["bytes"]) - float(s.get("shared_bytes") or 0.0)
+
+
 def roofline_of(s, pmc, model_name, launch_index=-1, n_launches=0):
-    """achieved = ALGORITHMIC bytes (or flops) of the launch / its mean hipEvent duration; traffic = HBM bytes per launch from
-    the committed rocprofv3 PMC passes: (2*FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 counts
-    128-B reads at 64 B).  The wall is chosen against the pipe the kernel ISSUES on (pipe_of): a launch is "mfma"-bound only if its arithmetic
-    intensity exceeds that pipe's ridge; below it the line is HBM bytes.  `frac_counted_traffic` = the counted HBM bytes over the same duration —
-    what really crosses HBM (algorithmic bytes that hit L2, e.g. a shared background image, are not in it)."""
+    """One definition for every launch: achieved = HBM-side bytes (hbm_bytes_of) — or useful flops — of the launch / its mean hipEvent duration; frac =
+    achieved / peak.  traffic = HBM bytes per launch from the committed rocprofv3 PMC passes: (2*FETCH_SIZE + WRITE_SIZE) KiB — FETCH_SIZE doubled per
+    MI355X_MICROARCH.md §HBM (gfx950 counts 128-B reads at 64 B); `frac_counted_traffic` = those bytes over the same duration.  The wall is chosen against the
+    pipe the kernel ISSUES on (pipe_of): a launch is "mfma"-bound only if its arithmetic intensity exceeds that pipe's ridge.  Figures that are NOT bandwidths —
+    the same launch priced with the cache-resident reads included, or at SURVEY 8(d)'s dense 10 B/px — carry their own names and never a `frac`."""
     traffic, kern = traffic_of(pmc, launch_index, n_launches, s["name"]) if pmc else (None, None)
     src = {}
     if traffic is not None:
@@ -296,34 +325,26 @@ def roofline_of(s, pmc, model_name, launch_index=-1, n_launches=0):
             src["traffic_stale_note"] = "backscrub_amd/csrc changed since the passes were collected (digest %s then, %s now)" % (pmc.get("csrc_digest"), csrc_digest())
     if kern:
         src["traffic_kernel"] = kern
+    sec = s["avg_ms"] * 1e-3
     pipe, peak_tf = pipe_of(model_name, s["name"])
-    counted = {"frac_counted_traffic": round(traffic / (s["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} if traffic and s["avg_ms"] > 0 else {}
-    if s["flops"] > 0 and s["flops"] / max(s["bytes"], 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
-        a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
+    hbm = hbm_bytes_of(s)
+    counted = {"frac_counted_traffic": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)} if traffic and sec > 0 else {}
+    if s["flops"] > 0 and s["flops"] / max(hbm, 1) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
+        a = s["flops"] / sec / 1e12
         return {"kernel": s["name"], "bound": "mfma", "pipe": pipe, "achieved": round(a, 3), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(a / peak_tf, 4),
                 "traffic": traffic, **src, **counted, "avg_ms": round(s["avg_ms"], 4), "algorithmic_flops_per_launch": int(s["flops"]),
-                "algorithmic_bytes_per_launch": int(s["bytes"])}
-    out = {"kernel": s["name"], "bound": "hbm", "achieved": round(s["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(s["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, **src, **counted, "avg_ms": round(s["avg_ms"], 4),
-           "algorithmic_bytes_per_launch": int(s["bytes"])}
-    if s.get("shared_bytes"):        # reads of the one background image every stream shares: algorithmic bytes, but L2 hits by construction
-        hs = (s["bytes"] - s["shared_bytes"]) / (s["avg_ms"] * 1e-3) / 1e9
-        out.update({"shared_background_bytes_per_launch": int(s["shared_bytes"]), "achieved_hbm_side": round(hs, 1), "frac_hbm_side": round(hs / HBM_PEAK_GBS, 4),
-                    "hbm_side_note": "achieved counts every algorithmic byte, incl. the reads of the ONE background image all streams share (cache hits); *_hbm_side leaves "
-                                     "them out = the bytes that must cross HBM; roofline_blend_per_stream_bg is the same kernel with every byte from HBM"})
-        if out["frac"] > 1.0:        # more algorithmic bytes per second than HBM can deliver: the line is only meaningful on its HBM side
-            out.update({"achieved_incl_shared_background": out["achieved"], "achieved": round(hs, 1), "frac": round(hs / HBM_PEAK_GBS, 4),
-                        "algorithmic_bytes_per_launch_incl_shared_background": out["algorithmic_bytes_per_launch"],
-                        "algorithmic_bytes_per_launch": int(s["bytes"] - s["shared_bytes"])})
-    if "bytes_dense" in s:           # the data-dependent fused mask + blend (measure()): what the launch had to move for this input, next to SURVEY §8(d)'s dense figure
-        out.update({"tiles": s["tiles"], "algorithmic_bytes_per_launch_dense_10Bpx": int(s["bytes_dense"]),
-                    "achieved_dense_10Bpx": round(s["bytes_dense"] / (s["avg_ms"] * 1e-3) / 1e9, 1),
-                    "note": "algorithmic bytes for THIS input: 11 B per ROI pixel on general tiles, 7 B on tiles whose mask is uniformly 0 / 255 (one operand is not read, "
-                            "the mask phases are skipped), 6 B outside the ROI; the *_dense_10Bpx fields price every pixel at SURVEY 8(d)'s 10 B and are NOT a bandwidth"})
+                "hbm_bytes_per_launch": int(hbm)}
+    a = hbm / sec / 1e9 if sec > 0 else 0.0
+    out = {"kernel": s["name"], "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+           "traffic": traffic, **src, **counted, "avg_ms": round(s["avg_ms"], 4), "hbm_bytes_per_launch": int(hbm)}
+    if s.get("shared_bytes"):
+        out.update({"cache_resident_bytes_per_launch": int(s["shared_bytes"]), "incl_cache_resident_GBps": round(s["bytes"] / sec / 1e9, 1)})
+    if "bytes_dense" in s:           # the data-dependent fused mask + blend (measure()): SURVEY §8(d)'s dense figure beside what the launch had to move for this input
+        out.update({"tiles": s["tiles"], "dense_10Bpx_bytes_per_launch": int(s["bytes_dense"]), "dense_10Bpx_GBps": round(s["bytes_dense"] / sec / 1e9, 1)})
     if s["flops"] > 0:
-        a = s["flops"] / (s["avg_ms"] * 1e-3) / 1e12
-        out.update({"algorithmic_flops_per_launch": int(s["flops"]), "flops_pipe": pipe, "flops_frac_of_pipe": round(a / peak_tf, 4),
-                    "intensity_flop_per_byte": round(s["flops"] / max(s["bytes"], 1), 1), "ridge_flop_per_byte": round(peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9), 1)})
+        fl = s["flops"] / sec / 1e12
+        out.update({"algorithmic_flops_per_launch": int(s["flops"]), "flops_pipe": pipe, "flops_frac_of_pipe": round(fl / peak_tf, 4),
+                    "intensity_flop_per_byte": round(s["flops"] / max(hbm, 1), 1), "ridge_flop_per_byte": round(peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9), 1)})
     return out
 
 
@@ -344,8 +365,30 @@ def solo_reference(coll, rank, fn):
     return v
 
 
-def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stream_bg=False, bg_ring=False, profile_iters=5, dump_launches="", ramp_s=0.0, coll=None,
-            profile=True):
+# ------------------------------------------------------------------------------------------------------------------------------
+# one measured configuration
+# ------------------------------------------------------------------------------------------------------------------------------
+def scene_ring(base, B, T, W, seed):
+    """[T][B,H,W,3] device-resident camera batches from `base` [D,H,W,3] (D noise-free scenes): time step t shifts the scene sideways by the sway of
+    synth.frame (1 % of the width x sin 0.7 t, whole pixels) and redraws +-6 uniform sensor noise — so outline pixels change class from step to step and the
+    temporal filter carries 0xE0 / 0xFC transients, as with a camera.  Stream i carries scene i mod D (its twins share every byte: the full-batch check relies on it).
+    Made on the GPU (an HD scene takes 0.4 s to render on the host); the parity leg downloads the very bytes it checks."""
+    import torch
+    D = base.shape[0]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0xB5C0 + seed)
+    ring = []
+    for t in range(T):
+        dx = int(round(0.01 * W * math.sin(0.7 * t)))
+        fr = torch.roll(base, shifts=dx, dims=2).to(torch.int16)
+        fr += torch.randint(-6, 7, fr.shape, generator=g, device="cuda", dtype=torch.int16)
+        fr = fr.clamp_(0, 255).to(torch.uint8)
+        ring.append(fr.repeat((B + D - 1) // D, 1, 1, 1)[:B].contiguous())
+    return ring
+
+
+def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stream_bg=False, bg_ring=False, profile_iters=8, dump_launches="", ramp_s=0.0, coll=None,
+            profile=True, moving=True, static_leg=False, parity_streams=2, parity_steps=0):
     """Run one configuration on this rank's GPU.  Returns a dict with the timed result and (rank 0) the per-launch profile and
     the samples the parity leg needs.  `coll` (backscrub_amd.dist.Collective) carries the barriers around the timed region and the one
     reduction of the job; None = this rank alone (N = 1, and rank 0's solo reference run at N > 1)."""
@@ -357,10 +400,10 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
 
     model_path, model_name, weights = resolve_model(model_key)
     mg = backscrub_amd.MaskGen(model_path, W, H, n_streams=B, device=local_rank)
-    # synthetic, device-resident inputs: each GPU owns its own B streams (seeded by global stream id); at 640x480 the first two
+    # synthetic, device-resident inputs: each GPU owns its own B streams (scenes seeded by rank); at 640x480 the first two
     # streams carry the two REAL webcam frames of tests/golden/photo_2x640x480.png so that the parity sample has a real person
     distinct = 16
-    host = synth.frames(distinct, W, H, t=rank)
+    host = np.stack([synth.frame(W, H, s + 16 * rank, 0, noise=0) for s in range(distinct)])
     photo = False
     if (W, H) == (640, 480):
         try:
@@ -369,29 +412,32 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
             photo = True
         except Exception:
             pass
-    d_base = torch.from_numpy(host).cuda()
-    d_frames = d_base.repeat((B + distinct - 1) // distinct, 1, 1, 1)[:B].contiguous()
+    T = RING if moving else 1
+    ring = scene_ring(torch.from_numpy(host).cuda(), B, T, W, seed=rank)
     bg_host = synth.background(W, H, seed=1 + rank)
     d_bg = torch.from_numpy(bg_host).cuda()
-    if per_stream_bg:      # [B,H,W,3]: one background frame per stream, rolled so that no two streams share bytes
-        d_bg = torch.stack([torch.roll(d_bg, shifts=3 * i, dims=1) for i in range(min(B, 64))]).repeat((B + 63) // 64, 1, 1, 1)[:B].contiguous()
-    d_out = torch.empty_like(d_frames)
-    ring = None
+    if per_stream_bg:      # [B,H,W,3]: one background frame per stream, no two streams share a byte (random bytes: nothing of it can come out of a cache)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(77 + rank)
+        d_bg = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty_like(ring[0])
+    bring = None
     if bg_ring:
         # animated background (configs[3]): the reference decodes the video on a host thread (app/background.cc:29-104) and
         # grab_background() resizes the current frame to the camera size EVERY frame (:186).  webm cannot be decoded in this image:
         # the decode is emulated by a ring of 36 pre-decoded 480x360 frames (the size of backgrounds/animated.gif) in PINNED host
         # memory; per step: H2D of the next frame + bsx_resize_bgr on the GPU, both inside the timed region.
-        ring = torch.from_numpy(np.stack([synth.background(480, 360, seed=100 + i) for i in range(36)])).pin_memory()
+        bring = torch.from_numpy(np.stack([synth.background(480, 360, seed=100 + i) for i in range(36)])).pin_memory()
         d_small = torch.empty((1, 360, 480, 3), dtype=torch.uint8, device="cuda")
 
-    def one_step(t):
-        if ring is not None:
-            d_small[0].copy_(ring[t % 36], non_blocking=True)
+    def one_step(t, frames=None):
+        fr = ring[t % T] if frames is None else frames
+        if bring is not None:
+            d_small[0].copy_(bring[t % 36], non_blocking=True)
             bg = mg.resize_bgr(d_small, W, H)[0]
-            mg.step(d_frames, bg, d_out)
+            mg.step(fr, bg, d_out)
         else:
-            mg.step(d_frames, d_bg, d_out)
+            mg.step(fr, d_bg, d_out)
 
     def barrier():
         torch.cuda.synchronize()
@@ -415,67 +461,20 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
 
     checksum = int(d_out[:, ::16, ::16].to(torch.int64).sum().item())
     total_frames, max_elapsed, checksum_all, rank_fps = finish_counters(coll, B * steps, elapsed, checksum)     # the only collective of the job
-    res = {"model_path": model_path, "model_name": model_name, "weights": weights, "B": B, "W": W, "H": H, "photo": photo,
+    res = {"model_path": model_path, "model_name": model_name, "weights": weights, "B": B, "W": W, "H": H, "photo": photo, "ring": T,
            "fps": total_frames / max_elapsed, "ms_per_step": 1e3 * max_elapsed / steps, "checksum": checksum_all, "mg": mg, "rank_fps": rank_fps,
-           "d_frames": d_frames, "d_bg": d_bg, "d_out": d_out, "host": host, "bg_host": bg_host}
+           "frames_ring": ring, "d_bg": d_bg, "d_out": d_out, "bg_host": bg_host, "steps": steps, "warmup": warmup}
     if rank == 0 and profile:
-        k = 4
-        if ring is not None:                 # parity needs ONE known background: re-run the last step over the still image
-            mg.step(d_frames, d_bg, d_out)
-            torch.cuda.synchronize()
-        res["masks_k"] = mg.masks()[:k].cpu().numpy()
-        res["out_k"] = d_out[:k].cpu().numpy()
-        # the same step without STORING the full-resolution mask (BSX_STEP_NO_MASK: 6 instead of 7 HBM bytes per pixel in the last launch) — reported beside
-        # `value`, never as it: the headline materialises the mask, as bs_maskgen_process does
-        if ring is None and not per_stream_bg and not os.environ.get("BSX_BENCH_NO_SIDE_PROBES"):
-            probe = max(3, min(steps, 100))
-            d_probe = torch.empty_like(d_out)
-            for t in range(3):
-                mg.step_ex(d_frames, d_bg, d_probe, no_mask=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for t in range(probe):
-                mg.step_ex(d_frames, d_bg, d_probe, no_mask=True)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            mg.step(d_frames, d_bg, d_out)                         # same temporal state → the composite must be the same bytes
-            torch.cuda.synchronize()
-            res["composite_only"] = {"what": "bsx_step_batch_ex(BSX_STEP_NO_MASK): composite written, full-resolution mask not stored", "steps": probe,
-                                     "value": round(B * probe / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / probe, 4),
-                                     "composite_identical_to_the_storing_step": bool(torch.equal(d_probe, d_out))}
-            # the same step as a two-deep pipeline (bsx_step_batch_pipelined): call k enqueues the mask pipeline of batch k and, on the context's own stream, the
-            # composite of batch k - 1 — the HBM-bound half under the latency-bound half, as the reference's CalcMask worker runs next to its blend loop
-            # (app/deepseg.cc:159-285).  `probe` calls = `probe` whole steps of work (the pipeline is primed before the clock starts and still holds one batch when
-            # it stops).  Reported beside `value`, never as it: `value` is the synchronous step.
-            try:
-                for t in range(3):
-                    mg.step_pipelined(d_frames, d_bg, d_probe)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for t in range(probe):
-                    mg.step_pipelined(d_frames, d_bg, d_probe)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
-                mg.flush_pipelined()
-                mg.step(d_frames, d_bg, d_out)
-                torch.cuda.synchronize()
-                res["pipelined"] = {"what": "bsx_step_batch_pipelined: mask pipeline of batch k on the caller's stream || mask tiles + blend of batch k - 1 on a low-priority "
-                                            "stream of the context; results bit-identical to the synchronous step, one call later", "steps": probe,
-                                    "value": round(B * probe / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / probe, 4),
-                                    "speedup_vs_value": round((B * probe / dt) / (total_frames / max_elapsed), 3) if world == 1 else None,
-                                    "composite_identical_to_the_synchronous_step": bool(torch.equal(d_probe, d_out))}
-            except Exception as e:  # noqa: BLE001 — an extra figure must not take the headline down
-                res["pipelined"] = {"error": str(e)[:200]}
-                try:
-                    mg.flush_pipelined()
-                except Exception:  # noqa: BLE001
-                    pass
-            del d_probe
+        last_t = warmup + steps - 1
         # EVERY stream of the batch, on the GPU: streams i and i + 16 carry the same scene (and, shared background, the same temporal history), so their
-        # masks and composites must be identical bytes whatever tile / workgroup / XCD they ran on; the first streams are then held to the oracle (parity_sample)
+        # masks and composites must be identical bytes whatever tile / workgroup / XCD they ran on; the first streams are then held to the oracle (parity_sequence)
         if per_stream_bg:
             res["full_batch"] = None
         else:
+            if bring is not None:                # twins need ONE known background: one more step over the still image
+                mg.step(ring[(last_t + 1) % T], d_bg, d_out)
+                last_t += 1
+                torch.cuda.synchronize()
             groups_ok = 0
             n_groups = B // distinct
             masks_all = mg.masks()[:B]
@@ -484,42 +483,57 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
                     groups_ok += 1
             res["full_batch"] = {"streams": B, "distinct_scenes": distinct, "groups_compared_with_group_0": max(n_groups - 1, 0), "groups_identical": groups_ok,
                                  "all_identical": groups_ok == max(n_groups - 1, 0)}
-        stats = mg.profile(d_frames, d_bg, d_out, iters=profile_iters)
+        # per-launch hipEvent times (bsx_profile_batch, one pass per call) over the NEXT batches of the ring, so that the data-dependent launch is timed on the
+        # moving scene's tile mix; its tile classification is read after every pass
+        acc, tiles_acc, P = None, {}, max(profile_iters, T)
+        for p in range(P):
+            st = mg.profile(ring[(last_t + 1 + p) % T], d_bg, d_out, iters=1)
+            if acc is None:
+                acc = st
+            else:
+                for a_, b_ in zip(acc, st):
+                    a_["avg_ms"] += b_["avg_ms"]
+            try:
+                ts = mg.mask_tile_stats(B)
+                for k_ in ("tiles", "uniform_255", "uniform_0", "general"):
+                    tiles_acc[k_] = tiles_acc.get(k_, 0) + ts[k_]
+            except Exception:  # noqa: BLE001 — accounting only
+                tiles_acc = None
+        stats = acc
+        for s in stats:
+            s["avg_ms"] /= P
+        last_t += P
         # The fused mask + blend launch is data dependent since round 4: a tile whose whole model-resolution source block is 0xFF / 0x00 (the temporal filter's steady
         # state away from the person's outline) skips the mask phases and reads only the operand its composite is a copy of.  Its algorithmic bytes are therefore
-        # stated for THIS input: per ROI pixel 11 B on a general tile (background 3 + frame 3 read, composite 3 + mask 1 written), 7 B on a uniform one; 6 B outside
-        # the ROI (background copied).  `bytes_dense` keeps SURVEY §8(d)'s 10 B/px figure.
-        try:
-            ts = mg.mask_tile_stats(B)
+        # stated for THIS input: per ROI pixel 11 B on a general tile (background 3 + frame 3 read, composite 3 + mask 1 written + the model-resolution source), 7 B
+        # on a uniform one; 6 B outside the ROI (background copied).  `bytes_dense` keeps SURVEY §8(d)'s 10 B/px figure.
+        ts = None
+        if tiles_acc:
+            ts = {k_: v / P for k_, v in tiles_acc.items()}
+            ts["tile"] = "128x32"
             i_ = mg.info
             roi_px, in_roi_px = i_["roi"][2] * i_["roi"][3], i_["in_roi"][2] * i_["in_roi"][3]
             f_uni = (ts["uniform_255"] + ts["uniform_0"]) / max(ts["tiles"], 1)
             aware = B * (in_roi_px + 6.0 * (W * H - roi_px) + roi_px * (11.0 * (1.0 - f_uni) + 7.0 * f_uni))
-            res["mask_tiles"] = {k: ts[k] for k in ("tiles", "uniform_255", "uniform_0", "general", "tile")}
+            res["mask_tiles"] = {**{k_: round(ts[k_], 1) for k_ in ("tiles", "uniform_255", "uniform_0", "general")}, "tile": "128x32", "uniform_fraction": round(f_uni, 4)}
             for s in stats:
                 if s["name"] == "mask_blend":
                     s["bytes_dense"] = s["bytes"]
                     s["bytes"] = aware
-                    s["tiles"] = {k: ts[k] for k in ("tiles", "uniform_255", "uniform_0", "general", "tile")}
-        except Exception:  # noqa: BLE001 — accounting only
-            pass
-        # ONE background image shared by all B streams (0.9 MB at VGA) is cache-resident by construction: its reads are part of the algorithmic bytes (10 B/px)
-        # but cannot be HBM traffic.  Stated per launch so that every blend line also carries its HBM-SIDE figure (roofline_of: *_hbm_side).
+                    s["tiles"] = res["mask_tiles"]
+        # ONE background image shared by all B streams (0.9 MB at VGA) is cache-resident by construction: its reads are algorithmic bytes (10 B/px)
+        # but cannot be HBM traffic — hbm_bytes_of() leaves them out of every bandwidth.
         if not per_stream_bg:
-            try:
-                i_ = mg.info
-                roi_px = i_["roi"][2] * i_["roi"][3]
-                ts_ = res.get("mask_tiles")
-                f_bg = (ts_["general"] + ts_["uniform_255"]) / max(ts_["tiles"], 1) if ts_ else 1.0      # tiles that read the background at all
-                for s in stats:
-                    if s["name"] == "mask_blend":
-                        s["shared_bytes"] = B * 3.0 * ((W * H - roi_px) + roi_px * f_bg)
-                    elif s["name"].startswith("blend"):
-                        s["shared_bytes"] = B * 3.0 * W * H
-            except Exception:  # noqa: BLE001 — accounting only
-                pass
+            i_ = mg.info
+            roi_px = i_["roi"][2] * i_["roi"][3]
+            f_bg = (ts["general"] + ts["uniform_255"]) / max(ts["tiles"], 1) if ts else 1.0      # tiles that read the background at all
+            for s in stats:
+                if s["name"] == "mask_blend":
+                    s["shared_bytes"] = B * 3.0 * ((W * H - roi_px) + roi_px * f_bg)
+                elif s["name"].startswith("blend"):
+                    s["shared_bytes"] = B * 3.0 * W * H
         for s in stats:
-            s["GBps"] = s["bytes"] / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
+            s["GBps"] = hbm_bytes_of(s) / (s["avg_ms"] * 1e-3) / 1e9 if s["avg_ms"] > 0 else 0.0
         extra = [s for s in stats if s["name"].endswith("(standalone)")]   # measured for its roofline line, not part of the step
         stats = [s for s in stats if not s["name"].endswith("(standalone)") and "(inside the launch before)" not in s["name"]]   # fused-away steps launch nothing
         if dump_launches:
@@ -529,22 +543,53 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
                     f.write("%3d %-22s %8.2f us %9.1f GB/s %8.2f GFLOP/s\n" % (i, s["name"], s["avg_ms"] * 1e3, s["GBps"], s["flops"] / max(s["avg_ms"], 1e-9) / 1e6))
         groups = {"prep": 0.0, "network": 0.0, "decode": 0.0, "mask": 0.0, "blend": 0.0}
         for s in stats:
-            g = {"prep_resize": "prep", "prep_bilateral": "prep", "prep": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend",
-                 "mask_blend": "blend"}.get(s["name"], "network")
-            groups[g] += s["avg_ms"]
-        net = [s for s in stats if {"prep_resize": 1, "prep_bilateral": 1, "prep": 1, "decode_iir": 1, "mask_upscale_blur": 1, "blend": 1, "mask_blend": 1}.get(s["name"]) is None]
+            groups[IMAGE_LAUNCHES.get(s["name"], "network")] += s["avg_ms"]
+        net = [s for s in stats if s["name"] not in IMAGE_LAUNCHES]
         res.update(stats=stats, extra=extra, groups=groups, net=net, net_ms=sum(s["avg_ms"] for s in net), net_flops=sum(s["flops"] for s in net),
                    net_launches=len(net))
+        # the SAME batch every step (rounds 1-4's protocol), in the same context, beside the moving scene: the temporal filter then settles on pure 0x00 / 0xFF
+        # and the uniform-tile shortcut takes its best case
+        if static_leg and moving and coll is None:
+            n_st = max(20, min(steps, 100))
+            for t in range(4):
+                one_step(t, ring[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for t in range(n_st):
+                one_step(t, ring[0])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            st = {"value": round(B * n_st / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_st, 4), "steps": n_st}
+            try:
+                ts_ = mg.mask_tile_stats(B)
+                st["uniform_fraction"] = round((ts_["uniform_255"] + ts_["uniform_0"]) / max(ts_["tiles"], 1), 4)
+            except Exception:  # noqa: BLE001
+                pass
+            res["static_scene"] = st
+        # parity sample: reset, then RING + 3 consecutive steps of the first streams, every step's mask and composite kept for the oracle (parity_sequence)
+        k = min(parity_streams, B)
+        S = parity_steps or ((T + 3) if moving else 4)
+        mg.reset()
+        seq = {"frames": [], "masks": [], "out": [], "need_person": photo,
+               "bg": (d_bg[:k] if per_stream_bg else d_bg).cpu().numpy()}
+        for t in range(S):
+            mg.step(ring[t % T], d_bg, d_out)
+            torch.cuda.synchronize()
+            seq["frames"].append(ring[t % T][:k].cpu().numpy())
+            seq["masks"].append(mg.masks()[:k].cpu().numpy())
+            seq["out"].append(d_out[:k].cpu().numpy())
+        res["parity_in"] = seq
     return res
 
 
 def summarize(res, pmc):
-    """→ the JSON fragment of one measured configuration (rank 0)."""
+    """→ the full JSON fragment of one measured configuration (rank 0); compact_config() cuts it down for the printed line."""
     stats, extra = res["stats"], res["extra"]
     dom = max(stats, key=lambda s: s["avg_ms"])
     blend = dict((extra or [s for s in stats if s["name"] in ("blend", "mask_blend")])[0], name="blend")
     n_l = len(stats)
-    out = {"value": round(res["fps"], 1), "unit": "frames/s", "ms_per_step": round(res["ms_per_step"], 4),
+    out = {"value": round(res["fps"], 1), "unit": "frames/s", "ms_per_step": round(res["ms_per_step"], 4), "steps": res["steps"], "warmup": res["warmup"],
+           "scene": "moving (ring of %d batches)" % res["ring"] if res["ring"] > 1 else "static (the same batch every step)",
            "roofline": roofline_of(dom, pmc, res["model_name"], stats.index(dom), n_l), "roofline_blend": roofline_of(blend, pmc, res["model_name"])}
     if extra:
         out["roofline_blend"]["note"] = "bsx_composite_batch kernel timed stand-alone; inside the step the blend is fused with mask upscale+blur (mask_blend)"
@@ -566,12 +611,9 @@ def summarize(res, pmc):
                                    "counted_GBps": round(traffic / ms / 1e9, 1) if traffic else None, "frac_hbm_counted_traffic": round(f_cnt, 4) if f_cnt else None,
                                    "peak_hbm_GBps": HBM_PEAK_GBS, "traffic": traffic, "avg_ms": round(res["net_ms"], 4),
                                    "note": "frac_of_issuing_pipes = sum over launches of useful flops / the peak of the pipe that launch issues on (pipe_of), over the measured time"}
-    if res.get("mask_tiles") is not None:      # how the fused mask + blend launch classified its tiles for this input (uniform tiles skip the mask phases and one operand)
-        out["mask_tiles"] = res["mask_tiles"]
-    if res.get("composite_only") is not None:
-        out["composite_only"] = res["composite_only"]
-    if res.get("pipelined") is not None:
-        out["pipelined"] = res["pipelined"]
+    for k_ in ("mask_tiles", "static_scene"):
+        if res.get(k_) is not None:
+            out[k_] = res[k_]
     if res.get("full_batch") is not None:
         out["full_batch_twin_streams"] = res["full_batch"]
     out["stage_ms"] = {k: round(v, 4) for k, v in res["groups"].items()}
@@ -583,7 +625,7 @@ def summarize(res, pmc):
 def release(res):
     import torch
     res["mg"].close()
-    for k in ("mg", "d_frames", "d_bg", "d_out"):
+    for k in ("mg", "frames_ring", "d_bg", "d_out", "parity_in"):
         res.pop(k, None)
     torch.cuda.empty_cache()
 
@@ -614,7 +656,7 @@ def single_stream_latency(model_key, W, H, calls):
 
 
 def multi_gpu_sections(coll, main, c4, solo1, solo4, world):
-    """The N > 1 part of the line (rank 0): what RCCL really connected, the per-rank rates behind `value`, the north-star job's per-GPU slice
+    """The N > 1 part of the record (rank 0): what RCCL really connected, the per-rank rates behind `value`, the north-star job's per-GPU slice
     (BASELINE configs[4]: 8192 x 1280x720 segm_full streams over 8 GPUs = 1024 per GPU, weak-scaled to N) and both against rank 0 running the
     same work ALONE on this box a moment earlier (the other ranks waiting at a barrier) — the driver computes its own efficiency from separate runs;
     this one is same-box, same-minute.  `main` / `c4`: {"fps", "ms_per_step", "rank_fps"}; solo*: frames/s or None."""
@@ -635,12 +677,190 @@ def multi_gpu_sections(coll, main, c4, solo1, solo4, world):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# the printed line
+# ------------------------------------------------------------------------------------------------------------------------------
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short_model(name):
+    return {v: k for k, v in NAMES.items()}.get(name, name)
+
+
+def compact_roofline(r):
+    """the task statement's roofline object {bound, achieved, peak, unit, frac, traffic} + the launch it is about, its hipEvent duration, the counted-traffic
+    fraction and (the data-dependent fused launch) the dense 10 B/px figure and the share of uniform tiles"""
+    if not isinstance(r, dict) or "frac" not in r:
+        return None
+    out = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac"))
+    out["traffic"] = r.get("traffic")
+    out.update(_pick(r, ("avg_ms", "frac_counted_traffic", "traffic_stale", "dense_10Bpx_GBps")))
+    if isinstance(r.get("tiles"), dict) and "uniform_fraction" in r["tiles"]:
+        out["uniform_tiles"] = r["tiles"]["uniform_fraction"]
+    return out
+
+
+def compact_parity(p):
+    if not isinstance(p, dict) or "mask_iou_min" not in p:
+        return None
+    out = {"iou_min": p["mask_iou_min"], "max_abs": p["composite_max_abs_diff"], "px_off_gt1": p["composite_pixels_off_by_more_than_1"], "streams": p["streams"], "steps": p.get("steps")}
+    if "warning" in p:
+        out["vacuous"] = True
+    return out
+
+
+def compact_cpu(c, full=False):
+    """{value, cores} (+ the 1- and 2-thread legs; the headline also kind / unit / sample / host)"""
+    if not isinstance(c, dict) or c.get("value") is None:
+        return _pick(c, ("value", "cores", "kind", "unit", "sample")) if isinstance(c, dict) else None
+    out = {"value": c["value"], "cores": c["cores"]}
+    for leg in c.get("legs", []):
+        if leg["threads"] in (1, 2):
+            out["t%d" % leg["threads"]] = leg["value"]
+    if full:
+        h = c.get("host", {})
+        out.update({"unit": c["unit"], "kind": c["kind"],
+                    "sample": "oracle -O3 port, OpenMP over streams: %s; best of 1/2/.../quota threads" % c["sample"].split(" through ")[0],
+                    "host": "%s, %s logical CPUs, cgroup quota %s" % (h.get("model"), h.get("logical_cpus"), h.get("cgroup_cpu_quota")),
+                    "stage_share": c.get("stage_share")})
+    return out
+
+
+def compact_config(tag, frag):
+    """one BASELINE configuration in the printed line: {baseline_config, value, ms_per_step, steps, frac (+ its kernel), iou_min, max_abs, cpu {value, cores}}"""
+    if "error" in frag:
+        return {"baseline_config": tag, "error": str(frag["error"])[:160]}
+    out = {"baseline_config": tag}
+    out.update(_pick(frag, ("net", "batch", "frame", "value", "ms_per_step", "steps")))
+    r = frag.get("roofline")
+    if isinstance(r, dict):
+        out.update({"kernel": r.get("kernel"), "bound": r.get("bound"), "frac": r.get("frac"), "kernel_ms": r.get("avg_ms")})
+        if r.get("frac_counted_traffic") is not None:
+            out["frac_counted"] = r["frac_counted_traffic"]
+    rn = frag.get("roofline_network")
+    if isinstance(rn, dict):
+        out["network"] = _pick(rn, ("bound", "frac", "avg_ms"))
+    if isinstance(frag.get("static_scene"), dict):
+        out["static_value"] = frag["static_scene"]["value"]
+    if isinstance(frag.get("mask_tiles"), dict):
+        out["uniform_tiles"] = frag["mask_tiles"].get("uniform_fraction")
+    p = compact_parity(frag.get("parity_sample"))
+    if p:
+        out.update({"iou_min": p["iou_min"], "max_abs": p["max_abs"]})
+    fb = frag.get("full_batch_twin_streams")
+    if isinstance(fb, dict):
+        out["twins_identical"] = fb["all_identical"]
+    c = compact_cpu(frag.get("cpu_baseline"))
+    if c:
+        out["cpu"] = c
+    return out
+
+
+def compact_line(d):
+    """The ONE line the driver parses, cut from the full record `d` (which goes to bench_detail.json): contract keys, `roofline`, `cpu_baseline`, and a short
+    entry per BASELINE configuration / opt-in mode.  No prose beyond `config.workload` and `cpu_baseline.sample`."""
+    out = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = d.get("config")
+    out["roofline"] = compact_roofline(d.get("roofline"))
+    for k in ("roofline_blend", "roofline_blend_per_stream_bg"):
+        r = compact_roofline(d.get(k))
+        if r:
+            out[k] = _pick(r, ("achieved", "frac", "avg_ms", "frac_counted_traffic"))
+    rn = d.get("roofline_network")
+    if isinstance(rn, dict):
+        out["roofline_network"] = _pick(rn, ("bound", "frac", "avg_ms", "flops_TFLOPs", "frac_of_issuing_pipes", "frac_hbm_counted_traffic"))
+    if d.get("stage_ms"):
+        out["stage_ms"] = d["stage_ms"]
+    if d.get("top_launches"):
+        out["top_launches"] = [[t["name"], t["ms"], t["GBps"]] for t in d["top_launches"][:4]]
+    c = d.get("cpu_baseline")
+    if isinstance(c, dict):
+        cc = compact_cpu(c, full=True) or {}
+        p = compact_parity(c.get("parity_sample"))
+        if p:
+            cc["parity_sample"] = p
+        out["cpu_baseline"] = cc
+    fb = d.get("full_batch_twin_streams")
+    if isinstance(fb, dict):
+        out["twins_identical"] = fb["all_identical"]
+    if isinstance(d.get("static_scene"), dict):
+        out["static_scene"] = _pick(d["static_scene"], ("value", "ms_per_step", "steps", "uniform_fraction"))
+    w = d.get("worst_case")
+    if isinstance(w, dict):
+        out["worst_case"] = w if "error" in w else {**_pick(w, ("value", "ms_per_step", "steps")), **_pick(w.get("roofline") or {}, ("frac", "avg_ms")),
+                                                    **({"iou_min": w["parity_sample"]["mask_iou_min"], "max_abs": w["parity_sample"]["composite_max_abs_diff"]}
+                                                       if isinstance(w.get("parity_sample"), dict) else {})}
+    if d.get("configs"):
+        out["configs"] = [compact_config(f.get("baseline_config"), f) for f in d["configs"]]
+    modes = []
+    for m in (d.get("gemm_modes") or []) + (d.get("act_modes") or []):
+        e = _pick(m, ("env", "cfg", "value", "ms_per_step", "steps"))
+        p = compact_parity(m.get("parity_sample"))
+        if p:
+            e.update({"iou_min": p["iou_min"], "max_abs": p["max_abs"], "within_1lsb": p["max_abs"] <= 1 and p["iou_min"] >= 0.999})
+        if "error" in m:
+            e["error"] = str(m["error"])[:100]
+        modes.append(e)
+    if modes:
+        out["opt_in_modes"] = modes
+    for k, keys in (("host_io", ("value", "ms_per_step", "steps")), ("yuyv_out", ("value", "bit_identical_to_step_then_bgr_to_yuyv")), ("bgblur_step", ("value", "speedup"))):
+        if isinstance(d.get(k), dict):
+            out[k] = _pick(d[k], keys)
+    if isinstance(d.get("single_stream"), dict) and d["single_stream"].get("runs"):
+        out["single_stream_p50_ms"] = {_short_model(r["network"]) + "/" + r["frame"]: r["p50_ms"] for r in d["single_stream"]["runs"]}
+    # N > 1
+    if d.get("collective"):
+        out["collective"] = d["collective"]
+        for k in ("configs1", "configs4"):
+            if isinstance(d.get(k), dict):
+                e = _pick(d[k], ("value", "ms_per_step", "per_rank_fps_min", "per_rank_fps_max", "rank0_alone_fps", "efficiency_vs_rank0_alone", "streams_total"))
+                r = d[k].get("roofline")
+                if isinstance(r, dict):
+                    e["frac"] = r.get("frac")
+                p = compact_parity(d[k].get("parity_sample"))
+                if p:
+                    e.update({"iou_min": p["iou_min"], "max_abs": p["max_abs"]})
+                out[k] = e
+        if d.get("gpu_sharing"):
+            out["gpu_sharing"] = True
+        s2 = d.get("second_device_check")
+        if isinstance(s2, dict):
+            out["second_device_check"] = _pick(s2, ("ran", "ok", "why"))
+    out["detail"] = d.get("detail_file", "bench_detail.json")
+    return out
+
+
+def emit(detail, path=""):
+    """write the full record, print the compact line (shrunk further, least important parts first, should it ever exceed LINE_LIMIT)"""
+    targets = [path] if path else [os.path.join(ROOT, "bench_detail.json")]
+    if not path and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        targets.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    for t in targets:
+        try:
+            with open(t, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError:
+            pass
+    line = compact_line(detail)
+    s = json.dumps(line, separators=(",", ":"))
+    for k in ("single_stream_p50_ms", "bgblur_step", "yuyv_out", "top_launches", "opt_in_modes", "roofline_blend", "stage_ms", "host_io", "roofline_network"):
+        if len(s.encode()) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+        s = json.dumps(line, separators=(",", ":"))
+    print(s, flush=True)
+    return s
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
 def selftest_dist(args):
     """CPU plumbing check of the multi-process path (tests/test_dist_gloo.py): the same launch, rendezvous, Collective (gloo instead of RCCL),
     barriers, counter reduction, per-rank gather and JSON assembly (multi_gpu_sections) as the GPU run — the GPU work replaced by made-up timings."""
-    from backscrub_amd.dist import Collective, shard_streams
+    from backscrub_amd.dist import Collective, bind_to_gpu_numa, shard_streams
     coll = Collective(gpu=False)
     world, rank = coll.world, coll.rank
+    numa = bind_to_gpu_numa(None, dry_run=True)
 
     def fake(B, W, H, name, steps, ms, c):                # what measure() does around its timed region, with a rank-dependent made-up duration
         if c is not None:
@@ -662,14 +882,14 @@ def selftest_dist(args):
     if rank == 0:
         line = {"metric": METRIC, "selftest": "dist", "value": main["fps"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": main["ms_per_step"], "higher_is_better": True, "scaling": "weak", "frames": main["frames"], "elapsed_max": main["elapsed_max"],
-                "checksum": main["checksum"], "host": cpu_description()}
+                "checksum": main["checksum"], "host": cpu_description(), "numa": numa}
         line.update(multi_gpu_sections(coll, main, c4, solo1, solo4, world))
     coll.close()
     if rank == 0:
         if not args.no_cpu_baseline:                      # kept at world > 1 (rank 0, after the other ranks have left)
             try:
                 path, _, _ = resolve_model(args.model)
-                line["cpu_baseline"] = cpu_baseline(path, args.width, args.height, args.cpu_seconds)
+                line["cpu_baseline"] = cpu_baseline(path, args.width, args.height, args.cpu_seconds, short=True)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
@@ -750,7 +970,7 @@ def main():
         return selftest_dist(args)
     import torch
 
-    from backscrub_amd.dist import Collective
+    from backscrub_amd.dist import Collective, bind_to_gpu_numa
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -763,45 +983,48 @@ def main():
     shared = world > n_dev                                     # more ranks than GPUs (e.g. `--gpus 2` on a 1-GPU box): ranks share devices round-robin — a plumbing run,
     local_rank = local_rank % n_dev                            # labelled `gpu_sharing` in the line; RCCL needs one GPU per rank, so the counters then travel over gloo
     torch.cuda.set_device(local_rank)
+    numa = bind_to_gpu_numa(local_rank) if world > 1 else None  # each rank's host threads (launch loop, pinned staging buffers of the host_io leg) next to its GPU
     coll = Collective(gpu=not shared) if world > 1 else None   # RCCL over xGMI, probed; labelled gloo fall-back if RCCL cannot be brought up
     if coll is not None and shared:
         coll.backend, coll.note = "gloo (ranks share GPUs)", "%d ranks on %d visible GPU(s): RCCL requires one GPU per rank" % (world, n_dev)
 
     W, H, B = args.width, args.height, args.batch
+    moving = not args.static_scene
     default_job = (args.model, W, H, B) == ("lite", 640, 480, 256) and not args.per_stream_bg and not args.bg_ring
+    side = not args.no_side_probes
     solo1 = solo4 = None
     if coll is not None:
         # rank 0 ALONE first (the others wait at the barrier): the N = 1 reference of this box, minutes — not runs — apart from the N-rank number
         def solo_main():
             r1 = measure(args.model, W, H, B, args.steps, args.warmup, 0, 1, local_rank, ramp_s=args.ramp_seconds, per_stream_bg=args.per_stream_bg, bg_ring=args.bg_ring,
-                         profile=False)
+                         profile=False, moving=moving)
             fps = r1["fps"]
             release(r1)
             return fps
         solo1 = solo_reference(coll, rank, solo_main)
     res = measure(args.model, W, H, B, args.steps, args.warmup, rank, world, local_rank, ramp_s=args.ramp_seconds, per_stream_bg=args.per_stream_bg, bg_ring=args.bg_ring,
-                  profile_iters=args.profile_iters, dump_launches=args.dump_launches, coll=coll)
+                  profile_iters=args.profile_iters, dump_launches=args.dump_launches, coll=coll, moving=moving, static_leg=side, parity_streams=4)
     multi = None
-    c4_frag = c4_samples = None
+    c4_frag = c4_parity_in = None
     if coll is not None:
         main_leg = {k: res[k] for k in ("B", "W", "H", "model_name", "fps", "ms_per_step", "rank_fps")}
         c4 = None
         if default_job and not args.no_extra_configs:
             # the north-star job's per-GPU slice on EVERY rank: BASELINE configs[4] = 8192 x HD segm_full streams / 8 GPUs = 1024 per GPU
-            n4 = max(3, args.steps // 4)
-            kw4 = dict(model_key="full", W=1280, H=720, B=1024)
+            n4 = max(20, args.steps // 4)
+            kw4 = dict(model_key="full", W=1280, H=720, B=1024, moving=moving)
             try:
                 def solo_c4():
-                    r4s = measure(steps=n4, warmup=2, rank=0, world=1, local_rank=local_rank, profile=False, **kw4)
+                    r4s = measure(steps=n4, warmup=3, rank=0, world=1, local_rank=local_rank, profile=False, **kw4)
                     fps = r4s["fps"]
                     release(r4s)
                     return fps
                 solo4 = solo_reference(coll, rank, solo_c4)
-                r4 = measure(steps=n4, warmup=2, rank=rank, world=world, local_rank=local_rank, profile_iters=2, coll=coll, **kw4)
+                r4 = measure(steps=n4, warmup=3, rank=rank, world=world, local_rank=local_rank, profile_iters=4, coll=coll, **kw4)
                 c4 = {k: r4[k] for k in ("B", "W", "H", "model_name", "fps", "ms_per_step", "rank_fps")}
                 if rank == 0:
                     c4_frag = summarize(r4, load_pmc(1024, 1280, 720, r4["model_name"]))
-                    c4_samples = (r4["model_path"], r4["host"][:2].copy(), r4["bg_host"], r4["masks_k"], r4["out_k"], r4["photo"])
+                    c4_parity_in = (r4["model_path"], r4["parity_in"])
                 release(r4)
             except Exception as e:  # noqa: BLE001 — every rank takes the same path: the exception classes here are allocation / model errors, identical on all ranks
                 c4 = None
@@ -812,33 +1035,39 @@ def main():
             if c4_frag is not None and "configs4" in multi:
                 multi["configs4"].update({k: v for k, v in c4_frag.items() if k in ("roofline", "stage_ms", "top_launches", "full_batch_twin_streams", "error")})
         coll.close()                                          # ranks > 0 are done; rank 0 goes on alone (parity, CPU baseline, the device check)
-    result = None
-    if rank == 0:
-        import backscrub_amd
-        mode = backscrub_amd.bs_tensorflow_version()
-        result = {
-            "metric": METRIC, "value": round(res["fps"], 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (network) / u8 (image kernels)", "data": "synthetic (%s)" % res["weights"],
-            "config": {"workload": "BASELINE configs[1]: batch=%d %dx%d frames, %s; 1 step = whole per-frame hot path (prep+network+decode+mask+blend), inputs resident in HBM; "
-                                   "mask IoU vs the CPU oracle: cpu_baseline.parity_sample" % (B, W, H, res["model_name"]),
-                       "streams_per_gpu": B, "frame": "%dx%d" % (W, H), "network": res["model_name"], "sharding": "streams/%d GPUs, no data-path collective" % world,
-                       "library": mode},
-            "checksum": res["checksum"], "host": cpu_description(),
-        }
-        result.update({k: v for k, v in summarize(res, load_pmc(B, W, H, res["model_name"])).items() if k not in ("value", "unit", "ms_per_step")})
-        if multi is not None:
-            result.update(multi)
-            if shared:
-                result["gpu_sharing"] = "%d ranks on %d GPU(s): throughput numbers of this line are a plumbing run, not a scaling measurement" % (world, n_dev)
+    if rank != 0:
+        release(res)
+        return
+    import backscrub_amd
+    mode = backscrub_amd.bs_tensorflow_version()
+    scene = ("moving scene: ring of %d batches, a new one every step" % RING) if moving else "static scene: the same batch every step"
+    result = {
+        "metric": METRIC, "value": round(res["fps"], 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (network) / u8 (image kernels)", "data": "synthetic (%s)" % res["weights"],
+        "config": {"workload": "BASELINE configs[1]: batch=%d %dx%d frames, %s; %s; 1 step = prep+network+decode+mask+blend, inputs resident in HBM"
+                               % (B, W, H, res["model_name"], scene),
+                   "streams_per_gpu": B, "sharding": "streams/%d GPUs, no data-path collective" % world, "library": mode},
+        "checksum": res["checksum"], "host": cpu_description(), "numa_binding": numa,
+        "definitions": {"roofline.frac": "bytes of the launch that must cross HBM (algorithmic bytes for this input minus reads of the one background image all streams share) "
+                                         "/ hipEvent duration / 8000 GB/s — for every launch of every configuration",
+                        "dense_10Bpx_GBps": "SURVEY 8(d)'s 10 B/px over the same duration: not a bandwidth (uniform tiles and the shared background move fewer bytes)",
+                        "static_scene": "the same batch every step (rounds 1-4's headline protocol): the uniform-tile shortcut's best case",
+                        "worst_case": "BSX_NO_UNIFORM_TILES=1 and one random background image per stream, moving scene: every byte from HBM, every tile on the general path"},
+    }
+    result.update({k: v for k, v in summarize(res, load_pmc(B, W, H, res["model_name"])).items() if k not in ("value", "unit", "ms_per_step", "steps", "warmup")})
+    if multi is not None:
+        result.update(multi)
+        if shared:
+            result["gpu_sharing"] = "%d ranks on %d GPU(s): throughput numbers of this line are a plumbing run, not a scaling measurement" % (world, n_dev)
+    mg, ring, d_bg, d_out = res["mg"], res["frames_ring"], res["d_bg"], res["d_out"]
+    d_frames = ring[0]
 
     # PCIe-inclusive variant: every step uploads its frames and downloads its composites through pinned buffers.
     # Copies run on their own HIP streams with double-buffered device frames / composites, so the upload of step t+1 and the
     # download of step t-1 overlap the compute of step t (the per-stream mask state keeps the compute steps in order).
-    if rank == 0 and world == 1 and not args.no_host_io:
-        from backscrub_amd import synth
-        mg, d_frames, d_bg, d_out = res["mg"], res["d_frames"], res["d_bg"], res["d_out"]
-        h_in = torch.from_numpy(synth.frames(B, W, H, distinct=16)).pin_memory()
+    if world == 1 and not args.no_host_io and side:
+        h_in = ring[0].cpu().pin_memory()
         h_out = torch.empty_like(h_in).pin_memory()
         s_in, s_out, s_cmp = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
         bufs = [(torch.empty_like(d_frames), torch.empty_like(d_out)) for _ in range(2)]
@@ -874,47 +1103,46 @@ def main():
         del bufs, h_in, h_out
 
     # the same step with the composite leaving as YUYV 4:2:2 (convert_rgb_to_yuyv fused into the blend epilogue): reported
-    # next to `value`, never as `value`; checked bit for bit against the two-call form on the last step
-    if rank == 0 and world == 1 and W % 2 == 0 and not args.no_extra_configs:
-        mg, d_frames, d_bg, d_out = res["mg"], res["d_frames"], res["d_bg"], res["d_out"]
+    # next to `value`, never as `value`; checked bit for bit against the two-call form
+    if world == 1 and W % 2 == 0 and not args.no_extra_configs and side:
         d_yuyv = torch.empty((B, H, W, 2), dtype=torch.uint8, device="cuda")
         mg.reset(); mg.step(d_frames, d_bg, d_out); a = mg.bgr_to_yuyv(d_out)          # both forms from the same (fresh) temporal state
         mg.reset(); mg.step_yuyv(d_frames, d_bg, d_yuyv)
         same = bool(torch.equal(a, d_yuyv))
-        for _ in range(args.warmup):
-            mg.step_yuyv(d_frames, d_bg, d_yuyv)
+        n_y = max(20, min(args.steps, 100))
+        for t in range(5):
+            mg.step_yuyv(ring[t % len(ring)], d_bg, d_yuyv)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            mg.step_yuyv(d_frames, d_bg, d_yuyv)
+        for t in range(n_y):
+            mg.step_yuyv(ring[t % len(ring)], d_bg, d_yuyv)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        result["yuyv_out"] = {"value": round(B * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
+        result["yuyv_out"] = {"value": round(B * n_y / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_y, 4), "steps": n_y,
                               "bit_identical_to_step_then_bgr_to_yuyv": same,
                               "note": "bsx_step_batch_yuyv: composite written as YUYV (2 B/px instead of 3), no separate packing pass"}
         del d_yuyv, a
 
     # `-p bgblur:25` without `-b` (deepseg.cc:652-661): background = GaussianBlur of the stream's own frame.  One pass (BSX_STEP_BGBLUR: blur tile → blend out of LDS)
     # against the two-call form (bsx_gaussian_blur_bgr into a per-stream background, then bsx_step_batch)
-    if rank == 0 and world == 1 and not args.no_extra_configs and W % 4 == 0:
-        mg, d_frames, d_out = res["mg"], res["d_frames"], res["d_out"]
+    if world == 1 and not args.no_extra_configs and W % 4 == 0 and side:
         d_two = torch.empty_like(d_out)
         d_blur = torch.empty_like(d_frames)
 
-        def two_call():
-            mg.gaussian_blur(d_frames, 25, out=d_blur)
-            mg.step(d_frames, d_blur, d_two)
+        def two_call(t):
+            mg.gaussian_blur(ring[t % len(ring)], 25, out=d_blur)
+            mg.step(ring[t % len(ring)], d_blur, d_two)
 
-        def one_pass():
-            mg.step_ex(d_frames, None, d_out, bgblur=25)
+        def one_pass(t):
+            mg.step_ex(ring[t % len(ring)], None, d_out, bgblur=25)
 
-        def timed(fn, iters=max(3, args.steps // 4)):
-            for _ in range(2):
-                fn()
+        def timed(fn, iters=max(20, args.steps // 4)):
+            for t in range(3):
+                fn(t)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(iters):
-                fn()
+            for t in range(iters):
+                fn(t)
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t1) / iters
         ms_two, ms_one = timed(two_call), timed(one_pass)
@@ -923,15 +1151,14 @@ def main():
                                  "note": "bsx_step_batch_ex(BSX_STEP_BGBLUR(25)): blur + blend in one pass over the frames vs bsx_gaussian_blur_bgr + bsx_step_batch"}
         del d_two, d_blur
 
-    # the blend kernel with ONE BACKGROUND PER STREAM (animated backgrounds): nothing of its 10 B/px comes out of L2, unlike the shared
-    # 0.9 MB picture of the default job whose roofline_blend line is flattered by cache hits (its PMC traffic is below the algorithmic bytes)
-    if rank == 0 and world == 1 and not args.no_extra_configs and not args.per_stream_bg:
-        mg, d_frames, d_out = res["mg"], res["d_frames"], res["d_out"]
+    # the blend kernel with ONE BACKGROUND PER STREAM (animated backgrounds): every byte of its 10 B/px is HBM traffic, unlike the shared 0.9 MB picture of the
+    # default job — the north star's "HBM roofline of the blend kernel" figure
+    if world == 1 and not args.per_stream_bg and side:
         d_bg_ps = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda")
         for _ in range(3):
             mg.composite(d_bg_ps, d_frames, None, d_out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 10
+        iters = 20
         e0.record()
         for _ in range(iters):
             mg.composite(d_bg_ps, d_frames, None, d_out)
@@ -941,101 +1168,108 @@ def main():
         by = 10.0 * W * H * B
         result["roofline_blend_per_stream_bg"] = {"kernel": "blend", "bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                                   "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms, 4),
-                                                  "algorithmic_bytes_per_launch": int(by),
+                                                  "hbm_bytes_per_launch": int(by),
                                                   "note": "bsx_composite_batch with a separate background image per stream: every byte of the 10 B/px is HBM traffic"}
         del d_bg_ps
 
-    main_samples = None
-    if rank == 0:
-        main_samples = (res["model_path"], res["host"][:4].copy(), res["bg_host"], res["masks_k"], res["out_k"], res["photo"])
+    main_parity_in = (res["model_path"], res["parity_in"])
+    del mg, ring, d_bg, d_out, d_frames
     release(res)
 
-    if rank == 0:
-        if world > 1:
-            result["second_device_check"] = run_second_device_check()
-            if c4_samples is not None and not args.no_cpu_baseline and "configs4" in result:
-                mp_, fr_, bg_, mk_, out_, photo_ = c4_samples
-                result["configs4"]["parity_sample"] = parity_sample(mp_, 1280, 720, fr_, bg_, mk_, out_, need_person=photo_)
-        if not args.no_cpu_baseline:                        # kept at N > 1: rank 0, after the other ranks have left (their GPUs idle, the host cores free)
+    if world > 1:
+        result["second_device_check"] = run_second_device_check()
+        if c4_parity_in is not None and not args.no_cpu_baseline and "configs4" in result:
+            result["configs4"]["parity_sample"] = parity_sequence(c4_parity_in[0], 1280, 720, c4_parity_in[1])
+    if not args.no_cpu_baseline:                        # kept at N > 1: rank 0, after the other ranks have left (their GPUs idle, the host cores free)
+        try:
+            result["cpu_baseline"] = cpu_baseline(main_parity_in[0], W, H, args.cpu_seconds)
+            result["cpu_baseline"]["parity_sample"] = parity_sequence(main_parity_in[0], W, H, main_parity_in[1])
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+
+    def extra_steps(ms_guess):
+        """≥ 20 timed steps everywhere; more where a step is short"""
+        return int(max(20, min(args.steps, 200, 400.0 / ms_guess)))
+
+    def run_config(tag, kw, steps, env=None, cpu=True, **mkw):
+        """one more configuration through measure() → its summarized fragment (+ parity sample and its own CPU baseline)"""
+        saved = {k_: os.environ.get(k_) for k_ in (env or {})}
+        os.environ.update(env or {})
+        try:
+            r = measure(steps=steps, warmup=3, rank=0, world=1, local_rank=local_rank, profile_iters=4, ramp_s=0.5, static_leg=True, **kw, **mkw)
+            frag = summarize(r, load_pmc(kw["B"], kw["W"], kw["H"], r["model_name"]))
+            frag = {"baseline_config": tag, "net": _short_model(r["model_name"]), "batch": kw["B"], "frame": "%dx%d" % (kw["W"], kw["H"]), **frag}
+            mp_, seq = r["model_path"], r["parity_in"]
+            release(r)
+            if not args.no_cpu_baseline:
+                frag["parity_sample"] = parity_sequence(mp_, kw["W"], kw["H"], seq)
+                if cpu:
+                    frag["cpu_baseline"] = cpu_baseline(mp_, kw["W"], kw["H"], args.cpu_seconds / 3.0, short=True)
+            return frag
+        finally:
+            for k_, v_ in saved.items():
+                if v_ is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v_
+
+    if world == 1 and side and not args.per_stream_bg:
+        # the worst case beside `value`: every mask tile on the general path, one random background image per stream (nothing cache-resident)
+        try:
+            w = run_config("worst_case", dict(model_key=args.model, W=W, H=H, B=B), extra_steps(0.5), env={"BSX_NO_UNIFORM_TILES": "1"}, cpu=False, per_stream_bg=True)
+            result["worst_case"] = w
+        except Exception as e:  # noqa: BLE001
+            result["worst_case"] = {"error": repr(e)}
+
+    if world == 1 and default_job and not args.no_extra_configs:
+        result["configs"] = []
+        # configs[0]: one VGA frame, MLKit, the reference's CPU path (plumbing) — the CPU oracle on one stream, next to the drop-in single-frame GPU path
+        try:
+            mp0, name0, _ = resolve_model("mlkit")
+            f0 = {"baseline_config": "configs[0]", "net": "mlkit", "batch": 1, "frame": "640x480"}
+            if not args.no_cpu_baseline:
+                f0["cpu_baseline"] = cpu_baseline(mp0, 640, 480, args.cpu_seconds / 3.0, short=True)
+            ss = single_stream_latency("mlkit", 640, 480, 100)
+            f0.update({"value": ss["fps_at_p50"], "ms_per_step": ss["p50_ms"], "steps": ss["calls"], "single_stream": ss,
+                       "what": "one stream through bsx_process_host (= bs_maskgen_process): H2D frame, mask pipeline, D2H mask, synchronous; cpu_baseline = the oracle on the same frame size"})
+            result["configs"].append(f0)
+        except Exception as e:  # noqa: BLE001
+            result["configs"].append({"baseline_config": "configs[0]", "error": repr(e)})
+        # the other single-GPU BASELINE configurations, same protocol
+        extra_cfgs = [
+            ("configs[2]", dict(model_key="mlkit", W=1280, H=720, B=256), 1.4, {}),
+            ("configs[3]", dict(model_key="deeplab", W=640, H=480, B=1024), 17.0, dict(bg_ring=True, parity_steps=5)),       # animated background: per-step H2D of a 480x360 frame + GPU resize, timed
+            ("configs[4]/8", dict(model_key="full", W=1280, H=720, B=1024), 3.2, {}),                          # the 8192-stream job's per-GPU slice
+        ]
+        for tag, kw, ms_guess, mkw in extra_cfgs:
             try:
-                result["cpu_baseline"] = cpu_baseline(main_samples[0], W, H, args.cpu_seconds)
-                if not args.per_stream_bg:
-                    mp_, fr_, bg_, mk_, out_, photo_ = main_samples
-                    result["cpu_baseline"]["parity_sample"] = parity_sample(mp_, W, H, fr_, bg_, mk_, out_, need_person=photo_)
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
-        if world == 1 and default_job and not args.no_extra_configs:
-            # the other single-GPU BASELINE configurations, same protocol with fewer steps (they are 3-70x longer per step)
-            extra_cfgs = [
-                ("configs[2]", "batch=256 1280x720 frames, %s" % NAMES["mlkit"], dict(model_key="mlkit", W=1280, H=720, B=256)),
-                ("configs[3]", "batch=1024 640x480 frames, %s, animated background: per-step H2D upload of a 480x360 frame from a pinned 36-frame ring + GPU resize "
-                               "(grab_background) inside the timed region" % NAMES["deeplab"], dict(model_key="deeplab", W=640, H=480, B=1024, bg_ring=True)),
-                ("configs[4] per-GPU slice", "batch=1024 1280x720 frames, %s (8192 streams / 8 GPUs)" % NAMES["full"], dict(model_key="full", W=1280, H=720, B=1024)),
-            ]
-            result["configs"] = []
-            for tag, desc, kw in extra_cfgs:
-                try:
-                    n_steps = max(3, args.steps // 4)
-                    r = measure(steps=n_steps, warmup=2, rank=0, world=1, local_rank=local_rank, profile_iters=2, **kw)
-                    frag = summarize(r, load_pmc(kw["B"], kw["W"], kw["H"], r["model_name"]))
-                    frag = {"baseline_config": tag, "workload": desc, "steps": n_steps, "warmup": 2, **frag}
-                    samples = (r["model_path"], r["host"][:2].copy(), r["bg_host"], r["masks_k"], r["out_k"], r["photo"])
-                    release(r)
-                    if not args.no_cpu_baseline:
-                        mp_, fr_, bg_, mk_, out_, photo_ = samples
-                        frag["parity_sample"] = parity_sample(mp_, kw["W"], kw["H"], fr_, bg_, mk_, out_, need_person=photo_)
-                    result["configs"].append(frag)
-                except Exception as e:
-                    result["configs"].append({"baseline_config": tag, "workload": desc, "error": repr(e)})
-            # g1: the reduced-precision GEMM modes of the per-launch (DeepLab) path next to the default, each with its own parity sample — the
-            # default (split-f16 MFMA, f32-grade) is the one `configs[3]` reports; "fast" (plain f16 operands) is opt-in and IoU-gated
-            result["gemm_modes"] = []
-            for mode, what in (("fast16", "fast + the depthwise outputs of the fused inverted-residual blocks stored as f16 (16-bit activation storage for the largest tensors that reach HBM)"),
-                               ("fast", "plain f16 MFMA operands (1 term), f32 accumulate — what SetAllowFp16PrecisionForFp32 permits (lib/libbackscrub.cc:225)"),
-                               ("off", "f32 MFMA (v_mfma_f32_16x16x4_f32), no fused expand+depthwise kernels")):
-                try:
-                    os.environ["BSX_F16_GEMM"] = mode
-                    r = measure(steps=3, warmup=1, rank=0, world=1, local_rank=local_rank, profile_iters=1, model_key="deeplab", W=640, H=480, B=1024, bg_ring=True)
-                    frag = {"BSX_F16_GEMM": mode, "what": what, "workload": "configs[3] geometry", "value": round(r["fps"], 1), "unit": "frames/s",
-                            "ms_per_step": round(r["ms_per_step"], 4)}
-                    samples = (r["model_path"], r["host"][:2].copy(), r["bg_host"], r["masks_k"], r["out_k"], r["photo"])
-                    release(r)
-                    if not args.no_cpu_baseline:
-                        mp_, fr_, bg_, mk_, out_, photo_ = samples
-                        frag["parity_sample"] = parity_sample(mp_, 640, 480, fr_, bg_, mk_, out_, need_person=photo_)
-                    result["gemm_modes"].append(frag)
-                except Exception as e:
-                    result["gemm_modes"].append({"BSX_F16_GEMM": mode, "error": repr(e)})
-                finally:
-                    os.environ.pop("BSX_F16_GEMM", None)
-            # g1 for Meet / MLKit: 16-bit activation STORAGE (BSX_ACT16=1: the tensors that cross kernel boundaries or spill out of LDS as halves, f32
-            # arithmetic), next to the f32 default that `value` / `configs[2]` report — opt-in, each with its own parity sample
-            result["act_modes"] = []
-            for tag, kw in (("configs[1]", dict(model_key="lite", W=640, H=480, B=256)), ("configs[2]", dict(model_key="mlkit", W=1280, H=720, B=256))):
-                try:
-                    os.environ["BSX_ACT16"] = "1"
-                    n_steps = max(3, args.steps // 4)
-                    r = measure(steps=n_steps, warmup=3, rank=0, world=1, local_rank=local_rank, profile_iters=2, **kw)
-                    frag = {"BSX_ACT16": 1, "what": "activation tensors in HBM stored as f16 (A, b0, B, c0, lo2, lo + the middle program's spilled tensors); arithmetic f32",
-                            "workload": tag + " geometry", "value": round(r["fps"], 1), "unit": "frames/s", "ms_per_step": round(r["ms_per_step"], 4), "steps": n_steps,
-                            "top_launches": [{"name": t["name"], "ms": round(t["avg_ms"], 4)} for t in sorted(r["stats"], key=lambda t: -t["avg_ms"])[:6]]}
-                    samples = (r["model_path"], r["host"][:2].copy(), r["bg_host"], r["masks_k"], r["out_k"], r["photo"])
-                    release(r)
-                    if not args.no_cpu_baseline:
-                        mp_, fr_, bg_, mk_, out_, photo_ = samples
-                        frag["parity_sample"] = parity_sample(mp_, kw["W"], kw["H"], fr_, bg_, mk_, out_, need_person=photo_)
-                    result["act_modes"].append(frag)
-                except Exception as e:
-                    result["act_modes"].append({"BSX_ACT16": 1, "workload": tag + " geometry", "error": repr(e)})
-                finally:
-                    os.environ.pop("BSX_ACT16", None)
+                result["configs"].append(run_config(tag, kw, extra_steps(ms_guess), **mkw))
+            except Exception as e:  # noqa: BLE001
+                result["configs"].append({"baseline_config": tag, "error": repr(e)})
+        # opt-in reduced-precision modes, each with its own parity sample (they FAIL the north star's <= 1 LSB bar and are never defaults):
+        # BSX_F16_GEMM (DeepLab's per-launch path: fast = plain f16 MFMA operands, fast16 = + f16 storage of the fused blocks' depthwise outputs, off = f32 MFMA)
+        # BSX_ACT16 (Meet / MLKit: activation tensors in HBM stored as f16, f32 arithmetic)
+        result["gemm_modes"], result["act_modes"] = [], []
+        for mode in ("fast16", "fast", "off"):
             try:
-                result["single_stream"] = {"what": "bsx_process_host per call (= bs_maskgen_process through the C++ shim): H2D frame, whole mask pipeline, D2H mask, synchronous",
-                                           "runs": [single_stream_latency("lite", 640, 480, 200), single_stream_latency("deeplab", 640, 480, 60)],
-                                           "published_context_not_measured_here": "reference README.md:177 ~10 FPS DeepLab on two i5 cores; Meet model card ~120 FPS inference on a laptop CPU"}
-            except Exception as e:
-                result["single_stream"] = {"error": repr(e)}
-        print(json.dumps(result), flush=True)
+                f = run_config("configs[3]", dict(model_key="deeplab", W=640, H=480, B=1024), 20, env={"BSX_F16_GEMM": mode}, cpu=False, bg_ring=True, parity_steps=4)
+                result["gemm_modes"].append({"env": "BSX_F16_GEMM=" + mode, "cfg": 3, **{k_: f[k_] for k_ in ("value", "ms_per_step", "steps", "parity_sample", "top_launches") if k_ in f}})
+            except Exception as e:  # noqa: BLE001
+                result["gemm_modes"].append({"env": "BSX_F16_GEMM=" + mode, "cfg": 3, "error": repr(e)})
+        for cfg, kw, ms_guess in ((1, dict(model_key="lite", W=640, H=480, B=256), 0.4), (2, dict(model_key="mlkit", W=1280, H=720, B=256), 1.4)):
+            try:
+                f = run_config("configs[%d]" % cfg, kw, extra_steps(ms_guess), env={"BSX_ACT16": "1"}, cpu=False)
+                result["act_modes"].append({"env": "BSX_ACT16=1", "cfg": cfg, **{k_: f[k_] for k_ in ("value", "ms_per_step", "steps", "parity_sample", "top_launches") if k_ in f}})
+            except Exception as e:  # noqa: BLE001
+                result["act_modes"].append({"env": "BSX_ACT16=1", "cfg": cfg, "error": repr(e)})
+        try:
+            result["single_stream"] = {"what": "bsx_process_host per call (= bs_maskgen_process through the C++ shim): H2D frame, whole mask pipeline, D2H mask, synchronous",
+                                       "runs": [single_stream_latency("lite", 640, 480, 200), single_stream_latency("deeplab", 640, 480, 60)],
+                                       "published_context_not_measured_here": "reference README.md:177 ~10 FPS DeepLab on two i5 cores; Meet model card ~120 FPS inference on a laptop CPU"}
+        except Exception as e:  # noqa: BLE001
+            result["single_stream"] = {"error": repr(e)}
+    result["detail_file"] = os.path.basename(args.detail) if args.detail else "bench_detail.json"
+    emit(result, args.detail)
 
 
 if __name__ == "__main__":

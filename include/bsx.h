@@ -177,9 +177,11 @@ BSX_API int bsx_step_batch_ex(bsx_ctx* ctx, const uint8_t* d_frames, const uint8
  *   - d_out(k) and bsx_masks_device() hold batch k's results once call k + 1 (or the flush) has completed on `stream`;
  *   - d_frames(k), d_bg(k) and d_out(k) must stay valid and unmodified until then; d_out must not overlap d_frames;
  *   - d_frames == NULL flushes: the pending composite runs on `stream` (all other arguments ignored); bsx_reset drops it;
+ *   - `stream` may differ from call to call (double-buffered callers): every call records the end of its mask pipeline on its own stream, and the composite of
+ *     that batch, the next call's network (it reuses the arena) and the flush wait for THAT event — the caller orders nothing across its streams;
  *   - flags: BSX_STEP_YUYV | BSX_STEP_FLIP_H | BSX_STEP_FLIP_V | BSX_STEP_NO_MASK (no BSX_STEP_BGBLUR); the geometry must be the fused tile kernel's
  *     (width, roi.x, roi.w multiples of 4, 4-byte aligned buffers) and no stage callback may be set — otherwise BSX_EINVAL, as does every other entry point
- *     that advances the temporal state while a composite is pending. */
+ *     that advances the temporal state while a composite is pending (bsx_process_batch / _host, bsx_step_batch*, bsx_profile_batch, bsx_debug_run_stage 1-3). */
 BSX_API int bsx_step_batch_pipelined(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
                              uint8_t* d_out, int n, void* stream, unsigned flags);
 

@@ -55,6 +55,9 @@ def main():
     for i in range(3):                       # two-deep pipeline: the first call only enqueues, the next ones fork the composite onto the context's own stream
         rc["step_pipelined_%d" % i] = L.bsx_step_batch_pipelined(ctx, p(frames), p(bg), 0, p(out), n, None, 0); caller_device_after("bsx_step_batch_pipelined")
     rc["step_while_pending_refused"] = 0 if L.bsx_step_batch(ctx, p(frames), p(bg), 0, p(out), n, None) == -1 else -1; caller_device_after("bsx_step_batch(pending)")
+    _st = (api.LaunchStat * (info.n_steps + 8))()
+    rc["profile_while_pending_refused"] = 0 if L.bsx_profile_batch(ctx, p(frames), p(bg), 0, p(out), n, 1, _st, info.n_steps + 8, None) == -1 else -1; caller_device_after("bsx_profile_batch(pending)")
+    rc["stage_while_pending_refused"] = 0 if all(L.bsx_debug_run_stage(ctx, st_, p(frames), n, None) == -1 for st_ in (1, 2, 3)) else -1; caller_device_after("bsx_debug_run_stage(pending)")
     rc["step_pipelined_flush"] = L.bsx_step_batch_pipelined(ctx, None, None, 0, None, 0, None, 0); caller_device_after("bsx_step_batch_pipelined(flush)")
     # argument checks of the pipelined entry point (each must refuse with BSX_EINVAL = -1 and leave nothing pending)
     rc["pipelined_refuses_bgblur"] = 0 if L.bsx_step_batch_pipelined(ctx, p(frames), p(bg), 0, p(out), n, None, 25 << 8) == -1 else -1

@@ -117,3 +117,33 @@ def test_bench_self_launches_its_ranks():
     assert c4["streams_total"] == 2048 and "segm_full_v679" in c4["workload"] and "1280x720" in c4["workload"] and len(c4["per_rank_fps"]) == 2
     assert abs(c4["value"] - 2 * 1024 * 1e3 / c4["ms_per_step"]) / c4["value"] < 1e-6
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["host"]["model"] and d["host"]["logical_cpus"] >= 1
+
+
+def test_ranks_bind_to_the_numa_node_of_their_gpu(tmp_path):
+    """bench.py at N > 1: each rank restricts itself to the CPUs of its GPU's NUMA node (sysfs: bus/pci/devices/<id>/numa_node → devices/system/node/nodeK/cpulist),
+    intersected with the affinity mask it was given; a platform that does not expose the topology (numa_node = -1, no sysfs entry) leaves the mask alone."""
+    from backscrub_amd.dist import bind_to_gpu_numa, gpu_numa_cpus, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == [] and parse_cpulist("5") == [5]
+    mine = sorted(os.sched_getaffinity(0))
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c5:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("%d,100000-100003\n" % mine[-1])           # one CPU we own + CPUs that do not exist here
+    assert gpu_numa_cpus("0000:C5:00.0", str(tmp_path)) == (1, [mine[-1], 100000, 100001, 100002, 100003])
+    rec = bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id="0000:c5:00.0", dry_run=True)
+    assert rec == {"bound": False, "pci": "0000:c5:00.0", "node": 1, "cpus": 1} and sorted(os.sched_getaffinity(0)) == mine
+    try:
+        rec = bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id="0000:c5:00.0")
+        assert rec["bound"] is True and sorted(os.sched_getaffinity(0)) == [mine[-1]]
+    finally:
+        os.sched_setaffinity(0, mine)
+    (dev / "numa_node").write_text("-1\n")
+    rec = bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id="0000:c5:00.0")
+    assert rec["bound"] is False and "why" in rec and sorted(os.sched_getaffinity(0)) == mine
+    assert bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id="0000:ff:00.0")["bound"] is False          # unknown device
+    assert bind_to_gpu_numa(None, dry_run=True) == {"bound": False, "why": "no device"}
+    (node / "cpulist").write_text("100000-100003\n")
+    (dev / "numa_node").write_text("1\n")
+    assert "affinity" in bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id="0000:c5:00.0")["why"] and sorted(os.sched_getaffinity(0)) == mine

@@ -217,3 +217,49 @@ def test_pipelined_step_is_bit_identical_one_call_later(bs, key, res, n, flags):
             mg.step_ex(seq[0], bg, o, **flags)
         torch.cuda.synchronize()
         mg.close()
+
+
+@pytest.mark.parametrize("key,res,n", [("lite", VGA, 64), ("full", HD, 16), ("deeplab", VGA, 8)])
+def test_pipelined_step_on_alternating_caller_streams(bs, key, res, n):
+    """a double-buffered caller hands bsx_step_batch_pipelined a DIFFERENT stream on every call.  The composite of batch k - 1 must still run
+    behind the network of batch k - 1 (ordered by an event the call that enqueued it recorded on ITS stream, not by one recorded on the next call's stream), and
+    call k's network behind call k - 1's (they share the arena).  No host synchronisation between the calls; the flush arrives on yet another stream.  While a
+    composite is pending, the profiling / stage-debug entry points that advance the temporal state refuse."""
+    from backscrub_amd import synth
+    W, H = res
+    T = 6
+    path = model_path(key)
+    bg = torch.from_numpy(synth.background(W, H)).cuda()
+    seq = [torch.from_numpy(np.stack([synth.frame(W, H, s % 5, t) for s in range(n)])).cuda() for t in range(T)]
+    ref = bs.MaskGen(path, W, H, n_streams=n)
+    want = []
+    for t in range(T):
+        o = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+        ref.step(seq[t], bg, o)
+        want.append(o)
+    want_masks, want_state = ref.masks()[:n].clone(), ref.ofinal().clone()
+    ref.close()
+    torch.cuda.synchronize()
+    mg = bs.MaskGen(path, W, H, n_streams=n)
+    outs = [torch.zeros((n, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(T)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(3):                                     # repeated: a race does not have to lose the first time
+        mg.reset()
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        for t in range(T):
+            with torch.cuda.stream(streams[t % 2]):
+                mg.step_pipelined(seq[t], bg, outs[t])
+        with pytest.raises(bs.BsxError):
+            mg.profile(seq[0], bg, outs[0], iters=1)
+        with pytest.raises(bs.BsxError):
+            mg.run_stage(2, n=n)
+        with torch.cuda.stream(streams[2]):
+            mg.flush_pipelined()
+        torch.cuda.synchronize()
+        for t in range(T):
+            assert torch.equal(outs[t], want[t]), "composite of batch %d, repetition %d" % (t, rep)
+        assert torch.equal(mg.masks()[:n], want_masks) and torch.equal(mg.ofinal(), want_state)
+    mg.close()
