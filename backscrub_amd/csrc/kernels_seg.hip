@@ -2,8 +2,8 @@
 //
 // Every kernel: grid = (tiles per frame, frames), 256 lanes = 4 waves per workgroup, several workgroups per CU.  A workgroup
 // owns one tile of its segment's OUTPUT pixels and recomputes the halo its depthwise 3x3 needs; intermediate tensors of the
-// tile live in LDS as dense [pixel][16] rows (conflict-free for both access patterns used here: the MFMA
-// epilogue stores and the (pixel, channel-quad) lanes of the depthwise phases), never in HBM.
+// tile live in LDS as [pixel][16] rows whose four channel quads are permuted per column (swz_a / swz_b / swz_l below: conflict-free
+// for every access pattern used here — MFMA epilogue stores, MFMA operand reads, stride-1 and stride-2 depthwise taps), never in HBM.
 //
 // 1x1 convolutions and the 3x3 stem run on v_mfma_f32_16x16x4_f32 — exact f32 FMA chains, so the results stay within
 // float rounding of the reference order (measured against the oracle: < 1e-5 relative on the logits).  Operand maps as
@@ -45,6 +45,26 @@ template <bool H16> __device__ __forceinline__ void stg4(float* base, unsigned i
   if (H16) *reinterpret_cast<h4s*>(reinterpret_cast<_Float16*>(base) + idx) = h4s{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
   else *reinterpret_cast<float4*>(base + idx) = v;
 }
+// ---- LDS tile layouts (bank model: MI355X_MICROARCH.md §LDS; evaluated for every access pattern of this file by tests/test_lds_layouts.py) ----------------------------
+// A tile pixel is 16 floats = four 16-byte channel quads.  Stored densely ([pixel][16], quad q at +4q) the MFMA epilogue's ds_write_b128 — 8 consecutive lanes = 8
+// consecutive pixels, ONE quad — touches two of the eight 16-byte slots of its 128-byte window (4-way conflict: 32 LDS cycles for an instruction that costs 13), the MFMA
+// operand read (ds_read_b128, 16-lane groups of 8 pixels x 2 quads) is 2-way, and so is every tap of a STRIDE-2 depthwise (even columns only: half of the banks).
+// SQ counters of round 4: 55 % (k2), 41 % (head), 40 % (tail) of the LDS-active cycles were conflict cycles.  Three layouts remove all of them:
+//   swz_a — stride-1 tiles (k2's B, k3 / tail's z and t): quad q of column x lives at quad position q ^ swz_a(x).  The 8 pixels of an epilogue store then cover all 8
+//           slots, the 16 (pixel, quad) pairs of an operand read all 16; the stride-1 depthwise (4 quads of one pixel per lane quad) is conflict-free under any permutation.
+//   swz_b — tiles a STRIDE-2 depthwise reads (head's x, k2's x): columns de-interleaved — a row is [even columns | odd columns] — so a tap is a stride-1 read of one plane,
+//           and quad position q ^ swz_b(x) (bit 1 = the plane) keeps the epilogue store (lanes alternate planes) on 8 distinct slots.
+//   swz_l — the staged low-resolution window (k3 / tail): stride 16 floats instead of 20 (the padding halved nothing: every tap read was 2-way) with a period-16 swizzle under
+//           which the 2x up-sampling taps (two neighbouring lanes share a source pixel) are conflict-free for every window alignment: 20 % less LDS for the window as well.
+// Written as single-expression functions so that the test evaluates the kernels' own source.
+__device__ __forceinline__ int swz_a(int x) { return (x >> 1) & 3; }
+__device__ __forceinline__ int swz_b(int x) { return ((x >> 2) & 1) | ((x & 1) << 1); }
+__device__ __forceinline__ int swz_l(int x) { return (((x >> 2) & 1) << 1) ^ ((x >> 3) & 1); }
+// float offset of quad q of column x inside a tile row: stride-1 layout / de-interleaved layout (half = (row width + 1) / 2 columns in the even plane)
+__device__ __forceinline__ int col_a(int x, int q) { return x * 16 + 4 * (q ^ swz_a(x)); }
+__device__ __forceinline__ int col_b(int x, int q, int half) { return ((x & 1) * half + (x >> 1)) * 16 + 4 * (q ^ swz_b(x)); }
+__device__ __forceinline__ int col_l(int x, int q) { return x * kSegLoStride + 4 * (q ^ swz_l(x)); }
+
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) { return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)); }
@@ -222,14 +242,15 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v ldv(const float* p) { return *reinterpret_cast<const f4v*>(p); }
 __device__ __forceinline__ f4v tov(float4 a) { f4v r = {a.x, a.y, a.z, a.w}; return r; }
 __device__ __forceinline__ float4 tof4(f4v a) { return make_float4(a.x, a.y, a.z, a.w); }
-template <int S>
-__device__ __forceinline__ f4v dw3x3(const float* __restrict__ zt, int RW, int py, int px, int q, const f4v (&wd)[9]) {
+// `co[fx]` = float offset of the lane's quad at column S * px + fx of a tile row (col_a / col_b: the layout's swizzle is folded into the three per-lane constants),
+// `row0` = the tile row of tap fy = 0, RWF = floats per tile row
+__device__ __forceinline__ f4v dw3x3(const float* __restrict__ zt, int RWF, int row0, const int (&co)[3], const f4v (&wd)[9]) {
   f4v acc = {0.f, 0.f, 0.f, 0.f};
-  const float* base = zt + ((S * py) * RW + S * px) * 16 + 4 * q;
+  const float* base = zt + row0 * RWF;
 #pragma unroll
   for (int fy = 0; fy < 3; fy++)
 #pragma unroll
-    for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(ldv(base + (fy * RW + fx) * 16), wd[fy * 3 + fx], acc);
+    for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(ldv(base + fy * RWF + co[fx]), wd[fy * 3 + fx], acc);
   return acc;
 }
 
@@ -354,7 +375,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   //    ([AR][RW][16]: 18 KB written, a barrier, 18 KB read) and the 1x1 was a second loop over the tiles; the same values enter the same instructions, so the results
   //    are the same bits.  x lands where that tile was (a_t's region: in_t is still being read by the other waves' stem tiles); zero outside the image = SAME padding
   //    of the depthwise.
-  float* x_f = a_t;
+  float* x_f = a_t;                                                 // DENSE [AR][AC][16] rows: the de-interleaved, swizzled form (col_b) removes this tile's bank conflicts as it does in
+                                                                    // k2 — and measured 4-5 % SLOWER here on all three networks (profiles/r05b: 44.4 -> 46.5 us lite, 389 -> 409 us segm_full / HD):
+                                                                    // the head is bound by VALU issue, and the odd row width AC makes the swizzled address arithmetic per tile, not per lane
   float wr[4];
   load_wtile(wr, w, d.pw, 0, li, g);
   const float4 bias_p = ld4(w + d.pw.b_off + cq4);
@@ -406,6 +429,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 #pragma unroll
   for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + 4 * quad);
   const f4v bias_d = ldv(w + d.dw.b_off + 4 * quad);
+  const int cox[3] = {(2 * px) * 16 + 4 * quad, (2 * px + 1) * 16 + 4 * quad, (2 * px + 2) * 16 + 4 * quad};
   __syncthreads();
 
   // 4. depthwise 3x3 / stride 2 → b0: one tile row per wave iteration
@@ -413,7 +437,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
   for (int py = wave; py < d.TR && !(d.dbg_skip & 4); py += 4) {
     if (r0 + py >= d.H2) break;
     if (px < d.TC && c0 + px < d.W2) {
-      const float4 v = clamp4(tof4(dw3x3<2>(x_f, AC, py, px, quad, wd) + bias_d), cl_dw);
+      const float4 v = clamp4(tof4(dw3x3(x_f, AC * 16, 2 * py, cox, wd) + bias_d), cl_dw);
       stg4<H16>(b0_out, (unsigned)(((r0 + py) * d.W2 + c0 + px) * 16 + 4 * quad), v);
       sumB = f4add(sumB, v);
     }
@@ -431,7 +455,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 // The expanded tensor x (72 channels) exists only 16 channels at a time, in LDS.
 // ==================================================================================================================================
 template <bool H16>
-__global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w, int n_frames) {
+__global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void seg_k2_k(const SegK2 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w, int n_frames) {
   unsigned f_, t_;
   xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
   const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
@@ -445,6 +469,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
   float* c0_out = fa + d.c0_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
   const int ntile = BR * ctiles, xe = li;
+  const int la = col_a(li, g), lb = col_b(li, g, RW >> 1);          // this lane's quad at column 16 ct + li of a B_t / x_t row = (16 | 8) ct columns further + these (the swizzles have period <= 16)
   // all of this wave's b0 operands are requested before the gate prologue (one memory round trip for the whole workgroup)
   constexpr int kB0 = 6;                                            // planner: ceil(BR * ctiles / 4) <= 6
   float4 b0v[kB0];
@@ -479,7 +504,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
     const int x2 = 16 * rt.ct + xe, hy = br0 + rt.row, hx = bc0 + x2;
     if (x2 < BC) {
       v = clamp4(f4add(v, bias_a), cl_a);
-      st4(B_t + (rt.row * RW + x2) * 16 + cq4, v);
+      st4(B_t + (rt.row * RW + 16 * rt.ct) * 16 + la, v);
       const bool row_owned = hy >= max(2 * r0, 0) && hy < min(2 * r0 + 2 * d.TR, d.H2);
       if (row_owned && hx >= 2 * c0 && hx < min(2 * c0 + 2 * d.TC, d.W2)) {
         stg4<H16>(B_out, (unsigned)((hy * d.W2 + hx) * 16 + cq4), v);
@@ -496,19 +521,20 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
   //    (requesting group g + 1's 1x1 tile while group g runs — 8 more registers, 5 instead of 6 waves per SIMD or 16 B of scratch at a cap of 6 — measured SLOWER:
   //     45.4 → 51.3 us at 256 VGA streams, 170 → 187 us for mlkit / HD, profiles/r03af)
   const int C = d.dw.C, ngrp = (C + 15) >> 4, quad = lane & 3, px = lane >> 2;
+  const int cox[3] = {col_b(2 * px, quad, RW >> 1), col_b(2 * px + 1, quad, RW >> 1), col_b(2 * px + 2, quad, RW >> 1)};   // x_t: de-interleaved columns (swz_b)
   for (int grp = 0; grp < ngrp && !(d.dbg_skip & 2); grp++) {
     load_wtile(wr, w, d.pw_b, 16 * grp, li, g);
     const float4 bias_b = ld4(w + d.pw_b.b_off + 16 * grp + cq4);
     for (int t = wave; t < ntile; t += 4) {
       const RowTile rt = row_tile(t, ctiles, d.m_ct);
-      const int bx = min(16 * rt.ct + li, BC - 1);
-      const f4acc acc = mma16(ld4(B_t + (rt.row * RW + bx) * 16 + 4 * g), wr);
+      // (columns >= BC of the row hold nothing: their lanes feed MFMA columns whose results are dropped below — a column of D depends on the same column of B only)
+      const f4acc acc = mma16(ld4(B_t + (rt.row * RW + 16 * rt.ct) * 16 + la), wr);
       float4 v = acc_quad(acc);
       const int x2 = 16 * rt.ct + xe, hy = br0 + rt.row, hx = bc0 + x2;
       if (x2 < BC) {
         const bool inside = hy >= 0 && hy < d.H2 && hx >= 0 && hx < d.W2;
         v = inside ? clamp4(f4add(v, bias_b), cl_b) : f4zero();
-        st4(x_t + (rt.row * RW + x2) * 16 + cq4, v);
+        st4(x_t + (rt.row * RW + 8 * rt.ct) * 16 + lb, v);
       }
     }
     const int ch = 16 * grp + 4 * quad;
@@ -522,7 +548,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
     __syncthreads();
     if (ch < C && px < d.TC && c0 + px < d.W3)
       for (int py = wave; py < d.TR && r0 + py < d.H3; py += 4) {
-        const float4 v = clamp4(tof4(dw3x3<2>(x_t, RW, py, px, quad, wd) + bias_d), cl_dw);
+        const float4 v = clamp4(tof4(dw3x3(x_t, RW * 16, 2 * py, cox, wd) + bias_d), cl_dw);
         stg4<H16>(c0_out, (unsigned)(((r0 + py) * d.W3 + c0 + px) * C + ch), v);
       }
     __syncthreads();
@@ -537,7 +563,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k2_k(const SegK2 d, float* __
 // instructions of the kernel (gated_prefetch): the lane's skip operand of each of its <= kGatedRows rows into registers, the
 // low-resolution rows/columns the tile interpolates from into LDS (l_t, [LR][LC][20]); the compute part then never touches HBM.
 constexpr int kGatedRows = 5;           // region rows per wave: (TR + 2 + 3) / 4 <= 5  →  TR <= 18
-constexpr int kLoStride = 20;           // floats per staged low-resolution pixel (16 + 4: spreads the 16-byte tap reads over the banks)
+constexpr int kLoStride = kSegLoStride; // floats per staged low-resolution pixel (16: dense, swizzled by swz_l)
 struct GatedPre { float4 s[kGatedRows]; int ly0, lx0, LC; };
 template <bool H16>
 __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ skip, const float* __restrict__ lo, int H, int W, int HL, int WL, bool half_pixel,
@@ -573,7 +599,7 @@ __device__ __forceinline__ GatedPre gated_prefetch(const float* __restrict__ ski
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     const int ly = wave + 4 * j;
-    if (ly < LR && lane < LC * 4) st4(l_t + (ly * LC + (lane >> 2)) * kLoStride + 4 * (lane & 3), v[j]);
+    if (ly < LR && lane < LC * 4) st4(l_t + ly * LC * kLoStride + col_l(lane >> 2, lane & 3), v[j]);
   }
   return pre;
 }
@@ -590,7 +616,7 @@ __device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* 
   int x0, x1;
   float dx;
   up_axis(min(max(ix, 0), W - 1), wsc, half_pixel, WL, &x0, &x1, &dx);
-  const int xo0 = (x0 - pre.lx0) * kLoStride + 4 * g, xo1 = (x1 - pre.lx0) * kLoStride + 4 * g;
+  const int xo0 = col_l(x0 - pre.lx0, g), xo1 = col_l(x1 - pre.lx0, g);
   const int xe = li;
   const bool ecol_in = xe < ZC && ix >= 0 && ix < W;
 #pragma unroll
@@ -614,7 +640,7 @@ __device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* 
     const f4acc acc = mma16(a, wr);
     float4 v = acc_quad(acc);
     v = (ecol_in && row_in) ? clamp4(f4add(v, bias), cl) : f4zero();
-    if (xe < ZC) st4(z_t + (zy * 16 + xe) * 16 + cq4, v);
+    if (xe < ZC) st4(z_t + zy * 256 + col_a(xe, g), v);
   }
 }
 
@@ -629,27 +655,24 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
   const int r0 = ty * d.TR, c0 = tx * d.TC, ZH = d.TR + 2, ZC = d.TC + 2;
   float* fa = arena + (size_t)f * (size_t)per_frame;
   float* z_t = seg_smem + kScrFloats;                               // [ZH][16][16]
-  float* t_t = z_t + ZH * 256;                                      // [TR][16][16]
-  float* l_t = t_t + d.TR * 256;                                    // staged window of lo2
+  float* l_t = z_t + ZH * 256;                                      // staged window of lo2
   float* lo_out = fa + d.lo_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
   const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo2_off, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.hs, d.ws, r0, c0, ZH, ZC, l_t);
   if (tid < 16) seg_smem[kScrGate + tid] = fa[d.g_off + tid];
   __syncthreads();
   gated_compute(pre, l_t, d.H2, d.W2, d.HL, d.WL, d.half_pixel != 0, d.hs, d.ws, seg_smem + kScrGate, d.pw1, w, r0, c0, ZH, ZC, z_t);
-  const int quad = lane & 3, px = lane >> 2;
+  // The depthwise runs on the MFMA's own lanes — lane (li, g) = (pixel of the row, channel quad) — so t = z + act(dw(z)) of the lane IS the B operand of pw2's four
+  // MFMAs (round 5).  Until then the depthwise used (pixel = lane >> 2, quad = lane & 3) lanes and t made a round trip through an LDS tile of its own ([TR][16][16]:
+  // 12 KB, a barrier): k3 34.8 -> 22.8 KiB per workgroup at a 12 x 14 tile.  Same values into the same instructions: bit-identical.  Under swz_a the (li, g) lanes read
+  // z_t without bank conflicts, exactly like an MFMA operand read.  Lanes 14, 15 (TC <= 14) repeat lane 13's columns; their results are dropped.
+  const int pc = min(li, 13);
+  const int coz[3] = {col_a(pc, g), col_a(pc + 1, g), col_a(pc + 2, g)};
   f4v wd[9];
 #pragma unroll
-  for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + 4 * quad);
-  const f4v bias_d = ldv(w + d.dw.b_off + 4 * quad);
+  for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + cq4);
+  const f4v bias_d = ldv(w + d.dw.b_off + cq4);
   const Clamp cl_dw = clamp_of(d.dw.act), cl_2 = clamp_of(d.pw2.act);
-  __syncthreads();
-  if (px < d.TC)
-    for (int py = wave; py < d.TR; py += 4) {
-      const f4v zc = ldv(z_t + ((py + 1) * 16 + px + 1) * 16 + 4 * quad);
-      const float4 dv = clamp4(tof4(dw3x3<1>(z_t, 16, py, px, quad, wd) + bias_d), cl_dw);
-      st4(t_t + (py * 16 + px) * 16 + 4 * quad, f4add(dv, tof4(zc)));       // dw epilogue: activation, then + residual z
-    }
   float wr[4];
   load_wtile(wr, w, d.pw2, 0, li, g);
   const float4 bias2 = ld4(w + d.pw2.b_off + cq4);
@@ -657,7 +680,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
   float4 sum = f4zero();
   const int xe = li;
   for (int py = wave; py < d.TR && r0 + py < d.H2; py += 4) {
-    const f4acc acc = mma16(ld4(t_t + (py * 16 + min(li, d.TC - 1)) * 16 + 4 * g), wr);
+    const f4v zc = ldv(z_t + (py + 1) * 256 + coz[1]);
+    const float4 dv = clamp4(tof4(dw3x3(z_t, 256, py, coz, wd) + bias_d), cl_dw);
+    const f4acc acc = mma16(f4add(dv, tof4(zc)), wr);                  // dw epilogue: activation, then + residual z; straight into pw2
     float4 v = acc_quad(acc);
     if (xe < d.TC && c0 + xe < d.W2) {
       v = clamp4(f4add(v, bias2), cl_2);
@@ -679,7 +704,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
 // that lane `quad` ends up with output position (fy, fx) = (quad >> 1, quad & 1) of its pixel.
 // ==================================================================================================================================
 template <int CO, bool LOGITS, bool SIGMOID, bool H16>
-__global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float* __restrict__ arena, long per_frame, float* __restrict__ net_out,
+__global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void seg_tail_k(const SegTail d, float* __restrict__ arena, long per_frame, float* __restrict__ net_out,
                                                           uint8_t* __restrict__ ofinal, const float* __restrict__ w, int n_frames) {
   unsigned f_, t_;
   xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
@@ -690,19 +715,26 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
   float* l_t = z_t + max(ZH * 256, kGateStageFloats);               // staged window of lo
   uint8_t* of = ofinal + (size_t)f * (size_t)(d.H0 * d.W0);
   float* no = net_out + (size_t)f * (size_t)(d.H0 * d.W0 * CO);
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), quad = lane & 3, px = lane >> 2;
-  const int fy = quad >> 1, fx = quad & 1, ix = c0 + px;
+  // Phase B lanes = the MFMA's: lane (li, g) = (pixel li of the tile row, channel quad g) runs the depthwise on its 4 channels; its t = z + act(dw(z)) is then the B
+  // operand of the transpose convolution, computed as ONE 16 x 16 MFMA tile per row (round 5): A = the 2x2xCO filter as 16 rows n = 4 * pos + oc (rows with oc >= CO are
+  // zero) over k = 16 channels, so the accumulator of lane (li, g) holds out[pos = g][oc = 0..CO) of pixel li — the lane ends up with output position (fy, fx) = (g >> 1, g & 1)
+  // of its pixel, as before.  Until then every lane held the 4 x CO filter quads of its channels (32 registers at CO = 2), did 16 CO FMAs and three DPP exchanges
+  // per output (quad_reduce_scatter): 124 registers = 4 workgroups per CU where LDS allows 5.  (Summation order over the 16 channels changes: within float rounding of
+  // the reference order, as every 1x1 convolution here.)
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), li = lane & 15, g = lane >> 4, cq4 = 4 * g;
+  const int fy = g >> 1, fx = g & 1, ix = c0 + li;
   // every global read of the workgroup is requested here, before the first wait: skip operands, the window of lo, the temporal
   // state bytes this lane will update, then (inside seg_gate) the pooled partial sums and the gate weights
   const GatedPre pre = gated_prefetch<H16>(fa + d.skip_off, fa + d.lo_off, d.H1, d.W1, d.HL, d.WL, d.half_pixel != 0, d.hs, d.ws, r0, c0, ZH, ZC, l_t);
   constexpr int kRowsB = 5;                                          // TR <= 18 → <= 5 tile rows per wave in phase B
+  const bool lane_on = li < d.TC && ix < d.W1;
   uint8_t prev[kRowsB];
   if (!LOGITS) {
 #pragma unroll
     for (int j = 0; j < kRowsB; j++) {
       const int py = wave + 4 * j, iy = r0 + py;
       prev[j] = 0;
-      if (py < d.TR && iy < d.H1 && px < d.TC && ix < d.W1) prev[j] = of[(unsigned)((2 * iy + fy) * d.W0 + 2 * ix + fx)];
+      if (py < d.TR && iy < d.H1 && lane_on) prev[j] = of[(unsigned)((2 * iy + fy) * d.W0 + 2 * ix + fx)];
     }
   }
   if (d.pre_gate_off >= 0) {                                          // computed once per frame by seg_gate_k
@@ -713,35 +745,30 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
   if (d.dbg_skip & 2) return;
   f4v wd[9];
 #pragma unroll
-  for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + 4 * quad);
-  const f4v bias_d = ldv(w + d.dw.b_off + 4 * quad);
-  float4 wt[4][CO];
+  for (int k = 0; k < 9; k++) wd[k] = ldv(w + d.dw.w_off + k * 16 + cq4);
+  const f4v bias_d = ldv(w + d.dw.b_off + cq4);
+  float wtr[4];                                                       // A operand: lane (li, g) holds Wt[n = li][k = 4 g + r], n = 4 * pos + oc
+#pragma unroll
+  for (int r = 0; r < 4; r++) wtr[r] = (li & 3) < CO ? w[d.tc_w_off + (unsigned)((((li >> 2) * CO + (li & 3)) * 16) + cq4 + r)] : 0.f;
   float bt[CO];
-#pragma unroll
-  for (int pos = 0; pos < 4; pos++)
-#pragma unroll
-    for (int oc = 0; oc < CO; oc++) wt[pos][oc] = ld4(w + d.tc_w_off + (unsigned)((pos * CO + oc) * 16 + 4 * quad));
 #pragma unroll
   for (int oc = 0; oc < CO; oc++) bt[oc] = w[d.tc_b_off + oc];
   const Clamp cl_dw = clamp_of(d.dw.act);
+  const int pc = min(li, 13);                                         // TC <= 14: lanes 14, 15 repeat lane 13's columns (dropped)
+  const int coz[3] = {col_a(pc, g), col_a(pc + 1, g), col_a(pc + 2, g)};
   __syncthreads();
-  if (px < d.TC && ix < d.W1)                                        // uniform inside a quad (all four lanes share the pixel)
 #pragma unroll
-    for (int j = 0; j < kRowsB; j++) {
-      const int py = wave + 4 * j, iy = r0 + py;
-      if (py >= d.TR || iy >= d.H1) break;
-      const f4v zc = ldv(z_t + ((py + 1) * 16 + px + 1) * 16 + 4 * quad);
-      const float4 t4 = f4add(clamp4(tof4(dw3x3<1>(z_t, 16, py, px, quad, wd) + bias_d), cl_dw), tof4(zc));
+  for (int j = 0; j < kRowsB; j++) {
+    const int py = wave + 4 * j, iy = r0 + py;
+    if (py >= d.TR || iy >= d.H1) break;                              // scalar: the MFMAs below run with every lane of the wave
+    const f4v zc = ldv(z_t + (py + 1) * 256 + coz[1]);
+    const float4 t4 = f4add(clamp4(tof4(dw3x3(z_t, 256, py, coz, wd) + bias_d), cl_dw), tof4(zc));
+    const f4acc acc = mma16(t4, wtr);
+    if (lane_on) {
       float o[CO];
 #pragma unroll
       for (int oc = 0; oc < CO; oc++) {
-        float pp[4];
-#pragma unroll
-        for (int pos = 0; pos < 4; pos++) {
-          const float4 wv = wt[pos][oc];
-          pp[pos] = fmaf(t4.w, wv.w, fmaf(t4.z, wv.z, fmaf(t4.y, wv.y, t4.x * wv.x)));
-        }
-        o[oc] = bt[oc] + quad_reduce_scatter(pp[0], pp[1], pp[2], pp[3], quad);
+        o[oc] = bt[oc] + acc[oc];
         if (SIGMOID) o[oc] = sigmoid1(o[oc]);
       }
       const int oy = 2 * iy + fy, ox = 2 * ix + fx;
@@ -756,6 +783,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_tail_k(const SegTail d, float
         of[opix] = (uint8_t)((val & 0xE0u) | ((uint32_t)prev[j] >> 3));
       }
     }
+  }
 }
 
 // the gate of one decoder level, once per frame: workgroup = frame; the prologue of the tile kernels as a kernel of its own (SegTail::pre_gate_off)
@@ -819,7 +847,10 @@ hipError_t launch_seg_k3(const SegK3& d, float* arena, long per_frame, const flo
 template <bool H16>
 static hipError_t launch_seg_tail_t(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s) {
   const dim3 grid((unsigned)(d.tiles_y * d.tiles_x) * (unsigned)n);
-  const size_t lds = (size_t)d.lds_floats * sizeof(float);
+  // BSX_SEG_TAIL_WGS=<k> (experiment switch, read once): pad the dynamic LDS so that at most k workgroups fit a CU — the A/B of the tail's 5th workgroup (round 5)
+  static const int wgs_cap = getenv("BSX_SEG_TAIL_WGS") ? atoi(getenv("BSX_SEG_TAIL_WGS")) : 0;
+  size_t lds = (size_t)d.lds_floats * sizeof(float);
+  if (wgs_cap > 0) lds = std::max(lds, (size_t)(160 * 1024 / (wgs_cap + 1) + 256));
   const bool sig = d.act3 == kActSigmoid;
   if (d.Co == 2 && !sig) {
     if (logits) seg_tail_k<2, true, false, H16><<<grid, kSegThreads, lds, s>>>(d, arena, per_frame, net_out, ofinal, weights, xcd_frames(n));

@@ -100,7 +100,8 @@ struct SegTail {
 
 // LDS floats each kernel needs for the tile sizes in its descriptor (the planner picks the tiles against these; the kernels
 // carve the same regions)
-constexpr int kSegLoTileFloats = 12 * 16 * 20;   // staged window of the low-resolution tensor a k3 / tail tile interpolates from: <= 12 rows x 16 columns x 20 floats
+constexpr int kSegLoStride = 16;                 // floats per pixel of the staged low-resolution window (dense; bank conflicts are removed by a swizzle: kernels_seg.hip swz_l)
+constexpr int kSegLoTileFloats = 12 * 16 * kSegLoStride;   // staged window of the low-resolution tensor a k3 / tail tile interpolates from: <= 12 rows x 16 columns
 constexpr int kSegScratchFloats = 640;   // gate vector / means / hidden / partial-sum meeting points
 constexpr int kSegGateStageFloats = 512 + 2 * (32 * 32 + 32);   // gate prologue staging (aliases the first tile region)
 inline int seg_row_width(int cols) { return (cols + 15) / 16 * 16; }
@@ -136,10 +137,10 @@ inline int seg_lo_window_floats(int H, int W, int HL, int WL, bool half_pixel, b
     seg_up_axis(std::min(c0 + TC, W - 1), ws, half_pixel, WL, &c, &e);
     lc = std::max(lc, e - a + 1);
   }
-  const int need = (lr + 1) * (lc + 1) * 20;
+  const int need = (lr + 1) * (lc + 1) * kSegLoStride;
   return need < kSegLoTileFloats ? need : kSegLoTileFloats;
 }
-inline int seg_k3_lds_floats(const SegK3& d) { return kSegScratchFloats + (d.TR + 2) * 256 + d.TR * 256 + (d.lo_floats > 0 ? d.lo_floats : kSegLoTileFloats); }
+inline int seg_k3_lds_floats(const SegK3& d) { return kSegScratchFloats + (d.TR + 2) * 256 + (d.lo_floats > 0 ? d.lo_floats : kSegLoTileFloats); }   // z tile + the window (t stays in registers)
 inline int seg_tail_lds_floats(const SegTail& d) { const int v = (d.TR + 2) * 256; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats) + (d.lo_floats > 0 ? d.lo_floats : kSegLoTileFloats); }
 
 struct SegPlan {

@@ -44,13 +44,17 @@ def _pick(rows, needle):
 
 def test_segment_kernels_keep_their_register_steps_and_never_spill(surveys):
     rows = surveys["kernels_seg.hip"]
-    for needle, cap in (("seg_head_k", 88), ("seg_k2_k", 80), ("seg_k3_k", 88), ("seg_gate_k", 64)):
+    # seg_k3_k (round 5): depthwise on the MFMA's lanes, t straight into pw2 — 100 registers = 4 workgroups per CU, what its LDS allowed before (34.8 KiB) and
+    # one more than MLKit's 45 KiB tile did; forcing 5 (amdgpu_waves_per_eu) spills 24 bytes
+    for needle, cap in (("seg_head_k", 88), ("seg_k2_k", 80), ("seg_k3_k", 104), ("seg_gate_k", 64)):
         for name, r in _pick(rows, needle).items():
             assert r["scratch"] == 0, "%s spills %d bytes" % (name, r["scratch"])
             assert r["vgpr"] <= cap, "%s: %d registers (cap %d: one wave per SIMD fewer beyond it)" % (name, r["vgpr"], cap)
     for name, r in _pick(rows, "seg_tail_k").items():
         assert r["scratch"] == 0, "%s spills %d bytes" % (name, r["scratch"])
-        assert r["vgpr"] <= 128, "%s: %d registers (4 waves per SIMD need <= 128)" % (name, r["vgpr"])
+        # round 5: the transpose convolution is one MFMA tile per row (4 operand registers instead of 4 x Co filter quads in every lane): <= 96 registers =
+        # 5 workgroups per CU, what the tail's LDS (27-30 KiB) allows; round 4 held 124 at Co = 2 = 4 per CU
+        assert r["vgpr"] <= 96, "%s: %d registers (5 waves per SIMD need <= 96)" % (name, r["vgpr"])
 
 
 def test_image_kernels_never_spill_and_fit_five_workgroups_of_lds(surveys):
