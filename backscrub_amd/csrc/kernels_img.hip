@@ -445,9 +445,11 @@ __device__ __forceinline__ uint32_t yuyv_pair(uint32_t a0, uint32_t a1, uint32_t
 // top of the kernel so that their HBM latency hides behind the LDS phases.
 struct TileBlendOperands { uint32_t a[kTileItems][3], b[kTileItems][3]; };
 // `uniform` (wave-uniform): 0 = both operands; 1 = the tile's mask is 255 everywhere → only the background is needed; 2 = 0 everywhere → only the frame
+// `parts` (wave-uniform): bit 0 = request the background operand, bit 1 = the frame operand — 3 = whatever `uniform` needs in one call; mask_tile_k requests a SHARED
+// background before it knows the tile's class (parts = 1) and the frame after (parts = 2)
 template <bool BLEND>
 __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
-                                                         int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int uniform = 0) {
+                                                         int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int uniform = 0, int parts = 3) {
   if constexpr (BLEND) {
     const int ly0 = tid / (kTW / 4), gx = tx0 + (tid % (kTW / 4)) * 4;
     const long pix0 = (long)(roi.y + ty0 + ly0) * W + roi.x + gx;        // frame coordinates of the ROI-relative tile pixel
@@ -455,12 +457,13 @@ __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, c
     const uint8_t* const b0 = frames + ((long)n * W * H + pix0) * 3;
 #pragma unroll
     for (int i = 0; i < kTileItems; i++) {
-      o.a[i][0] = o.a[i][1] = o.a[i][2] = o.b[i][0] = o.b[i][1] = o.b[i][2] = 0;
+      if (parts & 1) o.a[i][0] = o.a[i][1] = o.a[i][2] = 0;
+      if (parts & 2) o.b[i][0] = o.b[i][1] = o.b[i][2] = 0;
       if (ty0 + ly0 + 8 * i < roi.h && gx < roi.w) {
         const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0 + (long)(8 * i) * W * 3);
         const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * 3);
-        if (uniform != 2) { o.a[i][0] = ap[0]; o.a[i][1] = ap[1]; o.a[i][2] = ap[2]; }
-        if (uniform != 1) { o.b[i][0] = __builtin_nontemporal_load(bp); o.b[i][1] = __builtin_nontemporal_load(bp + 1); o.b[i][2] = __builtin_nontemporal_load(bp + 2); }   // streamed once
+        if ((parts & 1) && uniform != 2) { o.a[i][0] = ap[0]; o.a[i][1] = ap[1]; o.a[i][2] = ap[2]; }
+        if ((parts & 2) && uniform != 1) { o.b[i][0] = __builtin_nontemporal_load(bp); o.b[i][1] = __builtin_nontemporal_load(bp + 1); o.b[i][2] = __builtin_nontemporal_load(bp + 2); }   // streamed once
       }
     }
   }
@@ -544,7 +547,7 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
     }
     uint8_t* dst = dst0 + (long)(8 * i) * W;
     if (BLEND && (yuyv_flip & 8)) { /* composite only (BSX_STEP_NO_MASK): the full-resolution mask stays in registers */ }
-    else if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;
+    else if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;      // (nontemporal here: measured, no difference — profiles/r05d)
     else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
     if constexpr (BLEND) {
       uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * orow * obpp);
@@ -686,17 +689,24 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   //     barrier → operand loads cost the general path 6 %, profiles/r04e).  Bit-identical by construction; BSX_NO_UNIFORM_TILES=1 (read when the context is
   //     created) keeps every tile on the general path (A/B timing; the parity tests run both).
   int uniform = 0;
+  // A SHARED background (bg_stride == 0: one image for all streams, L2-resident) is requested BEFORE the tile's class is known (round 5): the class byte is a second
+  // dependent round trip behind the kernel arguments, and two thirds of the tiles (uniform 255: composite = background) then need nothing else.  A per-stream
+  // background is HBM traffic a uniform-0 tile must not pay: it keeps the order class -> operands.
+  const bool early_bg = BLEND && bg_stride == 0 && tab.tile_class != nullptr && !(yuyv & 16);
+  TileBlendOperands ops;
+  if (early_bg) tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 1);
   if (tab.tile_class) {                                     // the aligned word that holds the byte: a SCALAR load (uniform address), not a vector load + readfirstlane
     const uintptr_t ca = (uintptr_t)tab.tile_class + (size_t)n * (size_t)(ntx * nty) + (size_t)(tby * ntx + tbx);
     uniform = (int)((*reinterpret_cast<const uint32_t*>(ca & ~(uintptr_t)3) >> (8 * (unsigned)(ca & 3))) & 255u);
   }
   if (uniform) {                                           // wave-uniform: nothing of the general path below is even requested
-    TileBlendOperands uo;
-    tile_load_blend_operands<BLEND>(uo, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, uniform);
-    tile_vsum5_store<BLEND>(hq_hs, mask, outp, uo, n, W, H, roi, tx0, ty0, tid, yuyv, uniform);
+    tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, uniform, early_bg ? 2 : 3);
+    tile_vsum5_store<BLEND>(hq_hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv, uniform);
     return;
   }
   // extents of the source block: xofs / yofs are monotonic, so the extreme destination rows / columns give them
+  // (requesting these four scalar table reads together with the class byte — one scalar round trip instead of two in front of the general path — measured: no
+  //  difference on any configuration, profiles/r05e)
   const int gy_lo = max(ty0 - 2, 0), gy_hi = min(ty0 + kTH + 1, roi.h - 1);
   const int gx_lo = max(tx0 - 2, 0), gx_hi = min(tx0 + kTW + 1, roi.w - 1);
   const int smin = min(max(tab.yofs[gy_lo], 0), tab.sh - 1), smax = min(max(tab.yofs[gy_hi] + 1, 0), tab.sh - 1);
@@ -717,9 +727,8 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
     const int gy = reflect101(min(ty0 + (tid - 192) - 2, roi.h + 1), roi.h);
     t_s = tab.yofs[gy]; t_a0 = tab.ya[2 * gy]; t_a1 = tab.ya[2 * gy + 1];
   }
-  // (c) composite operands
-  TileBlendOperands ops;
-  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid);
+  // (c) composite operands (the shared background is already on its way)
+  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, early_bg ? 2 : 3);
   // 1. block and tables into LDS
 #pragma unroll
   for (int j = 0; j < 3; j++) if (br + 4 * j < nsr && bc < ncol) blk[(br + 4 * j) * ncol + bc] = (uint8_t)raw[j];
@@ -1130,6 +1139,8 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   const int nf = (xcd_on && shared_lines) ? n : 0;
   dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
   if (hipError_t e = launch_tile_class(ofinal, outW, outH, in_roi, tab, roi, n, s)) return e;
+  static const bool no_early_bg = getenv("BSX_NO_EARLY_BG") != nullptr;      // A/B timing: bit 4 of the flag word = request a shared background only after the tile's class is known (rounds 1-4)
+  if (no_early_bg) yuyv |= 16;
   if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   return hipGetLastError();
