@@ -180,6 +180,11 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
   const uint8_t* src = frames + n * (long)W * H * 3 + ((long)roi.y * W + roi.x) * 3;
   const unsigned msw = 0xFFFFFFFFu / (unsigned)SW + 1u;                    // i / SW for i < 2^16
   constexpr int kItems = (kPfS * kPfS + kThreads - 1) / kThreads;
+  // the colour-weight table of the bilateral filter: requested with the kernel's first loads (round 5) — staged where it is first used, behind the resize phase, its
+  // three loads per lane were one more memory round trip in front of the second barrier
+  float lut_v[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) lut_v[k] = bp.color_lut[tid + k * kThreads];
   if constexpr (LINEAR) {
     // INTER_LINEAR: everything that depends only on the tile COLUMN (reflected canvas x → source byte offset, coefficient pair, where the two taps sit inside the
     // 8 bytes loaded) or only on the tile ROW (source row offsets, coefficient pair) is worked out once per column / row by the first lanes and kept in LDS; an item
@@ -254,7 +259,8 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
       tile[ly * kPfS + lx] = v;
     }
   }
-  for (int k = tid; k < 768; k += kThreads) lut[k] = bp.color_lut[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) lut[tid + k * kThreads] = lut_v[k];
   __syncthreads();
   const int lx = tid & 31, x = tx0 + lx;
   if (lx >= TW || x >= inW) return;
