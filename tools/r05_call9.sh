@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5, call 9: prep_fused_k forms its resize table entries itself (no table round trip in front of the pixel loads): stage parity, then same-box A/B
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_batch.py -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/r05g_pytest.txt
+grep -q "failed\|error" gpurun_out/r05g_pytest.txt && { echo "PARITY FAILED — stopping"; exit 1; }
+run() { ( cd $1; timeout 300 python bench.py --no-cpu-baseline --no-host-io --no-extra-configs --no-side-probes --profile-iters 8 --steps 200 --warmup 20 --ramp-seconds 1.0 $3 --detail /tmp/ab_detail.json 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); f=json.load(open('/tmp/ab_detail.json')); t={x['name']:x['ms'] for x in f['top_launches']}
+print('$2', '$3', 'step', d['ms_per_step'], 'fps', d['value'], 'prep', f['stage_ms']['prep'])" ); }
+for cfg in "--model lite" "--model full --width 1280 --height 720 --batch 1024" "--model mlkit --width 1280 --height 720"; do
+  for i in 1 2 3; do run $ROOT/_ab_old old "$cfg"; run $ROOT new "$cfg"; done
+done 2>&1 | tee gpurun_out/r05g_prep_tables_ab.txt
