@@ -155,6 +155,10 @@ def test_low_resolution_window_reservation_covers_every_tile(tmp_path):
     exe = tmp_path / "lo"
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(ROOT, "backscrub_amd", "csrc"), str(src), "-o", str(exe)])
 
+    import re
+    stride = int(re.search(r"constexpr int kSegLoStride = (\d+);", open(os.path.join(ROOT, "backscrub_amd", "csrc", "segments.hpp")).read()).group(1))   # floats per staged pixel (16 since round 5: dense + swz_l)
+    assert stride == 16
+
     def axis(o, scale, half_pixel, in_size):
         f = np.float32
         v = (f(o) + f(0.5)) * f(scale) + f(-0.5) if half_pixel else f(o) * f(scale)
@@ -172,7 +176,7 @@ def test_low_resolution_window_reservation_covers_every_tile(tmp_path):
             for tx in range(tx_n):
                 cols = range(max(tx * TC - 1, 0), min(tx * TC + TC, W - 1) + 1)
                 lo_c = min(axis(c_, ws, hp, WL)[0] for c_ in cols); hi_c = max(axis(c_, ws, hp, WL)[1] for c_ in cols)
-                need = max(need, (hi_r - lo_r + 1) * (hi_c - lo_c + 1) * 20)
+                need = max(need, (hi_r - lo_r + 1) * (hi_c - lo_c + 1) * stride)
         return need, ty_n, tx_n
 
     cases = [(48, 80, 24, 40, 16, 14), (24, 40, 12, 20, 12, 14),                 # segm_lite: tail, k3
@@ -183,5 +187,5 @@ def test_low_resolution_window_reservation_covers_every_tile(tmp_path):
         for hp, al in ((1, 0), (0, 0), (0, 1)):
             need, ty_n, tx_n = brute(H, W, HL, WL, bool(hp), bool(al), TR, TC)
             got = int(subprocess.check_output([str(exe)] + [str(x) for x in (H, W, HL, WL, hp, al, TR, TC, ty_n, tx_n)]).decode())
-            assert got >= min(need, 12 * 16 * 20), ((H, W, HL, WL, hp, al, TR, TC), got, need)
-            assert got <= 12 * 16 * 20
+            assert got >= min(need, 12 * 16 * stride), ((H, W, HL, WL, hp, al, TR, TC), got, need)
+            assert got <= 12 * 16 * stride
