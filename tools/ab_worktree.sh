@@ -5,7 +5,7 @@
 #   then, in the gpurun script:            run() { cd $1; python bench.py --no-extra-configs --no-cpu-baseline ... ; }
 #                                            run $ROOT/_ab_old; run $ROOT; run $ROOT/_ab_old; run $ROOT      (alternate: clocks drift inside a call too)
 #   when done:                             git worktree remove --force _ab_old
-# Used from profiles/r03ai on (tools/r03_call42.sh … r03_call49.sh).
+# Used from profiles/r03ai on (tools/calls/r03_call42.sh … r03_call49.sh).
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=${1:-HEAD}
 cd "$R"

@@ -11,4 +11,4 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); t={x['name']:x['ms'] fo
 print('$2', '$3', 'step', d['ms_per_step'], 'fps', d['value'], 'mask_blend', t.get('mask_blend'))"; }
 M="--model mlkit --width 1280 --height 720"
 for i in 1 2; do run $ROOT/_ab_old old "$M"; run $ROOT new "$M"; done 2>&1 | tee gpurun_out/r04v_outside_roi_ab.txt
-cd $ROOT; bash tools/r04_call19.sh
+cd $ROOT; bash tools/calls/r04_call19.sh

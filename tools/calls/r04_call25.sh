@@ -20,4 +20,4 @@ print(1 if mean('new', False) <= mean('old', False) * 1.002 and mean('new', True
 PY
 )
 echo "not_slower=$OK"
-if [ "$OK" = "1" ]; then cd $ROOT; bash tools/r04_call19.sh; fi
+if [ "$OK" = "1" ]; then cd $ROOT; bash tools/calls/r04_call19.sh; fi

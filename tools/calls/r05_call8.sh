@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, call 8: evidence on the final kernels (tools/r05_call4.sh: kernel stats, HBM counters -> pmc_latest.json, SQ counters, roctx ranges), then the bench as the
+# round 5, call 8: evidence on the final kernels (tools/calls/r05_call4.sh: kernel stats, HBM counters -> pmc_latest.json, SQ counters, roctx ranges), then the bench as the
 # driver runs it and with its defaults
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT; mkdir -p gpurun_out
-bash tools/r05_call4.sh r05z > gpurun_out/r05z_collect.log 2>&1
+bash tools/calls/r05_call4.sh r05z > gpurun_out/r05z_collect.log 2>&1
 cp gpurun_out/pmc_latest.json profiles/pmc_latest.json          # (bench.py reads the committed copy; the digest must be the one of THIS tree)
 cd $ROOT
 S=$(date +%s)
