@@ -104,6 +104,24 @@ def test_blend_truncating_divide_and_endpoints(oracle):
     assert np.array_equal(out[0], bg[0]) and np.array_equal(out[1], fr[1])   # 255 ⇒ background, 0 ⇒ camera
 
 
+def test_packed_blend_identities_hold_on_the_whole_range():
+    """The integer forms the HIP blend uses (csrc/kernels_img.hip: pk_blend), over every value they can meet: t = a*m + b*(255-m) <= 65025 fits a u16 lane;
+    round 4's floor(t / 255) == (t + 1 + (t >> 8)) >> 8 and round 5's — with u = t + 1 formed by the multiply-adds themselves — floor((u - 1) / 255) == (u + (u >> 8)) >> 8,
+    every intermediate below 2^16; and every (a, b, m) byte triple through the u-form equals deepseg.cc:108-134's truncating divide."""
+    t = np.arange(0, 255 * 255 + 1, dtype=np.int64)
+    assert np.array_equal((t + 1 + (t >> 8)) >> 8, t // 255) and int((t + 1 + (t >> 8)).max()) < 65536
+    u = t + 1
+    assert np.array_equal((u + (u >> 8)) >> 8, t // 255) and int((u + (u >> 8)).max()) == 65280 and int(u.max()) == 65026
+    a = np.arange(256, dtype=np.int64)[:, None, None]
+    b = np.arange(256, dtype=np.int64)[None, :, None]
+    m = np.arange(256, dtype=np.int64)[None, None, :]
+    uu = a * m + 1                                   # first v_pk_mad_u16
+    assert int(uu.max()) <= 65026
+    uu = b * (255 - m) + uu                          # second
+    assert int(uu.max()) <= 65026 and int((255 ^ m).max()) == 255 and np.array_equal(255 ^ m, 255 - m)      # 0x00ff00ff ^ m == 255 - m per half
+    assert np.array_equal((uu + (uu >> 8)) >> 8, (a * m + b * (255 - m)) // 255)
+
+
 # ---- decode + IIR (lib/libbackscrub.cc:317-357) -----------------------------------------------------------
 def test_iir_reaches_steady_state_in_three_frames(oracle):
     prob = np.full((4, 4, 1), 0.1, np.float32)          # "not a person" → val 255
