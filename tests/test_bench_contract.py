@@ -161,3 +161,36 @@ def test_roofline_frac_has_one_definition():
 def test_committed_pmc_file_is_stamped():
     pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
     assert "csrc_digest" in pj and len(pj["csrc_digest"]) == 16
+
+
+def test_the_printed_line_of_a_multi_gpu_run_stays_small_and_carries_the_scaling_fields():
+    """N > 1: the per-rank arrays stay in the detail file; the line keeps what the driver and a reader need — collective, min / max rank rate, rank 0 alone,
+    the configs[4] slice with its roofline fraction and parity sample, the second-device check."""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = json.load(open(os.path.join(ROOT, "profiles", "r04z_bench.json")))
+    leg = {"workload": "w" * 200, "value": 5.6e6, "unit": "frames/s", "ms_per_step": 0.365, "per_rank_fps": [7.0e5 + i for i in range(8)], "per_rank_fps_min": 7.0e5, "per_rank_fps_max": 7.00007e5,
+           "rank0_alone_fps": 7.1e5, "efficiency_vs_rank0_alone": 0.9859}
+    c4 = dict(leg, streams_total=8192, roofline={"kernel": "mask_blend", "bound": "hbm", "frac": 0.66, "achieved": 5280.0, "peak": 8000.0, "unit": "GB/s"},
+              parity_sample={"mask_iou_min": 1.0, "composite_max_abs_diff": 0, "composite_pixels_off_by_more_than_1": 0, "streams": 2, "steps": 7},
+              top_launches=[{"name": "k", "ms": 1.0, "GBps": 1.0}] * 8)
+    d = dict(old, n_gpus=8, collective={"backend": "nccl (RCCL)", "ranks_seen": 8, "world_size": 8}, ranks_seen=8, configs1=leg, configs4=c4,
+             second_device_check={"ran": True, "ok": True, "devices": [0, 7], "models": {"x": {"y": True}}}, numa_binding={"bound": True, "node": 0, "cpus": 32})
+    d.pop("configs", None)
+    line = bench.compact_line(d)
+    s = json.dumps(line, separators=(",", ":"))
+    assert len(s.encode()) < 6144, len(s)
+    assert line["collective"]["ranks_seen"] == 8 and "per_rank_fps" not in line["configs1"] and line["configs1"]["per_rank_fps_min"] == 7.0e5
+    assert line["configs1"]["efficiency_vs_rank0_alone"] == 0.9859 and line["configs4"]["streams_total"] == 8192 and line["configs4"]["frac"] == 0.66
+    assert line["configs4"]["iou_min"] == 1.0 and line["second_device_check"] == {"ran": True, "ok": True}
+
+
+def test_documents_keep_to_160_columns():
+    """DESIGN.md had grown lines of 1 400+ characters.  Every markdown file of the repository that a reader is sent to stays within 160 columns
+    (tools/wrap_md.py re-flows; headings are exempt: they cannot wrap)."""
+    import glob
+    files = [os.path.join(ROOT, f) for f in ("README.md", "DESIGN.md", "INTEGRATION.md", os.path.join("profiles", "README.md"))] + sorted(glob.glob(os.path.join(ROOT, "docs", "design", "*.md")))
+    assert len(files) >= 16
+    for f in files:
+        for i, l in enumerate(open(f, encoding="utf-8").read().split("\n")):
+            assert len(l) <= 160 or l.startswith("#"), "%s:%d has %d columns" % (os.path.relpath(f, ROOT), i + 1, len(l))
