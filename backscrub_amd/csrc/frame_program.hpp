@@ -65,6 +65,8 @@ constexpr int kMicroTail = 101;              // MicroOp::kind of the fused pw â†
 constexpr int kMicroSe = 100;                // MicroOp::kind of the fused GAPâ†’FCâ†’FC chain
 constexpr int kFrameThreads = 1024;          // 16 waves: 4 per SIMD
 constexpr int kLdsTotalFloats = 160 * 256;   // 160 KiB
+constexpr int kLdsZeroFloats = 4;            // the LAST 16 bytes of the block stay 0.0f for the whole kernel (the specialised program zeroes them once): out-of-image taps of the
+constexpr int kLdsZeroOff = kLdsTotalFloats - kLdsZeroFloats;   // depthwise bodies read them through an address select instead of zeroing data registers (round 5)
 constexpr int kLdsScratchFloats = 2048;      // reduction scratch at the start of the LDS block (pooling partials, gemv partials, the tail's small weight set)
 constexpr int kLdsMaxStageFloats = 4224;     // largest weight block staged in LDS (128x32 weights + 128 bias)
 

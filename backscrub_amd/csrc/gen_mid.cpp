@@ -184,6 +184,10 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
         if (chunked) snprintf(name, sizeof name, "Op%d_%d", i, c); else snprintf(name, sizeof name, "Op%d", i);
         o.f("struct %s {\n  static constexpr int K = %d, S = %d, H = %d, W = %d, OH = %d, OW = %d, PT = %d, PL = %d, C = %d, CW = %d, YC0 = %d, ACT = %d, V = %d, TX = %d;\n", name, K, S,
             m.H, m.W, m.OH, m.OW, m.pt, m.pl, CKc, m.Cin, c * CK, m.act, V, TX);
+        // ZC: out-of-image taps through the zero cell (op_dw) — for depthwise ops that read a planned LDS tensor.  Not for the chunk-by-chunk form (input staged
+        // through an LDS workspace inside a loop over channel chunks): there the zero-cell form raised the register pressure of MLKit's kernel, which sits at 128
+        // registers, from 372 to 524 bytes of spill and cost 7 % (profiles/r05j)
+        o.f("  static constexpr bool ZC = %s;\n", (chunked || getenv("BSX_RTC_NO_ZERO_CELL")) ? "false" : "true");
         if (chunked) o.f("  static constexpr int X_SP = 1, X_OFF = %d, X_ST = %d;\n", m.ws_off, CK + 4); else loc(o, "X", m.in0);
         loc(o, "Y", m.out); loc(o, "R", m.res);
         if (staged) o.f("  static constexpr int W_SP = SP_LDS, W_OFF = %d, B_OFF = %d;\n};\n", m.w_lds + c * CK, m.w_lds + (int)(m.b_off - m.w_off) + c * CK);
@@ -245,8 +249,13 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
   }
   o.f("}  // namespace bsxm\n\nusing namespace bsxm;\n");
   o.f("extern \"C\" __global__ void __launch_bounds__(1024) bsx_mid(float* __restrict__ arena, long per_frame, const float* __restrict__ weights, unsigned long long* tl) {\n");
-  o.f("  __shared__ __attribute__((aligned(16))) float smem[%d];\n", plan.program_lds_floats);
+  // the whole 160 KiB block: the planner's tensors and slots end below kLdsZeroOff, the last 16 bytes are the zero cell the depthwise bodies read out-of-image taps from
+  static_assert(kLdsZeroOff + kLdsZeroFloats == kLdsTotalFloats, "zero cell at the top of the block");
+  if (plan.program_lds_floats > kLdsZeroOff) return fail("LDS plan reaches into the zero cell");
+  o.f("  static_assert(kZeroOff == %d, \"zero cell offset\");\n", kLdsZeroOff);
+  o.f("  __shared__ __attribute__((aligned(16))) float smem[%d];\n", kLdsTotalFloats);
   o.f("  lds_f* L = (lds_f*)smem;\n  glb_f* A = (glb_f*)(arena + (size_t)blockIdx.x * (size_t)per_frame);\n  const glb_f* W = (const glb_f*)weights;\n");
+  o.f("  if (threadIdx.x < %d) L[kZeroOff + threadIdx.x] = 0.f;      // visible to every wave behind the first op's barrier\n", kLdsZeroFloats);
   if (fine) o.f("  unsigned long long f_a = 0, f_b = 0;\n"
                 "#define FINE_END(i) do { const unsigned long long f_d = __builtin_readcyclecounter(); if (tl && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { "
                 "unsigned long long* f4 = tl + 1024 + ((i) * 16 + (threadIdx.x >> 6)) * 4; f4[0] = f_b - f_a; f4[1] = 0; f4[2] = f_d - f_b; f4[3] = f_a; } } while (0)\n");

@@ -27,6 +27,10 @@ namespace bsxm {
 enum { SP_NONE = 0, SP_LDS = 1, SP_GLB = 2, SP_GLB16 = 3 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 3, ACT_HSWISH = 100, ACT_SIGMOID = 101 };   // tflite_model.hpp: Activation
 constexpr int kThreads = 1024, kWaves = 16;
+// The last 16 bytes of the LDS block hold 0.0f for the whole kernel (frame_program.hpp: kLdsZeroOff; zeroed in the kernel's prologue, outside every planned block):
+// a depthwise tap that falls outside the image is READ from there through an address select — one v_cndmask on the address instead of one per data register
+// plus the zeroing of the weights of out-of-image rows (round 5: 130 of the 452 vector instructions of a 5x5 item were those selects).
+constexpr int kZeroOff = 160 * 256 - 4;
 
 typedef __attribute__((address_space(3))) float lds_f;
 typedef __attribute__((address_space(1))) float glb_f;
@@ -261,6 +265,8 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
   constexpr int K = T::K, S = T::S, TX = T::TX, V = T::V, C = T::C, CV = C / V, NIN = (TX - 1) * S + K;
   constexpr int NSTRIPS = (T::OW + TX - 1) / TX, TOTAL = CV * NSTRIPS * T::OH;
   typedef float vec_t __attribute__((ext_vector_type(V)));
+  // ZC: out-of-image taps are read from the zero cell — in the fully unrolled LDS form, where the generator found register room for it (T::ZC: gen_mid.cpp)
+  constexpr bool ZC = T::ZC && T::X_SP == SP_LDS && K * (NIN + K) * V <= 144;
   auto ldx = [&](int off) -> vec_t { if constexpr (V == 4) return ld4<T::X_SP>(L + T::X_OFF, A + T::X_OFF, off); else return ld2<T::X_SP>(L + T::X_OFF, A + T::X_OFF, off); };
   auto ldw = [&](int off) -> vec_t { if constexpr (V == 4) return ld4<T::W_SP>(L, Wg, off); else return ld2<T::W_SP>(L, Wg, off); };
 #pragma unroll
@@ -276,15 +282,26 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
     auto load_row = [&](int fy, vec_t (&xin)[NIN], vec_t (&wv)[K]) {
       const int iy = oy * S - T::PT + fy;
       const bool vy = iy >= 0 && iy < T::H;
-      const int rowo = min(max(iy, 0), T::H - 1) * T::W * T::X_ST + ch;
+      if constexpr (ZC) {
+        // LDS input: an out-of-image tap reads the zero cell (same +0.0f the select on the data produced: bit-identical); nothing is clamped, nothing zeroed afterwards
+        const int rowo = iy * T::W * T::X_ST + ch;
 #pragma unroll
-      for (int j = 0; j < NIN; j++) xin[j] = ldx(rowo + min(max(ix0 + j, 0), T::W - 1) * T::X_ST);
+        for (int j = 0; j < NIN; j++) { const int ix = ix0 + j; xin[j] = ldx((vy && ix >= 0 && ix < T::W) ? rowo + ix * T::X_ST : kZeroOff - T::X_OFF); }
 #pragma unroll
-      for (int fx = 0; fx < K; fx++) { wv[fx] = ldw(T::W_OFF + (fy * K + fx) * T::CW + ch); if (!vy) wv[fx] = (vec_t)(0.f); }
+        for (int fx = 0; fx < K; fx++) wv[fx] = ldw(T::W_OFF + (fy * K + fx) * T::CW + ch);
+      } else {
+        const int rowo = min(max(iy, 0), T::H - 1) * T::W * T::X_ST + ch;
+#pragma unroll
+        for (int j = 0; j < NIN; j++) xin[j] = ldx(rowo + min(max(ix0 + j, 0), T::W - 1) * T::X_ST);
+#pragma unroll
+        for (int fx = 0; fx < K; fx++) { wv[fx] = ldw(T::W_OFF + (fy * K + fx) * T::CW + ch); if (!vy) wv[fx] = (vec_t)(0.f); }
+      }
     };
     auto fma_row = [&](vec_t (&xin)[NIN], const vec_t (&wv)[K]) {
+      if constexpr (!ZC) {
 #pragma unroll
-      for (int j = 0; j < NIN; j++) { const int ix = ix0 + j; if (ix < 0 || ix >= T::W) xin[j] = (vec_t)(0.f); }
+        for (int j = 0; j < NIN; j++) { const int ix = ix0 + j; if (ix < 0 || ix >= T::W) xin[j] = (vec_t)(0.f); }
+      }
 #pragma unroll
       for (int k = 0; k < TX; k++) {
 #pragma unroll

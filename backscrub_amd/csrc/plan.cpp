@@ -167,10 +167,10 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       const int pad = ((C / 4) % 2 == 0) ? 4 : 8, need = (P * (C + pad) + 3) / 4 * 4;
       if (reserved + need > kLdsTotalFloats / 4) continue;
       reserved += need;
-      reserved_at[t] = kLdsTotalFloats - reserved;
+      reserved_at[t] = kLdsZeroOff - reserved;
     }
   }
-  const int cap = kLdsTotalFloats - reserved;      // everything that is not reserved allocates in [scratch, cap)
+  const int cap = kLdsZeroOff - reserved;          // everything that is not reserved allocates in [scratch, cap); [kLdsZeroOff, kLdsTotalFloats) is the zero cell
   int high = scratch;
   auto place = [&](int t, int s) {
     if (t < 0 || loc[t].space != kLocNone) return;

@@ -189,3 +189,30 @@ def test_low_resolution_window_reservation_covers_every_tile(tmp_path):
             got = int(subprocess.check_output([str(exe)] + [str(x) for x in (H, W, HL, WL, hp, al, TR, TC, ty_n, tx_n)]).decode())
             assert got >= min(need, 12 * 16 * stride), ((H, W, HL, WL, hp, al, TR, TC), got, need)
             assert got <= 12 * 16 * stride
+
+
+@pytest.mark.parametrize("key", ["lite", "full", "mlkit"])
+def test_zero_cell_of_the_middle_kernel(api, key, monkeypatch):
+    """Round 5: the last 16 bytes of the middle kernel's LDS block are a zero cell — the planner's blocks end below it, the kernel's prologue zeroes it, and the
+    depthwise ops that read a planned LDS tensor take their out-of-image taps from it (traits ZC = true); the chunk-by-chunk ops keep the zeroing form
+    (profiles/r05j: the zero-cell form costs MLKit's 128-register kernel 150 bytes of spill), and BSX_RTC_NO_ZERO_CELL=1 switches the form off everywhere."""
+    hdr = open(os.path.join(ROOT, "backscrub_amd", "csrc", "frame_program.hpp")).read()
+    total = eval(re.search(r"constexpr int kLdsTotalFloats = ([^;]+);", hdr).group(1))            # noqa: S307 — "160 * 256"
+    assert total == 160 * 256 and "kLdsZeroOff = kLdsTotalFloats - kLdsZeroFloats" in hdr and "constexpr int kLdsZeroFloats = 4;" in hdr
+    prelude = open(os.path.join(ROOT, "backscrub_amd", "csrc", "mid_prelude.hip")).read()
+    assert "constexpr int kZeroOff = 160 * 256 - 4;" in prelude and "kZeroOff - T::X_OFF" in prelude
+    desc = api.model_describe(model_path(key))
+    lds_floats = int(re.search(r"lds_floats=(\d+)", desc).group(1))
+    assert lds_floats <= total - 4 and "lds_check=ok" in desc                                        # no planned block reaches into the cell
+    src = api.model_kernel_source(model_path(key))
+    assert "static_assert(kZeroOff == %d" % (total - 4) in src and "float smem[%d];" % total in src
+    assert re.search(r"if \(threadIdx\.x < 4\) L\[kZeroOff \+ threadIdx\.x\] = 0\.f;", src)
+    structs = re.findall(r"struct (Op\d+(?:_\d+)?) \{\n  static constexpr int K = [^\n]+\n  static constexpr bool ZC = (true|false);\n  static constexpr int X_SP = (\d), X_OFF", src)
+    assert structs, "no depthwise traits found"
+    for name, zc, sp in structs:
+        chunk = "_" in name                                                                           # Op<i>_<c>: one channel chunk of a layer staged through an LDS workspace
+        assert (zc == "true") == (not chunk), (name, zc)
+    assert any(zc == "true" for _, zc, _ in structs)
+    monkeypatch.setenv("BSX_RTC_NO_ZERO_CELL", "1")
+    off = api.model_kernel_source(model_path(key))
+    assert "ZC = true" not in off and off.count("ZC = false") == len(structs)
