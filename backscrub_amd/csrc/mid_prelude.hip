@@ -266,7 +266,7 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
   constexpr int NSTRIPS = (T::OW + TX - 1) / TX, TOTAL = CV * NSTRIPS * T::OH;
   typedef float vec_t __attribute__((ext_vector_type(V)));
   // ZC: out-of-image taps are read from the zero cell — in the fully unrolled LDS form, where the generator found register room for it (T::ZC: gen_mid.cpp)
-  constexpr bool ZC = T::ZC && T::X_SP == SP_LDS && K * (NIN + K) * V <= 144;
+  constexpr bool ZC = T::ZC && T::X_SP == SP_LDS;
   auto ldx = [&](int off) -> vec_t { if constexpr (V == 4) return ld4<T::X_SP>(L + T::X_OFF, A + T::X_OFF, off); else return ld2<T::X_SP>(L + T::X_OFF, A + T::X_OFF, off); };
   auto ldw = [&](int off) -> vec_t { if constexpr (V == 4) return ld4<T::W_SP>(L, Wg, off); else return ld2<T::W_SP>(L, Wg, off); };
 #pragma unroll
@@ -284,9 +284,11 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
       const bool vy = iy >= 0 && iy < T::H;
       if constexpr (ZC) {
         // LDS input: an out-of-image tap reads the zero cell (same +0.0f the select on the data produced: bit-identical); nothing is clamped, nothing zeroed afterwards
-        const int rowo = iy * T::W * T::X_ST + ch;
+        // (one base per filter row; the column step j * X_ST is a compile-time term the ds_read carries as its immediate offset — the select picks between the row's
+        //  base and "zero cell minus that term", so a tap costs one v_cndmask and no address arithmetic)
+        const int rowo = (iy * T::W + ix0) * T::X_ST + ch;
 #pragma unroll
-        for (int j = 0; j < NIN; j++) { const int ix = ix0 + j; xin[j] = ldx((vy && ix >= 0 && ix < T::W) ? rowo + ix * T::X_ST : kZeroOff - T::X_OFF); }
+        for (int j = 0; j < NIN; j++) { const int ix = ix0 + j; xin[j] = ldx(((vy && ix >= 0 && ix < T::W) ? rowo : kZeroOff - T::X_OFF - j * T::X_ST) + j * T::X_ST); }
 #pragma unroll
         for (int fx = 0; fx < K; fx++) wv[fx] = ldw(T::W_OFF + (fy * K + fx) * T::CW + ch);
       } else {
