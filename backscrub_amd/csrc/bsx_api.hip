@@ -934,17 +934,19 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
                          mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
   const int L = (c->prep_split ? 2 : 1) + n_net + (fused_decode ? 0 : 1) + (fuse_tail ? 1 : 2) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
   if (cap < L) return BSX_EINVAL;
-  std::vector<hipEvent_t> ev((size_t)2 * L);
+  // ONE event between consecutive launches (round 6: L + 1 events, not 2 L): launch k is timed from the event behind launch k - 1 to the event behind itself, so
+  // the per-launch figures add up to the pass and carry one event's cost each instead of two (round 5's bracketing pairs read 11 % over the un-instrumented step)
+  std::vector<hipEvent_t> ev((size_t)L + 1);
   for (auto& e : ev) BSX_HIP(c, hipEventCreate(&e));
   std::vector<double> sum(L, 0.0);
   const double N = n, px = (double)c->width * c->height;
   for (int it = 0; it < iters; it++) {
     int k = 0;
+    BSX_HIP(c, hipEventRecord(ev[0], s));
 #define BSX_TIMED(call)                                    \
     do {                                                   \
-      BSX_HIP(c, hipEventRecord(ev[2 * k], s));            \
       BSX_HIP(c, (call));                                  \
-      BSX_HIP(c, hipEventRecord(ev[2 * k + 1], s));        \
+      BSX_HIP(c, hipEventRecord(ev[k + 1], s));            \
       k++;                                                 \
     } while (0)
     if (c->prep_split) {
@@ -982,7 +984,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     }
 #undef BSX_TIMED
     BSX_HIP(c, hipStreamSynchronize(s));
-    for (int j = 0; j < L; j++) { float ms = 0; BSX_HIP(c, hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1])); sum[j] += ms; }
+    for (int j = 0; j < L; j++) { float ms = 0; BSX_HIP(c, hipEventElapsedTime(&ms, ev[j], ev[j + 1])); sum[j] += ms; }
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   auto put = [&](int j, const std::string& name, double bytes, double flops) {

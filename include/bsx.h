@@ -278,13 +278,13 @@ BSX_API long bsx_model_kernel_source(const char* model_path, char* buf, size_t c
 /* ---- measurement ---- */
 typedef struct bsx_launch_stat {
   char name[64];      /* kernel / fused step label */
-  double avg_ms;      /* mean hipEvent-bracketed duration of this launch over `iters` repetitions */
+  double avg_ms;      /* mean duration of this launch over `iters` repetitions: from the hipEvent behind the launch in front of it to the one behind itself */
   double bytes;       /* ALGORITHMIC bytes this launch must move for n streams (inputs once + outputs once) */
   double flops;       /* 2*MAC for n streams (0 for byte kernels) */
 } bsx_launch_stat;
 
 /* Runs the whole per-batch sequence (prep, every fused network step, decode, upscale+blur, blend)
- * `iters` times, bracketing EVERY launch with hipEvents on `stream`, and writes one record per
+ * `iters` times with ONE hipEvent on `stream` between consecutive launches (the per-launch figures add up to the pass), and writes one record per
  * launch (in launch order) into out[0..cap).  Returns the number of launches, or a negative error.
  * The temporal state advances exactly as `iters` calls of bsx_step_batch would. */
 BSX_API int bsx_profile_batch(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out,

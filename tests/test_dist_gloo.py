@@ -119,6 +119,33 @@ def test_bench_self_launches_its_ranks():
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["host"]["model"] and d["host"]["logical_cpus"] >= 1
 
 
+def test_bench_walks_the_north_star_rank_count_world8():
+    """BASELINE configs[4] is an 8-rank job (8192 HD streams / 8 GPUs).  No node with more than one GPU existed in any round, so the exact rank count is walked
+    here on gloo: `bench.py --gpus 8 --selftest-dist` self-launches 8 ranks through torch.distributed.run on 127.0.0.1, every rank takes the same order of solo
+    runs, barriers and reductions as the GPU job, and rank 0 prints the line: 8 ranks seen by the collective, 8192 streams in the configs[4] leg, per-rank rates
+    from the gather, time = max over ranks (the slowest rank — 2.75x by construction — sets the job's rate)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--selftest-dist", "--batch", "256", "--steps", "4", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["collective"] == {"backend": "gloo", "ranks_seen": 8, "world_size": 8}
+    assert d["frames"] == 8 * 256 * 4 and d["checksum"] == sum(1000 + r for r in range(8))
+    assert abs(d["elapsed_max"] - 4 * 1e-3 * (1.0 + 0.25 * 7)) < 1e-9                 # the slowest rank's time
+    c1, c4 = d["configs1"], d["configs4"]
+    assert len(c1["per_rank_fps"]) == 8 and c1["per_rank_fps"] == sorted(c1["per_rank_fps"], reverse=True)        # rank r is (1 + r/4)x slower, gathered in rank order
+    assert abs(c1["efficiency_vs_rank0_alone"] - 1.0 / 2.75) < 1e-4                        # rounded to 4 places in the line
+    assert c4["streams_total"] == 8192 and "segm_full_v679" in c4["workload"] and "1280x720" in c4["workload"] and len(c4["per_rank_fps"]) == 8
+    assert abs(c4["value"] - 8 * 1024 * 1e3 / c4["ms_per_step"]) / c4["value"] < 1e-6
+
+
 def test_ranks_bind_to_the_numa_node_of_their_gpu(tmp_path):
     """bench.py at N > 1: each rank restricts itself to the CPUs of its GPU's NUMA node (sysfs: bus/pci/devices/<id>/numa_node → devices/system/node/nodeK/cpulist),
     intersected with the affinity mask it was given; a platform that does not expose the topology (numa_node = -1, no sysfs entry) leaves the mask alone."""
