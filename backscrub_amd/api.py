@@ -157,23 +157,26 @@ class MaskGen:
         n = self._n(frames)
         if out is None:
             out = torch.empty_like(frames)
-        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        stride = self._bg(bg, n)
         mp = C.c_void_p(masks.data_ptr()) if masks is not None else None
         _check(lib().bsx_composite_batch(self.h, C.c_void_p(bg.data_ptr()), stride, C.c_void_p(frames.data_ptr()), mp,
                                          C.c_void_p(out.data_ptr()), n, _stream_ptr()), self.h, "bsx_composite_batch")
         return out
 
     def _bg(self, bg, n):
-        """background operand of a step: ONE image [H,W,3] shared by all streams or one per stream [>=n,H,W,3]; contiguous cuda uint8 on the frames' device"""
-        ok = (bg.dtype == _torch().uint8 and bg.is_cuda and bg.is_contiguous() and bg.dim() in (3, 4) and tuple(bg.shape[-3:]) == (self.height, self.width, 3)
-              and (bg.dim() == 3 or bg.shape[0] >= n) and bg.device.index == self.device)
+        """background operand of a step → bg_frame_stride: ONE image [H,W,3] shared by all streams, or one per stream [>=n,H,W,3] — cuda uint8 on the context's
+        device with a contiguous [H,W,3] inside; the stream dimension may be strided or expanded (stride 0 = one image for all), which is what the C ABI's
+        bg_frame_stride serves.  (every entry point validates, not only step_pipelined.)"""
+        ok = (bg.dtype == _torch().uint8 and bg.is_cuda and bg.dim() in (3, 4) and tuple(bg.shape[-3:]) == (self.height, self.width, 3)
+              and tuple(bg.stride()[-3:]) == (self.width * 3, 3, 1) and (bg.dim() == 3 or bg.shape[0] >= n) and bg.device.index == self.device
+              and (bg.dim() == 3 or bg.stride(0) >= 0))
         if not ok:
-            raise BsxError("bg must be a contiguous cuda:%d uint8 tensor [%d,%d,3] or [>=%d,%d,%d,3]" % (self.device, self.height, self.width, n, self.height, self.width))
-        return 0 if bg.dim() == 3 else bg.stride(0)
+            raise BsxError("bg must be a cuda:%d uint8 tensor [%d,%d,3] or [>=%d,%d,%d,3] with contiguous images" % (self.device, self.height, self.width, n, self.height, self.width))
+        return 0 if bg.dim() == 3 else int(bg.stride(0))
 
     def step(self, frames, bg, out):
         n = self._n(frames)
-        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        stride = self._bg(bg, n)
         _check(lib().bsx_step_batch(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride,
                                     C.c_void_p(out.data_ptr()), n, _stream_ptr()), self.h, "bsx_step_batch")
         return out
@@ -184,40 +187,45 @@ class MaskGen:
         if (out_yuyv.dim() != 4 or tuple(out_yuyv.shape[1:]) != (self.height, self.width, 2) or out_yuyv.shape[0] < n or not out_yuyv.is_contiguous()
                 or not out_yuyv.is_cuda or out_yuyv.dtype != _torch().uint8):
             raise BsxError("out_yuyv must be a contiguous cuda uint8 tensor [>=%d,%d,%d,2]" % (n, self.height, self.width))
-        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        stride = self._bg(bg, n)
         _check(lib().bsx_step_batch_yuyv(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride,
                                          C.c_void_p(out_yuyv.data_ptr()), n, _stream_ptr()), self.h, "bsx_step_batch_yuyv")
         return out_yuyv
 
-    def step_ex(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False, no_mask=False, bgblur=0):
+    def step_ex(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False, no_mask=False, bgblur=0, yuyv_in=False):
         """one main-loop iteration with cv::flip of the composite (app/deepseg.cc:667-673) and / or the YUYV pack folded into the blend's store;
-        bgblur=<odd ksize>: the background is GaussianBlur(the stream's own frame) (-p bgblur:<n> without -b, deepseg.cc:652-661), `bg` may be None"""
-        n = self._n(frames)
+        bgblur=<odd ksize>: the background is GaussianBlur(the stream's own frame) (-p bgblur:<n> without -b, deepseg.cc:652-661), `bg` may be None;
+        yuyv_in: `frames` is the camera's raw YUYV 4:2:2 [n,H,W,2] (cv::COLOR_YUV2BGR_YUYV folded into the kernels that read it: BSX_STEP_YUYV_IN)"""
+        n = self._n(frames, yuyv_in)
         want = (self.height, self.width, 2 if yuyv else 3)
         if out.dim() != 4 or tuple(out.shape[1:]) != want or out.shape[0] < n or not out.is_contiguous() or not out.is_cuda or out.dtype != _torch().uint8:
             raise BsxError("out must be a contiguous cuda uint8 tensor [>=%d,%d,%d,%d]" % ((n,) + want))
         if bg is None and not bgblur:
             raise BsxError("bg is required unless bgblur is set")
-        stride = 0 if bg is None or bg.dim() == 3 else bg.stride(0)
-        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0) | ((int(bgblur) & 255) << 8)
+        stride = 0 if bg is None else self._bg(bg, n)
+        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0) | (16 if yuyv_in else 0) | ((int(bgblur) & 255) << 8)
         _check(lib().bsx_step_batch_ex(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr() if bg is not None else None), stride,
                                        C.c_void_p(out.data_ptr()), n, _stream_ptr(), flags), self.h, "bsx_step_batch_ex")
         return out
 
-    def step_pipelined(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False, no_mask=False):
+    def step_pipelined(self, frames, bg, out, flip_h=False, flip_v=False, yuyv=False, no_mask=False, yuyv_in=False):
         """throughput mode (bsx_step_batch_pipelined): enqueue the mask pipeline of THIS batch and, concurrently, the composite of the batch handed over by
         the previous call (the reference's CalcMask worker next to its blend loop, app/deepseg.cc:159-285).  `out` — and masks() — hold THIS batch's results
         once the NEXT call (or flush_pipelined()) has completed; frames / bg / out must stay untouched until then.  Bit-identical to step_ex per batch."""
-        n = self._n(frames)
+        n = self._n(frames, yuyv_in)
         want = (self.height, self.width, 2 if yuyv else 3)
         if out.dim() != 4 or tuple(out.shape[1:]) != want or out.shape[0] < n or not out.is_contiguous() or not out.is_cuda or out.dtype != _torch().uint8:
             raise BsxError("out must be a contiguous cuda uint8 tensor [>=%d,%d,%d,%d]" % ((n,) + want))
         stride = self._bg(bg, n)
-        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0)
+        flags = (1 if yuyv else 0) | (2 if flip_h else 0) | (4 if flip_v else 0) | (8 if no_mask else 0) | (16 if yuyv_in else 0)
         _check(lib().bsx_step_batch_pipelined(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride, C.c_void_p(out.data_ptr()), n, _stream_ptr(), flags),
                self.h, "bsx_step_batch_pipelined")
         # the composite of THIS batch is enqueued by the NEXT call, on a stream torch's caching allocator knows nothing about: the three tensors stay referenced
-        # here until then (a caller that drops them would otherwise have their memory handed out again under the pending kernel)
+        # here until then (a caller that drops them would otherwise have their memory handed out again under the pending kernel) — and for ONE MORE call: a caller
+        # that alternates streams gets composite k joined into the stream of call k + 1, so a block of call k's stream freed right after call k + 1 could be handed
+        # out again on that stream while the composite still runs (ADVICE r5).  Released after call k + 2, a flush or a reset.
+        held = getattr(self, "_pending", None)
+        self._pending_prev = held
         self._pending = (frames, bg, out)
         return out
 
@@ -231,13 +239,14 @@ class MaskGen:
         with the state.  (Between calls k and k + 1 the references move on by themselves: call k + 1 orders the caller's stream behind composite k — the launch that
         advances the temporal state waits for it — so memory freed after that call cannot be reused ahead of the composite.)"""
         self._pending = None
+        self._pending_prev = None
 
     def profile(self, frames, bg, out, iters=5):
         """per-launch hipEvent timings of the whole per-batch sequence → list of dicts"""
         n = self._n(frames)
         cap = self.info["n_steps"] + 8
         arr = (LaunchStat * cap)()
-        stride = 0 if bg.dim() == 3 else bg.stride(0)
+        stride = self._bg(bg, n)
         k = lib().bsx_profile_batch(self.h, C.c_void_p(frames.data_ptr()), C.c_void_p(bg.data_ptr()), stride, C.c_void_p(out.data_ptr()),
                                     n, iters, arr, cap, _stream_ptr())
         if k < 0:
@@ -327,7 +336,7 @@ class MaskGen:
 
     # ---- introspection (tests) --------------------------------------------------------------------
     def run_stage(self, stage, frames=None, n=None):
-        n = n if n is not None else (self._n(frames) if frames is not None else self.n_streams)
+        n = n if n is not None else (self._n(frames, yuyv_in=(stage == 4)) if frames is not None else self.n_streams)
         fp = C.c_void_p(frames.data_ptr()) if frames is not None else None
         _check(lib().bsx_debug_run_stage(self.h, stage, fp, n, _stream_ptr()), self.h, "bsx_debug_run_stage")
 
@@ -375,9 +384,10 @@ class MaskGen:
         _check(lib().bsx_debug_buffer(self.h, which, C.byref(p), C.byref(b)), self.h, "bsx_debug_buffer")
         return _as_torch(p.value, b.value, dtype, shape, self.device)
 
-    def _n(self, frames):
-        if frames.dim() != 4 or tuple(frames.shape[1:]) != (self.height, self.width, 3) or not frames.is_contiguous() or not frames.is_cuda:
-            raise BsxError("frames must be a contiguous cuda uint8 tensor [n,%d,%d,3]" % (self.height, self.width))
+    def _n(self, frames, yuyv_in=False):
+        ch = 2 if yuyv_in else 3                 # BSX_STEP_YUYV_IN: the camera's raw 4:2:2 frames, 2 bytes per pixel
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (self.height, self.width, ch) or not frames.is_contiguous() or not frames.is_cuda or frames.dtype != _torch().uint8:
+            raise BsxError("frames must be a contiguous cuda uint8 tensor [n,%d,%d,%d]" % (self.height, self.width, ch))
         if frames.shape[0] > self.n_streams:
             raise BsxError("batch larger than n_streams")
         return int(frames.shape[0])

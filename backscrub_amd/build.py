@@ -15,8 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbsx.so")
+# the same sources with -DBSX_DEBUG_SWITCHES (csrc/debug_switches.hpp): the A/B knobs, alternate code paths and work-skipping experiments the default build leaves
+# out.  Test infrastructure — tests/test_gpu_switch_variants.py and the tools/ experiments load it through BSX_LIBRARY; nothing ships or measures with it.
+OBJ_DBG = os.path.join(CSRC, "build_dbg")
+LIB_DBG = os.path.join(HERE, "libbsx_dbg.so")
 SOURCES = ["tflite_model.cpp", "plan.cpp", "gen_mid.cpp", "rtc.cpp", "media.cpp", "jpeg.cpp", "live.cpp", "kernels_nn.hip", "kernels_img.hip", "kernels_frame.hip", "kernels_seg.hip", "bsx_api.hip"]
-HEADERS = ["mid_prelude.hip", "gen_mid.hpp", "rtc.hpp", "media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", "roctx_ranges.hpp", os.path.join("..", "..", "include", "bsx.h")]
+HEADERS = ["mid_prelude.hip", "debug_switches.hpp", "gen_mid.hpp", "rtc.hpp", "media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", "roctx_ranges.hpp", os.path.join("..", "..", "include", "bsx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]      # only the BSX_API entry points of include/bsx.h are exported
@@ -29,31 +33,53 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def strip_line_comments(text):
+    """`// ...` comments removed (not inside string literals), line structure kept — hipRTC's diagnostics keep their line numbers, the embedded text loses a third of
+    its bytes and every switch name the comments mention."""
+    out = []
+    for line in text.split("\n"):
+        i, in_str, res = 0, False, None
+        while i < len(line):
+            ch = line[i]
+            if in_str:
+                if ch == "\\":
+                    i += 1
+                elif ch == '"':
+                    in_str = False
+            elif ch == '"':
+                in_str = True
+            elif ch == "/" and line[i:i + 2] == "//":
+                res = line[:i].rstrip()
+                break
+            i += 1
+        out.append(line if res is None else res)
+    return "\n".join(out)
+
+
 def embed_prelude():
-    """csrc/mid_prelude.hip → csrc/build/mid_prelude_str.inc: the device templates as a C++ raw string literal that gen_mid.cpp includes
+    """csrc/mid_prelude.hip → csrc/build/mid_prelude_str.inc: the device templates (comments stripped) as a C++ raw string literal that gen_mid.cpp includes
     (the specialised kernels are compiled from it by hipRTC when a context is created)."""
     src = os.path.join(CSRC, "mid_prelude.hip")
-    dst = os.path.join(OBJ, "mid_prelude_str.inc")
-    text = open(src).read()
+    text = strip_line_comments(open(src).read())
     assert ')BSXRTC"' not in text
     body = 'R"BSXRTC(' + text + ')BSXRTC"\n'
-    if not os.path.exists(dst) or open(dst).read() != body:
-        with open(dst, "w") as f:
-            f.write(body)
+    for d in (OBJ, OBJ_DBG):
+        dst = os.path.join(d, "mid_prelude_str.inc")
+        if not os.path.exists(dst) or open(dst).read() != body:
+            with open(dst, "w") as f:
+                f.write(body)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
-    embed_prelude()
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+def _build_one(objdir, lib, extra_flags, force, verbose):
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(objdir, "mid_prelude_str.inc")]
     objs = []
     procs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJ, src + ".o")
+        op = os.path.join(objdir, src + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + hdrs):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
+            cmd = [HIPCC] + FLAGS + extra_flags + ["-I", objdir] + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -67,12 +93,22 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("libbsx build failed")
-    if force or procs or _stale(LIB, objs + [os.path.join(CSRC, "libbsx.map")]):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,--version-script=" + os.path.join(CSRC, "libbsx.map"), "-o", LIB] + objs + ["-lz", "-lpthread", "-lhiprtc", "-ldl"]
+    if force or procs or _stale(lib, objs + [os.path.join(CSRC, "libbsx.map")]):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,--version-script=" + os.path.join(CSRC, "libbsx.map"), "-o", lib] + objs + ["-lz", "-lpthread", "-lhiprtc", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    build_shim_demo(force or bool(procs), verbose)
+    return bool(procs)
+
+
+def build(force=False, verbose=False, debug_lib=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(OBJ_DBG, exist_ok=True)
+    embed_prelude()
+    rebuilt = _build_one(OBJ, LIB, [], force, verbose)
+    if debug_lib:
+        _build_one(OBJ_DBG, LIB_DBG, ["-DBSX_DEBUG_SWITCHES"], force, verbose)
+    build_shim_demo(force or rebuilt, verbose)
     return LIB
 
 

@@ -3,6 +3,7 @@
 // bs_maskgen_process :279-376, bs_maskgen_delete :261-277) and of the compositing step of
 // app/deepseg.cc (:108-134, :649-661), re-designed for batches of independent streams
 // resident in HBM.
+#include "debug_switches.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -103,20 +104,19 @@ struct bsx_ctx {
   // the direct launches).  graph_state: 0 = not tried, 1 = usable, -1 = capture failed on this runtime (direct launches from then on).
   std::map<int, hipGraphExec_t> host_graphs;
   int graph_state = 0;
-  bool prep_split = false;          // BSX_PREP_SPLIT=1 (read at bsx_new): resize and bilateral as two launches through the canvas buffer (A/B timing; the default is prep_fused_k)
   bool in_u8 = false;               // the step's prep writes ONLY the 8-bit form and the stem normalises on load (seg_head_k / dl_head0_k; bit-identical).
                                     //   BSX_F32_INPUT=1 (read at bsx_new) keeps the f32 tensor for A/B timing; the stage-debug entry writes both.
   float* d_net_out = nullptr;       // network output [n][outH][outW][outC] f32 (read by the decode kernel)
   float* d_weights = nullptr;
   uint16_t* d_weights16 = nullptr;   // split-f16 copies of the large pointwise-conv weights (Plan::weights16)
   int f16_terms = 3;                 // per-launch path: 3 = split-f16 MFMA GEMM (f32-grade, default), 1 = plain f16 inputs (BSX_F16_GEMM=fast), 0 = f32 MFMA (BSX_F16_GEMM=off)
-  uint32_t* d_canvas = nullptr;
   uint8_t* d_ofinal = nullptr;
   uint8_t* d_masks = nullptr;
   uint8_t* d_host_frame = nullptr;  // staging for bsx_process_host
   uint8_t* d_bgr_scratch = nullptr; // BGR composite of bsx_step_batch_yuyv / _ex when the fused epilogue does not apply (lazy)
   uint8_t* d_bgr_scratch2 = nullptr; // ... its flipped copy when a YUYV pack follows (lazy)
   uint8_t* d_bgblur_scratch = nullptr; // BSX_STEP_BGBLUR when the single pass does not apply: the blurred frames (lazy)
+  uint8_t* d_bgr_in_scratch = nullptr; // BSX_STEP_YUYV_IN where the fused kernels do not apply: the batch converted to BGR (lazy)
   float* d_color_lut = nullptr;
   MicroOp* d_program = nullptr;     // per-frame network program (kernels_frame.hip)
   bool use_program = false;
@@ -233,11 +233,10 @@ int init_device_state(bsx_ctx* c) {
   BSX_HIP(c, hipMemcpy(c->d_weights16, c->plan.weights16.data(), c->plan.weights16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   // off = f32 MFMA; fast = plain f16 operands (1 term); fast16 = fast + the depthwise outputs of the fused blocks STORED as f16 (bit 4: kernels.hpp)
   if (const char* m = getenv("BSX_F16_GEMM")) c->f16_terms = !strcmp(m, "off") ? 0 : (!strcmp(m, "fast") ? 1 : (!strcmp(m, "fast16") ? 17 : 3));
-  if (const char* m = getenv("BSX_GEMM_RING")) { if (atoi(m) != 0 && c->f16_terms > 0) c->f16_terms |= 32; }       // LDS-DMA ring GEMM (experiment switch)
   // The per-frame program pays off when most tensors stay in LDS (Meet / MLKit families); graphs whose tensors mostly
   // spill (DeepLab: 33x33x480) run faster as one batch-wide launch per step.  BSX_FORCE_FRAME_PROGRAM / BSX_NO_FRAME_PROGRAM override.
-  c->use_program = !c->plan.program.empty() && getenv("BSX_NO_FRAME_PROGRAM") == nullptr &&
-                   (c->plan.seg.on || c->plan.program_lds_tensors >= c->plan.program_global_tensors || getenv("BSX_FORCE_FRAME_PROGRAM") != nullptr);
+  c->use_program = !c->plan.program.empty() && BSX_DBG_ENV("BSX_NO_FRAME_PROGRAM") == nullptr &&
+                   (c->plan.seg.on || c->plan.program_lds_tensors >= c->plan.program_global_tensors || BSX_DBG_ENV("BSX_FORCE_FRAME_PROGRAM") != nullptr);
   if (c->use_program) {
     BSX_HIP(c, hipMalloc(&c->d_program, c->plan.program.size() * sizeof(MicroOp)));
     BSX_HIP(c, hipMemcpy(c->d_program, c->plan.program.data(), c->plan.program.size() * sizeof(MicroOp), hipMemcpyHostToDevice));
@@ -248,7 +247,7 @@ int init_device_state(bsx_ctx* c) {
     // Anything the generator does not cover, or a failed compilation, leaves the interpreter in charge — never an error.
     const char* a16 = getenv("BSX_ACT16");
     c->act16 = a16 && atoi(a16) != 0 && c->plan.seg.on;
-    if (!getenv("BSX_NO_RTC")) {
+    if (!BSX_DBG_ENV("BSX_NO_RTC")) {
       std::string why, log;
       const std::string src = generate_mid_source(c->plan, &why, c->act16);
       if (src.empty()) c->mid_note = "interpreted (" + why + ")";
@@ -257,7 +256,7 @@ int init_device_state(bsx_ctx* c) {
         std::vector<char> code;
         bool cached = false;
         if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) c->mid_note = "interpreted (no device properties)";
-        else if (!rtc_build(src, prop.gcnArchName, &code, &log, &cached)) { c->mid_note = "interpreted (hipRTC: " + log.substr(0, 400) + ")"; if (getenv("BSX_RTC_DEBUG")) fprintf(stderr, "%s\n", log.c_str()); }
+        else if (!rtc_build(src, prop.gcnArchName, &code, &log, &cached)) { c->mid_note = "interpreted (hipRTC: " + log.substr(0, 400) + ")"; if (BSX_DBG_ENV("BSX_RTC_DEBUG")) fprintf(stderr, "%s\n", log.c_str()); }
         else if (rtc_load(code, "bsx_mid", &c->mid) != hipSuccess) { c->mid_note = "interpreted (code object did not load)"; (void)hipGetLastError(); }
         else c->mid_note = std::string("specialised kernel (hipRTC") + (cached ? ", from the cache)" : ", compiled now)");
       }
@@ -270,8 +269,8 @@ int init_device_state(bsx_ctx* c) {
   } else {
     BSX_HIP(c, nn_prepare());                 // per-launch path: the fused kernels' dynamic-LDS limits on this device
   }
-  if (const char* l = getenv("BSX_PIPE_WGS")) c->pipe_wgs = std::min(8, std::max(0, atoi(l)));
-  if (const char* l = getenv("BSX_LANES")) c->lanes = std::min(4, std::max(1, atoi(l)));
+  if (const char* l = BSX_DBG_ENV("BSX_PIPE_WGS")) c->pipe_wgs = std::min(8, std::max(0, atoi(l)));
+  if (const char* l = BSX_DBG_ENV("BSX_LANES")) c->lanes = std::min(4, std::max(1, atoi(l)));
   if (c->lanes > 1) {
     BSX_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int k = 1; k < c->lanes; k++) {
@@ -280,10 +279,8 @@ int init_device_state(bsx_ctx* c) {
     }
   }
   // stems with a byte path take the 8-bit network input: the segmented Meet / MLKit head and DeepLab's fused head kernel
-  c->prep_split = getenv("BSX_PREP_SPLIT") != nullptr;
-  if (getenv("BSX_NO_GRAPH")) c->graph_state = -1;
-  c->in_u8 = getenv("BSX_F32_INPUT") == nullptr && ((c->use_program && c->plan.seg.on) || (!c->use_program && head0_u8_ok(c->plan)));
-  BSX_HIP(c, hipMalloc(&c->d_canvas, N * canvas_elems(c->inW, c->inH) * sizeof(uint32_t)));
+  if (BSX_DBG_ENV("BSX_NO_GRAPH")) c->graph_state = -1;
+  c->in_u8 = BSX_DBG_ENV("BSX_F32_INPUT") == nullptr && ((c->use_program && c->plan.seg.on) || (!c->use_program && head0_u8_ok(c->plan)));
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
   BSX_HIP(c, hipMalloc(&c->d_masks, N * c->width * c->height));
   BSX_HIP(c, hipMemset(c->d_ofinal, 0, N * c->outW * c->outH));            // :257 leaves it uninitialised; defined as 0
@@ -330,16 +327,11 @@ int init_device_state(bsx_ctx* c) {
 hipStream_t pick(bsx_ctx*, void* s) { return (hipStream_t)s; }
 
 // with_f32: also materialise the f32 input tensor when the stem reads the 8-bit form (the stage-debug entry: tests inspect the tensor)
-int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s, bool with_f32 = false) {
+int run_prep(bsx_ctx* c, const uint8_t* d_frames, int n, hipStream_t s, bool with_f32 = false, bool yuyv_in = false) {
   bsx_roctx::Range range("bsx:prep");
   float* f32 = (!c->in_u8 || with_f32) ? c->tensor_ptr(c->plan.input) : nullptr;
   uint32_t* u8 = c->in_u8 ? c->d_net_in_u8 : nullptr;
-  if (!c->prep_split) {
-    BSX_HIP(c, launch_prep_fused(d_frames, c->width, c->height, c->roi, f32, u8, c->inW, c->inH, c->in_roi, c->tab_down.tab, c->bilateral, n, s));
-    return BSX_OK;
-  }
-  BSX_HIP(c, launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
-  BSX_HIP(c, launch_prep_bilateral(c->d_canvas, f32, u8, c->inW, c->inH, c->bilateral, n, s));
+  BSX_HIP(c, launch_prep_fused(d_frames, c->width, c->height, c->roi, f32, u8, c->inW, c->inH, c->in_roi, c->tab_down.tab, c->bilateral, n, s, yuyv_in));
   return BSX_OK;
 }
 // logits = true: the network output tensor is written (stage tests, the stand-alone decode follows); false: the tail kernel of a
@@ -356,7 +348,7 @@ hipError_t launch_program(bsx_ctx* c, int n, hipStream_t s, unsigned long long* 
     float* arena = c->d_arena;
     const float* weights = c->d_weights;
     void* args[] = {&arena, &pf, &weights, &timeline};
-    return hipModuleLaunchKernel(c->mid.fn, (unsigned)n, 1, 1, kFrameThreads, 1, 1, 0, s, args, nullptr);
+    return hipModuleLaunchKernel(c->mid.fn, (unsigned)n, 1, 1, (unsigned)c->plan.mid_lanes, 1, 1, 0, s, args, nullptr);
   }
   return launch_frame_program(c->d_program, (int)c->plan.program.size(), c->plan.program_lds_floats, c->d_arena, pf, c->d_net_in, c->d_net_out, c->d_weights, n, s,
                               timeline);
@@ -491,9 +483,9 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     report(nullptr, ondebug, caller_ctx, "error: model output has %d channels, unexpected for this model type\n", c->outC);
     return nullptr;
   }
-  bool no_reuse = getenv("BSX_ARENA_NO_REUSE") != nullptr;
+  bool no_reuse = BSX_DBG_ENV("BSX_ARENA_NO_REUSE") != nullptr;
   // the per-launch path (BSX_NO_FRAME_PROGRAM) executes the plain step list: it needs the unsegmented plan
-  const bool segments = getenv("BSX_NO_SEGMENTS") == nullptr && getenv("BSX_NO_FRAME_PROGRAM") == nullptr;
+  const bool segments = BSX_DBG_ENV("BSX_NO_SEGMENTS") == nullptr && BSX_DBG_ENV("BSX_NO_FRAME_PROGRAM") == nullptr;
   if (!build_plan(c->graph, &c->plan, &err, !no_reuse, segments)) { report(nullptr, ondebug, caller_ctx, "error: unable to build GPU plan: %s\n", err.c_str()); return nullptr; }
   // ROI geometry, float arithmetic truncated to int exactly as lib/libbackscrub.cc:230-246
   float ratio = (float)c->inH / (float)c->inW;
@@ -510,12 +502,12 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     report(nullptr, ondebug, caller_ctx, "error: frame/model geometry yields an empty or out-of-range ROI\n");
     return nullptr;
   }
-  c->no_mask_blend_fusion = getenv("BSX_NO_MASK_BLEND_FUSION") != nullptr;
-  c->no_bgblur_fusion = getenv("BSX_NO_BGBLUR_FUSION") != nullptr;
-  c->no_mask_tile = getenv("BSX_NO_MASK_TILE") != nullptr;
+  c->no_mask_blend_fusion = BSX_DBG_ENV("BSX_NO_MASK_BLEND_FUSION") != nullptr;
+  c->no_bgblur_fusion = BSX_DBG_ENV("BSX_NO_BGBLUR_FUSION") != nullptr;
+  c->no_mask_tile = BSX_DBG_ENV("BSX_NO_MASK_TILE") != nullptr;
   c->no_uniform_tiles = getenv("BSX_NO_UNIFORM_TILES") != nullptr;
-  c->tail_generic = getenv("BSX_TAIL_GENERIC") != nullptr;
-  c->keep_logits = getenv("BSX_KEEP_LOGITS") != nullptr;
+  c->tail_generic = BSX_DBG_ENV("BSX_TAIL_GENERIC") != nullptr;
+  c->keep_logits = BSX_DBG_ENV("BSX_KEEP_LOGITS") != nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
     report(nullptr, ondebug, caller_ctx, "error: HIP device %d not available (%d visible)\n", device, ndev); return nullptr; }
@@ -549,7 +541,7 @@ void bsx_delete(bsx_ctx* c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (auto& kv : c->host_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   rtc_unload(&c->mid);
-  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_canvas, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_bgblur_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16, c->d_tile_class};
+  void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_bgblur_scratch, c->d_bgr_in_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16, c->d_tile_class};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -650,30 +642,45 @@ namespace {
 // The context's batch buffers re-based to streams [f0, f0 + cap) for the launches enqueued inside the scope (one host thread enqueues a context's work).
 // Frame-major buffers simply start at stream f0; the batch-major arena of the per-launch path becomes the group's own compact arena laid out for `cap` streams.
 struct LaneView {
-  bsx_ctx* c; uint32_t* canvas; float* net_in; uint32_t* net_in_u8; float* net_out; float* arena; int n_streams;
-  LaneView(bsx_ctx* ctx, int f0, int cap) : c(ctx), canvas(ctx->d_canvas), net_in(ctx->d_net_in), net_in_u8(ctx->d_net_in_u8), net_out(ctx->d_net_out), arena(ctx->d_arena),
+  bsx_ctx* c; float* net_in; uint32_t* net_in_u8; float* net_out; float* arena; int n_streams;
+  LaneView(bsx_ctx* ctx, int f0, int cap) : c(ctx), net_in(ctx->d_net_in), net_in_u8(ctx->d_net_in_u8), net_out(ctx->d_net_out), arena(ctx->d_arena),
                                             n_streams(ctx->n_streams) {
-    c->d_canvas += (size_t)f0 * canvas_elems(c->inW, c->inH);
     c->d_net_in += (size_t)f0 * c->inW * c->inH * c->inC;
     c->d_net_in_u8 += (size_t)f0 * c->inW * c->inH;
     c->d_net_out += (size_t)f0 * c->outW * c->outH * c->outC;
     c->d_arena += (size_t)f0 * c->plan.arena_floats_per_stream;
     c->n_streams = cap;
   }
-  ~LaneView() { c->d_canvas = canvas; c->d_net_in = net_in; c->d_net_in_u8 = net_in_u8; c->d_net_out = net_out; c->d_arena = arena; c->n_streams = n_streams; }
+  ~LaneView() { c->d_net_in = net_in; c->d_net_in_u8 = net_in_u8; c->d_net_out = net_out; c->d_arena = arena; c->n_streams = n_streams; }
 };
 
 // flags (bsx.h): BSX_STEP_YUYV — the composite leaves as YUYV 4:2:2 (2 B/px), convert_rgb_to_yuyv (deepseg.cc:87-106) applied in the blend's epilogue;
 // BSX_STEP_FLIP_H / _V — cv::flip of the composite (deepseg.cc:667-673) folded into the epilogue's store addresses
 int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride, uint8_t* d_out, int n, void* stream, unsigned flags) {
   const int bgblur = (int)((flags >> 8) & 255u);                // BSX_STEP_BGBLUR(ksize): background = blur of the stream's own frame, d_bg unused
-  if (!c || !d_frames || (!d_bg && !bgblur) || !d_out || n <= 0 || n > c->n_streams || (flags & ~(15u | 0xFF00u))) return BSX_EINVAL;
+  if (!c || !d_frames || (!d_bg && !bgblur) || !d_out || n <= 0 || n > c->n_streams || (flags & ~(31u | 0xFF00u))) return BSX_EINVAL;
   if (bgblur && (bgblur > 31 || !(bgblur & 1) || d_frames == d_out)) return BSX_EINVAL;
   if (c->pend.active) { c->last_error = "error: a pipelined composite is pending (flush with bsx_step_batch_pipelined(ctx, NULL, ...) first)\n"; return BSX_EINVAL; }
   const int yuyv = (int)(flags & BSX_STEP_YUYV);
+  const bool yin = (flags & BSX_STEP_YUYV_IN) != 0;             // the camera's raw 4:2:2 frames (cv::COLOR_YUV2BGR_YUYV, app/deepseg.cc:553,725) instead of BGR
   const unsigned flip = flags & (BSX_STEP_FLIP_H | BSX_STEP_FLIP_V);
-  if (yuyv && (c->width & 1)) return BSX_EINVAL;                // 4:2:2 pairs pixels horizontally
+  if ((yuyv || yin) && (c->width & 1)) return BSX_EINVAL;       // 4:2:2 pairs pixels horizontally
   DeviceGuard guard(c->device);
+  const size_t px_frame = (size_t)c->width * c->height;
+  if (yin) {
+    // fused form: prep_fused_k and the mask tile kernel convert the pixels they read (2 B/px from HBM, no BGR frame in between).  Everything the fused kernels do
+    // not cover — a background blurred from the frame itself, a geometry the tile kernel or the 8-byte tap window does not take, buffers that overlap, stage
+    // callbacks — converts the batch into a context-owned BGR scratch first (bsx_yuyv_to_bgr's kernel) and runs the BGR step on it: same bytes, one more pass.
+    const size_t in_b = (size_t)n * px_frame * 2, out_b = (size_t)n * px_frame * (yuyv ? 2 : 3);
+    const bool ovl = d_out < d_frames + in_b && d_frames < d_out + out_b;
+    const bool direct = !bgblur && !ovl && !c->onmask && !c->no_mask_blend_fusion && (!yuyv || ((uintptr_t)d_out & 3) == 0) && prep_yuyv_fusable(c->width, c->roi, c->tab_down.tab) &&
+                        mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, yuyv ? d_frames : d_out);
+    if (!direct) {
+      if (!c->d_bgr_in_scratch) BSX_HIP(c, hipMalloc(&c->d_bgr_in_scratch, (size_t)c->n_streams * px_frame * 3));
+      BSX_HIP(c, launch_yuyv_to_bgr(d_frames, c->d_bgr_in_scratch, c->width, c->height, n, pick(c, stream)));
+      return step_impl(c, c->d_bgr_in_scratch, d_bg, bg_frame_stride, d_out, n, stream, flags & ~BSX_STEP_YUYV_IN);
+    }
+  }
   if (bgblur) {
     if (!(flags & 15u) && !c->no_bgblur_fusion && gauss_blend_fusable(d_frames, c->d_masks, d_out, c->width, bgblur)) {
       // masks as usual (prep → network → decode → upscale + blur), then ONE pass over the frames: blur tile → blend with the frame and the mask → composite
@@ -691,12 +698,13 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
   // frame pixel at (x, y) and stores the flipped (or YUYV-packed: 2 B/px) result at ANOTHER address, which a different tile may not have read yet — with overlapping
   // buffers those forms take the unfused sequence (composite into the context's scratch first).  A plain composite in place (same address read, then written, by the
   // same lane) is fine; partially overlapping buffers are refused.
-  const size_t in_bytes = (size_t)n * c->width * c->height * 3, out_bytes = (size_t)n * c->width * c->height * (yuyv ? 2 : 3);
-  const bool overlap = d_out < d_frames + in_bytes && d_frames < d_out + out_bytes;
+  const size_t in_bytes = (size_t)n * c->width * c->height * (yin ? 2 : 3), out_bytes = (size_t)n * c->width * c->height * (yuyv ? 2 : 3);
+  const bool overlap = d_out < d_frames + in_bytes && d_frames < d_out + out_bytes;      // (never with yin: overlapping YUYV input took the scratch route above)
   if (overlap && !yuyv && !flip && d_out != d_frames) return BSX_EINVAL;
   const bool fuse = !c->onmask && !c->no_mask_blend_fusion && (!yuyv || ((uintptr_t)d_out & 3) == 0) && !(overlap && (yuyv || flip)) &&
                     mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, yuyv ? d_frames : d_out);
   if (!fuse) {
+    if (yin) return BSX_EINVAL;                                   // unreachable: `direct` above implies `fuse`
     int rc = bsx_process_batch(c, d_frames, n, nullptr, stream);
     if (rc) return rc;
     if (!yuyv && !flip) return bsx_composite_batch(c, d_bg, bg_frame_stride, d_frames, nullptr, d_out, n, stream);
@@ -724,7 +732,7 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
   if (c->lanes > 1 && n >= 16 * c->lanes && !c->onprep && !c->oninfer && !c->keep_logits && (c->use_program || c->lanes * lane_per <= c->n_streams)) {
     const int K = c->lanes, per = lane_per;
     const bool fd = infer_decodes(c);
-    const size_t fb = (size_t)c->width * c->height * 3, ob = (size_t)c->width * c->height * (yuyv ? 2 : 3), sm = (size_t)c->outW * c->outH;
+    const size_t fb = (size_t)c->width * c->height * (yin ? 2 : 3), ob = (size_t)c->width * c->height * (yuyv ? 2 : 3), sm = (size_t)c->outW * c->outH;
     BSX_HIP(c, hipEventRecord(c->ev_fork, s));
     int lane_rc = BSX_OK;
     for (int k = 0; k < K && lane_rc == BSX_OK; k++) {
@@ -734,7 +742,7 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
       if (k > 0 && hipStreamWaitEvent(ls, c->ev_fork, 0) != hipSuccess) { lane_rc = BSX_EDEVICE; break; }
       {
         LaneView view(c, f0, per);
-        lane_rc = run_prep(c, d_frames + (size_t)f0 * fb, nb, ls);
+        lane_rc = run_prep(c, d_frames + (size_t)f0 * fb, nb, ls, false, yin);
         if (!lane_rc) lane_rc = run_infer(c, nb, ls, !fd, f0);
         if (!lane_rc && !fd) lane_rc = run_decode(c, nb, ls, f0);
       }
@@ -747,7 +755,7 @@ int step_impl(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, size_t b
     if (lane_rc == BSX_EDEVICE && c->last_error.empty()) c->last_error = "error: HIP failure while enqueuing a lane of the step\n";
     return lane_rc;
   }
-  if ((rc = run_prep(c, d_frames, n, s))) return rc;
+  if ((rc = run_prep(c, d_frames, n, s, false, yin))) return rc;
   if (c->onprep) { BSX_HIP(c, hipStreamSynchronize(s)); c->onprep(c->caller_ctx); }
   const bool fused_decode = infer_decodes(c);
   if ((rc = run_infer(c, n, s, !fused_decode, 0))) return rc;
@@ -781,7 +789,7 @@ int pipelined_objects(bsx_ctx* c) {
   if (c->comp_stream) return BSX_OK;
   // the composite fills the gaps of the network kernels, not the other way round: lowest priority the device offers (BSX_PIPE_PRIO=0: default priority)
   int lo = 0, hi = 0;
-  const char* pe = getenv("BSX_PIPE_PRIO");
+  const char* pe = BSX_DBG_ENV("BSX_PIPE_PRIO");
   if (!(pe && atoi(pe) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
     BSX_HIP(c, hipStreamCreateWithPriority(&c->comp_stream, hipStreamNonBlocking, lo));
   } else {
@@ -814,13 +822,15 @@ int bsx_step_batch_pipelined(bsx_ctx* c, const uint8_t* d_frames, const uint8_t*
     c->pend.active = false;
     return rc;
   }
-  if (!d_bg || !d_out || n <= 0 || n > c->n_streams || (flags & ~15u)) return BSX_EINVAL;
+  if (!d_bg || !d_out || n <= 0 || n > c->n_streams || (flags & ~31u)) return BSX_EINVAL;
   const int yuyv = (int)(flags & BSX_STEP_YUYV);
-  if (yuyv && (c->width & 1)) return BSX_EINVAL;
+  const bool yin = (flags & BSX_STEP_YUYV_IN) != 0;
+  if ((yuyv || yin) && (c->width & 1)) return BSX_EINVAL;
   // the pipeline exists for the fused tile kernel only; out(k) is written while frames(k + 1) are read, so the buffers of a call must not overlap at all
-  const size_t in_bytes = (size_t)n * c->width * c->height * 3, out_bytes = (size_t)n * c->width * c->height * (yuyv ? 2 : 3);
+  const size_t in_bytes = (size_t)n * c->width * c->height * (yin ? 2 : 3), out_bytes = (size_t)n * c->width * c->height * (yuyv ? 2 : 3);
   const bool overlap = d_out < d_frames + in_bytes && d_frames < d_out + out_bytes;
   const bool fuse = !c->onprep && !c->oninfer && !c->onmask && !c->no_mask_blend_fusion && !overlap && (!yuyv || ((uintptr_t)d_out & 3) == 0) &&
+                    (!yin || prep_yuyv_fusable(c->width, c->roi, c->tab_down.tab)) &&
                     mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_frame_stride, d_frames, yuyv ? d_frames : d_out);
   if (!fuse) { c->last_error = "error: bsx_step_batch_pipelined needs the fused mask + blend geometry, no stage callbacks and non-overlapping buffers\n"; return BSX_EINVAL; }
   int rc = pipelined_objects(c);
@@ -836,7 +846,7 @@ int bsx_step_batch_pipelined(bsx_ctx* c, const uint8_t* d_frames, const uint8_t*
     forked = true;
     if (!rc) c->wait_before_state = c->ev_pcomp;
   }
-  if (!rc) rc = run_prep(c, d_frames, n, s);
+  if (!rc) rc = run_prep(c, d_frames, n, s, false, yin);
   const bool fused_decode = infer_decodes(c);
   if (!rc) rc = run_infer(c, n, s, !fused_decode, 0);
   if (!rc && !fused_decode) rc = run_decode(c, n, s);
@@ -916,6 +926,9 @@ int bsx_debug_run_stage(bsx_ctx* c, int stage, const uint8_t* d_frames, int n, v
     case 1: return run_infer(c, n, s);
     case 2: return run_decode(c, n, s);
     case 3: return run_mask(c, n, s);
+    case 4:                                                       // stage 0 on raw YUYV 4:2:2 frames (BSX_STEP_YUYV_IN's prep): the f32 network input, for the stage tests
+      if (!d_frames || !prep_yuyv_fusable(c->width, c->roi, c->tab_down.tab)) return BSX_EINVAL;
+      return run_prep(c, d_frames, n, s, true, true);
     default: return BSX_EINVAL;
   }
 }
@@ -932,7 +945,7 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   const int n_net = c->use_program ? (seg ? (c->plan.seg.tail.pre_gate_off >= 0 ? 6 : 5) : 1) : (int)c->plan.steps.size();
   const bool fuse_tail = !c->onmask && !c->no_mask_blend_fusion &&
                          mask_blend_fusable(c->width, c->height, c->roi, d_bg, bg_stride, d_frames, d_out);
-  const int L = (c->prep_split ? 2 : 1) + n_net + (fused_decode ? 0 : 1) + (fuse_tail ? 1 : 2) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
+  const int L = 1 + n_net + (fused_decode ? 0 : 1) + (fuse_tail ? 1 : 2) + (fuse_tail ? 1 : 0);   // + a stand-alone blend launch when the step's tail is fused
   if (cap < L) return BSX_EINVAL;
   // ONE event between consecutive launches (round 6: L + 1 events, not 2 L): launch k is timed from the event behind launch k - 1 to the event behind itself, so
   // the per-launch figures add up to the pass and carry one event's cost each instead of two (round 5's bracketing pairs read 11 % over the un-instrumented step)
@@ -949,12 +962,8 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       BSX_HIP(c, hipEventRecord(ev[k + 1], s));            \
       k++;                                                 \
     } while (0)
-    if (c->prep_split) {
-      BSX_TIMED(launch_prep_resize(d_frames, c->width, c->height, c->roi, c->d_canvas, c->inW, c->inH, c->in_roi, c->tab_down.tab, n, s));
-      BSX_TIMED(launch_prep_bilateral(c->d_canvas, c->in_u8 ? nullptr : c->tensor_ptr(c->plan.input), c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH, c->bilateral, n, s));
-    } else
-      BSX_TIMED(launch_prep_fused(d_frames, c->width, c->height, c->roi, c->in_u8 ? nullptr : c->tensor_ptr(c->plan.input), c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH, c->in_roi,
-                                  c->tab_down.tab, c->bilateral, n, s));
+    BSX_TIMED(launch_prep_fused(d_frames, c->width, c->height, c->roi, c->in_u8 ? nullptr : c->tensor_ptr(c->plan.input), c->in_u8 ? c->d_net_in_u8 : nullptr, c->inW, c->inH, c->in_roi,
+                                c->tab_down.tab, c->bilateral, n, s));
     const long pf = (long)c->plan.arena_floats_per_stream;
     if (seg) {
       const SegPlan& sp = c->plan.seg;
@@ -995,13 +1004,9 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
   int j = 0;
   const double canvas = (double)c->inW * c->inH;
   // prep_resize: reads the TOUCHED source pixels of the ROI — a bilinear tap pair per destination column / row, i.e. at most 2 x 2 source
-  // pixels per canvas pixel of in_roi (a 5x down-scale touches 16 % of the ROI) — and writes the 4 B/px canvas with its apron
+  // pixels per canvas pixel of in_roi (a 5x down-scale touches 16 % of the ROI)
   const double touched = (double)std::min(c->roi.w, 2 * c->in_roi.w) * (double)std::min(c->roi.h, 2 * c->in_roi.h);
-  if (c->prep_split) {
-    put(j++, "prep_resize", N * (3.0 * touched + 4.0 * (double)canvas_elems(c->inW, c->inH)), 0);
-    put(j++, "prep_bilateral", N * (4.0 * canvas + (c->in_u8 ? 4.0 : 12.0) * canvas), 0);
-  } else
-    put(j++, "prep", N * (3.0 * touched + (c->in_u8 ? 4.0 : 12.0) * canvas), 0);       // fused: touched source pixels in, the network input out
+  put(j++, "prep", N * (3.0 * touched + (c->in_u8 ? 4.0 : 12.0) * canvas), 0);       // touched source pixels in, the network input out
   if (seg) {
     // algorithmic bytes of each segment = the tensors it must read once + write once (f32); flops from the fused steps it covers
     const std::vector<Step>& S = c->plan.steps;
@@ -1039,15 +1044,6 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
       const Step& d1 = c->plan.steps[1];
       const Step& p2 = c->plan.steps[2];
       put(j++, st.label + "+" + d1.label + "+" + p2.label, N * ((c->in_u8 ? 4.0 * st.H * st.W : 4.0 * in) + 4.0 * (double)p2.OH * p2.OW * p2.Cout), N * 2.0 * (st.macs + d1.macs + p2.macs));
-      continue;
-    }
-    const bool block_on = c->d_weights16 && (c->f16_terms & 15) > 0 && !(c->f16_terms & 16);
-    if (st.fused_into_block && block_on) { put(j++, st.label + " (inside the launch before)", 0, 0); continue; }
-    if (st.fuse_proj >= 0 && block_on) {                         // the whole block in one launch: reads the block's input (+ residual), writes the project's output
-      const Step& dd = c->plan.steps[st.fuse_dw];
-      const Step& pj = c->plan.steps[st.fuse_proj];
-      const double po = (double)pj.OH * pj.OW * pj.Cout;
-      put(j++, st.label + "+" + dd.label + "+" + pj.label, N * 4.0 * (in + po + (pj.residual >= 0 ? po : 0)), N * 2.0 * (st.macs + dd.macs + pj.macs));
       continue;
     }
     if (st.fuse_dw >= 0 && ir_on) {                              // expand + depthwise in one launch: reads the expand's input, writes the depthwise's output
@@ -1123,7 +1119,7 @@ int bsx_model_describe(const char* model_path, char* buf, size_t cap) {
     for (size_t i = 0; i < p.program_labels.size(); i++) out += "P" + std::to_string(i) + " " + p.program_labels[i] + "\n";
     if (p.seg.on) out += p.seg_text;
     if (!p.program.empty()) out += mid_barrier_line(p, false);
-    if (getenv("BSX_PLAN_BLOCKS"))           // debugging: the LDS reservations of the program (float offset, length, first / last step, owner)
+    if (BSX_DBG_ENV("BSX_PLAN_BLOCKS"))           // debugging: the LDS reservations of the program (float offset, length, first / last step, owner)
       for (const auto& b : p.program_blocks) { snprintf(head, sizeof head, "block off=%d len=%d steps=[%d,%d] %s\n", b.off, b.len, b.from, b.until, b.what.c_str()); out += head; }
   }
   } catch (const std::exception& e) { out = std::string("exception while reading the model: ") + e.what(); rc = BSX_EMODEL; }

@@ -4,6 +4,7 @@
 // Output: one HIP translation unit = the device templates of mid_prelude.hip + one traits struct per op + a kernel that calls the
 // op bodies in program order with one barrier between them.  Nothing in the kernel is read from a table at run time.
 // Graphs with micro-ops the templates do not cover return an empty string: the interpreter (kernels_frame.hip) runs them.
+#include "debug_switches.hpp"
 #include "gen_mid.hpp"
 
 #include <algorithm>
@@ -17,7 +18,7 @@ namespace bsx {
 namespace {
 
 const char kPrelude[] =
-#include "build/mid_prelude_str.inc"
+#include "mid_prelude_str.inc"      // written by build.py into the object directory (-I): csrc/mid_prelude.hip, comments stripped
     ;
 
 struct Out {
@@ -53,7 +54,7 @@ bool plain(const Loc& l) { return l.space == kLocNone || l.space == kLocLds || l
 static bool dw_geom_ok(const MicroOp& d) { return d.strip && d.dh == 1 && d.dw == 1 && d.kh == d.kw && (d.kh == 3 || d.kh == 5) && d.sh == d.sw && (d.sh == 1 || d.sh == 2) && d.Cin % 4 == 0; }
 bool mid_dw_chunked(const MicroOp& d) {
   return d.kind == (int)StepKind::DwConv && dw_geom_ok(d) && d.in0.space == kLocGlobal && d.band_rows > 0 && (d.Cin % d.band_rows) % 8 == 0 && d.res.space == kLocNone &&
-         !getenv("BSX_RTC_NO_DW_STAGE");
+         !BSX_DBG_ENV("BSX_RTC_NO_DW_STAGE");
 }
 // 1x1 → depthwise without the tensor in between (see generate_mid_source): is op j a 1x1 whose arena output is only read by the chunked depthwise j + 1, with every
 // LDS region the 1x1 still needs disjoint from what the depthwise places?  Shared with the planner's cost model (plan.cpp: program_arena_bytes) — an elided tensor
@@ -62,7 +63,7 @@ bool mid_pw_feeds_dw(const Plan& plan, int j) {
   const std::vector<MicroOp>& P = plan.program;
   const int n = (int)P.size();
   auto disjoint = [](long a0, long a1, long b0, long b1) { return a1 <= b0 || b1 <= a0; };
-  if (getenv("BSX_RTC_NO_PWDW") || j < 0 || j + 1 >= n) return false;
+  if (BSX_DBG_ENV("BSX_RTC_NO_PWDW") || j < 0 || j + 1 >= n) return false;
   const MicroOp& a = P[j];
   const MicroOp& d = P[j + 1];
   if (!(a.kind == (int)StepKind::PwConv && a.mfma && !a.gemv && a.stage_floats > 0 && a.out.space == kLocGlobal && a.res.space == kLocNone) || !mid_dw_chunked(d)) return false;
@@ -95,10 +96,12 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
   if (P.empty()) return fail("no program");
   // BSX_RTC_FINE=1 (timing experiments, tools/program_timeline.py --fine): per-wave shader-clock stamps around the barrier and the body of every op
   // (a different source, i.e. a different cache entry, from the product kernel)
-  const bool fine = getenv("BSX_RTC_FINE") != nullptr;
+  const bool fine = BSX_DBG_ENV("BSX_RTC_FINE") != nullptr;
   Out o;
   o.s.reserve(sizeof kPrelude + 64 * 1024);
-  if (getenv("BSX_RTC_EXP_MFMA")) o.s += "#define BSXM_EXP_MFMA_QUARTER 1   // timing experiment: WRONG RESULTS (mid_prelude.hip op_pw)\n";
+  if (BSX_DBG_ENV("BSX_RTC_EXP_MFMA")) o.s += "#define BSXM_EXP_MFMA_QUARTER 1   // timing experiment: WRONG RESULTS (mid_prelude.hip op_pw)\n";
+  // the workgroup's geometry (Plan::mid_lanes, Plan::lds_total_floats): the prelude's kThreads / kWaves / kZeroOff come from these two macros
+  o.f("#define BSXM_LANES %d\n#define BSXM_ZERO_OFF %d\n", plan.mid_lanes, plan.lds_zero_off());
   o.s += kPrelude;
   o.f("\nnamespace bsxm {\n");
   std::string body;
@@ -146,7 +149,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
     };
     auto early = [&](int j) {        // may the loads of SE op j be issued at the top of op j - 1?  (unstaged weights only: a staged block lands at j's barrier)
       if (j <= 0 || j >= n || P[j].kind != kMicroSe || P[j].fc_stage[0] > 0 || P[j].fc_stage[1] > 0) return false;
-      if (getenv("BSX_RTC_NO_EARLY_FC")) return false;
+      if (BSX_DBG_ENV("BSX_RTC_NO_EARLY_FC")) return false;
       // register budget: up to 34 live FC registers + the op's own.  1x1 ops need ~35; the depthwise bodies 60-78 in their fully unrolled LDS form
       // (op_dw: K (NIN + K) V <= 144) and ~105 in the one-row-ahead form, which would spill
       const MicroOp& pv = P[j - 1];
@@ -163,7 +166,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
       loc(o, "X", m.in0); loc(o, "Y", m.out); loc(o, "R", m.res); loc(o, "D", m.in2);
       o.f("  static constexpr int S_OFF = %d, W_LDS = %d, B_LDS = %d;\n", m.scale.space == kLocLds ? m.scale.off : -1, m.w_lds, m.w_lds + (int)(m.b_off - m.w_off));
       o.f("  static constexpr int N0 = 0, NCOLS = %d, YSUB = 0;\n", m.cout_pad);
-      o.f("  static constexpr bool NFAST = %s;\n};\n", ((m.out.space == kLocGlobal && !getenv("BSX_RTC_NO_NFAST")) || (m.in0.space == kLocGlobal && m.cout_pad > 16 && !getenv("BSX_RTC_NO_NFAST_IN"))) ? "true" : "false");      // arena INPUT: the column tiles of one row tile run back to back, its A rows are fetched once
+      o.f("  static constexpr bool NFAST = %s;\n};\n", ((m.out.space == kLocGlobal && !BSX_DBG_ENV("BSX_RTC_NO_NFAST")) || (m.in0.space == kLocGlobal && m.cout_pad > 16 && !BSX_DBG_ENV("BSX_RTC_NO_NFAST_IN"))) ? "true" : "false");      // arena INPUT: the column tiles of one row tile run back to back, its A rows are fetched once
       if (pw_feeds_dw(i)) k.f("  // (computed chunk by chunk inside P%d: the tensor between them is never written)\n", i + 1);
       else k.f("  op_pw<Op%d>(L, A);\n", i);
     } else if (m.kind == (int)StepKind::DwConv) {
@@ -187,7 +190,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
         // ZC: out-of-image taps through the zero cell (op_dw) — for depthwise ops that read a planned LDS tensor.  Not for the chunk-by-chunk form (input staged
         // through an LDS workspace inside a loop over channel chunks): there the zero-cell form raised the register pressure of MLKit's kernel, which sits at 128
         // registers, from 372 to 524 bytes of spill and cost 7 % (profiles/r05j)
-        o.f("  static constexpr bool ZC = %s;\n", (chunked || getenv("BSX_RTC_NO_ZERO_CELL")) ? "false" : "true");
+        o.f("  static constexpr bool ZC = %s;\n", (chunked || BSX_DBG_ENV("BSX_RTC_NO_ZERO_CELL")) ? "false" : "true");
         if (chunked) o.f("  static constexpr int X_SP = 1, X_OFF = %d, X_ST = %d;\n", m.ws_off, CK + 4); else loc(o, "X", m.in0);
         loc(o, "Y", m.out); loc(o, "R", m.res);
         if (staged) o.f("  static constexpr int W_SP = SP_LDS, W_OFF = %d, B_OFF = %d;\n};\n", m.w_lds + c * CK, m.w_lds + (int)(m.b_off - m.w_off) + c * CK);
@@ -248,12 +251,15 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
     }
   }
   o.f("}  // namespace bsxm\n\nusing namespace bsxm;\n");
-  o.f("extern \"C\" __global__ void __launch_bounds__(1024) bsx_mid(float* __restrict__ arena, long per_frame, const float* __restrict__ weights, unsigned long long* tl) {\n");
-  // the whole 160 KiB block: the planner's tensors and slots end below kLdsZeroOff, the last 16 bytes are the zero cell the depthwise bodies read out-of-image taps from
-  static_assert(kLdsZeroOff + kLdsZeroFloats == kLdsTotalFloats, "zero cell at the top of the block");
-  if (plan.program_lds_floats > kLdsZeroOff) return fail("LDS plan reaches into the zero cell");
-  o.f("  static_assert(kZeroOff == %d, \"zero cell offset\");\n", kLdsZeroOff);
-  o.f("  __shared__ __attribute__((aligned(16))) float smem[%d];\n", kLdsTotalFloats);
+  // two workgroups per CU (<= half of the LDS) must also fit the register file twice: 16 waves per CU = 4 per SIMD = 128 registers — said to the compiler, which would
+  // otherwise take the 256 a lone 512-lane workgroup could have
+  const bool two_per_cu = plan.mid_lanes <= 512 && plan.lds_total_floats <= kLdsTotalFloats / 2;
+  o.f("extern \"C\" __global__ void __launch_bounds__(%d)%s bsx_mid(float* __restrict__ arena, long per_frame, const float* __restrict__ weights, unsigned long long* tl) {\n", plan.mid_lanes,
+      two_per_cu ? " __attribute__((amdgpu_waves_per_eu(4, 4)))" : "");
+  // the plan's whole LDS block: the planner's tensors and slots end below its zero cell — the last 16 bytes, which the depthwise bodies read out-of-image taps from
+  if (plan.program_lds_floats > plan.lds_zero_off()) return fail("LDS plan reaches into the zero cell");
+  o.f("  static_assert(kZeroOff == %d && kThreads == %d, \"geometry macros\");\n", plan.lds_zero_off(), plan.mid_lanes);
+  o.f("  __shared__ __attribute__((aligned(16))) float smem[%d];\n", plan.lds_total_floats);
   o.f("  lds_f* L = (lds_f*)smem;\n  glb_f* A = (glb_f*)(arena + (size_t)blockIdx.x * (size_t)per_frame);\n  const glb_f* W = (const glb_f*)weights;\n");
   o.f("  if (threadIdx.x < %d) L[kZeroOff + threadIdx.x] = 0.f;      // visible to every wave behind the first op's barrier\n", kLdsZeroFloats);
   if (fine) o.f("  unsigned long long f_a = 0, f_b = 0;\n"

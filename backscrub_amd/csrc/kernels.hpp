@@ -21,7 +21,7 @@ namespace bsx {
 // kernels store their output as f16 and the project GEMM that consumes it reads f16 (opt-in reduced-precision storage, BSX_F16_GEMM=fast16)
 hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* net_in, float* net_out, const float* weights, int n, int n_cap,
                        hipStream_t s, const uint16_t* weights16 = nullptr, int f16_terms = 0, const uint32_t* net_in_u8 = nullptr, float in_scale = 0.f, float in_offset = 0.f);
-// net_in_u8: the network input as 8-bit pixels (prep_bilateral_k<2>) — taken by the fused DeepLab head (dl_head0_k<true>), which normalises on load
+// net_in_u8: the network input as 8-bit pixels (prep_fused_k<2>) — taken by the fused DeepLab head (dl_head0_k<true>), which normalises on load
 inline bool head0_u8_ok(const Plan& plan) {
   if (plan.steps.empty() || !plan.steps[0].fuse_head0) return false;
   const Step& st = plan.steps[0];
@@ -80,19 +80,14 @@ struct BilateralParams {
   float scale, offset;
 };
 
-// The model canvas carries a 2-pixel BORDER_REFLECT_101 apron: (inW + 4) x (inH + 4) packed RGBX u32 per frame.
-constexpr int kCanvasPad = 2;
-inline size_t canvas_elems(int inW, int inH) { return (size_t)(inW + 2 * kCanvasPad) * (size_t)(inH + 2 * kCanvasPad); }
+constexpr int kCanvasPad = 2;        // radius of the bilateral filter: the halo of prep_fused_k's tiles (BORDER_REFLECT_101)
 bool bilateral_taps_match(const BilateralParams& bp);   // host table order == the kernel's hard-wired 13 taps
-// frame ROI ↓ → model canvas (packed RGBX u32, bars = 0, apron filled).  libbackscrub.cc:285-290
-hipError_t launch_prep_resize(const uint8_t* frames, int W, int H, Rect4 roi, uint32_t* canvas, int inW, int inH, Rect4 in_roi,
-                              ResizeTab tab, int n, hipStream_t s);
-// bilateral(5,100,100) + convertTo f32 → network input [n][inH][inW][3].  libbackscrub.cc:295-302
-// launch_prep_resize + launch_prep_bilateral as ONE kernel (no canvas in memory); outputs as in launch_prep_bilateral
-hipError_t launch_prep_fused(const uint8_t* frames, int W, int H, Rect4 roi, float* input, uint32_t* input_u8, int inW, int inH, Rect4 in_roi, ResizeTab tab,
-                             BilateralParams bp, int n, hipStream_t s);
+// frame ROI ↓ → model canvas → bilateral(5,100,100) → convertTo: ONE kernel, no canvas in memory.  libbackscrub.cc:285-302
 // input (f32 [n][inH][inW][3]) and / or input_u8 (R|G<<8|B<<16 [n][inH][inW]): whichever is non-null is written
-hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, uint32_t* input_u8, int inW, int inH, BilateralParams bp, int n, hipStream_t s);
+// yuyv_in: `frames` is YUYV 4:2:2 (2 B/px; BSX_STEP_YUYV_IN) — only where prep_yuyv_fusable() holds
+hipError_t launch_prep_fused(const uint8_t* frames, int W, int H, Rect4 roi, float* input, uint32_t* input_u8, int inW, int inH, Rect4 in_roi, ResizeTab tab,
+                             BilateralParams bp, int n, hipStream_t s, bool yuyv_in = false);
+bool prep_yuyv_fusable(int W, Rect4 roi, const ResizeTab& tab);
 // decode + temporal IIR on the model-resolution mask.  libbackscrub.cc:317-357
 hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, int npix, int nch, int n, hipStream_t s);
 // ofinal(in_roi) ↑ roi size, 5x5 box blur (REFLECT_101 on the ROI), write into mask(roi).  libbackscrub.cc:367-371

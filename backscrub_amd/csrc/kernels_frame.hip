@@ -23,6 +23,7 @@
 // Numerics: f32 FMA chains with the bias added last (the MFMA forms sum k in a fixed, different order
 // than ci-ascending), un-contracted bilinear taps; the single-pixel GEMV steps and the global average
 // pools use tree reductions.  Measured against the oracle: max relative logit error < 1e-5.
+#include "debug_switches.hpp"
 #include <cstdlib>
 
 #include "frame_program.hpp"
@@ -1317,7 +1318,7 @@ hipError_t frame_program_prepare(int lds_floats) {
 
 hipError_t launch_frame_program(const MicroOp* d_ops, int n_ops, int lds_floats, float* arena, long per_frame_floats, float* net_in, float* net_out,
                                 const float* weights, int n, hipStream_t s, unsigned long long* timeline) {
-  static const int repeat = getenv("BSX_PROGRAM_REPEAT") ? atoi(getenv("BSX_PROGRAM_REPEAT")) : 1;
+  static const int repeat = BSX_DBG_ENV("BSX_PROGRAM_REPEAT") ? atoi(BSX_DBG_ENV("BSX_PROGRAM_REPEAT")) : 1;
   frame_program_k<<<n, kFrameThreads, (size_t)lds_floats * sizeof(float), s>>>(d_ops, n_ops, arena, per_frame_floats, net_in, net_out, weights, timeline,
                                                                                repeat > 0 ? repeat : 1);
   return hipGetLastError();

@@ -4,13 +4,13 @@
 // paths and of the reference's own loops; all are HBM-bound byte work, so the design rules
 // are: 16-byte vector accesses per lane, LDS tiles for neighbourhood ops, no GEMM shapes.
 //
-//   prep_resize_k        libbackscrub.cc:285-290  ROI crop + cv::resize(INTER_LINEAR) + BGR2RGB
-//   prep_bilateral_k     libbackscrub.cc:295-302  cv::bilateralFilter(5,100,100) + convertTo(CV_32FC3)
+//   prep_fused_k         libbackscrub.cc:285-302  ROI crop + cv::resize(INTER_LINEAR) + BGR2RGB + cv::bilateralFilter(5,100,100) + convertTo(CV_32FC3)
 //   decode_k             libbackscrub.cc:317-357  argmax / threshold / softmax-2 + temporal IIR
 //   mask_upscale_blur_k  libbackscrub.cc:367-371  cv::resize ↑ + cv::blur 5x5 into the persistent mask ROI
-//   blend16_k            deepseg.cc:108-134       alpha_blend
+//   blend4x4_k           deepseg.cc:108-134       alpha_blend
 //   resize_bgr_k         background.cc:186,190    cv::resize of the background
 //   yuyv_k               deepseg.cc:87-106        convert_rgb_to_yuyv
+#include "debug_switches.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -77,32 +77,7 @@ __device__ __forceinline__ void sample_linear(const uint8_t* __restrict__ src, l
   }
 }
 
-// ---- prep 1: frame ROI → model canvas, packed R | G<<8 | B<<16 (bars stay 0) -----------------
-// Index math is 32-bit inside a frame (grid.y = frame): a 64-bit div/mod pair per lane costs more than the sample itself.
-// The canvas is stored WITH its BORDER_REFLECT_101 apron (kCanvasPad pixels on every side, (inW+4) x (inH+4)): the
-// bilateral taps of the next kernel are then unconditional loads at fixed offsets (border arithmetic per tap was most of
-// its instruction count).  An apron pixel is the sample of the interior pixel it mirrors.
-__global__ __launch_bounds__(kThreads) void prep_resize_k(const uint8_t* __restrict__ frames, int W, int H, Rect4 roi,
-                                                         uint32_t* __restrict__ canvas, int inW, int inH, Rect4 q, ResizeTab tab) {
-  const int PW = inW + 2 * kCanvasPad, PH = inH + 2 * kCanvasPad;
-  const unsigned p = blockIdx.x * kThreads + threadIdx.x;
-  if (p >= (unsigned)(PW * PH)) return;
-  const long n = blockIdx.y;
-  const int py = (int)(p / (unsigned)PW), px = (int)(p - (unsigned)py * (unsigned)PW);
-  const int x = reflect101(px - kCanvasPad, inW), y = reflect101(py - kCanvasPad, inH);
-  uint32_t v = 0;
-  int dx = x - q.x, dy = y - q.y;
-  if (dx >= 0 && dx < q.w && dy >= 0 && dy < q.h) {
-    const uint8_t* src = frames + n * (long)W * H * 3 + ((long)roi.y * W + roi.x) * 3;
-    int bgr[3];
-    sample_linear<3>(src, (long)W * 3, tab, dx, dy, bgr);
-    v = (uint32_t)bgr[2] | ((uint32_t)bgr[1] << 8) | ((uint32_t)bgr[0] << 16);  // BGR2RGB
-  }
-  canvas[n * (long)PW * PH + p] = v;
-}
-
-// ---- prep 2: bilateral d=5 on the RGB canvas + u8→f32 normalise -----------------------------
-// f32 accumulation in tap order with separate multiply and add (no FMA contraction), then
+// ---- prep: bilateral d=5 constants (libbackscrub.cc:295-302).  f32 accumulation in tap order with separate multiply and add (no FMA contraction), then
 // cvRound(sum * (1/wsum)) — the association the oracle defines.
 constexpr int kBilPix = 4;   // pixels per lane: amortises the 768-entry LUT fill + barrier of every workgroup
 // the 13 taps of a radius-2 disc in OpenCV's (dy, dx) row-major order; bsx_api.hip builds bp.space_w in the same order
@@ -112,60 +87,55 @@ __device__ constexpr int kTapX[13] = {0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0}
 // OUT bit 0: the network input as f32 [n][inH][inW][3] = convertTo (libbackscrub.cc:302) — what stems without a byte path and the stage tests read;
 // bit 1: the filtered pixel itself, R | G<<8 | B<<16 [n][inH][inW] u32 — the stems that take it (seg_head_k, dl_head0_k) apply the SAME two roundings
 // `fadd(fmul(float(q), scale), offset)` when they stage their input window, so the 12 B/px tensor never exists (bit-identical by construction).
-template <int OUT>
-__global__ __launch_bounds__(kThreads) void prep_bilateral_k(const uint32_t* __restrict__ canvas, float* __restrict__ input, uint32_t* __restrict__ input_u8, int inW, int inH,
-                                                            BilateralParams bp) {
-  __shared__ float lut[768];
-  for (int k = threadIdx.x; k < 768; k += kThreads) lut[k] = bp.color_lut[k];
-  __syncthreads();
-  const int PW = inW + 2 * kCanvasPad, PH = inH + 2 * kCanvasPad;
-  const long n = blockIdx.z;
-  const uint32_t* img = canvas + n * (long)PW * PH;
-  // workgroup = 32 x 32 output pixels (lane = column, 8 rows per pass): no index division anywhere
-  const int x = (int)blockIdx.x * 32 + (int)(threadIdx.x & 31), yb = (int)blockIdx.y * 32 + (int)(threadIdx.x >> 5);
-  if (x >= inW) return;
-#pragma unroll 2
-  for (int it = 0; it < kBilPix; it++) {
-    const int y = yb + 8 * it;
-    if (y >= inH) return;
-    const unsigned p = (unsigned)(y * inW + x);
-    const uint32_t* row[5];
-#pragma unroll
-    for (int d = 0; d < 5; d++) row[d] = img + (y + d) * PW + (x + kCanvasPad);     // canvas rows y-2 .. y+2 at column x
-    const uint32_t c0 = row[2][0];                // R | G<<8 | B<<16, top byte 0
-    float sr = 0.f, sg = 0.f, sb = 0.f, ws = 0.f;
-#pragma unroll
-    for (int k = 0; k < 13; k++) {
-      const uint32_t c = row[kTapY[k] + 2][kTapX[k]];
-      // |dR| + |dG| + |dB| in one instruction (v_sad_u8 over the four bytes; the top bytes are both 0)
-      const float w = __fmul_rn(bp.space_w[k], lut[__builtin_amdgcn_sad_u8(c, c0, 0u)]);
-      const float rr = (float)(c & 255), gg = (float)((c >> 8) & 255), bb = (float)((c >> 16) & 255);
-      sr = __fadd_rn(sr, __fmul_rn(rr, w));
-      sg = __fadd_rn(sg, __fmul_rn(gg, w));
-      sb = __fadd_rn(sb, __fmul_rn(bb, w));
-      ws = __fadd_rn(ws, w);
-    }
-    ws = __fdiv_rn(1.f, ws);
-    int qr = __float2int_rn(__fmul_rn(sr, ws)), qg = __float2int_rn(__fmul_rn(sg, ws)), qb = __float2int_rn(__fmul_rn(sb, ws));
-    qr = min(max(qr, 0), 255); qg = min(max(qg, 0), 255); qb = min(max(qb, 0), 255);
-    if (OUT & 1) {
-      float* o = input + (n * (long)inW * inH + p) * 3;
-      o[0] = __fadd_rn(__fmul_rn((float)qr, bp.scale), bp.offset);
-      o[1] = __fadd_rn(__fmul_rn((float)qg, bp.scale), bp.offset);
-      o[2] = __fadd_rn(__fmul_rn((float)qb, bp.scale), bp.offset);
-    }
-    if (OUT & 2) input_u8[n * (long)inW * inH + p] = (uint32_t)qr | ((uint32_t)qg << 8) | ((uint32_t)qb << 16);
-  }
+// ---- YUYV -> BGR inside the kernels that read the camera frame (BSX_STEP_YUYV_IN: cv::COLOR_YUV2BGR_YUYV, app/deepseg.cc:553,725) --------------------------------
+// The same integers as yuyv_to_bgr_k below (BT.601 limited range, 20-bit fixed point): a step that takes the camera's raw 2 B/px never materialises
+// the 3 B/px BGR frame.  Every product is a full-rate 24-bit multiply (|c| < 2^23, |operand| <= 255).
+constexpr int kYuvSH = 20, kYuvCY = 1220542, kYuvCUB = 2116026, kYuvCUG = -409993, kYuvCVG = -852492, kYuvCVR = 1673527;
+// Saturating pack: sat_u8(lo >> 20) | sat_u8(hi >> 20) << 8 in ONE instruction (gfx950's v_ashr_pk_u8_i32) — spelled out, with its upper half masked, because the
+// compiler's own use of the instruction is wrong on this toolchain (ROCm 7.2, clang 22): it forms it from `min(max(x >> 20, 0), 255)` pairs and then ORs further
+// bytes into the result as if bits 31:16 were zero, while the hardware leaves whatever the destination register held there (found by tools/dbg_conv.hip: bytes 2-3
+// of every word built that way carried bits of the unshifted sums).  Through the asm the compiler cannot see what the value is, so the mask stays.
+__device__ __forceinline__ uint32_t sat_pk2_shr20(int lo, int hi) {
+  uint32_t d;
+  asm("v_ashr_pk_u8_i32 %0, %1, %2, 20" : "=v"(d) : "v"(lo), "v"(hi));
+  return d;                                                      // bits 15:0 valid; callers mask or shift the rest away
+}
+__device__ __forceinline__ void yuv_chroma(int u, int v, int* buv, int* guv, int* ruv) {      // u, v already minus 128
+  *ruv = (1 << (kYuvSH - 1)) + __mul24(kYuvCVR, v);
+  *guv = (1 << (kYuvSH - 1)) + __mul24(kYuvCVG, v) + __mul24(kYuvCUG, u);
+  *buv = (1 << (kYuvSH - 1)) + __mul24(kYuvCUB, u);
+}
+__device__ __forceinline__ int yuv_luma(uint32_t y) { return __mul24(max(0, (int)y - 16), kYuvCY); }
+// one tap of prep_fused_k: Y | U << 8 | V << 16 (pulled out of the 8-byte window by v_perm_b32) -> B | G << 8 | R << 16
+__device__ __forceinline__ uint32_t yuv_tap_to_bgr(uint32_t t) {
+  int buv, guv, ruv;
+  yuv_chroma((int)((t >> 8) & 255u) - 128, (int)((t >> 16) & 255u) - 128, &buv, &guv, &ruv);
+  const int ya = yuv_luma(t & 255u);
+  return (sat_pk2_shr20(ya + buv, ya + guv) & 0xffffu) | ((sat_pk2_shr20(ya + ruv, 0) & 0xffu) << 16);
+}
+// four pixels = two YUYV words (Y0 U Y1 V) -> the three words of four packed BGR pixels (the operand form of blend_quad): six saturating packs, one per byte pair
+// of the output — B0 G0 | R0 B1 | G1 R1 | B2 G2 | R2 B3 | G3 R3
+__device__ __forceinline__ void yuyv4_to_bgr3(uint32_t p0, uint32_t p1, uint32_t o[3]) {
+  int bu0, gu0, ru0, bu1, gu1, ru1;
+  yuv_chroma((int)((p0 >> 8) & 255u) - 128, (int)(p0 >> 24) - 128, &bu0, &gu0, &ru0);
+  yuv_chroma((int)((p1 >> 8) & 255u) - 128, (int)(p1 >> 24) - 128, &bu1, &gu1, &ru1);
+  const int y0 = yuv_luma(p0 & 255u), y1 = yuv_luma((p0 >> 16) & 255u), y2 = yuv_luma(p1 & 255u), y3 = yuv_luma((p1 >> 16) & 255u);
+  o[0] = (sat_pk2_shr20(y0 + bu0, y0 + gu0) & 0xffffu) | (sat_pk2_shr20(y0 + ru0, y1 + bu0) << 16);
+  o[1] = (sat_pk2_shr20(y1 + gu0, y1 + ru0) & 0xffffu) | (sat_pk2_shr20(y2 + bu1, y2 + gu1) << 16);
+  o[2] = (sat_pk2_shr20(y2 + ru1, y3 + bu1) & 0xffffu) | (sat_pk2_shr20(y3 + gu1, y3 + ru1) << 16);
 }
 
 // ---- prep, both steps in ONE kernel: the workgroup resizes the (TW + 4) x (TH + 4) canvas pixels its bilateral tile reads straight into LDS -------
-// (every sample of a lane requested before its first use: <= 6 independent tap pairs in flight per lane, where prep_resize_k had one), filters from LDS and
-// writes the network input.  The 4 B/px canvas with its stored apron — one write and one read of it, a launch boundary, and a kernel whose lanes each waited
-// for one dependent pair of loads — is gone; the halo is recomputed (1.27x the samples of a 32 x 32 tile, L2 hits).  Same arithmetic as the two-kernel form
-// (sample_linear, the tap order and roundings of prep_bilateral_k): bit-identical, and the stage-0 tests read its output.  Tile sizes are chosen per model so
-// that the tiles cover the canvas without a sliver (257 = 9 x 29, not 8 x 32 + 1).
+// (every sample of a lane requested before its first use: <= 6 independent tap pairs in flight per lane), filters from LDS and writes the network input.  The
+// two-kernel form of rounds 1-2 (resize into a 4 B/px canvas with a stored BORDER_REFLECT_101 apron, then the bilateral reading it back: one write and one read of
+// the canvas, a launch boundary, lanes that each waited for one dependent pair of loads) was bit-identical to this and was deleted in round 6; the halo is
+// recomputed (1.27x the samples of a 32 x 32 tile, L2 hits).  The stage-0 tests read its output.  Tile sizes are chosen per model so that the tiles cover the
+// canvas without a sliver (257 = 9 x 29, not 8 x 32 + 1).
 constexpr int kPfS = 36;                    // LDS row stride of the tile (TW <= 32)
-template <int OUT, bool LINEAR>             // LINEAR: tab.mode == 0 (cv::resize INTER_LINEAR proper — the other modes are a copy and the exact 2x2 area average)
+// YIN (BSX_STEP_YUYV_IN, LINEAR only): `frames` holds YUYV 4:2:2 (Y0 U Y1 V per pixel pair, 2 B/px) — the two taps of a sample are converted with
+// cv::COLOR_YUV2BGR_YUYV's integers (yuv_tap_to_bgr) as they leave the 8-byte window, then resized exactly as BGR taps are: the same network input, bit for bit,
+// as bsx_yuyv_to_bgr followed by the BGR step, without the 3 B/px frame in between.  The ROI must start on an even column (a macropixel).
+template <int OUT, bool LINEAR, bool YIN = false>             // LINEAR: tab.mode == 0 (cv::resize INTER_LINEAR proper — the other modes are a copy and the exact 2x2 area average)
 __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restrict__ frames, int W, int H, Rect4 roi, float* __restrict__ input, uint32_t* __restrict__ input_u8,
                                                         int inW, int inH, Rect4 q, ResizeTab tab, BilateralParams bp, int TW, int TH, int ntx, int nty, int n_frames) {
   __shared__ float lut[768];
@@ -177,7 +147,8 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
   const int tby = (int)t_ / ntx, tbx = (int)t_ - tby * ntx;
   const int tx0 = tbx * TW, ty0 = tby * TH;
   const int SW = TW + 2 * kCanvasPad, total = SW * (TH + 2 * kCanvasPad);
-  const uint8_t* src = frames + n * (long)W * H * 3 + ((long)roi.y * W + roi.x) * 3;
+  constexpr int FB = YIN ? 2 : 3;                                         // bytes per frame pixel
+  const uint8_t* src = frames + n * (long)W * H * FB + ((long)roi.y * W + roi.x) * FB;
   const unsigned msw = 0xFFFFFFFFu / (unsigned)SW + 1u;                    // i / SW for i < 2^16
   constexpr int kItems = (kPfS * kPfS + kThreads - 1) / kThreads;
   // the colour-weight table of the bilateral filter: requested with the kernel's first loads (round 5) — staged where it is first used, behind the resize phase, its
@@ -193,14 +164,23 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
     // 8 source bytes [offc, offc + 8) cover both taps: offc = min(3 sx, row_bytes - 8) never reads past the image row; the taps are bytes s0.. and s1.. of them
     // (s1 = s0 + 3, or s0 where cv::resize clamps the second tap onto the first), pulled out by v_perm_b32 with per-column selectors.  Same integers as sample_linear.
     __shared__ int4 colT[kPfS], rowT[kPfS];                                // {offc | -1, a0 | a1 << 16, sel0, sel1}, {o0 | -1, o1, b0, b1}
-    const int rowlim = (W - roi.x) * 3, SHt = TH + 2 * kCanvasPad;
+    const int rowlim = (W - roi.x) * FB, SHt = TH + 2 * kCanvasPad;
     if (tid < SW) {
       const int dx = reflect101(tx0 + tid - kCanvasPad, inW) - q.x;
       int4 e = make_int4(-1, 0, 0, 0);
       if (dx >= 0 && dx < q.w) {
-        const int sx = tab.xofs[dx], same = sx + 1 > tab.sw - 1, offb = sx * 3, offc = max(min(offb, rowlim - 8), 0), s0 = offb - offc, s1 = same ? s0 : s0 + 3;
+        const int sx = tab.xofs[dx], same = sx + 1 > tab.sw - 1;
         const int a0 = tab.xa[2 * dx], a1 = tab.xa[2 * dx + 1];
-        e = make_int4(offc, (a0 & 0xffff) | (a1 << 16), 0x0c000000 | ((s0 + 2) << 16) | ((s0 + 1) << 8) | s0, 0x0c000000 | ((s1 + 2) << 16) | ((s1 + 1) << 8) | s1);
+        if constexpr (YIN) {
+          // the 8 bytes from the macropixel of tap 0 hold both taps' macropixels (tap 1 = pixel sx + 1 sits in the same or in the next one; the window is pulled
+          // back by 4 where it would pass the row end — tap 1 is then in tap 0's macropixel).  Selector of a tap: its Y, its macropixel's U and V.
+          const int p1 = same ? sx : sx + 1, mb = (sx >> 1) * 4, offc = max(min(mb, rowlim - 8), 0), m0 = mb - offc, m1 = (p1 >> 1) * 4 - offc;
+          const int y0 = m0 + 2 * (sx & 1), y1 = m1 + 2 * (p1 & 1);
+          e = make_int4(offc, (a0 & 0xffff) | (a1 << 16), 0x0c000000 | ((m0 + 3) << 16) | ((m0 + 1) << 8) | y0, 0x0c000000 | ((m1 + 3) << 16) | ((m1 + 1) << 8) | y1);
+        } else {
+          const int offb = sx * 3, offc = max(min(offb, rowlim - 8), 0), s0 = offb - offc, s1 = same ? s0 : s0 + 3;
+          e = make_int4(offc, (a0 & 0xffff) | (a1 << 16), 0x0c000000 | ((s0 + 2) << 16) | ((s0 + 1) << 8) | s0, 0x0c000000 | ((s1 + 2) << 16) | ((s1 + 1) << 8) | s1);
+        }
       }
       colT[tid] = e;
     } else if (tid >= 64 && tid < 64 + SHt) {
@@ -208,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
       int4 e = make_int4(-1, 0, 0, 0);
       if (dy >= 0 && dy < q.h) {
         const int sy = tab.yofs[dy], sy0 = min(max(sy, 0), tab.sh - 1), sy1 = min(max(sy + 1, 0), tab.sh - 1);
-        e = make_int4(sy0 * W * 3, sy1 * W * 3, tab.ya[2 * dy], tab.ya[2 * dy + 1]);
+        e = make_int4(sy0 * W * FB, sy1 * W * FB, tab.ya[2 * dy], tab.ya[2 * dy + 1]);
       }
       rowT[ly] = e;
     }
@@ -230,8 +210,9 @@ __global__ __launch_bounds__(kThreads) void prep_fused_k(const uint8_t* __restri
         const int ly = (int)__umulhi((unsigned)i, msw), lx = i - ly * SW;
         const int4 c = colT[lx], r = rowT[ly];
         const int a0 = (short)(c.y & 0xffff), a1 = c.y >> 16, b0 = r.z, b1 = r.w;
-        const uint32_t t00 = __builtin_amdgcn_perm(hi0[k], lo0[k], (uint32_t)c.z), t01 = __builtin_amdgcn_perm(hi0[k], lo0[k], (uint32_t)c.w);   // row 0: tap 0 / tap 1 as B | G << 8 | R << 16
-        const uint32_t t10 = __builtin_amdgcn_perm(hi1[k], lo1[k], (uint32_t)c.z), t11 = __builtin_amdgcn_perm(hi1[k], lo1[k], (uint32_t)c.w);   // row 1
+        uint32_t t00 = __builtin_amdgcn_perm(hi0[k], lo0[k], (uint32_t)c.z), t01 = __builtin_amdgcn_perm(hi0[k], lo0[k], (uint32_t)c.w);   // row 0: tap 0 / tap 1 as B | G << 8 | R << 16
+        uint32_t t10 = __builtin_amdgcn_perm(hi1[k], lo1[k], (uint32_t)c.z), t11 = __builtin_amdgcn_perm(hi1[k], lo1[k], (uint32_t)c.w);   // row 1
+        if constexpr (YIN) { t00 = yuv_tap_to_bgr(t00); t01 = yuv_tap_to_bgr(t01); t10 = yuv_tap_to_bgr(t10); t11 = yuv_tap_to_bgr(t11); }      // (the taps arrived as Y | U << 8 | V << 16)
         uint32_t v = 0;                                                    // the model canvas outside in_roi (the bars) is 0
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -402,7 +383,7 @@ constexpr int kTW = 128, kTH = 32, kHW = kTW + 4, kHH = kTH + 4, kMaxSrcRows = 4
 constexpr int kTileItems = kTH * (kTW / 4) / kThreads;     // 4-pixel groups per lane in the last step
 static_assert(kTileItems * kThreads == kTH * (kTW / 4) && kThreads == 8 * (kTW / 4), "tile / lane mapping: item i of a lane sits 8 rows below item i-1");
 
-// ---- packed alpha-blend arithmetic (deepseg.cc:108-134), shared by the mask tile kernels and blend16_k --------------------
+// ---- packed alpha-blend arithmetic (deepseg.cc:108-134), shared by the mask tile kernels and blend4x4_k --------------------
 // Packed form of the same integers (v_pk_*_u16, two bytes per instruction):  a*m + b*(255-m) <= 255*255 fits a u16 lane,
 // and floor(t/255) == (t + 1 + (t >> 8)) >> 8 for every t in [0, 65025] (exhaustively checked; the sum stays < 65536).
 // Round 5: u = a*m + 1 + b*(255-m) as two v_pk_mad_u16 (u <= 65026 fits a u16 lane) and floor((u-1)/255) == (u + (u >> 8)) >> 8 (exhaustive: tests/test_oracle_image.py;
@@ -457,26 +438,37 @@ struct TileBlendOperands { uint32_t a[kTileItems][3], b[kTileItems][3]; };
 // `uniform` (wave-uniform): 0 = both operands; 1 = the tile's mask is 255 everywhere → only the background is needed; 2 = 0 everywhere → only the frame
 // `parts` (wave-uniform): bit 0 = request the background operand, bit 1 = the frame operand — 3 = whatever `uniform` needs in one call; mask_tile_k requests a SHARED
 // background before it knows the tile's class (parts = 1) and the frame after (parts = 2)
+// `yin` (wave-uniform; BSX_STEP_YUYV_IN): `frames` holds YUYV 4:2:2 — a lane's four pixels are 8 bytes (b[i][0..1]), converted where they are consumed
+// (tile_frame_bgr below); b[i][2] is then unused
 template <bool BLEND>
 __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
-                                                         int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int uniform = 0, int parts = 3) {
+                                                         int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int uniform = 0, int parts = 3, bool yin = false) {
   if constexpr (BLEND) {
     const int ly0 = tid / (kTW / 4), gx = tx0 + (tid % (kTW / 4)) * 4;
     const long pix0 = (long)(roi.y + ty0 + ly0) * W + roi.x + gx;        // frame coordinates of the ROI-relative tile pixel
+    const int fb = yin ? 2 : 3;                                          // bytes per frame pixel
     const uint8_t* const a0 = bg + (bg_stride ? n * bg_stride : 0) + pix0 * 3;
-    const uint8_t* const b0 = frames + ((long)n * W * H + pix0) * 3;
+    const uint8_t* const b0 = frames + ((long)n * W * H + pix0) * fb;
 #pragma unroll
     for (int i = 0; i < kTileItems; i++) {
       if (parts & 1) o.a[i][0] = o.a[i][1] = o.a[i][2] = 0;
       if (parts & 2) o.b[i][0] = o.b[i][1] = o.b[i][2] = 0;
       if (ty0 + ly0 + 8 * i < roi.h && gx < roi.w) {
         const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0 + (long)(8 * i) * W * 3);
-        const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * 3);
+        const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * fb);
         if ((parts & 1) && uniform != 2) { o.a[i][0] = ap[0]; o.a[i][1] = ap[1]; o.a[i][2] = ap[2]; }
-        if ((parts & 2) && uniform != 1) { o.b[i][0] = __builtin_nontemporal_load(bp); o.b[i][1] = __builtin_nontemporal_load(bp + 1); o.b[i][2] = __builtin_nontemporal_load(bp + 2); }   // streamed once
+        if ((parts & 2) && uniform != 1) {                               // streamed once
+          o.b[i][0] = __builtin_nontemporal_load(bp); o.b[i][1] = __builtin_nontemporal_load(bp + 1);
+          if (!yin) o.b[i][2] = __builtin_nontemporal_load(bp + 2);
+        }
       }
     }
   }
+}
+// the frame operand of item i as three BGR words, whatever form it was loaded in
+__device__ __forceinline__ void tile_frame_bgr(const TileBlendOperands& o, int i, bool yin, uint32_t b3[3]) {
+  if (yin) yuyv4_to_bgr3(o.b[i][0], o.b[i][1], b3);
+  else { b3[0] = o.b[i][0]; b3[1] = o.b[i][1]; b3[2] = o.b[i][2]; }
 }
 // Step 3: vertical pass of cv::resize, 4 pixels per lane (64-bit LDS reads of the two source rows, one 32-bit write).
 // row0 / row1: LDS tables of the two hq rows of every halo row; (y, xg) advance without a division.
@@ -532,7 +524,7 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
   const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
   const int gx = tx0 + lx;
   const int yuyv = yuyv_flip & 1;
-  const bool fh = (yuyv_flip & 2) != 0, fv = (yuyv_flip & 4) != 0;
+  const bool fh = (yuyv_flip & 2) != 0, fv = (yuyv_flip & 4) != 0, yin = (yuyv_flip & 16) != 0;      // bit 4 = BSX_STEP_YUYV_IN: the frame operand arrived as YUYV
   const int obpp = yuyv ? 2 : 3;                                 // composite written as packed BGR or as YUYV 4:2:2 (convert_rgb_to_yuyv fused in)
   uint8_t* const dst0 = mask + (long)n * W * H + (long)(roi.y + ty0 + ly0) * W + roi.x + gx;
   const int oy0 = fv ? H - 1 - (roi.y + ty0 + ly0) : roi.y + ty0 + ly0, ox = fh ? W - 4 - (roi.x + gx) : roi.x + gx;
@@ -563,8 +555,8 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
       uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * orow * obpp);
       uint32_t o3[3];
       if (uniform == 1) { o3[0] = o.a[i][0]; o3[1] = o.a[i][1]; o3[2] = o.a[i][2]; }
-      else if (uniform == 2) { o3[0] = o.b[i][0]; o3[1] = o.b[i][1]; o3[2] = o.b[i][2]; }
-      else blend_quad(o.a[i], o.b[i], packed, o3);
+      else if (uniform == 2) tile_frame_bgr(o, i, yin, o3);
+      else { uint32_t b3[3]; tile_frame_bgr(o, i, yin, b3); blend_quad(o.a[i], b3, packed, o3); }
       if (fh) reverse4px(o3);
       if (yuyv) {                                                  // deepseg.cc:87-106 on the four composited pixels: 8 bytes instead of 12
         __builtin_nontemporal_store(yuyv_pair(o3[0] & 255u, (o3[0] >> 8) & 255u, (o3[0] >> 16) & 255u, o3[0] >> 24, o3[1] & 255u, (o3[1] >> 8) & 255u), op);
@@ -599,7 +591,7 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
   const uint8_t* src = ofinal + (long)n * outW * outH + (long)q.y * outW + q.x;
   const int tid = threadIdx.x;
   TileBlendOperands ops;
-  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid);
+  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 3, (yuyv & 16) != 0);
   if (tid == 0) { s_min = 1 << 30; s_max = -1; }
   __syncthreads();
   // 1. column / row tables
@@ -702,15 +694,16 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   // A SHARED background (bg_stride == 0: one image for all streams, L2-resident) is requested BEFORE the tile's class is known (round 5): the class byte is a second
   // dependent round trip behind the kernel arguments, and two thirds of the tiles (uniform 255: composite = background) then need nothing else.  A per-stream
   // background is HBM traffic a uniform-0 tile must not pay: it keeps the order class -> operands.
-  const bool early_bg = BLEND && bg_stride == 0 && tab.tile_class != nullptr && !(yuyv & 16);
+  const bool early_bg = BLEND && bg_stride == 0 && tab.tile_class != nullptr && !(yuyv & 64);      // (bit 6: the debug build's A/B switch for this order)
+  const bool yin = (yuyv & 16) != 0;                                                                // BSX_STEP_YUYV_IN
   TileBlendOperands ops;
-  if (early_bg) tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 1);
+  if (early_bg) tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 1, yin);
   if (tab.tile_class) {                                     // the aligned word that holds the byte: a SCALAR load (uniform address), not a vector load + readfirstlane
     const uintptr_t ca = (uintptr_t)tab.tile_class + (size_t)n * (size_t)(ntx * nty) + (size_t)(tby * ntx + tbx);
     uniform = (int)((*reinterpret_cast<const uint32_t*>(ca & ~(uintptr_t)3) >> (8 * (unsigned)(ca & 3))) & 255u);
   }
   if (uniform) {                                           // wave-uniform: nothing of the general path below is even requested
-    tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, uniform, early_bg ? 2 : 3);
+    tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, uniform, early_bg ? 2 : 3, yin);
     tile_vsum5_store<BLEND>(hq_hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv, uniform);
     return;
   }
@@ -738,7 +731,7 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
     t_s = tab.yofs[gy]; t_a0 = tab.ya[2 * gy]; t_a1 = tab.ya[2 * gy + 1];
   }
   // (c) composite operands (the shared background is already on its way)
-  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, early_bg ? 2 : 3);
+  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, early_bg ? 2 : 3, yin);
   // 1. block and tables into LDS
 #pragma unroll
   for (int j = 0; j < 3; j++) if (br + 4 * j < nsr && bc < ncol) blk[(br + 4 * j) * ncol + bc] = (uint8_t)raw[j];
@@ -769,38 +762,11 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   tile_vsum5_store<BLEND>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv);               // 5.
 }
 
-// ---- alpha blend: 16 pixels (16 mask bytes, 48+48 source bytes, 48 output bytes) per lane (helpers: see blend_quad above) -----
-__global__ __launch_bounds__(kThreads) void blend16_k(const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ fr,
-                                                     const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, unsigned groups_per_frame,
-                                                     long npix) {
-  const unsigned g = blockIdx.x * kThreads + threadIdx.x;      // 16-pixel group inside frame blockIdx.y
-  if (g >= groups_per_frame) return;
-  const long n = blockIdx.y;
-  const long pix = n * npix + (long)g * 16;
-  const uint4 mv = *reinterpret_cast<const uint4*>(mask + pix);
-  const uint4* ap = reinterpret_cast<const uint4*>(bg + (bg_stride ? n * bg_stride : 0) + (long)g * 48);
-  const uint4* bp = reinterpret_cast<const uint4*>(fr + pix * 3);
-  uint4* op = reinterpret_cast<uint4*>(out + pix * 3);
-  uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
-  uint32_t aw[12], bw[12], ow[12];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    uint4 a = ap[k], b = bp[k];
-    aw[4 * k] = a.x; aw[4 * k + 1] = a.y; aw[4 * k + 2] = a.z; aw[4 * k + 3] = a.w;
-    bw[4 * k] = b.x; bw[4 * k + 1] = b.y; bw[4 * k + 2] = b.z; bw[4 * k + 3] = b.w;
-  }
-  // word j of the 12 covers bytes 4j..4j+3 → pixels (4j)/3 .. (4j+3)/3 ; every 3 words = 4 pixels = 1 mask word
-#pragma unroll
-  for (int q = 0; q < 4; q++) blend_quad(&aw[3 * q], &bw[3 * q], mw[q], &ow[3 * q]);
-#pragma unroll
-  for (int k = 0; k < 3; k++) op[k] = make_uint4(ow[4 * k], ow[4 * k + 1], ow[4 * k + 2], ow[4 * k + 3]);
-}
-
-// The same blend with every memory instruction COALESCED ACROSS LANES (round 4).  blend16_k gives a lane 16 consecutive pixels: its 16-byte loads and stores are
-// 48 bytes apart from the neighbouring lane's, so one wave instruction touches a third of each of 24 cache lines and every line is visited by three instructions.
-// Here a lane owns kB4 groups of FOUR pixels, group j of lane l at group index (block * kB4 + j) * 256 + l: one wave instruction = 64 lanes x 12 contiguous bytes
+// ---- alpha blend (deepseg.cc:108-134), stand-alone: bsx_composite_batch ---------------------------------------------------------------
+// Every memory instruction COALESCED ACROSS LANES (round 4; the 16-consecutive-pixels-per-lane form it replaced — 16-byte accesses 48 bytes apart between
+// neighbouring lanes, every line visited by three instructions — moved 4.8 TB/s and was deleted in round 6).  A lane owns kB4 groups of FOUR pixels, group j of lane l at group index (block * kB4 + j) * 256 + l: one wave instruction = 64 lanes x 12 contiguous bytes
 // = 768 bytes = six whole lines (global_load_dwordx3 / global_store_dwordx3, 4-byte aligned), the mask 64 x 4 bytes = two lines.  tools/microbench_mix.hip: a
-// plain streaming kernel with this mix and coalesced accesses moves 5.7-6.2 TB/s through HBM where blend16_k moved 4.8.
+// plain streaming kernel with this mix and coalesced accesses moves 5.7-6.2 TB/s through HBM.
 constexpr int kB4 = 4;
 __global__ __launch_bounds__(kThreads) void blend4x4_k(const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ fr,
                                                       const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, unsigned quads_per_frame, long npix) {
@@ -966,34 +932,33 @@ __global__ __launch_bounds__(kThreads) void fill_k(uint4* p, uint4 v, long n16) 
 
 }  // namespace
 
-hipError_t launch_prep_resize(const uint8_t* frames, int W, int H, Rect4 roi, uint32_t* canvas, int inW, int inH, Rect4 in_roi, ResizeTab tab,
-                              int n, hipStream_t s) {
-  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {     // grid.y carries the frame index
-    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
-    prep_resize_k<<<dim3(blocks_for((long)canvas_elems(inW, inH)), nn), kThreads, 0, s>>>(frames + (size_t)n0 * W * H * 3, W, H, roi,
-                                                                                          canvas + (size_t)n0 * canvas_elems(inW, inH), inW, inH, in_roi, tab);
-  }
-  return hipGetLastError();
+// resize + bilateral in one launch (prep_fused_k); input (f32 [n][inH][inW][3]) and / or input_u8 (R|G<<8|B<<16 [n][inH][inW]): whichever is non-null is written
+bool prep_yuyv_fusable(int W, Rect4 roi, const ResizeTab& tab) {      // the YIN form of prep_fused_k: INTER_LINEAR proper, whole macropixels, an 8-byte window inside the row
+  return tab.mode == 0 && (W & 1) == 0 && (roi.x & 1) == 0 && (W - roi.x) * 2 >= 8;
 }
 
-// resize + bilateral in one launch (prep_fused_k); input / input_u8 as in launch_prep_bilateral
 hipError_t launch_prep_fused(const uint8_t* frames, int W, int H, Rect4 roi, float* input, uint32_t* input_u8, int inW, int inH, Rect4 in_roi, ResizeTab tab,
-                             BilateralParams bp, int n, hipStream_t s) {
+                             BilateralParams bp, int n, hipStream_t s, bool yuyv_in) {
   if (!input && !input_u8) return hipErrorInvalidValue;
+  if (yuyv_in && !prep_yuyv_fusable(W, roi, tab)) return hipErrorInvalidValue;      // (the caller converts the frames first: bsx_api.hip step_impl)
   const int ntx = (inW + 31) / 32, nty = (inH + 31) / 32, TW = (inW + ntx - 1) / ntx, TH = (inH + nty - 1) / nty;      // even tiles, <= 32 x 32
   const long per_frame = (long)inW * inH;
-  static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
+  static const bool xcd_on = !(BSX_DBG_ENV("BSX_XCD_TILES") && atoi(BSX_DBG_ENV("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
   const int chunk = 1 << 20;                                            // frames per launch: keeps the 1-D grid far below 2^31 workgroups
   for (int n0 = 0; n0 < n; n0 += chunk) {
     const int nn = n - n0 < chunk ? n - n0 : chunk;
     const dim3 grid((unsigned)(ntx * nty) * (unsigned)nn);
-    const uint8_t* fr = frames + (size_t)n0 * W * H * 3;
+    const uint8_t* fr = frames + (size_t)n0 * W * H * (yuyv_in ? 2 : 3);
     float* f = input ? input + (size_t)n0 * per_frame * 3 : nullptr;
     uint32_t* u = input_u8 ? input_u8 + (size_t)n0 * per_frame : nullptr;
 #define BSX_PF(O, L) prep_fused_k<O, L><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0)
+#define BSX_PFY(O) prep_fused_k<O, true, true><<<grid, kThreads, 0, s>>>(fr, W, H, roi, f, u, inW, inH, in_roi, tab, bp, TW, TH, ntx, nty, xcd_on ? nn : 0)
+    if (yuyv_in) { if (f && u) BSX_PFY(3); else if (u) BSX_PFY(2); else BSX_PFY(1); }
+    else
     if (tab.mode == 0 && (W - roi.x) * 3 >= 8) { if (f && u) BSX_PF(3, true); else if (u) BSX_PF(2, true); else BSX_PF(1, true); }   // (the 8-byte tap window needs an 8-byte row)
     else { if (f && u) BSX_PF(3, false); else if (u) BSX_PF(2, false); else BSX_PF(1, false); }
 #undef BSX_PF
+#undef BSX_PFY
   }
   return hipGetLastError();
 }
@@ -1004,22 +969,6 @@ bool bilateral_taps_match(const BilateralParams& bp) {
   return true;
 }
 
-hipError_t launch_prep_bilateral(const uint32_t* canvas, float* input, uint32_t* input_u8, int inW, int inH, BilateralParams bp, int n, hipStream_t s) {
-  const long per_frame = (long)inW * inH;
-  if (!input && !input_u8) return hipErrorInvalidValue;
-  for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
-    const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
-    static_assert(kBilPix * (kThreads / 32) == 32, "32 x 32 pixel workgroup tile");
-    const dim3 grid((inW + 31) / 32, (inH + 31) / 32, nn);
-    const uint32_t* cv = canvas + (size_t)n0 * canvas_elems(inW, inH);
-    float* f = input ? input + (size_t)n0 * per_frame * 3 : nullptr;
-    uint32_t* u = input_u8 ? input_u8 + (size_t)n0 * per_frame : nullptr;
-    if (f && u) prep_bilateral_k<3><<<grid, kThreads, 0, s>>>(cv, f, u, inW, inH, bp);
-    else if (u) prep_bilateral_k<2><<<grid, kThreads, 0, s>>>(cv, f, u, inW, inH, bp);
-    else prep_bilateral_k<1><<<grid, kThreads, 0, s>>>(cv, f, u, inW, inH, bp);
-  }
-  return hipGetLastError();
-}
 
 hipError_t launch_decode(int model_type, const float* logits, uint8_t* ofinal, int npix, int nch, int n, hipStream_t s) {
   long total = (long)n * npix;
@@ -1057,7 +1006,7 @@ hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, R
                                     int n, hipStream_t s) {
   const int ntx = (roi.w + kTW - 1) / kTW, nty = (roi.h + kTH - 1) / kTH;
   if ((unsigned long long)ntx * nty * (unsigned long long)n >= (1ull << 31)) return hipErrorInvalidValue;
-  static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
+  static const bool xcd_on = !(BSX_DBG_ENV("BSX_XCD_TILES") && atoi(BSX_DBG_ENV("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
   // one-XCD-per-frame order only where neighbouring tiles SHARE cache lines, i.e. the ROI's rows do not start on a 128-byte line (roi.x = 80 / 280: measured
   // mask+blend 0.480 -> 0.464 ms at 256 HD MLKit streams); on line-aligned geometries nothing is shared and the plain order measured 2-3 % faster (profiles/r03o)
   const bool shared_lines = ((roi.x * 3) & 127) != 0 || ((W * 3) & 127) != 0;
@@ -1132,7 +1081,8 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   // 160 KB / (static + pad) workgroups fit a CU
   // outside the ROI the persistent mask is 255 forever (libbackscrub.cc:248-249), i.e. the composite there IS the background
   // ((a*255 + b*0)/255 == a): those strips are copied, the ROI is composited by the mask tiles
-  // `yuyv`: bit 0 = YUYV output, bits 1-2 = horizontal / vertical flip of the composite, bit 3 = do not store the full-resolution mask (bsx.h: BSX_STEP_*)
+  // `yuyv`: bit 0 = YUYV output, bits 1-2 = horizontal / vertical flip of the composite, bit 3 = do not store the full-resolution mask, bit 4 = `frames` is YUYV
+  // 4:2:2 (bsx.h: BSX_STEP_*); outside the ROI no frame pixel is read
   if ((yuyv & 6) && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
     outside_roi_flip_k<<<dim3(blocks_for((long)(W / 4) * H), n), kThreads, 0, s>>>(bg, (long)bg_stride, out, W, H, roi, yuyv);
   else if ((yuyv & 1) && (roi.x != 0 || roi.y != 0 || roi.w != W || roi.h != H))
@@ -1142,15 +1092,15 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
                                                                                                                                  roi);
   const int ntx = (roi.w + kTW - 1) / kTW, nty = (roi.h + kTH - 1) / kTH;
   if ((unsigned long long)ntx * nty * (unsigned long long)n >= (1ull << 31)) return hipErrorInvalidValue;
-  static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
+  static const bool xcd_on = !(BSX_DBG_ENV("BSX_XCD_TILES") && atoi(BSX_DBG_ENV("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
   // one-XCD-per-frame order only where neighbouring tiles SHARE cache lines, i.e. the ROI's rows do not start on a 128-byte line (roi.x = 80 / 280: measured
   // mask+blend 0.480 -> 0.464 ms at 256 HD MLKit streams); on line-aligned geometries nothing is shared and the plain order measured 2-3 % faster (profiles/r03o)
   const bool shared_lines = ((roi.x * 3) & 127) != 0 || ((W * 3) & 127) != 0;
   const int nf = (xcd_on && shared_lines) ? n : 0;
   dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
   if (hipError_t e = launch_tile_class(ofinal, outW, outH, in_roi, tab, roi, n, s)) return e;
-  static const bool no_early_bg = getenv("BSX_NO_EARLY_BG") != nullptr;      // A/B timing: bit 4 of the flag word = request a shared background only after the tile's class is known (rounds 1-4)
-  if (no_early_bg) yuyv |= 16;
+  static const bool no_early_bg = BSX_DBG_ENV("BSX_NO_EARLY_BG") != nullptr;      // A/B timing: bit 6 of the flag word = request a shared background only after the tile's class is known (rounds 1-4)
+  if (no_early_bg) yuyv |= 64;
   if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   return hipGetLastError();
@@ -1158,12 +1108,9 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
 
 hipError_t launch_blend(const uint8_t* bg, size_t bg_stride, const uint8_t* frames, const uint8_t* masks, uint8_t* out, size_t npix, int n,
                         hipStream_t s) {
-  bool aligned = (((uintptr_t)bg | (uintptr_t)frames | (uintptr_t)masks | (uintptr_t)out) & 15) == 0 && (npix % 16 == 0) && (bg_stride % 16 == 0);
-  const long groups = aligned ? (long)(npix / 16) : 0;
-  // lane-coalesced form: 4-byte alignment and whole 4-pixel groups are enough.  BSX_BLEND16=1 keeps the 16-pixels-per-lane kernel (A/B timing, tests)
-  static const bool use16 = getenv("BSX_BLEND16") != nullptr;
+  // lane-coalesced form: 4-byte alignment and whole 4-pixel groups are enough; anything else takes the per-pixel kernel
   const bool quad_ok = (((uintptr_t)bg | (uintptr_t)frames | (uintptr_t)masks | (uintptr_t)out) & 3) == 0 && (npix % 4 == 0) && (bg_stride % 4 == 0) && npix / 4 < (1l << 31);
-  const long quads = quad_ok && !(use16 && groups) ? (long)(npix / 4) : 0;
+  const long quads = quad_ok ? (long)(npix / 4) : 0;
   for (int n0 = 0; n0 < n; n0 += kMaxGridY) {
     const int nn = n - n0 < kMaxGridY ? n - n0 : kMaxGridY;
     const uint8_t* bgp = bg + (size_t)n0 * bg_stride;
@@ -1171,7 +1118,6 @@ hipError_t launch_blend(const uint8_t* bg, size_t bg_stride, const uint8_t* fram
     const uint8_t* mp = masks + (size_t)n0 * npix;
     uint8_t* op = out + (size_t)n0 * npix * 3;
     if (quads) blend4x4_k<<<dim3((unsigned)((quads + kThreads * kB4 - 1) / (kThreads * kB4)), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (unsigned)quads, (long)npix);
-    else if (groups) blend16_k<<<dim3(blocks_for(groups), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (unsigned)groups, (long)npix);
     else blend1_k<<<dim3(blocks_for((long)npix), nn), kThreads, 0, s>>>(bgp, (long)bg_stride, fp, mp, op, (long)npix);
   }
   return hipGetLastError();
@@ -1372,11 +1318,11 @@ bool gauss_coeff_words(int ksize, int shift, uint32_t* c4, uint32_t* c2) {
   return true;
 }
 static bool gauss_words(const void* a, const void* b, const void* c, int w) {      // whole-dword output groups: 4 pixels = 12 bytes at 4-byte aligned addresses
-  static const bool off = [] { const char* e = getenv("BSX_GAUSS_BYTE_STORE"); return e && *e == '1'; }();
+  static const bool off = [] { const char* e = BSX_DBG_ENV("BSX_GAUSS_BYTE_STORE"); return e && *e == '1'; }();
   return !off && (w & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 3) == 0;
 }
 static int gauss_opts(const void* src, int w) {                                    // bit 0: 4-pixel staging of interior tiles (dword aligned rows)
-  static const bool off = [] { const char* e = getenv("BSX_GAUSS_BYTE_STAGE"); return e && *e == '1'; }();
+  static const bool off = [] { const char* e = BSX_DBG_ENV("BSX_GAUSS_BYTE_STAGE"); return e && *e == '1'; }();
   return !off && (w & 3) == 0 && (((uintptr_t)src) & 3) == 0 ? 1 : 0;
 }
 template <int MODE>

@@ -17,6 +17,7 @@
 //    row segment; neighbouring lanes re-use taps through L1.
 //  * Accumulation is ci-ascending FMA with the bias added last, the same association as
 //    the TFLite reference kernels the CPU oracle restates (differences are FMA rounding).
+#include "debug_switches.hpp"
 #include <cstdlib>
 #include <type_traits>
 
@@ -285,8 +286,7 @@ __device__ __forceinline__ void split8(const Q v0, const Q v1, h8v& hi, h8v& lo)
 constexpr int kHSA = kGemmBK + 8;        // halves per LDS row: 80 B → the 16-byte reads of 16 consecutive rows hit distinct bank quads
 // (An unpadded 64-byte row with the chunk XOR-swizzled by (0, 3, 2, 1)[row / 4] is conflict-free for the real ds_read_b128 lane groups — the padded
 //  rows leave SQ_LDS_BANK_CONFLICT at 50 % of SQ_LDS_IDX_ACTIVE — but measured 1-3 % SLOWER: the kernel is not LDS-bound and the swizzle costs VALU
-//  in the staging stores.  The ring kernel below, whose layout is produced by the DMA for free, uses it: hsw.)
-__device__ __forceinline__ int hsw(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+//  in the staging stores.)
 // NTW = 16-channel tiles per workgroup (4: a 128 x 64 tile; a 128 x 160 variant for the projection layers measured 25 % slower: registers)
 // XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 and every XCD has its own L2, so "consecutive workgroups
 // share the A tile" only helps if consecutive means consecutive ON ONE XCD.  A 1-D grid is re-indexed so that XCD k walks its own
@@ -498,137 +498,15 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
   gemm_store_tile<NTW>(acc, m_base + 32 * wave, li, g, nt, n_base, M, HW, Cout, bias, fbias, res, y, act);
 }
 
-// ---- the same split-f16 GEMM with BOTH operands delivered by LDS-DMA rings (f32 activations, no prologue ops) ----------------------------------
-// pw_gemm_f16s_k keeps at most ONE K slab per workgroup in flight, in registers (16 floats per lane: two slabs ahead cost the fourth workgroup per
-// CU and lost), and PMC shows its waves waiting on memory for 71-79 % of their cycles at ~4.1 TB/s: too few bytes in flight, not too few MFMAs
-// (MFMA pipe 10-18 % busy).  Here nothing in flight occupies a register: every wave moves ITS OWN 32 rows x 32 floats of A (4 pieces of 1 KB) and its
-// share of the weight slab with global_load_lds_dwordx4 into a ring of kRingD stages, kRingD - 1 slabs ahead of the one being multiplied — 2 workgroups
-// per CU x 2 stages x 16 KB = 64 KB per CU continuously outstanding.  A stays f32 in LDS and is split into halves by the wave that multiplies it
-// (a wave owns its rows: every element is converted exactly once, as before); A needs no barrier at all (own rows, own vmcnt), the weights one per slab.
-// Ring reads are inline-asm ds_read_b128: the compiler orders any LDS read it can see behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which
-// would collapse the ring to depth 1; the waits below are explicit (vmcnt counts in order: stage k is complete when at most the pieces of the newer
-// stages remain).  Layouts are XOR-swizzled ON THE GLOBAL SIDE (the DMA writes lane l at base + 16 l): A row r holds float4 chunk c at position
-// c ^ asw(r), weights chunk c of channel row r at c ^ hsw(r) — both conflict-free for the b128 lane groups (see hsw above).
-constexpr int kRingD = 3;
+// ---- helpers of the LDS-DMA staged operand path (ir_expand_dw_k's STAGE form) -----------------------------------------------------------------------
+// (Round 3's ring GEMM — both operands of pw_gemm_f16s_k delivered by global_load_lds rings, f32 activations only — never beat the register-staged kernel above
+//  and was deleted in round 6 with its switch; its swizzles live on in the staged expand below.)
 typedef __attribute__((address_space(3))) void* lds_vp_t;
 typedef const __attribute__((address_space(1))) void* glb_vp_t;
 __device__ __forceinline__ int asw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
 template <int OFF> __device__ __forceinline__ f4v lds_rd_f4(unsigned addr) { f4v v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); return v; }
 template <int OFF> __device__ __forceinline__ h8v lds_rd_h8(unsigned addr) { h8v v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); return v; }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int TERMS, int NTW>
-__global__ __launch_bounds__(kThreads, 2) void pw_gemm_ring_k(const float* __restrict__ x, const _Float16* __restrict__ w16, const float* __restrict__ bias,
-                                                              const float* __restrict__ res, float* __restrict__ y, long M, int HW, int Cin, int Kp, int Cout,
-                                                              int cout_pad, int act, const float* __restrict__ fbias, int dbg = 0) {
-  extern __shared__ __attribute__((aligned(16))) float ring[];
-  constexpr int PL = TERMS == 3 ? 2 : 1;                    // weight planes (hi | lo)
-  constexpr int NPB = PL * NTW;                             // 1 KB weight pieces per slab (16 channels x 32 halves each)
-  constexpr int NBW = (NPB + 3) / 4;                        // ... per wave (the last ones may repeat a piece: same bytes to the same place)
-  constexpr int NP = 4 + NBW;                               // DMA instructions per wave and stage
-  constexpr int kAStage = kGemmBM * kGemmBK * 4, kBStage = NPB * 1024;       // bytes
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
-  unsigned tcol; long trow;
-  xcd_tile((unsigned)((Cout + NTW * 16 - 1) / (NTW * 16)), &tcol, &trow);
-  const long m_base = trow * kGemmBM;
-  const int n_base = (int)tcol * (NTW * 16);
-  const int nt = min(NTW, (cout_pad - n_base) >> 4);
-  const unsigned lds0 = (unsigned)(unsigned long)(lds_vp_t)ring;             // A stages first, then the weight stages
-  char* ringb = reinterpret_cast<char*>(ring);
-  // ---- DMA sources.  A piece p = rows 8p .. 8p+7 of the wave's 32; lane = (row l >> 3, chunk position l & 7)
-  const float* pa[4];
-  int ca[4];
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
-    const int r = 8 * p + (lane >> 3);
-    const long m = min(((dbg & 1) ? 0 : m_base) + 32 * wave + r, M - 1);                      // rows past the end: a valid row, results dropped
-    ca[p] = 4 * ((lane & 7) ^ asw(r & 15));
-    pa[p] = x + m * Cin + ca[p];
-  }
-  const _Float16* pb[NBW];
-  int qb[NBW];
-#pragma unroll
-  for (int j = 0; j < NBW; j++) {
-    const int qq = (wave + 4 * j) % NPB, plane = qq / NTW, tile = qq - plane * NTW, r = lane >> 2;
-    const int ch = min(n_base + 16 * tile + r, cout_pad - 1);
-    qb[j] = qq;
-    pb[j] = w16 + ((size_t)plane * cout_pad + ch) * Kp + 8 * ((lane & 3) ^ hsw(r));
-  }
-  auto issue = [&](int slab, int stage) {
-    const int k0 = slab * kGemmBK;
-    char* as = ringb + stage * kAStage + wave * 4096;
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const float* src = pa[p] + k0;
-      if (k0 + ca[p] >= Cin) src -= ca[p];                                  // K tail: any finite value (chunk 0 of the slab); its weights are zero
-      __builtin_amdgcn_global_load_lds((glb_vp_t)src, (lds_vp_t)(as + p * 1024), 16, 0, 0);
-    }
-    char* bs = ringb + kRingD * kAStage + stage * kBStage;
-#pragma unroll
-    for (int j = 0; j < NBW; j++) __builtin_amdgcn_global_load_lds((glb_vp_t)(pb[j] + k0), (lds_vp_t)(bs + qb[j] * 1024), 16, 0, 0);
-  };
-  f4acc acc[2][NTW];
-#pragma unroll
-  for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-    for (int ni = 0; ni < NTW; ni++) acc[mi][ni] = f4acc{0.f, 0.f, 0.f, 0.f};
-  // fragment addresses inside a stage: A row li (+16 for the second m-tile = offset 2048), chunks 2g and 2g + 1 (positions differ in bit 0: ^ 16 bytes)
-  const unsigned a_lane = lds0 + wave * 4096 + li * 128 + (((2 * g) ^ asw(li)) << 4);
-  const unsigned b_lane = lds0 + kRingD * kAStage + li * 64 + ((g ^ hsw(li)) << 4);
-  const int nslab = Kp / kGemmBK;
-#pragma unroll
-  for (int sl = 0; sl < kRingD - 1; sl++) if (sl < nslab) issue(sl, sl);
-  int stage = 0;
-  for (int k = 0; k < nslab; k++) {
-    // stage k complete for THIS wave (newer stages may still be in flight), then for everyone (the weights are shared)
-    if (k + kRingD - 2 < nslab) wait_vm<(kRingD - 2) * NP>();
-    else wait_vm<0>();                                                      // (kRingD = 3: the last slab has nothing newer behind it)
-    asm volatile("s_barrier" ::: "memory");           // (as a builtin the compiler puts s_waitcnt vmcnt(0) in front of it on gfx9: every stage would drain)
-    if (k + kRingD - 1 < nslab) issue(k + kRingD - 1, stage == 0 ? kRingD - 1 : stage - 1);      // the stage everybody finished before the barrier
-    const unsigned av = a_lane + stage * kAStage, bv = b_lane + stage * kBStage;
-    f4v a00 = lds_rd_f4<0>(av), a01 = lds_rd_f4<0>(av ^ 16u), a10 = lds_rd_f4<2048>(av), a11 = lds_rd_f4<2048>(av ^ 16u);
-    h8v bh = lds_rd_h8<0>(bv), bl = bh;
-    if (TERMS == 3) bl = lds_rd_h8<NTW * 1024>(bv);
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11) : "n"(TERMS == 3 ? 2 : 1) : "memory");   // A landed; the weights may still be on their way
-    h8v ah[2], al[2];
-    auto split = [&](const f4v v0, const f4v v1, h8v& hi, h8v& lo) {
-      split8<TERMS>(v0, v1, hi, lo);
-    };
-    split(a00, a01, ah[0], al[0]);
-    split(a10, a11, ah[1], al[1]);
-    auto mul = [&](auto NI, h8v& wh_, h8v& wl_) {
-      constexpr int ni = decltype(NI)::value;
-      h8v nh = wh_, nl = wl_;
-      if (ni + 1 < NTW) {                                                  // next tile's weights requested before this tile's MFMAs
-        nh = lds_rd_h8<(ni + 1) * 1024>(bv);
-        nl = nh;
-        if (TERMS == 3) nl = lds_rd_h8<(NTW + ni + 1) * 1024>(bv);
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(wh_), "+v"(wl_) : "n"(TERMS == 3 ? 2 : 1) : "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh_), "+v"(wl_)::"memory");
-      }
-      if (ni < nt) {
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], wh_, acc[mi][ni], 0, 0, 0);
-          if (TERMS == 3) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], wh_, acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], wl_, acc[mi][ni], 0, 0, 0);
-          }
-        }
-      }
-      wh_ = nh; wl_ = nl;
-    };
-    mul(std::integral_constant<int, 0>{}, bh, bl);
-    if constexpr (NTW > 1) mul(std::integral_constant<int, 1>{}, bh, bl);
-    if constexpr (NTW > 2) mul(std::integral_constant<int, 2>{}, bh, bl);
-    if constexpr (NTW > 3) mul(std::integral_constant<int, 3>{}, bh, bl);
-    if constexpr (NTW > 4) mul(std::integral_constant<int, 4>{}, bh, bl);
-    stage = stage + 1 == kRingD ? 0 : stage + 1;
-  }
-  if (dbg & 2) { if (acc[0][0][0] != 12345.678f) return; }
-  gemm_store_tile<NTW>(acc, m_base + 32 * wave, li, g, nt, n_base, M, HW, Cout, bias, fbias, res, y, act);
-}
 
 // ---- inverted-residual front half: expand 1x1 (+act) → depthwise 3x3 (+act) as ONE kernel ----------------------------------------------
 // Workgroup = (frame, row band, chunk of CH expanded channels).  Phase 1: the chunk of the expanded tensor for the band's rows (+ the rows
@@ -691,8 +569,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 || (SLABS == 1 && CH == 1
     // STAGE (32-channel chunks): the MFMA A layout wants lane (li, g) to hold 32 bytes of ROW li — sixteen different rows in sixteen consecutive
     // lanes, i.e. one cache-line lookup per lane: the phase ran at ~64 cycles per 1 KB load instruction (measured: time = 7k + 64 x instructions
     // cycles per workgroup for K = 32 / 64 / 96).  Instead eight consecutive lanes read one row's 128 bytes (8 lines per instruction, not 64),
-    // each wave re-orders the tile through its own 2 KB of LDS (written at lane x 16 B, the chunk order XOR-swizzled on the GLOBAL side exactly
-    // as in pw_gemm_ring_k, fragments read back with two conflict-free ds_read_b128) — no barrier: the LDS serves one wave's operations in order.
+    // each wave re-orders the tile through its own 2 KB of LDS (written at lane x 16 B, the chunk order XOR-swizzled on the GLOBAL side
+    // (asw above), fragments read back with two conflict-free ds_read_b128) — no barrier: the LDS serves one wave's operations in order.
     constexpr bool STAGE = CH == 32 && THREADS == 512;              // (the 1024-lane form has no LDS left for sixteen 2 KB buffers)
     const int lr = lane >> 3, lp = lane & 7;
     int koff[SLABS][2];
@@ -896,235 +774,16 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 || (SLABS == 1 && CH == 1
   }
 }
 
-// ---- a WHOLE inverted-residual block as one kernel, for the layers whose input is small: expand 1x1 → depthwise 3x3 → project 1x1 (+ residual) ----
-// ir_expand_dw_k keeps the expanded tensor out of HBM; its depthwise output — still the block's largest tensor (0.8 - 1.2 MB per frame at 65 x 65) — made
-// one HBM round trip into the project GEMM.  Here a workgroup owns (frame, band of output rows) and LOOPS over the chunks of CH expanded channels:
-//   phase 1  expand chunk of the band's rows (+ the rows the 3x3 window reaches) → LDS E, split-f16 MFMA exactly as in ir_expand_dw_k;
-//   phase 2  depthwise from E → LDS D ([band pixel][CH + 4]: the pad makes the 16-byte fragment reads of 8 consecutive pixels hit distinct banks);
-//   phase 3  project: acc += D · Wp[chunk] on the matrix cores (A fragments = a lane's 8 depthwise values of one pixel, split hi + lo in registers;
-//            K = 32 per instruction with the slots past CH zeroed), accumulators in registers across the chunk loop;
-// then bias, activation, residual and ONE store of the block's output.  The block input is re-read once per chunk, which is why this form is for
-// Cin <= 16 (8 / 12 channels at 129 x 129 / 65 x 65: the band's input is a few KB and stays in L2): at 33 x 33 x 80 the same loop re-reads 348 KB per chunk
-// and the project accumulators alone are 348 KB — see DESIGN.md §8.  Two barriers per chunk; <= 80 KB of LDS so that two workgroups share a CU.
-constexpr int kIrbMT = 3;                 // project m-tiles per wave: band pixels <= 8 waves x 3 x 16
-template <int TERMS, int CH>
-__global__ __launch_bounds__(kIrThreads, 4) void ir_block_k(const float* __restrict__ x, const _Float16* __restrict__ w16e, const float* __restrict__ be,
-                                                          const float* __restrict__ dww, const float* __restrict__ dwb, const _Float16* __restrict__ w16p,
-                                                          const float* __restrict__ bp, const float* __restrict__ res, float* __restrict__ y, int H, int W, int Cin,
-                                                          int Kpe, int Cexp, int cpad_e, int act1, int act2, int d, int S, int pt, int pl, int OH, int OW, int BH,
-                                                          int nbands, int rows_cap, int Cout, int Kpp, int cpad_p, int act3) {
-  extern __shared__ __attribute__((aligned(16))) float ir_ex[];
-  constexpr int NT = (CH + 15) / 16, CQ = CH / 4, CHP = CH + 4, THREADS = kIrThreads;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4, q = li & 3;
-  unsigned band; long frame;
-  xcd_tile((unsigned)nbands, &band, &frame);                               // a frame's bands run back to back on one XCD: halo rows are L2 hits
-  const int oy0 = (int)band * BH, oy1 = min(oy0 + BH, OH);
-  const int e0 = max(S * oy0 - pt, 0), e1 = min(S * (oy1 - 1) - pt + 2 * d + 1, H);      // expanded rows [e0, e1) of this band
-  const int HWb = (e1 - e0) * W, OPX = (oy1 - oy0) * OW;
-  const ClampK k1 = clamp_of(act1), k2 = clamp_of(act2), k3 = clamp_of(act3);
-  const float* xf = x + ((size_t)frame * (size_t)H + (size_t)e0) * (size_t)W * Cin;
-  float* dwl = ir_ex + (size_t)rows_cap * W * CH;                          // [9][CH] weights, [CH] bias, a quad of zeros
-  float* Dl = dwl + 10 * CH + 4;                                           // [BH * OW][CHP]
-  f4acc pacc[kIrbMT];
-#pragma unroll
-  for (int t = 0; t < kIrbMT; t++) pacc[t] = f4acc{0.f, 0.f, 0.f, 0.f};
-  const _Float16* wh = w16e;
-  const _Float16* wl = w16e + (size_t)cpad_e * Kpe;
-  const _Float16* wph = w16p;
-  const _Float16* wpl = w16p + (size_t)cpad_p * Kpp;
-  const f4v zero = {0.f, 0.f, 0.f, 0.f};
-  const int nchunks = Cexp / CH;
-  for (int chunk = 0; chunk < nchunks; chunk++) {
-    const int n_base = chunk * CH;
-    // ---- phase 1: expand chunk → E (one K slab: Cin <= 32)
-    {
-      h8v bh[NT], bl[NT];
-      float bch[NT];
-#pragma unroll
-      for (int ni = 0; ni < NT; ni++) {
-        bh[ni] = h8v{0, 0, 0, 0, 0, 0, 0, 0}; bl[ni] = bh[ni]; bch[ni] = 0.f;
-        if (16 * ni + li < CH) {
-          bh[ni] = *reinterpret_cast<const h8v*>(wh + (size_t)(n_base + 16 * ni + li) * Kpe + 8 * g);
-          if (TERMS == 3) bl[ni] = *reinterpret_cast<const h8v*>(wl + (size_t)(n_base + 16 * ni + li) * Kpe + 8 * g);
-          bch[ni] = be[n_base + 16 * ni + li];
-        }
-      }
-      const int ntile = (HWb + 15) >> 4, nw = THREADS >> 6;
-      constexpr int kPf = 2;
-      f4v ra[kPf][2];
-      int koff[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) { const int k = 8 * g + 4 * h; koff[h] = k < Cin ? k : 0; }      // quads past Cin: any finite value, their weights are zero
-      auto fetch = [&](f4v (&dst)[2], int rt) {
-        const float* rp = xf + (size_t)min(rt * 16 + li, HWb - 1) * Cin;
-        dst[0] = *reinterpret_cast<const f4v*>(rp + koff[0]);
-        dst[1] = *reinterpret_cast<const f4v*>(rp + koff[1]);
-      };
-      const int cnt = wave < ntile ? (ntile - wave + nw - 1) / nw : 0;
-#pragma unroll
-      for (int j = 0; j < kPf; j++) if (j < cnt) fetch(ra[j], wave + j * nw);
-      auto tile = [&](int j, int k) {
-        const int rt = wave + k * nw;
-        h8v ah, al;
-        split8<TERMS>(ra[j][0], ra[j][1], ah, al);
-        if (k + kPf < cnt) fetch(ra[j], wave + (k + kPf) * nw);
-        f4acc acc[NT];
-#pragma unroll
-        for (int ni = 0; ni < NT; ni++) {
-          acc[ni] = f4acc{0.f, 0.f, 0.f, 0.f};
-          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ni], acc[ni], 0, 0, 0);
-          if (TERMS == 3) {
-            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ni], acc[ni], 0, 0, 0);
-            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ni], acc[ni], 0, 0, 0);
-          }
-        }
-        const int pb = rt * 16 + 4 * g;
-#pragma unroll
-        for (int ni = 0; ni < NT; ni++) {
-          if (CH % 16 != 0 && 16 * ni + li >= CH) continue;
-          float* dst = ir_ex + (size_t)pb * CH + 16 * ni + li;
-#pragma unroll
-          for (int r = 0; r < 4; r++) if (pb + r < HWb) dst[r * CH] = clampf(acc[ni][r] + bch[ni], k1);
-        }
-      };
-      for (int k0 = 0; k0 < cnt; k0 += kPf) {
-#pragma unroll
-        for (int j = 0; j < kPf; j++) {
-          if (k0 + j >= cnt) break;
-          tile(j, k0 + j);
-        }
-      }
-    }
-    if (tid < 4) dwl[10 * CH + tid] = 0.f;
-    for (int i = tid; i < 10 * CQ; i += THREADS) {
-      const int k = i / CQ, cq = i - k * CQ;
-      *reinterpret_cast<f4v*>(dwl + k * CH + 4 * cq) = k < 9 ? *reinterpret_cast<const f4v*>(dww + (size_t)k * Cexp + n_base + 4 * cq)
-                                                             : *reinterpret_cast<const f4v*>(dwb + n_base + 4 * cq);
-    }
-    __syncthreads();                       // E and the depthwise weights are complete; every wave is past its phase 3 of the previous chunk (D is free)
-    // ---- phase 2: depthwise → D
-    if (S == 1) {
-      const int L = (oy1 - oy0 + d - 1) / d, nseg = (L + kIrSeg - 1) / kIrSeg, cols = d * W, total = nseg * cols * CQ;
-      const unsigned mcols = 0xFFFFFFFFu / (unsigned)cols + 1u, mw = 0xFFFFFFFFu / (unsigned)W + 1u;
-      const float* zq = dwl + 10 * CH;
-      for (int item = tid; item < total; item += THREADS) {
-        const int t = item / CQ, cq = item - t * CQ, seg = (int)__umulhi((unsigned)t, mcols), rc = t - seg * cols, r = (int)__umulhi((unsigned)rc, mw), xx = rc - r * W;
-        f4v wq[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) wq[k] = *reinterpret_cast<const f4v*>(dwl + k * CH + 4 * cq);
-        const f4v bq = *reinterpret_cast<const f4v*>(dwl + 9 * CH + 4 * cq);
-        const bool vl = xx - d >= 0, vr = xx + d < W;
-        if (!vl) { wq[0] = zero; wq[3] = zero; wq[6] = zero; }
-        if (!vr) { wq[2] = zero; wq[5] = zero; wq[8] = zero; }
-        const int xl = vl ? xx - d : xx, xr = vr ? xx + d : xx, rstep = d * W * CH;
-        const float* col = ir_ex + (size_t)xx * CH + 4 * cq;
-        const float* coll = ir_ex + (size_t)xl * CH + 4 * cq;
-        const float* colr = ir_ex + (size_t)xr * CH + 4 * cq;
-        auto row = [&](int yy, int off, f4v (&o)[3]) {
-          const bool in = yy >= 0 && yy < H;
-          o[0] = *reinterpret_cast<const f4v*>(in ? coll + off : zq);
-          o[1] = *reinterpret_cast<const f4v*>(in ? col + off : zq);
-          o[2] = *reinterpret_cast<const f4v*>(in ? colr + off : zq);
-        };
-        int yy = oy0 + r + seg * kIrSeg * d;
-        int off = (yy - e0) * W * CH;
-        f4v pa[3], pb3[3], pc[3];
-        row(yy - d, off - rstep, pa); row(yy, off, pb3);
-        for (int left = kIrSeg; left > 0 && yy < oy1; left--) {
-          row(yy + d, off + rstep, pc);
-          f4v acc = zero;
-#pragma unroll
-          for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(pa[fx], wq[fx], acc);
-#pragma unroll
-          for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(pb3[fx], wq[3 + fx], acc);
-#pragma unroll
-          for (int fx = 0; fx < 3; fx++) acc = __builtin_elementwise_fma(pc[fx], wq[6 + fx], acc);
-          acc += bq;
-          *reinterpret_cast<f4v*>(Dl + (size_t)((yy - oy0) * OW + xx) * CHP + 4 * cq) = f4v{clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2)};
-#pragma unroll
-          for (int fx = 0; fx < 3; fx++) { pa[fx] = pb3[fx]; pb3[fx] = pc[fx]; }
-          yy += d; off += rstep;
-        }
-      }
-    } else {
-      const int total = OPX * CQ;
-      for (int item = tid; item < total; item += THREADS) {
-        const int t = item / CQ, cq = item - t * CQ, oyl = t / OW, ox = t - oyl * OW, oy = oy0 + oyl;
-        f4v acc = zero;
-#pragma unroll
-        for (int fy = 0; fy < 3; fy++) {
-          const int iy = S * oy - pt + fy;
-#pragma unroll
-          for (int fx = 0; fx < 3; fx++) {
-            const int ix = S * ox - pl + fx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-              const f4v xv = *reinterpret_cast<const f4v*>(ir_ex + ((size_t)(iy - e0) * W + ix) * CH + 4 * cq);
-              const f4v wv = *reinterpret_cast<const f4v*>(dwl + (fy * 3 + fx) * CH + 4 * cq);
-              acc = __builtin_elementwise_fma(xv, wv, acc);
-            }
-          }
-        }
-        acc += *reinterpret_cast<const f4v*>(dwl + 9 * CH + 4 * cq);
-        *reinterpret_cast<f4v*>(Dl + (size_t)t * CHP + 4 * cq) = f4v{clampf(acc.x, k2), clampf(acc.y, k2), clampf(acc.z, k2), clampf(acc.w, k2)};
-      }
-    }
-    __syncthreads();                       // D is complete; E and the depthwise weights are free for the next chunk's phase 1
-    // ---- phase 3: project, accumulators in registers
-    {
-      const bool kv = 8 * g < CH;                                           // this lane's 8 K slots are inside the chunk (CH is a multiple of 8)
-      const int kofs = kv ? n_base + 8 * g : 0;
-      h8v bh = h8v{0, 0, 0, 0, 0, 0, 0, 0}, bl = bh;
-      if (li < cpad_p) {
-        bh = *reinterpret_cast<const h8v*>(wph + (size_t)li * Kpp + kofs);
-        if (TERMS == 3) bl = *reinterpret_cast<const h8v*>(wpl + (size_t)li * Kpp + kofs);
-      }
-      const int ntile3 = (OPX + 15) >> 4;
-#pragma unroll
-      for (int t = 0; t < kIrbMT; t++) {
-        const int mt = wave + 8 * t;
-        if (mt < ntile3) {
-          const float* dp = Dl + (size_t)min(16 * mt + li, OPX - 1) * CHP + (kv ? 8 * g : 0);
-          f4v v0 = *reinterpret_cast<const f4v*>(dp), v1 = *reinterpret_cast<const f4v*>(dp + 4);
-          if (!kv) { v0 = zero; v1 = zero; }
-          h8v ah, al;
-          split8<TERMS>(v0, v1, ah, al);
-          pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, pacc[t], 0, 0, 0);
-          if (TERMS == 3) {
-            pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, pacc[t], 0, 0, 0);
-            pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, pacc[t], 0, 0, 0);
-          }
-        }
-      }
-    }
-  }
-  // ---- bias, activation, residual, store: lane (g, li) owns pixel 4g + (li & 3) of its tiles, channels (li & ~3) .. +3
-  {
-    const int c0 = li & ~3, ntile3 = (OPX + 15) >> 4;
-    const float4 b4 = c0 < Cout ? *reinterpret_cast<const float4*>(bp + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t px0 = ((size_t)frame * OH + (size_t)oy0) * (size_t)OW;
-#pragma unroll
-    for (int t = 0; t < kIrbMT; t++) {
-      const int mt = wave + 8 * t;
-      if (mt < ntile3) {
-        const float4 v = quad_transpose(pacc[t], q);
-        const int px = 16 * mt + 4 * g + q;
-        if (px < OPX && c0 < Cout) {
-          const size_t o = (px0 + (size_t)px) * (size_t)Cout + c0;
-          float4 r = make_float4(clampf(v.x + b4.x, k3), clampf(v.y + b4.y, k3), clampf(v.z + b4.z, k3), clampf(v.w + b4.w, k3));
-          if (res) { const float4 e = *reinterpret_cast<const float4*>(res + o); r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w; }
-          *reinterpret_cast<float4*>(y + o) = r;
-        }
-      }
-    }
-  }
-}
+// (Round 3's whole-block kernel — expand → depthwise → project + residual in one launch for the layers with <= 16 input channels, the project accumulators
+//  held across a loop over expanded-channel chunks — was parity-green and slower than this kernel + the project GEMM (spills at 128 registers, the block input
+//  re-read once per chunk); it was deleted in round 6.  docs/design/08-rejected-and-next-r1-r4.md has its measurements.)
 
 // ---- DeepLab's first three layers in one kernel: stem conv 3x3/s2 (3 → 16) → depthwise 3x3 → 1x1 (16 → C2 <= 16) ------------------------
 // Workgroup = (frame, band of BH output rows).  The input rows the band needs, the stem's band (+1 halo row each side: SAME padding of the
 // depthwise = zero rows outside the image) and the depthwise's band live in LDS; only the C2-channel result is written.  Unfused, the two
 // 16-channel tensors at stem resolution (1 MB per frame each at 129x129) were written and read back: 5.6 MB of traffic per frame for 0.8 MB
 // of input and 0.5 MB of output.  Plain f32 FMAs (3 / 16 input channels: an MFMA slab would be mostly padding), (fy, fx, ci) ascending, bias last.
-// U8IN: x is the 8-bit network input (one u32 R | G<<8 | B<<16 per pixel, prep_bilateral_k<2>), normalised while it is staged with convertTo's two
+// U8IN: x is the 8-bit network input (one u32 R | G<<8 | B<<16 per pixel, prep_fused_k<2>), normalised while it is staged with convertTo's two
 // roundings fadd(fmul(float(q), in_scale), in_offset) (libbackscrub.cc:302): a quarter of the bytes of the f32 tensor, the same values bit for bit.
 constexpr int kH0Threads = 512;
 template <bool U8IN>
@@ -1833,7 +1492,7 @@ hipError_t launch_resize_argmax_iir(const Step& st, const float* x, uint8_t* ofi
   const int ntx = (st.OW + kFusedTW - 1) / kFusedTW, nty = (st.OH + kFusedTH - 1) / kFusedTH;
   if ((unsigned long long)ntx * nty * (unsigned long long)n >= (1ull << 31)) return hipErrorInvalidValue;
   const dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
-  static const bool xcd_on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
+  static const bool xcd_on = !(BSX_DBG_ENV("BSX_XCD_TILES") && atoi(BSX_DBG_ENV("BSX_XCD_TILES")) == 0);      // A/B timing: 0 = plain frame-major workgroup order
   const int nf = xcd_on ? n : 0;
   const int person = 15;                                           // lib/libbackscrub.cc:330 (pascal VOC class 15)
   if (!generic && st.Cin == 21 && person == 15) resize_argmax_iir_k<true, 21, 15><<<grid, kThreads, 0, s>>>(x, ofinal, st.H, st.W, st.Cin, st.OH, st.OW, hs, ws, st.half_pixel, person, ntx, nty, nf);   // DeepLab / PASCAL VOC
@@ -1853,12 +1512,9 @@ hipError_t nn_prepare() {
 #define BSX_ATTR_IR16(T, SL) BSX_ATTR((ir_expand_dw_k<T, SL, 32, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 24, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 16, true>))
   BSX_ATTR_IR16(1, 1); BSX_ATTR_IR16(1, 2); BSX_ATTR_IR16(1, 3); BSX_ATTR_IR16(3, 1); BSX_ATTR_IR16(3, 2); BSX_ATTR_IR16(3, 3);
 #undef BSX_ATTR_IR16
-  BSX_ATTR((ir_block_k<3, 24>)); BSX_ATTR((ir_block_k<3, 16>)); BSX_ATTR((ir_block_k<1, 24>)); BSX_ATTR((ir_block_k<1, 16>));
   BSX_ATTR(dl_head0_k<false>);
   BSX_ATTR(dl_head0_k<true>);
   BSX_ATTR((ir_expand_dw_k<3, 1, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 2, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 3, 32, false, 1024>));
-  BSX_ATTR((pw_gemm_ring_k<3, 3>)); BSX_ATTR((pw_gemm_ring_k<3, 4>)); BSX_ATTR((pw_gemm_ring_k<3, 5>));
-  BSX_ATTR((pw_gemm_ring_k<1, 3>)); BSX_ATTR((pw_gemm_ring_k<1, 4>)); BSX_ATTR((pw_gemm_ring_k<1, 5>));
 #undef BSX_ATTR_IR
 #undef BSX_ATTR
   return hipSuccess;
@@ -1880,28 +1536,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       dim3 grid(blocks_for(M), st.cout_pad / st.cout_tile);
       int HW = st.OH * st.OW;
       if (st.fused_away && plan.steps[0].fuse_head0) break;          // ran inside dl_head0_k (the planner decides: BSX_NO_HEAD0 is read there)
-      static const bool no_gemm = getenv("BSX_NO_PW_GEMM") != nullptr;
-      // the whole inverted-residual block (expand + depthwise + project + residual) in one kernel: whenever the split / plain f16 GEMM modes are on and
-      // the reduced-precision STORAGE mode (bit 4: f16 depthwise tensors in HBM — there is no such tensor here) is not what is being measured
-      const bool block_on = weights16 && (f16_terms & 15) > 0 && !(f16_terms & 16);
-      if (st.fused_into_block && block_on) break;                    // ran inside ir_block_k, launched by the expand step two steps before
-      if (st.fuse_proj >= 0 && block_on) {
-        const Step& dws = plan.steps[st.fuse_dw];
-        const Step& pj = plan.steps[st.fuse_proj];
-        const IrGeom bg = ir_block_geometry(st.OH, st.OW, st.Cout, dws.OH, dws.OW, dws.sh, dws.dh);
-        if (bg.CH == 0 || (long)bg.rows * st.OW * dws.dh >= 65536) return hipErrorInvalidValue;      // the planner checked the same function
-        const _Float16* w16e = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
-        const _Float16* w16p = reinterpret_cast<const _Float16*>(weights16) + pj.w16_off;
-        const size_t lds = (size_t)ir_block_lds_bytes(bg.rows, st.OW, bg.CH, bg.BH, dws.OW);
-        const dim3 gb((unsigned)bg.nbands * (unsigned)n);
-#define BSX_IRB(T, C) ir_block_k<T, C><<<gb, kIrThreads, lds, s>>>(P(st.in0), w16e, b, weights + dws.w_off, weights + dws.b_off, w16p, weights + pj.b_off, P(pj.residual), P(pj.out), \
-                                                                 st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, \
-                                                                 bg.BH, bg.nbands, bg.rows, pj.Cout, pj.k16_pad, pj.cout_pad, pj.act)
-        if ((f16_terms & 15) == 3) { if (bg.CH == 24) BSX_IRB(3, 24); else BSX_IRB(3, 16); }
-        else { if (bg.CH == 24) BSX_IRB(1, 24); else BSX_IRB(1, 16); }
-#undef BSX_IRB
-        break;
-      }
+      static const bool no_gemm = BSX_DBG_ENV("BSX_NO_PW_GEMM") != nullptr;
       if (st.fuse_dw >= 0 && weights16 && f16_terms > 0) {          // expand 1x1 + depthwise 3x3 of an inverted-residual block in one kernel
         const Step& dws = plan.steps[st.fuse_dw];
         const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dws.OH, dws.sh, dws.dh);
@@ -1911,7 +1546,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         if ((long)ig.rows * st.OW * dws.dh >= 65536) return hipErrorInvalidValue;   // the kernel divides item indices by multiplication
         const dim3 gi((unsigned)(st.Cout / ig.CH) * (unsigned)ig.nbands * (unsigned)n);
         const int slabs = st.k16_pad / 32;
-        static const int ir_phases = getenv("BSX_IR_PHASES") ? atoi(getenv("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
+        static const int ir_phases = BSX_DBG_ENV("BSX_IR_PHASES") ? atoi(BSX_DBG_ENV("BSX_IR_PHASES")) : 3;      // timing experiments: 1 = expand only, 2 = depthwise only
         // reduced-precision storage (f16_terms bit 4): only when the depthwise output's single reader is a GEMM that will take the f16 form (same M rule)
         const bool out16 = (f16_terms & 16) && (size_t)st.fuse_dw + 1 < plan.steps.size() && plan.steps[st.fuse_dw + 1].in_from_fused_dw &&
                            plan.steps[st.fuse_dw + 1].in0 == dws.out && (long)n * dws.OH * dws.OW >= 8192 && !no_gemm;
@@ -1919,7 +1554,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         // buffers) for the whole-frame 32-channel layers.  Measured per K: 16 input channels (64-byte rows: nothing to coalesce) 149 -> 134 us;
         // 32 channels equal; 48 (two slabs) +5 %; 80 (three slabs) spills at 128 registers, 1.06 -> 1.72 ms.  Default: the 16-channel layers only
         // (BSX_IR_WAVES16 = bit mask over the slab count, for experiments; 0 = never).
-        static const int w16_mask = getenv("BSX_IR_WAVES16") ? atoi(getenv("BSX_IR_WAVES16")) : -1;
+        static const int w16_mask = BSX_DBG_ENV("BSX_IR_WAVES16") ? atoi(BSX_DBG_ENV("BSX_IR_WAVES16")) : -1;
         const bool w16_on = w16_mask < 0 ? (slabs == 1 && st.Cin <= 16) : ((w16_mask >> (slabs - 1)) & 1) != 0;
         if ((f16_terms & 15) == 3 && !out16 && ig.CH == 32 && ig.nbands == 1 && slabs >= 1 && slabs <= 3 && w16_on) {
 #define BSX_IR16(SL) ir_expand_dw_k<3, SL, 32, false, 1024><<<gi, 1024, lds, s>>>(P(st.in0), w16, b, weights + dws.w_off, weights + dws.b_off, P(dws.out), st.OH, st.OW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, dws.act, dws.dh, dws.sh, dws.pad_t, dws.pad_l, dws.OH, dws.OW, ig.BH, ig.nbands, ir_phases)
@@ -1953,23 +1588,13 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
           const _Float16* w16 = reinterpret_cast<const _Float16*>(weights16) + st.w16_off;
           // column tiles: 64 channels (NTW = 4), or 80 / 48 in ONE tile where that covers the whole layer (NTW = 5 / 3: the A block is
           // staged and split once instead of once per column tile — the 480 -> 80 and 288 -> 48 project layers)
-          static const bool wide_ok = getenv("BSX_NO_GEMM_NTW") == nullptr;
-          static const int gemm_dbg = getenv("BSX_GEMM_DBG") ? atoi(getenv("BSX_GEMM_DBG")) : 0;      // timing experiments: 1 = A from one L2-resident block, 2 = no stores
+          static const bool wide_ok = BSX_DBG_ENV("BSX_NO_GEMM_NTW") == nullptr;
+          static const int gemm_dbg = BSX_DBG_ENV("BSX_GEMM_DBG") ? atoi(BSX_DBG_ENV("BSX_GEMM_DBG")) : 0;      // timing experiments: 1 = A from one L2-resident block, 2 = no stores
           // (128-column tiles for the 256-channel ASPP layers — A staged twice instead of four times — measured 35-43 % SLOWER: 168 registers, 3 workgroups per CU)
           const int ntw = (wide_ok && st.Cout % 80 == 0) ? 5 : ((wide_ok && st.Cout == 48) ? 3 : 4);
           const unsigned ncol = (unsigned)((st.Cout + ntw * 16 - 1) / (ntw * 16));
           if ((unsigned long long)gg.x * ncol >= (1ull << 31)) return hipErrorInvalidValue;
           const dim3 gw(gg.x * ncol);                              // 1-D: the kernel derives (column tile, row block) XCD-aware
-          // f32 activations, no prologue ops: both operands through the LDS-DMA rings (bit 5 of f16_terms; BSX_GEMM_RING=0 clears it)
-          if ((f16_terms & 32) && st.in_scale < 0 && st.in2 < 0 && !((f16_terms & 16) && st.in_from_fused_dw)) {
-            const int terms = f16_terms & 15;
-            const size_t lds = (size_t)kRingD * (kGemmBM * kGemmBK * 4 + (terms == 3 ? 2 : 1) * ntw * 1024);
-#define BSX_RING(T, N) pw_gemm_ring_k<T, N><<<gw, kThreads, lds, s>>>(P(st.in0), w16, b, P(st.residual), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias), gemm_dbg)
-            if (terms == 3) { if (ntw == 5) BSX_RING(3, 5); else if (ntw == 3) BSX_RING(3, 3); else BSX_RING(3, 4); }
-            else { if (ntw == 5) BSX_RING(1, 5); else if (ntw == 3) BSX_RING(1, 3); else BSX_RING(1, 4); }
-#undef BSX_RING
-            break;
-          }
 #define BSX_F16S(T, N) pw_gemm_f16s_k<T, N><<<gw, kThreads, 0, s>>>(P(st.in0), w16, b, P(st.residual), P(st.in_scale), P(st.in2), P(st.out), M, HW, st.Cin, st.k16_pad, st.Cout, st.cout_pad, st.act, P(st.out_bias), gemm_dbg)
           if ((f16_terms & 15) == 3) { if (ntw == 5) BSX_F16S(3, 5); else if (ntw == 3) BSX_F16S(3, 3); else BSX_F16S(3, 4); }
           else if ((f16_terms & 16) && st.in_from_fused_dw) {        // its input was stored as f16 by the fused kernel before it (same M rule on both sides)
@@ -1996,8 +1621,8 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const Step& p2 = plan.steps[2];
         const int BH = head0_band_rows(st.W, st.OW), nb = (st.OH + BH - 1) / BH;
         const size_t fl = (size_t)head0_lds_floats(st.W, st.OW, BH);
-        static const int h0_phases = getenv("BSX_H0_PHASES") ? atoi(getenv("BSX_H0_PHASES")) : 15;   // timing experiments
-        static const bool h0_xcd = getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 2;      // one-XCD-per-frame band order: measured SLOWER here (0.927 vs 0.908 ms, profiles/r03o) — only with BSX_XCD_TILES=2
+        static const int h0_phases = BSX_DBG_ENV("BSX_H0_PHASES") ? atoi(BSX_DBG_ENV("BSX_H0_PHASES")) : 15;   // timing experiments
+        static const bool h0_xcd = BSX_DBG_ENV("BSX_XCD_TILES") && atoi(BSX_DBG_ENV("BSX_XCD_TILES")) == 2;      // one-XCD-per-frame band order: measured SLOWER here (0.927 vs 0.908 ms, profiles/r03o) — only with BSX_XCD_TILES=2
         const bool u8_fits = (long)(2 * (BH + 2) + 1) * st.W <= 4 * 3 * kH0Threads;                // three 4-pixel loads per lane cover the band's rows
         if (net_in_u8 && st.in0 == plan.input && !u8_fits) return hipErrorInvalidValue;            // (bsx_api decides with the same rule: head0_u8_ok)
         if (net_in_u8 && st.in0 == plan.input)
@@ -2021,7 +1646,7 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       if (st.fused_away && weights16 && f16_terms > 0) break;       // ran inside the expand convolution before it (ir_expand_dw_k)
       long total = (long)n * st.OH * st.OW * (st.Cin / 4);
       ConvGeom g{st.H, st.W, st.Cin, st.OH, st.OW, st.Cout, st.cout_pad, st.kh, st.kw, st.sh, st.sw, st.dh, st.dw, st.pad_t, st.pad_l};
-      static const bool no_col = getenv("BSX_NO_DW_COL") != nullptr;
+      static const bool no_col = BSX_DBG_ENV("BSX_NO_DW_COL") != nullptr;
       if (!no_col && st.kh == 3 && st.kw == 3 && st.sh == 1 && st.sw == 1 && st.dh == st.dw && st.pad_t == st.dh && st.pad_l == st.dw && st.OH == st.H && st.OW == st.W &&
           st.H >= 4 * st.dh) {                                   // SAME 3x3, stride 1: the sliding-window column walk
         const long lanes = (long)n * st.dh * st.W * (st.Cin / 4);

@@ -13,6 +13,7 @@
 // Reference operators covered (file:line into /root/reference): Interpreter::Invoke() lib/libbackscrub.cc:307 — CONV_2D,
 // DEPTHWISE_CONV_2D, RESIZE_BILINEAR (half-pixel), MUL/ADD gates, AVERAGE_POOL_2D (as partial sums), FULLY_CONNECTED /
 // 1x1 gate convs; Convolution2DTransposeBias lib/transpose_conv_bias.cc:37-114; decode + IIR lib/libbackscrub.cc:317-357.
+#include "debug_switches.hpp"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -280,7 +281,7 @@ __device__ __forceinline__ RowTile row_tile(int t, int ctiles, unsigned m_ct) {
 // head: stem conv3x3/s2 (3 → 16) → 1x1 (16 → 16) → depthwise 3x3/s2; writes A (skip of the last decoder level), b0, and the
 // pooled partial sums of both.  Tile = TR (<= 4) x TC (<= 15) pixels of b0.
 // ==================================================================================================================================
-// U8IN: the network input arrives as the filtered 8-bit pixels (R | G<<8 | B<<16 per pixel, prep_bilateral_k<2>) and is normalised here with the
+// U8IN: the network input arrives as the filtered 8-bit pixels (R | G<<8 | B<<16 per pixel, prep_fused_k<2>) and is normalised here with the
 // same two roundings convertTo applies (libbackscrub.cc:302): fadd(fmul(float(q), scale), offset) — bit-identical to reading the f32 tensor.
 template <bool STEM_HSWISH, bool H16, bool U8IN>
 __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float* __restrict__ arena, long per_frame, const float* __restrict__ net_in,
@@ -815,10 +816,10 @@ hipError_t seg_prepare() {
 }
 
 // n_frames = 0 tells xcd_frame_tile to keep the plain (frame-major) workgroup order: BSX_XCD_TILES=0, read once per process, for A/B timing
-static int xcd_frames(int n) { static const bool on = !(getenv("BSX_XCD_TILES") && atoi(getenv("BSX_XCD_TILES")) == 0); return on ? n : 0; }
+static int xcd_frames(int n) { static const bool on = !(BSX_DBG_ENV("BSX_XCD_TILES") && atoi(BSX_DBG_ENV("BSX_XCD_TILES")) == 0); return on ? n : 0; }
 
 // h16: the boundary tensors are stored as halves (BSX_ACT16; the middle program must have been generated for the same storage)
-// u8: net_in points at the 8-bit network input ([n][H0][W0] u32 pixels, prep_bilateral_k<2>) and (scale, offset) is the model's normalisation
+// u8: net_in points at the 8-bit network input ([n][H0][W0] u32 pixels, prep_fused_k<2>) and (scale, offset) is the model's normalisation
 hipError_t launch_seg_head(const SegHead& d, float* arena, long per_frame, const void* net_in, const float* weights, int n, hipStream_t s, bool h16, bool u8, float in_scale,
                            float in_offset) {
   const dim3 grid((unsigned)(d.tiles_y * d.tiles_x) * (unsigned)n);
@@ -848,7 +849,7 @@ template <bool H16>
 static hipError_t launch_seg_tail_t(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s) {
   const dim3 grid((unsigned)(d.tiles_y * d.tiles_x) * (unsigned)n);
   // BSX_SEG_TAIL_WGS=<k> (experiment switch, read once): pad the dynamic LDS so that at most k workgroups fit a CU — the A/B of the tail's 5th workgroup (round 5)
-  static const int wgs_cap = getenv("BSX_SEG_TAIL_WGS") ? atoi(getenv("BSX_SEG_TAIL_WGS")) : 0;
+  static const int wgs_cap = BSX_DBG_ENV("BSX_SEG_TAIL_WGS") ? atoi(BSX_DBG_ENV("BSX_SEG_TAIL_WGS")) : 0;
   size_t lds = (size_t)d.lds_floats * sizeof(float);
   if (wgs_cap > 0) lds = std::max(lds, (size_t)(160 * 1024 / (wgs_cap + 1) + 256));
   const bool sig = d.act3 == kActSigmoid;

@@ -1,4 +1,5 @@
 // plan.cpp — graph → fused step list + weight packing + activation arena layout.
+#include "debug_switches.hpp"
 #include "plan.hpp"
 #include "gen_mid.hpp"
 
@@ -84,14 +85,6 @@ std::string Plan::describe() const {
              st.residual, st.in_scale, st.macs, st.in0, st.out);
     s += line;
     if (st.fuse_head0) { s += "      ^ fused with steps 1 and 2 (stem + depthwise + 1x1 in one tiled kernel)\n"; }
-    if (st.fuse_proj >= 0) {
-      const Step& dd = steps[st.fuse_dw];
-      const IrGeom bg = ir_block_geometry(st.OH, st.OW, st.Cout, dd.OH, dd.OW, dd.sh, dd.dh);
-      char line[200];
-      snprintf(line, sizeof line, "      ^ fused with steps %d and %d (the whole inverted-residual block in one kernel: %d channels x %d rows per chunk and band, %d band(s))\n", st.fuse_dw, st.fuse_proj, bg.CH,
-               bg.BH, bg.nbands);
-      s += line;
-    } else
     if (st.fuse_dw >= 0) {
       const Step& dd = steps[st.fuse_dw];
       const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dd.OH, dd.sh, dd.dh);
@@ -111,6 +104,7 @@ std::string Plan::describe() const {
 static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<Step>& steps, const std::vector<int>& ext, const std::map<int, int>& part_n,
                                 const std::map<int, int>& part_hw, const int scratch, const unsigned policy = 0) {
   const bool long_to_hbm = (policy & 1u) != 0, elide_expand = (policy & 2u) != 0, small_top = (policy & 4u) != 0;
+  const int kLdsTotal = plan->lds_total_floats, kLdsZero = plan->lds_zero_off();      // the block THIS plan's workgroup owns (Plan::mid_lanes / lds_total_floats)
   plan->program.clear();
   plan->program_scratch_floats = scratch;
   plan->program_labels.clear();
@@ -142,13 +136,13 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       const Step& d = steps[s + 1];
       if (!(a.kind == StepKind::PwConv && a.residual < 0 && a.out >= 0 && last[a.out] == s + 1 && d.kind == StepKind::DwConv && d.in0 == a.out && d.residual < 0 && d.dh == 1 && d.dw == 1)) continue;
       if (a.out == g.output || std::find(ext.begin(), ext.end(), a.out) != ext.end() || g.tensors[a.out].dims[3] % 8 || a.cout_pad < (g.tensors[a.out].dims[3] + 15) / 16 * 16) continue;
-      const int P = g.tensors[a.out].dims[1] * g.tensors[a.out].dims[2], need = padded(a.out), need_o = padded(d.out), ws = (P * 20 + 3) / 4 * 4 /* the 16-channel chunk */, room = kLdsTotalFloats - scratch - 2 * kLdsMaxStageFloats;
+      const int P = g.tensors[a.out].dims[1] * g.tensors[a.out].dims[2], need = padded(a.out), need_o = padded(d.out), ws = (P * 20 + 3) / 4 * 4 /* the 16-channel chunk */, room = kLdsTotal - scratch - 2 * kLdsMaxStageFloats;
       if (need + need_o > room && (need_o > room ? ws : need_o + ws) <= room) {     // (a depthwise output too large for LDS lives in the arena either way: then only the chunk workspace must fit)
         elide[s] = 1;
         for (int t : {a.in0, a.in2, a.in_scale}) if (t >= 0) last[t] = std::max(last[t], s + 1);
       }
     }
-  const bool no_lds = getenv("BSX_PROGRAM_NO_LDS") != nullptr;  // debugging: every tensor in the HBM arena
+  const bool no_lds = BSX_DBG_ENV("BSX_PROGRAM_NO_LDS") != nullptr;  // debugging: every tensor in the HBM arena
   std::vector<Loc> loc(NT);
   struct Blk { int off, len, until; };
   std::vector<Blk> live;
@@ -157,7 +151,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
   int reserved = 0;
   std::vector<int> firstdef(NT, -1);
   for (int s = 0; s < NS; s++) if (steps[s].out >= 0 && firstdef[steps[s].out] < 0) firstdef[steps[s].out] = s;
-  if (!getenv("BSX_PLAN_NO_TOPDOWN")) {
+  if (!BSX_DBG_ENV("BSX_PLAN_NO_TOPDOWN")) {
     for (int t = 0; t < NT; t++) {
       if (firstdef[t] < 0 || last[t] - firstdef[t] <= 8 || t == g.input || t == g.output) continue;
       if (std::find(ext.begin(), ext.end(), t) != ext.end()) continue;
@@ -165,12 +159,12 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       const int C = ti.dims[3], P = ti.dims[1] * ti.dims[2];
       if (C % 4 || P <= 1) continue;
       const int pad = ((C / 4) % 2 == 0) ? 4 : 8, need = (P * (C + pad) + 3) / 4 * 4;
-      if (reserved + need > kLdsTotalFloats / 4) continue;
+      if (reserved + need > kLdsTotal / 4) continue;
       reserved += need;
-      reserved_at[t] = kLdsZeroOff - reserved;
+      reserved_at[t] = kLdsZero - reserved;
     }
   }
-  const int cap = kLdsZeroOff - reserved;          // everything that is not reserved allocates in [scratch, cap); [kLdsZeroOff, kLdsTotalFloats) is the zero cell
+  const int cap = kLdsZero - reserved;          // everything that is not reserved allocates in [scratch, cap); [kLdsZero, kLdsTotal) is the zero cell
   int high = scratch;
   auto place = [&](int t, int s) {
     if (t < 0 || loc[t].space != kLocNone) return;
@@ -184,7 +178,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
     int need = (P * stride + 3) / 4 * 4;
     // a tensor that would leave no room for the weight slots of the ops around it turns those ops into their slow unstaged
     // forms (MLKit's 16x16x128 tensors are 132 KB): such a tensor goes to HBM instead
-    if (need > kLdsTotalFloats - scratch - 2 * kLdsMaxStageFloats && !getenv("BSX_PLAN_NO_SLOT_RESERVE")) lds_ok = false;
+    if (need > kLdsTotal - scratch - 2 * kLdsMaxStageFloats && !BSX_DBG_ENV("BSX_PLAN_NO_SLOT_RESERVE")) lds_ok = false;
     // Policy `long_to_hbm`: a LONG-LIVED tensor (a skip connection: alive across more than 8 steps) that is too large for the reserved zone would sit in the
     // general area for its whole life and push every large short-lived tensor of the levels below it into the arena (segm_full: the 72 KB level-3 skip keeps the
     // 76 KB depthwise outputs of all three level-4 blocks in HBM).  It is written once and read twice: it goes to the arena instead, and the short-lived tensors,
@@ -206,7 +200,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       // HBM although 110 KB were free).
       auto rz = reserved_at.find(t);
       if (rz != reserved_at.end()) pos = rz->second;
-      else if (small_top && need <= kLdsTotalFloats / 6) {
+      else if (small_top && need <= kLdsTotal / 6) {
         // Policy `small_top`: small tensors (block inputs / residuals: <= 1/6 of the block) allocate from the TOP like the weight slots, so that they do not end up
         // in the middle of the block — above whatever large tensor was alive when they were placed — and split the space the next large tensor needs
         // (segm_full: the 20 KB block input at 57 KB kept the 76 KB depthwise output out of a block with 80 KB free)
@@ -255,7 +249,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
     long range = ((long)st.b_off - (long)st.w_off) + ((nb + 3) / 4) * 4;
     // FC layers of a GAP → FC [→ FC] chain (fused into one squeeze-excite micro-op below): [bias | [co][ci] weights] is one contiguous
     // range of the weight arena; it is staged while the op BEFORE the pool runs, so that the FCs read LDS instead of waiting for L2/HBM
-    if (st.kind == StepKind::PwConv && st.OH * st.OW == 1 && st.w2_off > st.b_off && !getenv("BSX_NO_FC_STAGE")) {
+    if (st.kind == StepKind::PwConv && st.OH * st.OW == 1 && st.w2_off > st.b_off && !BSX_DBG_ENV("BSX_NO_FC_STAGE")) {
       auto fc1px = [&](int k) { const Step& f = steps[k]; return f.kind == StepKind::PwConv && f.OH * f.OW == 1; };
       int q0 = s;
       while (q0 > 0 && fc1px(q0 - 1)) q0--;
@@ -283,7 +277,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
   std::vector<std::string> labels;
   std::vector<int> tail_ws(NS, -1), tail_rows(NS, 0);
   auto tail_pattern = [&](int s) {
-    if (s + 2 >= NS || getenv("BSX_PROGRAM_NO_TAIL")) return false;
+    if (s + 2 >= NS || BSX_DBG_ENV("BSX_PROGRAM_NO_TAIL")) return false;
     const Step& a = steps[s];
     const Step& b = steps[s + 1];
     const Step& c2 = steps[s + 2];
@@ -302,7 +296,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       // weight slots live for two steps and are small: placed from the TOP of the block (like the skip tensors) they leave the bottom
       // contiguous for the large activation tensors (a 9.6 KB slot at 54 KB kept segm_lite's 96 KB expanded tensor out of LDS)
       int pos = -1, hi = cap;
-      if (!getenv("BSX_PLAN_NO_TOPDOWN")) {
+      if (!BSX_DBG_ENV("BSX_PLAN_NO_TOPDOWN")) {
         for (int k = (int)live.size() - 1; k >= -1; k--) {
           const int lo = k >= 0 ? live[k].off + live[k].len : scratch;
           if (hi - lo >= need) { pos = hi - need; break; }
@@ -327,7 +321,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       auto need_for = [&](int r) { return (r + 2) * st.W * (st.Cout + 4); };
       live.erase(std::remove_if(live.begin(), live.end(), [&](const Blk& b) { return b.until < s; }), live.end());
       std::sort(live.begin(), live.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
-      const int rmax = getenv("BSX_TAIL_ROWS") ? atoi(getenv("BSX_TAIL_ROWS")) : 16;
+      const int rmax = BSX_DBG_ENV("BSX_TAIL_ROWS") ? atoi(BSX_DBG_ENV("BSX_TAIL_ROWS")) : 16;
       for (int R = rmax; R >= 1 && tail_ws[s] < 0; R = R > 4 ? R - 2 : R - 1) {
         const int need = need_for(R);
         if ((R + 2) * st.W > 64 * 16 * 4) continue;           // phase A: <= 4 tiles per wave and band
@@ -348,7 +342,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
     m.cout_pad = st.cout_pad; m.cout_tile = st.cout_tile;
     m.w_off = (long long)st.w_off; m.b_off = (long long)st.b_off; m.w2_off = (long long)st.w2_off;
     m.gemv = gemv_form(st) ? 1 : 0;
-    m.strip = (st.kind == StepKind::DwConv && !getenv("BSX_NO_DW_STRIP")) ? 1 : 0;
+    m.strip = (st.kind == StepKind::DwConv && !BSX_DBG_ENV("BSX_NO_DW_STRIP")) ? 1 : 0;
     auto L = [&](int t) { return t >= 0 ? loc[t] : Loc(); };
     m.in0 = L(st.in0); m.in1 = L(st.in1); m.in2 = L(st.in2); m.res = L(st.residual); m.scale = L(st.in_scale); m.out = L(st.out);
     if (st.concat_in.size() > 4) return;
@@ -393,7 +387,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
         high = std::max(high, pos + need);
       }
     }
-    if (st.kind == StepKind::DwConv && m.strip && m.in0.space == kLocGlobal && st.dh == 1 && st.dw == 1 && st.residual < 0 && !getenv("BSX_PLAN_NO_DW_STAGE")) {
+    if (st.kind == StepKind::DwConv && m.strip && m.in0.space == kLocGlobal && st.dh == 1 && st.dw == 1 && st.residual < 0 && !BSX_DBG_ENV("BSX_PLAN_NO_DW_STAGE")) {
       // Depthwise on a tensor that lives in the arena: every input element is needed by K output rows and ~2 strips, i.e. it is read ~10 times — from an L2 that
       // 32 frames' tensors share.  Where LDS has room the specialised kernel walks the channels in chunks of CK: the chunk of the WHOLE input ([H*W][CK + 4]) is
       // brought into an LDS workspace once, coalesced, and the taps run from there (gen_mid.cpp).  ws_off / band_rows (= CK) carry the reservation; the
@@ -414,8 +408,8 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
       }
     }
     if (m.scale.space != kLocNone && m.scale.space != kLocLds) return;   // the pw micro-op reads SE scales with ds_read only
-    if (getenv("BSX_PROGRAM_NOP")) m.kind = 99;
-    if (const char* only = getenv("BSX_PROGRAM_ONLY")) { if (atoi(only) != s) m.kind = 99; }   // timing experiments: one live op
+    if (BSX_DBG_ENV("BSX_PROGRAM_NOP")) m.kind = 99;
+    if (const char* only = BSX_DBG_ENV("BSX_PROGRAM_ONLY")) { if (atoi(only) != s) m.kind = 99; }   // timing experiments: one live op
     prog.push_back(m);
     {
       char buf[200];
@@ -425,7 +419,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
     }
   }
   // peephole: GAP → FC(act) [→ FC(act)] on single-pixel vectors → one fused micro-op (means/hidden stay in their LDS slots)
-  if (!getenv("BSX_PROGRAM_NO_SE")) {
+  if (!BSX_DBG_ENV("BSX_PROGRAM_NO_SE")) {
     std::vector<MicroOp> fusedp;
     std::vector<std::string> flabels;
     for (size_t i = 0; i < prog.size(); i++) {
@@ -481,7 +475,7 @@ static void lower_frame_program(const Graph& g, Plan* plan, const std::vector<St
   plan->program = std::move(prog);
   plan->program_labels = std::move(labels);
   plan->program_lds_floats = high;
-  if (getenv("BSX_PLAN_DEBUG"))
+  if (BSX_DBG_ENV("BSX_PLAN_DEBUG"))
     for (const auto& b : plan->program_blocks) fprintf(stderr, "lds block [%6d, %6d) steps [%2d, %2d] %s\n", b.off, b.off + b.len, b.from, b.until, b.what.c_str());
   plan->program_check = verify_program_lds(*plan);
   if (plan->program_check != "ok") plan->program.clear();      // never run a program whose LDS reservations collide
@@ -511,7 +505,7 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
                                 const std::map<int, int>& part_n = {}, const std::map<int, int>& part_hw = {}) {
   auto lower = [&](unsigned policy) {
     lower_frame_program(g, plan, steps, ext, part_n, part_hw, kLdsScratchFloats, policy);
-    if (plan->program.empty() || getenv("BSX_PLAN_FULL_SCRATCH")) return;
+    if (plan->program.empty() || BSX_DBG_ENV("BSX_PLAN_FULL_SCRATCH")) return;
     for (const MicroOp& m : plan->program)
       if ((m.kind == (int)StepKind::PwConv && m.gemv) || m.kind == kMicroTail || m.kind == (int)StepKind::Conv) return;
     lower_frame_program(g, plan, steps, ext, part_n, part_hw, 64, policy);
@@ -521,7 +515,7 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
   // bit 0 long-lived tensors to the arena, bit 1 expanded tensors elided, bit 2 small tensors from the top).  All eight combinations are lowered — microseconds on the
   // host — and the one whose program touches the fewest arena bytes per frame is kept; ties keep the lowest policy number (0 = the round-3 planner).
   // BSX_PLAN_POLICY=<0..7> forces one (A/B timing).
-  if (const char* force = getenv("BSX_PLAN_POLICY")) { plan->program_policy = (unsigned)atoi(force) & 7u; lower(plan->program_policy); plan->program_arena_bytes = program_arena_bytes(*plan); return; }
+  if (const char* force = BSX_DBG_ENV("BSX_PLAN_POLICY")) { plan->program_policy = (unsigned)atoi(force) & 7u; lower(plan->program_policy); plan->program_arena_bytes = program_arena_bytes(*plan); return; }
   unsigned best = 0;
   long best_b = -1;
   for (unsigned pol = 0; pol < 8; pol++) {
@@ -536,11 +530,11 @@ static void build_frame_program(const Graph& g, Plan* plan, const std::vector<St
 }
 
 // Independent check of the lowering: no two LDS reservations that are alive at the same step may share a float, every block
-// stays inside [kLdsScratchFloats, kLdsTotalFloats), and every LDS operand of every micro-op lies inside the block area.
+// stays inside [scratch, Plan::lds_zero_off()) — below the zero cell —, and every LDS operand of every micro-op lies inside the block area.
 std::string verify_program_lds(const Plan& plan) {
   const auto& b = plan.program_blocks;
   for (size_t i = 0; i < b.size(); i++) {
-    if (b[i].off < plan.program_scratch_floats || b[i].off + b[i].len > kLdsTotalFloats || b[i].len <= 0 || b[i].from > b[i].until)
+    if (b[i].off < plan.program_scratch_floats || b[i].off + b[i].len > plan.lds_zero_off() || b[i].len <= 0 || b[i].from > b[i].until)      // (the zero cell above is nobody's: ADVICE r5)
       return "block out of range: " + b[i].what;
     for (size_t j = i + 1; j < b.size(); j++) {
       const bool time = b[i].from <= b[j].until && b[j].from <= b[i].until;
@@ -593,7 +587,7 @@ int tiles_for(int extent, int target) { return (extent + target - 1) / target; }
 
 // Recognise  head | k2 | middle | k3 | tail  in the fused step list and lower it: four segment descriptors + the per-frame
 // program for the middle.  Returns false (plan untouched apart from scratch) when the graph does not have this shape.
-static bool seg_fail(int where) { if (getenv("BSX_SEG_DEBUG")) fprintf(stderr, "segmentation: check %d failed\n", where); return false; }
+static bool seg_fail(int where) { if (BSX_DBG_ENV("BSX_SEG_DEBUG")) fprintf(stderr, "segmentation: check %d failed\n", where); return false; }
 static bool build_segments(Graph& g, Plan* plan) {
   const std::vector<Step>& S = plan->steps;
   const int NS = (int)S.size();
@@ -672,7 +666,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   // k2 TC <= 15; k3 / tail TC <= 14 (TC + 2 <= 16: one MFMA tile per halo-region row)
   int tgt[8] = {4, 14, 4, 7, 16, 14, 18, 14};       // (tail rows 16 -> 18, round 4: segm_full's 72 rows split into 4 x 18 instead of 5 x 15 — no padded rows, one halo pair fewer:
                                                    //  tail 466 -> 414 us at 1024 HD streams, profiles/r04q; 48 and 128 rows still split into 16s)
-  if (const char* e = getenv("BSX_SEG_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &tgt[0], &tgt[1], &tgt[2], &tgt[3], &tgt[4], &tgt[5], &tgt[6], &tgt[7]);
+  if (const char* e = BSX_DBG_ENV("BSX_SEG_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &tgt[0], &tgt[1], &tgt[2], &tgt[3], &tgt[4], &tgt[5], &tgt[6], &tgt[7]);
   auto split = [&](int extent, int target, int* tile, int* n) { *n = tiles_for(extent, std::max(1, target)); *tile = (extent + *n - 1) / *n; };
 
   SegHead& h = sp.head;
@@ -695,7 +689,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   k3.pw1 = conv_w(kp1); k3.pw2 = conv_w(kp2); k3.dw = dw_w(kd);
   split(k3.H2, tgt[4], &k3.TR, &k3.tiles_y); split(k3.W2, tgt[5], &k3.TC, &k3.tiles_x);
   k3.hs = seg_up_scale(k3.HL, k3.H2, k3.align_corners != 0); k3.ws = seg_up_scale(k3.WL, k3.W2, k3.align_corners != 0);
-  if (!getenv("BSX_SEG_LO_WORST")) k3.lo_floats = seg_lo_window_floats(k3.H2, k3.W2, k3.HL, k3.WL, k3.half_pixel != 0, k3.align_corners != 0, k3.TR, k3.TC, k3.tiles_y, k3.tiles_x);
+  if (!BSX_DBG_ENV("BSX_SEG_LO_WORST")) k3.lo_floats = seg_lo_window_floats(k3.H2, k3.W2, k3.HL, k3.WL, k3.half_pixel != 0, k3.align_corners != 0, k3.TR, k3.TC, k3.tiles_y, k3.tiles_x);
   k3.lds_floats = seg_k3_lds_floats(k3);
   if (k3.TC > 14 || k3.TR > 18) return seg_fail(32);
   SegTail& tl = sp.tail;
@@ -703,7 +697,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   tl.pw = conv_w(tpw); tl.dw = dw_w(tdw); tl.tc_w_off = (long long)ttc.w_off; tl.tc_b_off = (long long)ttc.b_off; tl.Co = ttc.Cout; tl.act3 = ttc.act;
   split(tl.H1, tgt[6], &tl.TR, &tl.tiles_y); split(tl.W1, tgt[7], &tl.TC, &tl.tiles_x);
   tl.hs = seg_up_scale(tl.HL, tl.H1, tl.align_corners != 0); tl.ws = seg_up_scale(tl.WL, tl.W1, tl.align_corners != 0);
-  if (!getenv("BSX_SEG_LO_WORST")) tl.lo_floats = seg_lo_window_floats(tl.H1, tl.W1, tl.HL, tl.WL, tl.half_pixel != 0, tl.align_corners != 0, tl.TR, tl.TC, tl.tiles_y, tl.tiles_x);
+  if (!BSX_DBG_ENV("BSX_SEG_LO_WORST")) tl.lo_floats = seg_lo_window_floats(tl.H1, tl.W1, tl.HL, tl.WL, tl.half_pixel != 0, tl.align_corners != 0, tl.TR, tl.TC, tl.tiles_y, tl.tiles_x);
   tl.lds_floats = seg_tail_lds_floats(tl);
   if (tl.TC > 14 || tl.TR > 18) return seg_fail(33);
   const int lds_cap = 160 * 256;
@@ -716,7 +710,7 @@ static bool build_segments(Graph& g, Plan* plan) {
   // The tail's gate (two pooled means → FC → FC: identical for every tile of a frame) is computed once per frame by a one-workgroup-per-frame launch between k3
   // and the tail instead of by each of the tail's workgroups: the prologue — partial sums of two tensors, two weight blocks, three barriers — measured a quarter of
   // the tail kernel (lite 67.7 -> 50.8 us, MLKit/HD 260 -> 192 us with the prologue skipped).  BSX_SEG_NO_GATE_KERNEL=1 keeps it inside the tail.
-  const int pgt = getenv("BSX_SEG_NO_GATE_KERNEL") ? -1 : synth("gate(tail)", 1, 16);
+  const int pgt = BSX_DBG_ENV("BSX_SEG_NO_GATE_KERNEL") ? -1 : synth("gate(tail)", 1, 16);
   if (pgt >= 0) plan->tensor_off[pgt] = reserve(16);
   for (int t : {A, b0, B, c0, lo2, lo, kf2.out, pA, pb0, pB, plo}) plan->tensor_off[t] = reserve(g.tensors[t].elems());
   // tensors that exist only inside a segment kernel are never materialised
@@ -736,8 +730,8 @@ static bool build_segments(Graph& g, Plan* plan) {
   tl.gate.part[0].off = plan->tensor_off[pA]; tl.gate.part[0].n = h.tiles_y * h.tiles_x; tl.gate.part[0].C = 16; tl.gate.part[0].hw = (float)(h.H1 * h.W1);
   tl.gate.part[1].off = plan->tensor_off[plo]; tl.gate.part[1].n = k3.tiles_y * k3.tiles_x; tl.gate.part[1].C = 16; tl.gate.part[1].hw = (float)(k3.H2 * k3.W2);
   tl.gate.fc[0] = fc_w(tf1); tl.gate.fc[1] = fc_w(tf2);
-  if (getenv("BSX_SEG_GATE_SKIP")) k2.gate.timing_skip = tl.gate.timing_skip = 1;
-  if (const char* e = getenv("BSX_SEG_SKIP")) sscanf(e, "%d,%d,%d,%d", &h.dbg_skip, &k2.dbg_skip, &k3.dbg_skip, &tl.dbg_skip);      // "head,k2,k3,tail" phase masks
+  if (BSX_DBG_ENV("BSX_SEG_GATE_SKIP")) k2.gate.timing_skip = tl.gate.timing_skip = 1;
+  if (const char* e = BSX_DBG_ENV("BSX_SEG_SKIP")) sscanf(e, "%d,%d,%d,%d", &h.dbg_skip, &k2.dbg_skip, &k3.dbg_skip, &tl.dbg_skip);      // "head,k2,k3,tail" phase masks
   tl.pre_gate_off = pgt >= 0 ? plan->tensor_off[pgt] : -1;
   if (tl.gate.fc[0].Cin != (tl.gate.sum_parts ? 16 : 32) || k2.gate.fc[0].Cin != 16) return seg_fail(27);
 
@@ -771,8 +765,19 @@ static bool build_segments(Graph& g, Plan* plan) {
 }
 
 
+MidGeometry mid_geometry_default() {
+  static const MidGeometry geo = [] {
+    MidGeometry m{kFrameThreads, kLdsTotalFloats};
+    if (const char* e = BSX_DBG_ENV("BSX_MID_LANES")) { const int v = atoi(e); if (v == 512 || v == 1024) m.lanes = v; }
+    if (const char* e = BSX_DBG_ENV("BSX_MID_LDS_KB")) { const int v = atoi(e); if (v >= 64 && v <= 160) m.lds_floats = v * 256; }
+    return m;
+  }();
+  return geo;
+}
+
 bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_arena, bool segments) {
   auto fail = [&](const std::string& m) { if (err) *err = m; return false; };
+  { const MidGeometry geo = mid_geometry_default(); plan->mid_lanes = geo.lanes; plan->lds_total_floats = geo.lds_floats; }
   Graph g = g_in;                       // local copy: the rewrite passes below may append synthetic tensors
   int NT = (int)g.tensors.size();
   const int NN = (int)g.nodes.size();
@@ -977,7 +982,7 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
             for (size_t k = 0; k < steps.size(); k++) {
               const Step& e = steps[k];
               if (e.kind == StepKind::Eltwise && e.out == st.in0 && e.elt == kEltAdd && !e.bcast1 && e.act == kActNone && e.in1 >= 0 &&
-                  !getenv("BSX_NO_GAP_SUM")) {
+                  !BSX_DBG_ENV("BSX_NO_GAP_SUM")) {
                 st.concat_in = {e.in0, e.in1}; st.concat_c = {st.Cin, st.Cin}; st.gap_sum = true; st.in0 = e.in0;
                 steps.erase(steps.begin() + k);
                 st.label = "gapsum#" + std::to_string(n.index);
@@ -1057,7 +1062,7 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   // ---- linear-algebra rewrites on the step list ------------------------------------------------------------------
   // operand slots reading tensor t (steps that list their parts in concat_in repeat the first part in in0: counted once)
   auto uses_of = [&](int t) { int n = 0; for (const Step& q : steps) { for (int u : {q.concat_in.empty() ? q.in0 : -1, q.in1, q.in2, q.residual, q.in_scale, q.out_bias}) n += (u == t); for (int u : q.concat_in) n += (u == t); } return n + (t == g.output); };
-  const bool no_rewrites = getenv("BSX_NO_REWRITES") != nullptr;
+  const bool no_rewrites = BSX_DBG_ENV("BSX_NO_REWRITES") != nullptr;
   // (a) pw(resize(x)) → resize(pw(x)): a 1x1 convolution without activation commutes with bilinear interpolation (both
   //     are linear and the interpolation weights sum to 1, so the bias passes through); done at the LOW resolution the
   //     convolution costs 1/4 of the MACs and the up-sampled many-channel tensor is never materialised.  The result differs
@@ -1244,7 +1249,7 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   plan->steps = std::move(steps);
   plan->seg = SegPlan();
   bool seg_ok = false;
-  if (segments && !getenv("BSX_NO_SEGMENTS")) {
+  if (segments && !BSX_DBG_ENV("BSX_NO_SEGMENTS")) {
     // build_segments re-points tensor offsets, grows the arena and appends synthetic tensors BEFORE its last checks (an unsupported middle):
     // a failed attempt must leave the plan exactly as the unsegmented paths expect it
     const std::vector<long> off0 = plan->tensor_off;
@@ -1258,11 +1263,11 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   }
   // ---- per-launch path (graphs without a frame program: DeepLab): expand 1x1 → depthwise 3x3 pairs of the inverted-residual blocks run as
   // ONE kernel (kernels_nn.hip: ir_expand_dw_k) — the 6x-expanded tensor, the largest write and read of the block, lives only in LDS.
-  if (plan->program.empty() && !getenv("BSX_NO_IR_FUSE")) {
+  if (plan->program.empty() && !BSX_DBG_ENV("BSX_NO_IR_FUSE")) {
     std::vector<Step>& S = plan->steps;
     auto uses = [&](int t) { int n = 0; for (const Step& q : S) { for (int u : {q.concat_in.empty() ? q.in0 : -1, q.in1, q.in2, q.residual, q.in_scale, q.out_bias}) n += (u == t); for (int u : q.concat_in) n += (u == t); } return n + (t == g.output); };
     // stem conv 3x3/s2 (3 → 16) → depthwise 3x3 → 1x1 (16 → ≤16): one tiled kernel, the two 16-channel full-resolution tensors only in LDS
-    if (S.size() > 3 && !getenv("BSX_NO_HEAD0")) {
+    if (S.size() > 3 && !BSX_DBG_ENV("BSX_NO_HEAD0")) {
       Step& c0 = S[0]; Step& d1 = S[1]; Step& p2 = S[2];
       const bool ok = c0.kind == StepKind::Conv && c0.kh == 3 && c0.kw == 3 && c0.sh == 2 && c0.sw == 2 && c0.dh == 1 && c0.dw == 1 && c0.Cin == 3 && c0.Cout == 16 &&
                       c0.cout_pad == 16 && c0.residual < 0 && c0.act < kActHswish && c0.in0 == g.input && uses(c0.out) == 1 &&
@@ -1292,19 +1297,6 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
         if (pj.kind == StepKind::PwConv && pj.in0 == d.out && uses(d.out) == 1 && pj.k16_pad > 0 && pj.in_scale < 0 && pj.in2 < 0 && (pj.Cin & 3) == 0 &&
             pj.cout_pad % 16 == 0 && pj.OH == d.OH && pj.OW == d.OW)
           pj.in_from_fused_dw = true;
-        // the WHOLE block in one kernel where its input is small (ir_block_k): one K slab of <= 16 input channels, <= 16 output channels.
-        // OPT-IN (BSX_IR_BLOCK=1): parity-green but measured SLOWER than expand+depthwise kernel + project GEMM on every layer it applies to (1024 streams:
-        // conv#6 block 0.897 vs 0.496 + 0.371 ms, conv#3 block 1.507 vs 0.829 + 0.195, conv#10 0.642 vs 0.311 + 0.086, conv#13 0.347 vs 0.137 + 0.141 —
-        // profiles/r03l): the chunk loop serialises three phases behind two barriers per chunk in a workgroup that has to share its 80 KB between the
-        // expanded band and the depthwise band (smaller bands = more halo rows), where the two-kernel form runs three times as many independent workgroups.
-        const int block_minw = getenv("BSX_IR_BLOCK_MINW") ? atoi(getenv("BSX_IR_BLOCK_MINW")) : 0;      // A/B timing: only layers at least this wide
-        const bool block_on = getenv("BSX_IR_BLOCK") != nullptr && atoi(getenv("BSX_IR_BLOCK")) != 0;       // (plan time: read per plan, like the planner's other switches)
-        if (pj.in_from_fused_dw && block_on && a.OW >= block_minw && a.k16_pad == 32 && a.Cin <= 16 && pj.cout_pad == 16 && pj.Cout % 4 == 0 && pj.out_bias < 0 &&
-            pj.act < kActHswish && pj.out != g.output && a.OW == d.W && (long)a.OH * a.OW * d.dh < 65536 &&
-            ir_block_geometry(a.OH, a.OW, a.Cout, d.OH, d.OW, d.sh, d.dh).CH != 0) {
-          a.fuse_proj = (int)i + 2;
-          pj.fused_into_block = true;
-        }
       }
     }
   }

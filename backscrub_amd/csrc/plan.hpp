@@ -8,6 +8,7 @@
 // activation tensors live in one arena with liveness-based reuse so a batch of streams
 // stays resident in the Infinity Cache between layers.
 #pragma once
+#include "debug_switches.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstddef>
@@ -51,8 +52,6 @@ struct Step {
   int last_node = -1;                 // file operator index of the last fused op
   int fuse_dw = -1;                   // per-launch path, PwConv: index of the depthwise step this expand convolution is fused with (ir_expand_dw_k)
   bool in_from_fused_dw = false;      // per-launch path, PwConv: in0 is the output of a fused expand+depthwise pair and has no other reader (may be stored as f16)
-  int fuse_proj = -1;                 // per-launch path, PwConv with fuse_dw: index of the project 1x1 that ALSO runs in the same kernel (ir_block_k: the whole inverted-residual block)
-  bool fused_into_block = false;      // per-launch path, PwConv: this project convolution runs inside the block kernel of the expand step two steps before
   bool fused_away = false;            // per-launch path: the step runs inside an earlier one
   bool fuse_head0 = false;            // per-launch path, stem Conv: runs together with the depthwise and the 1x1 after it (dl_head0_k)
 };
@@ -65,7 +64,7 @@ struct IrGeom { int CH = 0, BH = 0, nbands = 0, rows = 0; };
 inline long ir_stage_floats(int CH) { return CH == 32 ? 8 * 512 : 0; }
 inline long ir_lds_bytes(int rows, int W, int CH) { return ((long)rows * W * CH + 10 * CH + 4 + ir_stage_floats(CH)) * 4; }
 inline IrGeom ir_geometry(int H, int W, int Cexp, int OH, int S, int d) {
-  if (const char* e = getenv("BSX_IR_GEOM")) {                     // timing experiments: "W:CH,BH" overrides the choice for layers W pixels wide
+  if (const char* e = BSX_DBG_ENV("BSX_IR_GEOM")) {                     // timing experiments: "W:CH,BH" overrides the choice for layers W pixels wide
     int w = 0, ch = 0, bh = 0;
     if (sscanf(e, "%d:%d,%d", &w, &ch, &bh) == 3 && w == W && ch > 0 && Cexp % ch == 0 && bh > 0) {
       IrGeom g; g.CH = ch; g.BH = bh < OH ? bh : OH; g.nbands = (OH + g.BH - 1) / g.BH;
@@ -97,34 +96,13 @@ inline IrGeom ir_geometry(int H, int W, int Cexp, int OH, int S, int d) {
   return best;
 }
 
-// Geometry of the whole-block kernel (kernels_nn.hip: ir_block_k): expanded band chunk + depthwise weights + the depthwise chunk of the band ([px][CH + 4]) in
-// at most 80 KB (two workgroups per CU), at most 384 output pixels per band (3 project tiles per wave).  CH = 0: the block does not fit.
-inline long ir_block_lds_bytes(int rows, int W, int CH, int BH, int OW) { return ((long)rows * W * CH + 10 * CH + 4 + (long)BH * OW * (CH + 4)) * 4; }
-inline IrGeom ir_block_geometry(int H, int W, int Cexp, int OH, int OW, int S, int d) {
-  auto rows_for = [&](int bh) { const int r = S * (bh - 1) + 2 * d + 1; return r < H ? r : H; };
-  IrGeom best;
-  double best_score = 0;
-  for (int CH : {24, 16}) {
-    if (Cexp % CH) continue;
-    int BH = OH;
-    auto fits = [&](int bh) { return ir_block_lds_bytes(rows_for(bh), W, CH, bh, OW) <= 80 * 1024 && (long)bh * OW <= 384; };
-    while (BH > 1 && !fits(BH)) BH--;
-    if (BH < 2 || !fits(BH)) continue;
-    const int nb = (OH + BH - 1) / BH;
-    BH = (OH + nb - 1) / nb;
-    const double score = (double)(S * BH) / rows_for(BH) * CH / ((CH + 15) / 16 * 16);
-    if (score > best_score) { best_score = score; best.CH = CH; best.BH = BH; best.nbands = nb; best.rows = rows_for(BH); }
-  }
-  return best;
-}
-
 // rows of the stem's output one workgroup of dl_head0_k owns (its LDS holds the input rows, the stem band and the depthwise band)
 inline long head0_lds_floats(int W0, int W1, int bh) {            // the depthwise band aliases the input rows (dead after the stem)
   const long in_t = (((2l * (bh + 2) + 1) * (W0 + 2) * 3 + 3) & ~3l), dband = (long)bh * W1 * 16;
   return (in_t > dband ? in_t : dband) + (long)(bh + 2) * W1 * 16 + 1024;
 }
 inline int head0_band_rows(int W0, int W1) {
-  if (const char* e = getenv("BSX_H0_BH")) { const int bh = atoi(e); if (bh >= 1 && bh <= 8 && head0_lds_floats(W0, W1, bh) * 4 <= 156 * 1024) return bh; }   // timing experiments
+  if (const char* e = BSX_DBG_ENV("BSX_H0_BH")) { const int bh = atoi(e); if (bh >= 1 && bh <= 8 && head0_lds_floats(W0, W1, bh) * 4 <= 156 * 1024) return bh; }   // timing experiments
   for (int bh = 8; bh >= 2; bh--)                                // two workgroups per CU (their phases overlap) if a band of >= 2 rows allows it
     if (head0_lds_floats(W0, W1, bh) * 4 <= 80 * 1024) return bh;
   for (int bh = 8; bh >= 2; bh--)
@@ -143,6 +121,11 @@ struct Plan {
   // whole-network per-frame program (empty when some step has no micro-op form)
   std::vector<MicroOp> program;
   std::vector<std::string> program_labels;
+  // geometry of the workgroup that runs the program for one frame (round 6): lanes per workgroup and the LDS block it may plan into.  1024 lanes + the whole 160 KiB
+  // = one frame per CU (rounds 1-5); 512 lanes + 80 KiB = two frames per CU at the same 16 waves.  Chosen per plan by mid_geometry_for() below.
+  int mid_lanes = kFrameThreads;
+  int lds_total_floats = kLdsTotalFloats;
+  int lds_zero_off() const { return lds_total_floats - kLdsZeroFloats; }      // the zero cell is the last 16 bytes of the block the program may use
   int program_lds_floats = 0;         // dynamic LDS the program needs (scratch included)
   int program_scratch_floats = 0;     // reduction scratch at the bottom of the LDS block: kLdsScratchFloats, or 64 when no micro-op of the lowering uses it
   int program_lds_tensors = 0, program_global_tensors = 0;
@@ -159,6 +142,12 @@ struct Plan {
   std::string seg_text;                 // one line per segment kernel (tiles, LDS) for bsx_plan_describe
   std::string describe() const;
 };
+
+// Lanes / LDS budget of the per-frame workgroup a plan is built for: 1024 lanes and the whole 160 KiB block.  The debug build reads BSX_MID_LANES = 512 | 1024 and
+// BSX_MID_LDS_KB = 64..160 (once per process): round 6's same-box A/B of 512 lanes / 80 KiB — two frames per CU — lost on every configuration
+// (profiles/r06b_mid_geometry.txt, docs/design/10-round6.md), so the geometry stays a parameter of the plan and the generator, not a user mode.
+struct MidGeometry { int lanes, lds_floats; };
+MidGeometry mid_geometry_default();
 
 // Build the plan.  Returns false with `err` for unsupported graph features.
 // `reuse_arena=false` gives every tensor its own slot (layer-by-layer debugging).

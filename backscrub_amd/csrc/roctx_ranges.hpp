@@ -6,6 +6,7 @@
 // profiler, a box without either library runs unmarked, and BSX_NO_ROCTX=1 skips the lookup.  Without a tool attached a push / pop pair is two indirect calls
 // into a library that finds no registered client — tens of nanoseconds against launches of tens of microseconds.
 #pragma once
+#include "debug_switches.hpp"
 #include <dlfcn.h>
 
 #include <cstdlib>
@@ -17,7 +18,7 @@ struct Api {
   push_fn push = nullptr;
   pop_fn pop = nullptr;
   Api() {
-    if (getenv("BSX_NO_ROCTX")) return;
+    if (BSX_DBG_ENV("BSX_NO_ROCTX")) return;
     for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
       void* h = dlopen(name, RTLD_LAZY | RTLD_LOCAL);
       if (!h) continue;

@@ -46,7 +46,7 @@ RING = 4                   # time steps per stream of the moving scene
 METRIC = "composited frames/sec at 640×480 (batch), 1/2/4/8 MI355X + mask IoU vs CPU ref"
 NAMES = {"lite": "segm_lite_v681.tflite", "full": "segm_full_v679.tflite",
          "mlkit": "selfiesegmentation_mlkit-256x256-2021_01_19-v1215.f16.tflite", "deeplab": "deeplabv3_257_mv_gpu.tflite"}
-PMC_NAMES = {"frame_program": ("bsx_mid", "frame_program_k"), "blend": "blend16_k", "blend(standalone)": "blend16_k", "mask_blend": "mask_tile_k<true>",
+PMC_NAMES = {"frame_program": ("bsx_mid", "frame_program_k"), "blend": "blend4x4_k", "blend(standalone)": "blend4x4_k", "mask_blend": "mask_tile_k<true>",
              "mask_upscale_blur": "mask_tile_k<false>", "prep": "prep_fused_k", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k",
              "seg_head": "seg_head_k", "seg_k2": "seg_k2_k", "seg_k3": "seg_k3_k", "seg_tail": "seg_tail_k", "seg_tail+decode": "seg_tail_k", "seg_gate": "seg_gate_k"}
 IMAGE_LAUNCHES = {"prep_resize": "prep", "prep_bilateral": "prep", "prep": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend", "mask_blend": "blend"}
@@ -827,7 +827,8 @@ def compact_line(d):
         modes.append(e)
     if modes:
         out["opt_in_modes"] = modes
-    for k, keys in (("host_io", ("value", "ms_per_step", "steps")), ("yuyv_out", ("value", "bit_identical_to_step_then_bgr_to_yuyv")), ("bgblur_step", ("value", "speedup"))):
+    for k, keys in (("host_io", ("value", "ms_per_step", "steps")), ("host_io_yuyv", ("value", "ms_per_step", "steps")), ("yuyv_out", ("value", "bit_identical_to_step_then_bgr_to_yuyv")),
+                    ("yuyv_in_out", ("value", "ms_per_step", "bit_identical_to_yuyv_to_bgr_then_step_yuyv")), ("bgblur_step", ("value", "speedup"))):
         if isinstance(d.get(k), dict):
             out[k] = _pick(d[k], keys)
     if isinstance(d.get("single_stream"), dict) and d["single_stream"].get("runs"):
@@ -867,7 +868,7 @@ def emit(detail, path=""):
             pass
     line = compact_line(detail)
     s = json.dumps(line, separators=(",", ":"))
-    for k in ("single_stream_p50_ms", "bgblur_step", "yuyv_out", "top_launches", "opt_in_modes", "roofline_blend", "stage_ms", "host_io", "roofline_network"):
+    for k in ("single_stream_p50_ms", "bgblur_step", "yuyv_out", "top_launches", "opt_in_modes", "roofline_blend", "stage_ms", "yuyv_in_out", "host_io_yuyv", "host_io", "roofline_network"):
         if len(s.encode()) <= LINE_LIMIT:
             break
         line.pop(k, None)
@@ -1148,6 +1149,72 @@ def main():
                               "bit_identical_to_step_then_bgr_to_yuyv": same,
                               "note": "bsx_step_batch_yuyv: composite written as YUYV (2 B/px instead of 3), no separate packing pass"}
         del d_yuyv, a
+
+    # YUYV in -> YUYV out as ONE step (BSX_STEP_YUYV_IN | BSX_STEP_YUYV, SURVEY §8 f3 + f1): the camera's raw 4:2:2 frames in, the loop-back device's wire format out —
+    # 7 B/px of device traffic instead of 9, 4 B/px over PCIe instead of 6.  Device-resident leg + the PCIe-inclusive leg next to `host_io`; both beside `value`.
+    if world == 1 and W % 4 == 0 and not args.no_extra_configs and side:
+        def to_camera_yuyv(bgr):                                           # BT.601 limited range, Y0 U Y1 V: what a YUYV webcam would deliver for this scene
+            f = bgr.to(torch.float32)
+            b_, g_, r_ = f[..., 0], f[..., 1], f[..., 2]
+            y = 16 + 0.257 * r_ + 0.504 * g_ + 0.098 * b_
+            u = 128 - 0.148 * r_ - 0.291 * g_ + 0.439 * b_
+            v = 128 + 0.439 * r_ - 0.368 * g_ - 0.071 * b_
+            o = torch.empty(bgr.shape[:-1] + (2,), dtype=torch.uint8, device=bgr.device)
+            o[..., 0] = y.round().clamp(0, 255).to(torch.uint8)
+            o[:, :, 0::2, 1] = ((u[:, :, 0::2] + u[:, :, 1::2]) / 2).round().clamp(0, 255).to(torch.uint8)
+            o[:, :, 1::2, 1] = ((v[:, :, 0::2] + v[:, :, 1::2]) / 2).round().clamp(0, 255).to(torch.uint8)
+            return o
+        raw_ring = [to_camera_yuyv(fr) for fr in ring]
+        d_y = torch.empty((B, H, W, 2), dtype=torch.uint8, device="cuda")
+        mg.reset(); bgr0 = mg.yuyv_to_bgr(raw_ring[0]); mg.step_yuyv(bgr0, d_bg, d_y); a = d_y.clone()       # convert + BGR step with YUYV out, from a fresh temporal state
+        mg.reset(); mg.step_ex(raw_ring[0], d_bg, d_y, yuyv=True, yuyv_in=True)
+        same = bool(torch.equal(a, d_y))
+        del a, bgr0
+        n_y = max(20, min(args.steps, 100))
+        for t in range(5):
+            mg.step_ex(raw_ring[t % len(ring)], d_bg, d_y, yuyv=True, yuyv_in=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(n_y):
+            mg.step_ex(raw_ring[t % len(ring)], d_bg, d_y, yuyv=True, yuyv_in=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        result["yuyv_in_out"] = {"value": round(B * n_y / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_y, 4), "steps": n_y,
+                                 "bit_identical_to_yuyv_to_bgr_then_step_yuyv": same,
+                                 "note": "bsx_step_batch_ex(BSX_STEP_YUYV_IN | BSX_STEP_YUYV): raw camera frames in (2 B/px), composite out as YUYV (2 B/px); no BGR frame in between"}
+        if not args.no_host_io:
+            h_in = raw_ring[0].cpu().pin_memory()
+            h_out = torch.empty_like(h_in).pin_memory()
+            s_in, s_out, s_cmp = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
+            bufs = [(torch.empty_like(raw_ring[0]), torch.empty_like(d_y)) for _ in range(2)]
+            ev_in, ev_cmp, ev_out = ([torch.cuda.Event() for _ in range(2)] for _ in range(3))
+
+            def run_y(steps):
+                for t in range(steps):
+                    fr, out = bufs[t & 1]
+                    with torch.cuda.stream(s_in):
+                        s_in.wait_event(ev_cmp[t & 1])
+                        fr.copy_(h_in, non_blocking=True)
+                        ev_in[t & 1].record(s_in)
+                    s_cmp.wait_event(ev_in[t & 1])
+                    s_cmp.wait_event(ev_out[t & 1])
+                    mg.step_ex(fr, d_bg, out, yuyv=True, yuyv_in=True)
+                    ev_cmp[t & 1].record(s_cmp)
+                    with torch.cuda.stream(s_out):
+                        s_out.wait_event(ev_cmp[t & 1])
+                        h_out.copy_(out, non_blocking=True)
+                        ev_out[t & 1].record(s_out)
+                torch.cuda.synchronize()
+            run_y(2)
+            io_steps = max(20, min(args.steps, 100))
+            t1 = time.perf_counter()
+            run_y(io_steps)
+            dt = time.perf_counter() - t1
+            result["host_io_yuyv"] = {"value": round(B * io_steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / io_steps, 3), "steps": io_steps,
+                                      "note": "the YUYV in -> YUYV out step + H2D of %d raw frames and D2H of %d YUYV composites per step (2 B/px each way, pinned, "
+                                              "copy streams overlapped with compute); %.1f GB/s each way" % (B, B, B * W * H * 2 / (dt / io_steps) / 1e9)}
+            del bufs, h_in, h_out
+        del raw_ring, d_y
 
     # `-p bgblur:25` without `-b` (deepseg.cc:652-661): background = GaussianBlur of the stream's own frame.  One pass (BSX_STEP_BGBLUR: blur tile → blend out of LDS)
     # against the two-call form (bsx_gaussian_blur_bgr into a per-stream background, then bsx_step_batch)

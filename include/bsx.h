@@ -17,7 +17,7 @@
  *   bsx_composite_batch    alpha_blend()                  app/deepseg.cc:108-134 (file-static)
  *   bsx_step_batch         one main-loop iteration        app/deepseg.cc:634-661
  *   bsx_step_batch_yuyv    … with convert_rgb_to_yuyv fused app/deepseg.cc:634-681
- *   bsx_step_batch_ex      … with cv::flip (and YUYV) fused  app/deepseg.cc:667-681
+ *   bsx_step_batch_ex      … with cv::flip (and YUYV) fused  app/deepseg.cc:667-681; BSX_STEP_YUYV_IN: … and VideoCapture's YUYV->BGR  app/deepseg.cc:553,725
  *   bsx_step_batch_pipelined  … with the CalcMask worker's overlap of segmentation and blending  app/deepseg.cc:159-285, 634-661
  *                          (set_input_frame → mask → alpha_blend), batched
  *   bsx_resize_bgr         grab_background() cv::resize   app/background.cc:178-194
@@ -160,6 +160,14 @@ BSX_API int bsx_step_batch_yuyv(bsx_ctx* ctx, const uint8_t* d_frames, const uin
  * Nothing later depends on it: every frame's mask is rebuilt from the model-resolution temporal state, which advances as usual; bsx_masks_device() then keeps
  * the last mask a call WITHOUT this flag stored.  For main loops that only need the composite (app/deepseg.cc:661 uses the mask for nothing else unless -d -d). */
 #define BSX_STEP_NO_MASK 8u
+/* BSX_STEP_YUYV_IN: d_frames holds the camera's RAW YUYV 4:2:2 frames, [n][height][width][2] bytes Y0 U Y1 V — what a V4L2 webcam delivers and what the reference's
+ * capture converts with cv::COLOR_YUV2BGR_YUYV (CAP_PROP_CONVERT_RGB, app/deepseg.cc:553; explicit form :725) — instead of packed BGR.  The conversion (the integers
+ * of bsx_yuyv_to_bgr) is folded into the two kernels that read the frame: the prep kernel converts the two taps of every resize sample, the mask tile kernel the four
+ * pixels it composites, so the 3 B/px BGR frame is never written or read.  With BSX_STEP_YUYV the step is YUYV in -> YUYV out: 7 B/px of device traffic instead of 9
+ * (frame 2 + background 3 in, composite 2 out) and 4 B/px over PCIe instead of 6.  Results are bit-identical to bsx_yuyv_to_bgr followed by the same step on the BGR
+ * frames; that two-pass sequence is what runs, through a context-owned scratch, where the fused kernels do not apply (BSX_STEP_BGBLUR, a ROI that starts on an odd
+ * column, width % 4 != 0, overlapping or unaligned buffers, an onmask callback).  width must be even.  Also accepted by bsx_step_batch_pipelined. */
+#define BSX_STEP_YUYV_IN 16u
 /* BSX_STEP_BGBLUR(ksize): the background of every stream is cv::GaussianBlur(its own camera frame, Size(ksize, ksize), 0) — `-p bgblur:<ksize>` without `-b`,
  * the reference's default way to run (app/deepseg.cc:652-661).  d_bg is ignored (may be NULL).  The blur and the alpha blend are ONE pass over the frames: each
  * tile of the blurred frame is composited while it is still in LDS, so the blurred image is never written or read back and the frame is read once, not twice.
@@ -179,7 +187,7 @@ BSX_API int bsx_step_batch_ex(bsx_ctx* ctx, const uint8_t* d_frames, const uint8
  *   - d_frames == NULL flushes: the pending composite runs on `stream` (all other arguments ignored); bsx_reset drops it;
  *   - `stream` may differ from call to call (double-buffered callers): every call records the end of its mask pipeline on its own stream, and the composite of
  *     that batch, the next call's network (it reuses the arena) and the flush wait for THAT event — the caller orders nothing across its streams;
- *   - flags: BSX_STEP_YUYV | BSX_STEP_FLIP_H | BSX_STEP_FLIP_V | BSX_STEP_NO_MASK (no BSX_STEP_BGBLUR); the geometry must be the fused tile kernel's
+ *   - flags: BSX_STEP_YUYV | BSX_STEP_FLIP_H | BSX_STEP_FLIP_V | BSX_STEP_NO_MASK | BSX_STEP_YUYV_IN (no BSX_STEP_BGBLUR); the geometry must be the fused tile kernel's
  *     (width, roi.x, roi.w multiples of 4, 4-byte aligned buffers) and no stage callback may be set — otherwise BSX_EINVAL, as does every other entry point
  *     that advances the temporal state while a composite is pending (bsx_process_batch / _host, bsx_step_batch*, bsx_profile_batch, bsx_debug_run_stage 1-3). */
 BSX_API int bsx_step_batch_pipelined(bsx_ctx* ctx, const uint8_t* d_frames, const uint8_t* d_bg, size_t bg_frame_stride,
@@ -237,7 +245,8 @@ BSX_API int bsx_live_timings(const bsx_live* live, long* waitns, long* loopns);
 /* Device pointer + element count of: 0 = model input tensor [n_streams][in_h][in_w][in_c] f32,
  * 1 = model output tensor f32, 2 = ofinal u8 [n_streams][out_h][out_w], 3 = masks u8. */
 BSX_API int bsx_debug_buffer(bsx_ctx* ctx, int which, void** d_ptr, size_t* bytes);
-/* Run single stages on the current buffers (n streams): 0 = prep, 1 = infer, 2 = decode+IIR, 3 = upscale+blur. */
+/* Run single stages on the current buffers (n streams): 0 = prep, 1 = infer, 2 = decode+IIR, 3 = upscale+blur, 4 = prep on raw YUYV 4:2:2 frames
+ * (BSX_STEP_YUYV_IN's form of stage 0; BSX_EINVAL where the fused form does not apply). */
 BSX_API int bsx_debug_run_stage(bsx_ctx* ctx, int stage, const uint8_t* d_frames, int n, void* stream);
 /* Per-launch description of the fused plan, one line per GPU launch; returned string is owned by ctx. */
 BSX_API const char* bsx_plan_describe(bsx_ctx* ctx);

@@ -45,3 +45,19 @@ def oracle():
     from oracle import oracle_py
     oracle_py.build()
     return oracle_py
+
+
+@pytest.fixture
+def debug_switches(monkeypatch):
+    """The A/B knobs, alternate code paths and work-skipping experiments (csrc/debug_switches.hpp) are compiled out of libbsx.so; tests that cross-check an
+    alternate path against the default one run against libbsx_dbg.so (same sources, -DBSX_DEBUG_SWITCHES; built by backscrub_amd/build.py).  For the duration of the
+    test the Python binding is re-pointed at it; contexts must be closed inside the test."""
+    from backscrub_amd import api, build
+    if not os.path.exists(build.LIB_DBG):
+        pytest.fail("libbsx_dbg.so is missing: run `python -m backscrub_amd.build`")
+    saved = api._LIB
+    api._LIB = None
+    monkeypatch.setenv("BSX_LIBRARY", build.LIB_DBG)
+    api.lib()
+    yield api
+    api._LIB = saved

@@ -82,3 +82,31 @@ def test_library_exports_only_the_c_abi(built):
     hdr = open(os.path.join(ROOT, "include", "bsx.h")).read()
     declared = set(re.findall(r"^BSX_API [^;(]*?\b(bsx_\w+)\(", hdr, re.M))
     assert declared == set(names), (sorted(declared - set(names)), sorted(set(names) - declared))
+
+
+def test_release_library_carries_no_debug_switches(built):
+    """~60 BSX_* environment switches — A/B knobs, retired code paths, experiments that make kernels SKIP WORK — used to be readable by the
+    release library.  Now: csrc/debug_switches.hpp compiles every one of them out of libbsx.so (only the documented user modes are left: <= 12 lines of `strings`
+    mention BSX_ at all, none of them a work-skipping or planner knob), the debug build libbsx_dbg.so — test infrastructure — still has them, and no source file
+    reads a BSX_ variable with a bare getenv() unless it is a documented user mode."""
+    import glob
+    import subprocess
+    from backscrub_amd import build
+    user_modes = {"BSX_DEVICE", "BSX_F16_GEMM", "BSX_ACT16", "BSX_NO_UNIFORM_TILES", "BSX_KERNEL_CACHE", "BSX_KERNEL_CACHE_OFF"}
+    rel = subprocess.run(["strings", build.LIB], capture_output=True, text=True, check=True).stdout.splitlines()
+    mentions = [l for l in rel if "BSX_" in l]
+    assert len(mentions) <= 12, mentions
+    names = set(re.findall(r"BSX_[A-Z0-9_]+", "\n".join(mentions)))
+    assert names <= user_modes, sorted(names - user_modes)
+    for gone in ("BSX_SEG_SKIP", "BSX_SEG_GATE_SKIP", "BSX_PROGRAM_NOP", "BSX_PROGRAM_ONLY", "BSX_PLAN_POLICY", "BSX_NO_RTC", "BSX_PREP_SPLIT", "BSX_BLEND16", "BSX_IR_BLOCK", "BSX_GEMM_RING"):
+        assert not any(gone in l for l in rel), gone
+    dbg = subprocess.run(["strings", build.LIB_DBG], capture_output=True, text=True, check=True).stdout
+    assert "BSX_SEG_SKIP" in dbg and "BSX_PLAN_POLICY" in dbg and "BSX_NO_RTC" in dbg
+    for retired in ("BSX_PREP_SPLIT", "BSX_BLEND16", "BSX_IR_BLOCK", "BSX_GEMM_RING"):          # deleted paths: in neither build
+        assert retired not in dbg, retired
+    csrc = os.path.join(ROOT, "backscrub_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))):
+        if f.endswith("debug_switches.hpp"):
+            continue
+        for name in re.findall(r'(?<!BSX_DBG_ENV\()(?<![A-Za-z_])getenv\("(BSX_[A-Z0-9_]+)"\)', open(f).read()):
+            assert name in user_modes, "%s reads %s with a bare getenv()" % (os.path.basename(f), name)

@@ -85,7 +85,7 @@ def test_every_stream_of_a_full_batch(bs, oracle, key, res, n, oracle_scenes):
 
 
 @pytest.mark.parametrize("n,env", [(5, {}), (7, {}), (2, {"BSX_NO_PW_GEMM": "1"})])
-def test_deeplab_between_the_small_and_the_gemm_batch_sizes(bs, oracle, monkeypatch, n, env):
+def test_deeplab_between_the_small_and_the_gemm_batch_sizes(bs, oracle, monkeypatch, n, env, debug_switches):
     """M = n * 33 * 33 rows: 4..7 streams fall between the lane-per-output form (M <= 4096) and the MFMA GEMMs (M >= 8192).  The ASPP
     pool branch is folded into conv#66 as a per-frame bias, which only those two forms took (round-2 advisor finding: BSX_EINVAL)."""
     from backscrub_amd import synth

@@ -253,7 +253,7 @@ def test_deeplab_decode_edge_logits(bs, oracle):
 
 
 @pytest.mark.parametrize("res", [VGA, (322, 242)])
-def test_generic_mask_kernel_matches_tile_kernel(bs, oracle, res, monkeypatch):
+def test_generic_mask_kernel_matches_tile_kernel(bs, oracle, res, monkeypatch, debug_switches):
     """The single-round-trip tile kernel (default) and the generic mask kernel (BSX_NO_MASK_TILE=1; also the fallback when
     a tile's source block does not fit LDS) must both be bit-exact against the oracle, stand-alone and fused with the blend."""
     from backscrub_amd import synth
@@ -318,7 +318,6 @@ NETWORK_PATHS = {
               ("one launch per step", {"BSX_NO_FRAME_PROGRAM": "1"}, "frame program: off")],
     # DeepLab runs per launch: the split-f16 MFMA GEMM (default) and the f32 MFMA GEMM, with and without the planner's rewrites
     "deeplab": [("split-f16 MFMA GEMM, fused head and expand+depthwise kernels", {}, "fused with step"),
-                ("whole inverted-residual blocks as one kernel where the block input is small (opt-in: measured slower)", {"BSX_IR_BLOCK": "1"}, "the whole inverted-residual block in one kernel"),
                 ("f32 MFMA GEMM", {"BSX_F16_GEMM": "off"}, "conv#66-pool"),
                 ("no graph rewrites", {"BSX_NO_REWRITES": "1"}, "concat#65"),
                 ("one launch per layer (no fused head, no fused expand+depthwise)", {"BSX_NO_IR_FUSE": "1", "BSX_NO_HEAD0": "1"}, "conv#66-pool")],
@@ -326,7 +325,7 @@ NETWORK_PATHS = {
 
 
 @pytest.mark.parametrize("key", ["lite", "mlkit", "deeplab"])
-def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, key, monkeypatch):
+def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, key, monkeypatch, debug_switches):
     """Same plan, different executions (segment kernels + per-frame middle program / whole-network program / one launch per
     step; f32 vs split-f16 MFMA GEMMs; with and without the linear-algebra rewrites): every one within 1e-4 of the oracle's logits."""
     from backscrub_amd import synth
@@ -336,7 +335,7 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc = oracle.Ctx(path, W, H)
     oc.prep(f)
     want = oc.infer()
-    knobs = ("BSX_PREP_SPLIT", "BSX_F32_INPUT", "BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0", "BSX_IR_BLOCK", "BSX_IR_BLOCK_MINW")
+    knobs = ("BSX_F32_INPUT", "BSX_ACT16", "BSX_NO_RTC", "BSX_NO_SEGMENTS", "BSX_NO_FRAME_PROGRAM", "BSX_F16_GEMM", "BSX_NO_REWRITES", "BSX_FORCE_FRAME_PROGRAM", "BSX_NO_IR_FUSE", "BSX_NO_HEAD0")
     for name, env, marker in NETWORK_PATHS[key]:
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
@@ -356,19 +355,15 @@ def test_every_execution_path_of_the_network_agrees_with_the_oracle(bs, oracle, 
     oc.close()
 
 
-@pytest.mark.parametrize("ring", ["0", "1"])
-def test_deeplab_batch_of_eight_uses_the_gemm_kernels_on_every_level(bs, oracle, monkeypatch, ring):
+def test_deeplab_batch_of_eight_uses_the_gemm_kernels_on_every_level(bs, oracle):
     """With 8 streams even the 33x33 layers have M >= 8192 rows, i.e. every pointwise convolution runs as the split-f16 MFMA GEMM (64-, 80- and
-    48-column tiles) next to the fused kernels: logits of all eight streams within 1e-4 of the oracle's.  Both GEMM kernels: operands staged
-    through registers (ring = 0) and delivered by the LDS-DMA rings (ring = 1); 8 x 1089 rows = 68 full 128-row blocks + a block of 8 rows."""
+    48-column tiles) next to the fused kernels: logits of all eight streams within 1e-4 of the oracle's; 8 x 1089 rows = 68 full 128-row blocks + a block of 8 rows."""
     from backscrub_amd import synth
     path = model_path("deeplab")
     W, H = VGA
     n = 8
     frames = np.stack([synth.frame(W, H, i % 3, i) for i in range(n)])
-    monkeypatch.setenv("BSX_GEMM_RING", ring)
     mg = bs.MaskGen(path, W, H, n_streams=n)
-    monkeypatch.delenv("BSX_GEMM_RING")
     mg.run_stage(0, _dev(frames))
     mg.run_stage(1, n=n)
     got = mg.output_tensor().cpu().numpy()
@@ -410,31 +405,28 @@ def test_deeplab_f16_storage_mode_is_gated_by_iou(bs, oracle, monkeypatch):
     mg.close()
 
 
-@pytest.mark.parametrize("key,res", CASES + [("lite", (322, 242)), ("deeplab", (641, 479))])
-def test_prep_in_one_kernel_equals_prep_through_the_canvas(bs, monkeypatch, key, res):
-    """prep_fused_k (resize of the tile + halo into LDS, bilateral from LDS: the default) against the two-launch form through the stored canvas
-    (BSX_PREP_SPLIT=1): the same f32 input tensor and the same 8-bit pixels, bit for bit, on every geometry incl. odd frame sizes and a noise stream.
-    (Both forms are also held to the oracle: test_stages_match_oracle runs the default.)"""
+@pytest.mark.parametrize("key,res", [("lite", (322, 242)), ("deeplab", (641, 479)), ("mlkit", (322, 242))])
+def test_prep_on_odd_frame_sizes_matches_the_oracle(bs, oracle, key, res):
+    """prep_fused_k (resize of the tile + halo into LDS, bilateral from LDS) on geometries whose tiles do not divide the canvas and whose rows are not dword
+    multiples, incl. a stream of pure noise: the network input bit for bit the oracle's.  (Round 6 deleted the two-launch form through a stored canvas this kernel
+    used to be cross-checked against; the oracle is the check, as in test_stages_match_oracle.)"""
     from backscrub_amd import synth
     path = model_path(key)
     W, H = res
     frames = np.stack([synth.frame(W, H, 0), synth.frame(W, H, 1, 3), synth.random_u8((H, W, 3), 7)])
-    outs = []
-    for split in (False, True):
-        if split:
-            monkeypatch.setenv("BSX_PREP_SPLIT", "1")
-        mg = bs.MaskGen(path, W, H, n_streams=4)
-        monkeypatch.delenv("BSX_PREP_SPLIT", raising=False)
-        mg.run_stage(0, _dev(frames))
-        mg.run_stage(1, n=3)
-        outs.append((mg.input_tensor()[:3].clone(), mg.output_tensor()[:3].clone()))
-        mg.close()
-    assert torch.equal(outs[0][0], outs[1][0]), "f32 network input differs"
-    assert torch.equal(outs[0][1], outs[1][1]), "logits differ (the stems read the 8-bit form)"
+    mg = bs.MaskGen(path, W, H, n_streams=4)
+    oc = oracle.Ctx(path, W, H)
+    mg.run_stage(0, _dev(frames))
+    got = mg.input_tensor()[:3].cpu().numpy()
+    for i in range(3):
+        want = oc.prep(frames[i])
+        assert np.array_equal(got[i], want), "stream %d: %d values differ" % (i, (got[i] != want).sum())
+    oc.close()
+    mg.close()
 
 
 @pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", HD), ("full", HD), ("deeplab", VGA)])
-def test_stems_that_read_the_8bit_input_are_bit_identical_to_the_f32_tensor(bs, monkeypatch, key, res):
+def test_stems_that_read_the_8bit_input_are_bit_identical_to_the_f32_tensor(bs, monkeypatch, key, res, debug_switches):
     """The step's prep hands the stem the filtered 8-bit pixels and the stem applies convertTo's two roundings while it stages its input window
     (seg_head_k<.., U8IN>, dl_head0_k<true>): the 12 B/px f32 input tensor of libbackscrub.cc:302 is never written.  Same logits, bit for bit, as
     the form that reads the f32 tensor (BSX_F32_INPUT=1) — incl. a stream of pure noise and a partial batch."""
@@ -641,7 +633,7 @@ def test_deeplab_argmax_agreement(bs, oracle):
     mg.close()
 
 
-def test_deeplab_tail_forms_agree(bs, monkeypatch):
+def test_deeplab_tail_forms_agree(bs, monkeypatch, debug_switches):
     """The fused resize + argmax + IIR tail has two forms: 24-float LDS pixels read as quads with the person test from two running maxima (21
     classes), and the scalar first-maximum scan over 32-float pixels (what more than 24 classes would take, BSX_TAIL_GENERIC=1).  Same
     interpolation arithmetic, same decision: on the photo fixture (a real person: both byte values occur) the decoded `ofinal` bytes after three
@@ -770,6 +762,106 @@ def test_step_with_fused_yuyv_output(bs, oracle, key, res):
     mg_a.step(frames, bg1, out)
     mg_b.step_yuyv(frames, bg1, yuyv)
     assert np.array_equal(yuyv.cpu().numpy(), mg_a.bgr_to_yuyv(out).cpu().numpy())
+    mg_a.close()
+    mg_b.close()
+
+
+def _camera_yuyv(bs_mg, W, H, n, t, rng):
+    """what a YUYV webcam would deliver for the synthetic scene: the BGR frame packed by the product's own packer is NOT it (that packer swaps U and V the way
+    convert_rgb_to_yuyv does) — build Y0 U Y1 V from BT.601 directly, plus streams of pure noise (every byte value, out-of-range Y / chroma: the clamps)."""
+    from backscrub_amd import synth
+    fr = np.stack([synth.frame(W, H, i, t) for i in range(n)]).astype(np.float32)
+    b, g, r = fr[..., 0], fr[..., 1], fr[..., 2]
+    y = 16 + 0.257 * r + 0.504 * g + 0.098 * b
+    u = 128 - 0.148 * r - 0.291 * g + 0.439 * b
+    v = 128 + 0.439 * r - 0.368 * g - 0.071 * b
+    yuyv = np.empty((n, H, W, 2), np.uint8)
+    yuyv[..., 0] = np.clip(np.rint(y), 0, 255)
+    yuyv[:, :, 0::2, 1] = np.clip(np.rint((u[:, :, 0::2] + u[:, :, 1::2]) / 2), 0, 255)
+    yuyv[:, :, 1::2, 1] = np.clip(np.rint((v[:, :, 0::2] + v[:, :, 1::2]) / 2), 0, 255)
+    yuyv[n - 1] = rng.integers(0, 256, size=(H, W, 2), dtype=np.uint8)
+    return yuyv
+
+
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", VGA), ("full", (1280, 720)), ("lite", (322, 242)), ("deeplab", VGA), ("mlkit", (1280, 720))])
+def test_step_that_takes_the_cameras_raw_yuyv(bs, oracle, key, res):
+    """BSX_STEP_YUYV_IN: cv::COLOR_YUV2BGR_YUYV (app/deepseg.cc:553,725) folded into the two kernels that read the frame.  Context B takes the
+    raw 4:2:2 frames; context A gets them converted by bsx_yuyv_to_bgr (itself bit-exact against the oracle: test_yuyv_to_bgr_matches_oracle) and runs the BGR step.
+    Same composite — as BGR and as YUYV out (YUYV in -> YUYV out in ONE step) —, same persistent masks, same temporal state, bit for bit, over three time steps,
+    with per-stream and shared backgrounds; on the four geometries of test_step_with_fused_yuyv_output (full-frame ROI, ROI with strips outside, HD, and 322x242,
+    which the fused kernels do not take: conversion into the context's scratch first) + DeepLab + MLKit/HD.  One stream is pure noise."""
+    import torch
+    W, H = res
+    n = 3
+    rng = np.random.default_rng(41)
+    mg_a = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    mg_b = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    mg_c = bs.MaskGen(model_path(key), W, H, n_streams=n)
+    bg = _dev(rng.integers(0, 256, size=(n, H, W, 3), dtype=np.uint8))
+    out_a = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    out_b = torch.empty_like(out_a)
+    y_c = torch.empty((n, H, W, 2), dtype=torch.uint8, device="cuda")
+    for t in range(3):
+        raw = _dev(_camera_yuyv(mg_a, W, H, n, t, rng))
+        bgr = mg_a.yuyv_to_bgr(raw)
+        if t == 0:
+            assert np.array_equal(bgr[0].cpu().numpy(), oracle.yuyv_to_bgr(raw[0].cpu().numpy()))
+            if W % 4 == 0:                                                 # the prep stage alone (stage 4 = stage 0 on raw frames): the oracle's network input
+                mg_b.run_stage(4, raw)
+                oc = oracle.Ctx(model_path(key), W, H)
+                got_in = mg_b.input_tensor().cpu().numpy()
+                for i in range(n):
+                    assert np.array_equal(got_in[i], oc.prep(oracle.yuyv_to_bgr(raw[i].cpu().numpy()))), "prep on YUYV frames, stream %d" % i
+                oc.close()
+        b = bg if t != 1 else bg[1].contiguous()                          # per-stream backgrounds, and once ONE shared image
+        mg_a.step(bgr, b, out_a)
+        mg_b.step_ex(raw, b, out_b, yuyv_in=True)
+        mg_c.step_ex(raw, b, y_c, yuyv=True, yuyv_in=True)
+        assert torch.equal(out_b, out_a), "t=%d: %d composite bytes differ" % (t, int((out_b != out_a).sum()))
+        assert torch.equal(mg_b.masks(), mg_a.masks()) and torch.equal(mg_b.ofinal(), mg_a.ofinal())
+        assert torch.equal(y_c, mg_a.bgr_to_yuyv(out_a)), "t=%d: YUYV in -> YUYV out differs from convert + step + pack" % t
+        assert torch.equal(mg_c.masks(), mg_a.masks()) and torch.equal(mg_c.ofinal(), mg_a.ofinal())
+    # flips and composite-only, and the forms that cannot be fused (background blurred from the frame itself; output over the input buffer)
+    mg_a.step_ex(bgr, bg, out_a, flip_h=True, flip_v=True, no_mask=True)
+    mg_b.step_ex(raw, bg, out_b, flip_h=True, flip_v=True, no_mask=True, yuyv_in=True)
+    assert torch.equal(out_b, out_a)
+    if W % 4 == 0:
+        mg_a.step_ex(bgr, None, out_a, bgblur=9)
+        mg_b.step_ex(raw, None, out_b, bgblur=9, yuyv_in=True)
+        assert torch.equal(out_b, out_a)
+    buf = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    buf.view(-1)[:raw.numel()].copy_(raw.view(-1))                         # the YUYV batch at the start of the buffer the composite is written to
+    mg_a.step(bgr, bg, out_a)
+    mg_b.step_ex(buf.view(-1)[:raw.numel()].view(n, H, W, 2), bg, buf, yuyv_in=True)
+    assert torch.equal(buf, out_a)
+    with pytest.raises(bs.BsxError):
+        mg_b.step_ex(bgr, bg, out_b, yuyv_in=True)                         # a BGR tensor where 4:2:2 frames are announced
+    for m in (mg_a, mg_b, mg_c):
+        m.close()
+
+
+def test_pipelined_step_takes_yuyv_frames(bs):
+    """bsx_step_batch_pipelined with BSX_STEP_YUYV_IN | BSX_STEP_YUYV: the composite of batch k — enqueued by call k + 1 on the context's own stream — reads the raw
+    4:2:2 frames of batch k; results equal the synchronous YUYV in -> YUYV out step, one call later."""
+    import torch
+    W, H = VGA
+    n, T = 4, 4
+    rng = np.random.default_rng(43)
+    mg_a = bs.MaskGen(model_path("lite"), W, H, n_streams=n)
+    mg_b = bs.MaskGen(model_path("lite"), W, H, n_streams=n)
+    bg = _dev(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8))
+    raws = [_dev(_camera_yuyv(mg_a, W, H, n, t, rng)) for t in range(T)]
+    want, got = [], [torch.empty((n, H, W, 2), dtype=torch.uint8, device="cuda") for _ in range(T)]
+    for t in range(T):
+        o = torch.empty((n, H, W, 2), dtype=torch.uint8, device="cuda")
+        mg_a.step_ex(raws[t], bg, o, yuyv=True, yuyv_in=True)
+        want.append(o)
+        mg_b.step_pipelined(raws[t], bg, got[t], yuyv=True, yuyv_in=True)
+    mg_b.flush_pipelined()
+    torch.cuda.synchronize()
+    for t in range(T):
+        assert torch.equal(got[t], want[t]), "batch %d" % t
+    assert torch.equal(mg_b.masks(), mg_a.masks()) and torch.equal(mg_b.ofinal(), mg_a.ofinal())
     mg_a.close()
     mg_b.close()
 
@@ -1126,3 +1218,40 @@ def test_argument_errors(bs):
     assert bs.lib().bsx_process_batch(None, None, 1, None, None) == -1      # BSX_EINVAL on a NULL context (libbackscrub.cc:280)
     assert bs.lib().bsx_process_batch(mg.h, None, 1, None, None) == -1
     mg.close()
+
+
+def test_release_library_ignores_the_work_skipping_switches(bs, monkeypatch):
+    """BSX_SEG_SKIP makes the segment kernels leave phases out (a timing experiment: the logits are then WRONG).  The release library must not even read it:
+    same logits, bit for bit, with and without the variable — while the debug build (libbsx_dbg.so, test infrastructure) honours it."""
+    from backscrub_amd import api, build, synth
+    path = model_path("lite")
+    W, H = VGA
+    f = _dev(np.stack([synth.frame(W, H, 5), synth.frame(W, H, 6)]))
+
+    def logits():
+        mg = bs.MaskGen(path, W, H, n_streams=2)
+        plan = mg.plan()
+        mg.run_stage(0, f)
+        mg.run_stage(1, n=2)
+        out = mg.output_tensor().clone()
+        mg.close()
+        return out, plan
+    for k in ("BSX_SEG_SKIP", "BSX_SEG_GATE_SKIP", "BSX_PROGRAM_NOP"):
+        monkeypatch.delenv(k, raising=False)
+    assert os.path.samefile(api.lib_path(), build.LIB)
+    want, plan = logits()
+    assert "program execution: specialised kernel" in plan
+    monkeypatch.setenv("BSX_SEG_SKIP", "255,255,255,255")
+    monkeypatch.setenv("BSX_SEG_GATE_SKIP", "1")
+    monkeypatch.setenv("BSX_PROGRAM_NOP", "1")
+    got, plan2 = logits()
+    assert torch.equal(got, want) and plan2 == plan, "the release library read a debug switch"
+    saved = api._LIB
+    try:                                          # the same variables under the debug build: the experiment takes effect — every micro-op of the middle program is a
+        api._LIB = None                           # no-op (kind 99), which the generator refuses, so the plan falls back to the interpreter.  (The logits are not
+        monkeypatch.setenv("BSX_LIBRARY", build.LIB_DBG)      # compared: kernels that skip their stores leave whatever the allocation held — usually the run before.)
+        _, plan3 = logits()
+        assert "micro-op kind 99" in plan3 and "program execution: specialised kernel" not in plan3
+    finally:
+        monkeypatch.delenv("BSX_LIBRARY", raising=False)
+        api._LIB = saved

@@ -36,23 +36,17 @@ def _device_fn(name):
     return eval("lambda row: " + expr)                      # noqa: S307 — the character class above admits integer operators only
 
 
-hsw = _device_fn("hsw")      # f16 operand rows of 64 bytes (4 chunks of 8 halves)
 asw = _device_fn("asw")      # f32 activation rows of 128 bytes (8 chunks of 4 floats)
 
 
 def test_the_kernels_use_the_swizzles_where_the_model_says():
-    """the address expressions of the ring GEMM / the fused kernel's re-order buffers, as written in the source"""
+    """the address expressions of the fused expand kernel's staged (LDS-DMA) operand buffer, as written in the source (float units there: 32 floats = 128 bytes per
+    row, chunk << 2 = 16 bytes).  The ring GEMM whose weight rows used the second swizzle (hsw) was deleted in round 6."""
     import os
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "backscrub_amd", "csrc", "kernels_nn.hip")).read()
-    for needle in ("li * 128 + (((2 * g) ^ asw(li)) << 4)", "li * 64 + ((g ^ hsw(li)) << 4)", "(lane & 7) ^ asw(r & 15)", "(lane & 3) ^ hsw(r)"):
+    for needle in ("li * 32 + (((2 * g) ^ asw(li)) << 2)", "4 * (lp ^ asw(8 * h + lr))"):
         assert needle in src, needle
-
-
-def test_weight_rows_are_conflict_free_with_hsw_and_not_without():
-    read = lambda sw: extra_cycles(lambda l: (l & 15) * 64 + (((l >> 4) ^ sw(l & 15)) << 4))
-    assert read(hsw) == 0
-    assert read(lambda r: 0) > 0
-    assert extra_cycles(lambda l: (l & 15) * 80 + (l >> 4) * 16) > 0      # the padded 80-byte rows of pw_gemm_f16s_k: free for 16 CONSECUTIVE lanes only
+    assert "pw_gemm_ring_k" not in src and "hsw(" not in src
 
 
 def test_activation_rows_are_conflict_free_with_asw_and_not_without():
@@ -71,13 +65,6 @@ def test_dma_side_and_reader_side_agree():
             lds[(row, l & 7)] = (l & 7) ^ asw(row & 15)
         for row, c in itertools.product(range(8 * piece, 8 * piece + 8), range(8)):
             assert lds[(row, c ^ asw(row & 15))] == c
-    # weight piece: 16 channel rows x 4 chunk positions
-    lds = {}
-    for l in range(64):
-        row = l >> 2
-        lds[(row, l & 3)] = (l & 3) ^ hsw(row)
-    for row, c in itertools.product(range(16), range(4)):
-        assert lds[(row, c ^ hsw(row))] == c
 
 
 def test_fragment_reads_use_xor_16_for_the_second_quad():

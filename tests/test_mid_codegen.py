@@ -65,7 +65,7 @@ def test_act16_variant_stores_arena_activations_as_halves(api, key, tmp_path, mo
     assert "v_cvt_f16_f32" in asm or "v_cvt_pk" in asm
 
 
-def test_arena_tensors_of_the_larger_graphs_are_staged_and_fused(api, monkeypatch):
+def test_arena_tensors_of_the_larger_graphs_are_staged_and_fused(api, monkeypatch, debug_switches):
     """MLKit / segm_full keep their 16x16x{96,128} (9x16) level-4 tensors in the arena.  The generator then (a) stages the depthwise inputs through the LDS
     workspace the planner reserved, chunk by chunk, and (b) where the 1x1 in front is the only producer computes each chunk straight into that workspace, so the
     expanded tensor is never stored; (c) 1x1 convolutions that write to the arena walk N-tile fastest.  segm_lite keeps those tensors in LDS: nothing to stage."""
@@ -104,7 +104,7 @@ def test_prelude_is_a_valid_translation_unit_on_its_own():
     assert r.returncode == 0, r.stderr[-2000:]
 
 
-def test_placement_search_keeps_the_cheapest_valid_plan(api, monkeypatch):
+def test_placement_search_keeps_the_cheapest_valid_plan(api, monkeypatch, debug_switches):
     """plan.cpp: build_frame_program lowers the program under eight placement policies and keeps the one that touches the fewest arena bytes per frame.  For every
     model and every forced policy the plan must pass the independent LDS check (no two live reservations overlap — also with the lifetimes an elided 1x1 extends),
     the default must be the minimum over the forced ones (ties: the lowest policy number), segm_lite / MLKit must stay on the round-3 plan (policy 0, i.e. the
@@ -192,7 +192,7 @@ def test_low_resolution_window_reservation_covers_every_tile(tmp_path):
 
 
 @pytest.mark.parametrize("key", ["lite", "full", "mlkit"])
-def test_zero_cell_of_the_middle_kernel(api, key, monkeypatch):
+def test_zero_cell_of_the_middle_kernel(api, key, monkeypatch, debug_switches):
     """Round 5: the last 16 bytes of the middle kernel's LDS block are a zero cell — the planner's blocks end below it, the kernel's prologue zeroes it, and the
     depthwise ops that read a planned LDS tensor take their out-of-image taps from it (traits ZC = true); the chunk-by-chunk ops keep the zeroing form
     (profiles/r05j: the zero-cell form costs MLKit's 128-register kernel 150 bytes of spill), and BSX_RTC_NO_ZERO_CELL=1 switches the form off everywhere."""
@@ -200,12 +200,15 @@ def test_zero_cell_of_the_middle_kernel(api, key, monkeypatch):
     total = eval(re.search(r"constexpr int kLdsTotalFloats = ([^;]+);", hdr).group(1))            # noqa: S307 — "160 * 256"
     assert total == 160 * 256 and "kLdsZeroOff = kLdsTotalFloats - kLdsZeroFloats" in hdr and "constexpr int kLdsZeroFloats = 4;" in hdr
     prelude = open(os.path.join(ROOT, "backscrub_amd", "csrc", "mid_prelude.hip")).read()
-    assert "constexpr int kZeroOff = 160 * 256 - 4;" in prelude and "kZeroOff - T::X_OFF" in prelude
+    # the cell's offset reaches the device templates from the PLAN (gen_mid.cpp emits BSXM_ZERO_OFF = Plan::lds_zero_off() in front of the prelude: ADVICE r5), the
+    # literal in the prelude is only the stand-alone syntax check's default
+    assert "constexpr int kZeroOff = BSXM_ZERO_OFF;" in prelude and "#define BSXM_ZERO_OFF (160 * 256 - 4)" in prelude and "kZeroOff - T::X_OFF" in prelude
     desc = api.model_describe(model_path(key))
     lds_floats = int(re.search(r"lds_floats=(\d+)", desc).group(1))
     assert lds_floats <= total - 4 and "lds_check=ok" in desc                                        # no planned block reaches into the cell
     src = api.model_kernel_source(model_path(key))
-    assert "static_assert(kZeroOff == %d" % (total - 4) in src and "float smem[%d];" % total in src
+    assert "#define BSXM_LANES 1024\n#define BSXM_ZERO_OFF %d\n" % (total - 4) in src
+    assert "static_assert(kZeroOff == %d && kThreads == 1024" % (total - 4) in src and "float smem[%d];" % total in src
     assert re.search(r"if \(threadIdx\.x < 4\) L\[kZeroOff \+ threadIdx\.x\] = 0\.f;", src)
     structs = re.findall(r"struct (Op\d+(?:_\d+)?) \{\n  static constexpr int K = [^\n]+\n  static constexpr bool ZC = (true|false);\n  static constexpr int X_SP = (\d), X_OFF", src)
     assert structs, "no depthwise traits found"

@@ -95,7 +95,7 @@ def test_frame_program_lds_reservations_do_not_collide(key, real):
 
 
 @pytest.mark.parametrize("real", [True, False])
-def test_deeplab_plan_fuses_the_head_and_every_expand_depthwise_pair(real, monkeypatch):
+def test_deeplab_plan_fuses_the_head_and_every_expand_depthwise_pair(real, monkeypatch, debug_switches):
     """Host-only check of the per-launch planner (plan.cpp): DeepLab's first three layers form the tiled head kernel, all 16 expand 1x1 → depthwise 3x3
     pairs fuse, every fused pair's LDS geometry (plan.hpp ir_geometry) fits — whole frame at 33x33, row bands of <= 78 KB (two workgroups per CU) above —
     and the switches that turn the fusions off produce the plain per-layer plan."""
