@@ -212,6 +212,30 @@ int upload_tab(bsx_ctx* c, const HostResizeTab& h, DevResizeTab* d) {
   return BSX_OK;
 }
 
+// The graph-specialised middle kernel of `plan`, compiled (or fetched from the cache) for `arch` — in the form that spills least.  The plain form lets the compiler share
+// every lane-derived value between ops; where that pushes the kernel into scratch (MLKit: 352 bytes at 128 registers) the opaque-lane-index form (mid_prelude.hip:
+// tid_now; 92 registers, no scratch) is compiled too and taken if its scratch is smaller — read from the code objects' kernel descriptors, so the choice needs no GPU and
+// bsx_model_precompile makes the same one a context makes later (both code objects sit in the cache).  Returns "" and fills *code, or the reason there is no kernel.
+struct MidBuild { std::vector<char> code; std::string source, note; bool cached = false, opaque_tid = false; long scratch = -1; };
+std::string build_mid_kernel(const Plan& plan, bool act16, const std::string& arch, MidBuild* out) {
+  std::string why, log;
+  int force = -1;                                                 // debug build: BSX_RTC_TID=0 | 1 forces the plain / the opaque form (A/B timing)
+  if (const char* e = BSX_DBG_ENV("BSX_RTC_TID")) force = atoi(e) != 0;
+  auto build = [&](bool opaque, MidBuild* b) -> std::string {
+    b->source = generate_mid_source(plan, &why, act16, opaque);
+    if (b->source.empty()) return "interpreted (" + why + ")";
+    if (!rtc_build(b->source, arch, &b->code, &log, &b->cached)) { if (BSX_DBG_ENV("BSX_RTC_DEBUG")) fprintf(stderr, "%s\n", log.c_str()); return "interpreted (hipRTC: " + log.substr(0, 400) + ")"; }
+    b->opaque_tid = opaque;
+    b->scratch = code_object_scratch_bytes(b->code, "bsx_mid");
+    return "";
+  };
+  std::string err = build(force == 1, out);
+  if (!err.empty() || force >= 0 || out->scratch <= 0) return err;
+  MidBuild alt;
+  if (build(true, &alt).empty() && alt.scratch >= 0 && alt.scratch < out->scratch) *out = std::move(alt);
+  return "";
+}
+
 int model_type_from_name(const std::string& n) {  // lib/libbackscrub.cc:116-130 (same precedence)
   if (n.find("body-pix") != n.npos) return BSX_MODEL_BODYPIX;
   if (n.find("deeplab") != n.npos) return BSX_MODEL_DEEPLAB;
@@ -248,17 +272,15 @@ int init_device_state(bsx_ctx* c) {
     const char* a16 = getenv("BSX_ACT16");
     c->act16 = a16 && atoi(a16) != 0 && c->plan.seg.on;
     if (!BSX_DBG_ENV("BSX_NO_RTC")) {
-      std::string why, log;
-      const std::string src = generate_mid_source(c->plan, &why, c->act16);
-      if (src.empty()) c->mid_note = "interpreted (" + why + ")";
+      hipDeviceProp_t prop;
+      MidBuild mb;
+      if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) c->mid_note = "interpreted (no device properties)";
       else {
-        hipDeviceProp_t prop;
-        std::vector<char> code;
-        bool cached = false;
-        if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) c->mid_note = "interpreted (no device properties)";
-        else if (!rtc_build(src, prop.gcnArchName, &code, &log, &cached)) { c->mid_note = "interpreted (hipRTC: " + log.substr(0, 400) + ")"; if (BSX_DBG_ENV("BSX_RTC_DEBUG")) fprintf(stderr, "%s\n", log.c_str()); }
-        else if (rtc_load(code, "bsx_mid", &c->mid) != hipSuccess) { c->mid_note = "interpreted (code object did not load)"; (void)hipGetLastError(); }
-        else c->mid_note = std::string("specialised kernel (hipRTC") + (cached ? ", from the cache)" : ", compiled now)");
+        const std::string err = build_mid_kernel(c->plan, c->act16, prop.gcnArchName, &mb);
+        if (!err.empty()) c->mid_note = err;
+        else if (rtc_load(mb.code, "bsx_mid", &c->mid) != hipSuccess) { c->mid_note = "interpreted (code object did not load)"; (void)hipGetLastError(); }
+        else c->mid_note = std::string("specialised kernel (hipRTC") + (mb.cached ? ", from the cache" : ", compiled now") + (mb.opaque_tid ? ", lane indices re-derived per op" : "") +
+                           (mb.scratch > 0 ? ", " + std::to_string(mb.scratch) + " B of scratch" : "") + ")";
       }
     } else c->mid_note = "interpreted (BSX_NO_RTC)";
     if (c->act16 && !c->mid.fn) {            // the interpreter has f32 tensors only: the mode needs the generated kernel
@@ -1135,10 +1157,17 @@ long bsx_model_kernel_source(const char* model_path, char* buf, size_t cap) {
     std::string err, why;
     if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { snprintf(buf, cap, "%s", err.c_str()); return BSX_EMODEL; }
     const char* a16 = getenv("BSX_ACT16");
-    const std::string src = generate_mid_source(p, &why, a16 && atoi(a16) != 0 && p.seg.on);
-    if (src.empty()) { snprintf(buf, cap, "%s", why.c_str()); return 0; }
-    snprintf(buf, cap, "%s", src.c_str());
-    return (long)src.size();
+    if (p.program.empty()) { snprintf(buf, cap, "no program"); return 0; }
+    MidBuild mb;                                                    // the source of the kernel a context would RUN (the form build_mid_kernel picks: compiles, no GPU needed)
+    const std::string e = build_mid_kernel(p, a16 && atoi(a16) != 0 && p.seg.on, "gfx950", &mb);
+    if (!e.empty()) {
+      const std::string src = generate_mid_source(p, &why, a16 && atoi(a16) != 0 && p.seg.on);      // a compiler failure still shows the source; a graph without a body shows why
+      if (src.empty()) { snprintf(buf, cap, "%s", why.c_str()); return 0; }
+      snprintf(buf, cap, "%s", src.c_str());
+      return (long)src.size();
+    }
+    snprintf(buf, cap, "%s", mb.source.c_str());
+    return (long)mb.source.size();
   } catch (...) { snprintf(buf, cap, "exception while reading the model"); return BSX_EMODEL; }
 }
 
@@ -1149,12 +1178,12 @@ int bsx_model_precompile(const char* model_path, const char* arch, char* msg, si
     std::string err, why, log;
     if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { snprintf(msg, cap, "%s", err.c_str()); return BSX_EMODEL; }
     const char* a16 = getenv("BSX_ACT16");                         // the variant a context created under the same environment would ask for
-    const std::string src = generate_mid_source(p, &why, a16 && atoi(a16) != 0 && p.seg.on);
-    if (src.empty()) { snprintf(msg, cap, "interpreted (%s)", why.c_str()); return BSX_OK; }
-    std::vector<char> code;
-    bool cached = false;
-    if (!rtc_build(src, arch ? arch : "gfx950", &code, &log, &cached)) { snprintf(msg, cap, "hipRTC failed: %s", log.c_str()); return BSX_EMODEL; }
-    snprintf(msg, cap, "%s (%zu bytes of source, %zu bytes of code object, cache %s)", cached ? "cached" : "compiled", src.size(), code.size(), rtc_cache_dir().c_str());
+    if (p.program.empty()) { snprintf(msg, cap, "interpreted (no program)"); return BSX_OK; }
+    MidBuild mb;
+    const std::string e = build_mid_kernel(p, a16 && atoi(a16) != 0 && p.seg.on, arch ? arch : "gfx950", &mb);
+    if (!e.empty()) { snprintf(msg, cap, "%s", e.c_str()); return e.compare(0, 19, "interpreted (hipRTC") == 0 ? BSX_EMODEL : BSX_OK; }
+    snprintf(msg, cap, "%s (%zu bytes of source, %zu bytes of code object, %ld B of scratch%s, cache %s)", mb.cached ? "cached" : "compiled", mb.source.size(), mb.code.size(), mb.scratch,
+             mb.opaque_tid ? ", lane indices re-derived per op" : "", rtc_cache_dir().c_str());
     return BSX_OK;
   } catch (...) { snprintf(msg, cap, "exception while reading the model"); return BSX_EMODEL; }
 }

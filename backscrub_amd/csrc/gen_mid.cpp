@@ -87,7 +87,7 @@ bool mid_pw_feeds_dw(const Plan& plan, int j) {
   return true;
 }
 
-std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) {
+std::string generate_mid_source(const Plan& plan, std::string* why, bool act16, bool opaque_tid) {
   // address space of an ACTIVATION tensor operand: arena tensors are packed halves in the 16-bit storage mode (mid_prelude.hip: SP_GLB16)
   auto asp = [&](const Loc& l) { const int sp = sp_of(l); return (sp == 2 && act16) ? 3 : sp; };
   auto loc = [&](Out& o, const char* p, const Loc& l) { o.f("  static constexpr int %s_SP = %d, %s_OFF = %d, %s_ST = %d;\n", p, asp(l), p, l.off, p, l.stride); };
@@ -102,6 +102,7 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
   if (BSX_DBG_ENV("BSX_RTC_EXP_MFMA")) o.s += "#define BSXM_EXP_MFMA_QUARTER 1   // timing experiment: WRONG RESULTS (mid_prelude.hip op_pw)\n";
   // the workgroup's geometry (Plan::mid_lanes, Plan::lds_total_floats): the prelude's kThreads / kWaves / kZeroOff come from these two macros
   o.f("#define BSXM_LANES %d\n#define BSXM_ZERO_OFF %d\n", plan.mid_lanes, plan.lds_zero_off());
+  if (opaque_tid) o.s += "#define BSXM_OPAQUE_TID 1\n";      // every op re-derives its lane indices (mid_prelude.hip: tid_now) — the form for graphs whose plain kernel spills
   o.s += kPrelude;
   o.f("\nnamespace bsxm {\n");
   std::string body;
@@ -187,10 +188,11 @@ std::string generate_mid_source(const Plan& plan, std::string* why, bool act16) 
         if (chunked) snprintf(name, sizeof name, "Op%d_%d", i, c); else snprintf(name, sizeof name, "Op%d", i);
         o.f("struct %s {\n  static constexpr int K = %d, S = %d, H = %d, W = %d, OH = %d, OW = %d, PT = %d, PL = %d, C = %d, CW = %d, YC0 = %d, ACT = %d, V = %d, TX = %d;\n", name, K, S,
             m.H, m.W, m.OH, m.OW, m.pt, m.pl, CKc, m.Cin, c * CK, m.act, V, TX);
-        // ZC: out-of-image taps through the zero cell (op_dw) — for depthwise ops that read a planned LDS tensor.  Not for the chunk-by-chunk form (input staged
-        // through an LDS workspace inside a loop over channel chunks): there the zero-cell form raised the register pressure of MLKit's kernel, which sits at 128
-        // registers, from 372 to 524 bytes of spill and cost 7 % (profiles/r05j)
-        o.f("  static constexpr bool ZC = %s;\n", (chunked || BSX_DBG_ENV("BSX_RTC_NO_ZERO_CELL")) ? "false" : "true");
+        // ZC: out-of-image taps through the zero cell (op_dw) — for every depthwise op whose input is in LDS: a planned tensor, or (round 6) the workspace of the
+        // chunk-by-chunk form.  Round 5 had to leave the chunked form out: MLKit's kernel sat at 128 registers and the zero-cell form took its spill from 372 to 524
+        // bytes (+7 %, profiles/r05j); with the lane index read through tid_now() (mid_prelude.hip) that kernel needs 92 registers and nothing spills.
+        // (debug build: BSX_RTC_NO_ZERO_CELL=1 switches the form off everywhere, BSX_RTC_NO_ZC_CHUNK=1 for the chunked ops only — the A/B switches)
+        o.f("  static constexpr bool ZC = %s;\n", ((chunked && BSX_DBG_ENV("BSX_RTC_NO_ZC_CHUNK")) || BSX_DBG_ENV("BSX_RTC_NO_ZERO_CELL")) ? "false" : "true");
         if (chunked) o.f("  static constexpr int X_SP = 1, X_OFF = %d, X_ST = %d;\n", m.ws_off, CK + 4); else loc(o, "X", m.in0);
         loc(o, "Y", m.out); loc(o, "R", m.res);
         if (staged) o.f("  static constexpr int W_SP = SP_LDS, W_OFF = %d, B_OFF = %d;\n};\n", m.w_lds + c * CK, m.w_lds + (int)(m.b_off - m.w_off) + c * CK);

@@ -564,7 +564,8 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
       } else {
         // ONE 12-byte store (global_store_dwordx3): the 32 lanes of a tile row then write 384 contiguous bytes per instruction — as three dword stores each
         // instruction wrote 4 of every 12 bytes (a third of every line, three times over)
-        __builtin_nontemporal_store(u3v{o3[0], o3[1], o3[2]}, reinterpret_cast<u3v*>(op));
+        if (yuyv_flip & 128) *reinterpret_cast<u3v*>(op) = u3v{o3[0], o3[1], o3[2]};      // (debug build: plain instead of nontemporal stores, A/B — round 6)
+        else __builtin_nontemporal_store(u3v{o3[0], o3[1], o3[2]}, reinterpret_cast<u3v*>(op));
       }
     }
   }
@@ -1101,6 +1102,8 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   if (hipError_t e = launch_tile_class(ofinal, outW, outH, in_roi, tab, roi, n, s)) return e;
   static const bool no_early_bg = BSX_DBG_ENV("BSX_NO_EARLY_BG") != nullptr;      // A/B timing: bit 6 of the flag word = request a shared background only after the tile's class is known (rounds 1-4)
   if (no_early_bg) yuyv |= 64;
+  static const bool plain_stores = BSX_DBG_ENV("BSX_TILE_PLAIN_STORES") != nullptr;      // A/B timing: bit 7 = the composite leaves with plain instead of nontemporal stores
+  if (plain_stores) yuyv |= 128;
   if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   return hipGetLastError();

@@ -57,7 +57,18 @@ typedef __attribute__((address_space(1))) _Float16 glb_h;
 #define BSXM_G(T, g, off) ((T*)((glb_c*)(g) + (unsigned)((off) * 4)))
 #define BSXM_H(T, g, off) ((T*)((glb_c*)(g) + (unsigned)((off) * 2)))          // the same tensor (same arena offset) as halves: element `off` at 2 * off bytes
 
-__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// The lane index as every op reads it.  BSXM_OPAQUE_TID (gen_mid.cpp emits it for the graphs whose plain form SPILLS): through an opaque asm, so that what an op
+// derives from it (pixel, channel quad, LDS offsets ...) is recomputed by the next op — a handful of VALU instructions — instead of being kept alive across the
+// whole straight-line kernel by common-subexpression elimination.  Left alone the compiler carries dozens of such values through the 100-register depthwise
+// bodies: MLKit's kernel sat at 128 registers with 352 bytes of scratch, stores in the first ops and loads all the way down; opaque it needs 92 registers and
+// none (round 6: middle kernel -3.5 %).  Where nothing spills the shared values are free and recomputing them only costs issue slots (segm_lite: +6 %), so the
+// choice is made per graph from the scratch size of the compiled code object (bsx_api.hip: build_mid_kernel).
+#ifdef BSXM_OPAQUE_TID
+__device__ __forceinline__ int tid_now() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#else
+__device__ __forceinline__ int tid_now() { return (int)threadIdx.x; }
+#endif
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(tid_now() >> 6); }
 
 // compile-time address-space loads / stores: one ds_* or global_* instruction, never a flat access and never a branch.  Global offsets are
 // UNSIGNED: uniform base + zero-extended 32-bit lane offset is the `global_load … v_off, s[base]` form — a signed offset makes the compiler
@@ -128,7 +139,7 @@ template <int FLOATS> __device__ __forceinline__ void stage(const glb_f* src, ld
   typedef __attribute__((address_space(3))) void* lds_vp;
   typedef const __attribute__((address_space(1))) void* glb_vp;
   if constexpr (FLOATS > 0) {
-    const int lane4 = (int)(threadIdx.x & 63) * 4, w = wave_id();
+    const int lane4 = (tid_now() & 63) * 4, w = wave_id();
     constexpr int CH = (FLOATS + 255) / 256;                      // 1 KiB chunks
 #pragma unroll
     for (int i = 0; i < (CH + kWaves - 1) / kWaves; i++) {
@@ -156,7 +167,7 @@ template <class T> __device__ __forceinline__ void op_pw(lds_f* L, glb_f* A) {
   constexpr int P = T::P, CIN = T::CIN, CPAD = T::CPAD, MT = (P + 15) / 16, NT = T::NCOLS / 16, TILES = MT * NT;
   constexpr int NJ = CIN / 16, TAIL = CIN % 16, TM = TAIL / 4;      // TM = MFMAs of the tail (0..3)
   static_assert(CIN % 4 == 0 && CPAD % 16 == 0, "op_pw: channel counts");
-  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, wave = wave_id();
+  const int lane = tid_now() & 63, li = lane & 15, g = lane >> 4, wave = wave_id();
   const lds_f* wl = L + T::W_LDS;
   const lds_f* bl = L + T::B_LDS;
 #pragma unroll
@@ -250,12 +261,12 @@ __device__ __forceinline__ void load_chunk(lds_f* L, const glb_f* A) {
   f4v v[IT];
 #pragma unroll
   for (int it = 0; it < IT; it++) {
-    const int i = min((int)threadIdx.x + it * kThreads, TOTAL - 1), px = i / Q, q = i - px * Q;
+    const int i = min(tid_now() + it * kThreads, TOTAL - 1), px = i / Q, q = i - px * Q;
     v[it] = ld4<SP>(L, A + X_OFF, px * CFULL + C0 + 4 * q);
   }
 #pragma unroll
   for (int it = 0; it < IT; it++) {
-    const int i = (int)threadIdx.x + it * kThreads, px = i / Q, q = i - px * Q;
+    const int i = tid_now() + it * kThreads, px = i / Q, q = i - px * Q;
     if (i < TOTAL) *(lds_v4*)(L + WS + px * WST + 4 * q) = v[it];
   }
 }
@@ -278,7 +289,7 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
   auto ldw = [&](int off) -> vec_t { if constexpr (V == 4) return ld4<T::W_SP>(L, Wg, off); else return ld2<T::W_SP>(L, Wg, off); };
 #pragma unroll
   for (int it = 0; it < (TOTAL + kThreads - 1) / kThreads; it++) {
-    const int item = (int)threadIdx.x + it * kThreads;
+    const int item = tid_now() + it * kThreads;
     if (item >= TOTAL) break;
     const int t = item / CV, cq = item - t * CV, oy = t / NSTRIPS, sx = t - oy * NSTRIPS;
     const int ch = cq * V, ox0 = sx * TX, ix0 = ox0 * S - T::PL;
@@ -374,7 +385,7 @@ template <class T> __device__ __forceinline__ void op_dw(lds_f* L, glb_f* A, con
 template <int SP, int OFF, int ST, int ROWS, int C, int HW, int COFF, bool ACCUM, int MEAN_OFF>
 __device__ __forceinline__ void gap_part(lds_f* L, glb_f* A) {
   constexpr int C4 = C / 4;
-  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int lane = tid_now() & 63, wave = wave_id();
 #pragma unroll
   for (int it = 0; it < (C4 + kWaves - 1) / kWaves; it++) {
     const int cq = wave + it * kWaves;
@@ -413,7 +424,7 @@ template <int CIN, int COUT> struct FcRegs { f4v w[FcGeom<CIN, COUT>::IT][FcGeom
 template <int CIN, int COUT, int W_SP, int W_OFF, int B_OFF>
 __device__ __forceinline__ void fc_load(const lds_f* L, const glb_f* Wg, FcRegs<CIN, COUT>& r) {
   typedef FcGeom<CIN, COUT> G;
-  const int sub = threadIdx.x & (G::LK - 1), co0 = threadIdx.x / G::LK;
+  const int sub = tid_now() & (G::LK - 1), co0 = tid_now() / G::LK;
   // The weights are read-only memory: left alone, the compiler hoists these loads above the barrier into the op in front — wherever IT likes,
   // e.g. into a 91-register depthwise body, which then spills.  Where the loads go is the generator's decision (gen_mid.cpp: `early`): the
   // base pointer passes through an opaque asm here, so they stay behind whatever precedes this call.
@@ -430,7 +441,7 @@ __device__ __forceinline__ void fc_load(const lds_f* L, const glb_f* Wg, FcRegs<
 template <int CIN, int COUT, int ACT, int X_OFF, int Y_SP, int Y_OFF>
 __device__ __forceinline__ void fc_apply(lds_f* L, glb_f* A, const FcRegs<CIN, COUT>& r) {
   typedef FcGeom<CIN, COUT> G;
-  const int sub = threadIdx.x & (G::LK - 1), co0 = threadIdx.x / G::LK;
+  const int sub = tid_now() & (G::LK - 1), co0 = tid_now() / G::LK;
   f4v xv[G::Q];
 #pragma unroll
   for (int q = 0; q < G::Q; q++) {
@@ -473,7 +484,7 @@ template <class T> __device__ __forceinline__ void op_resize(lds_f* L, glb_f* A)
   const float ws = (T::ALIGN && T::OW > 1) ? (float)(T::W - 1) / (float)(T::OW - 1) : (float)T::W / (float)T::OW;
 #pragma unroll
   for (int it = 0; it < (TOTAL + kThreads - 1) / kThreads; it++) {
-    const int item = (int)threadIdx.x + it * kThreads;
+    const int item = tid_now() + it * kThreads;
     if (item >= TOTAL) break;
     const int p = item / CV, ch = (item - p * CV) * 4, oy = p / T::OW, ox = p - oy * T::OW;
     float dy, dx; int y0, y1, x0, x1;

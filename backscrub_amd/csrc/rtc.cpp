@@ -113,6 +113,43 @@ bool rtc_build(const std::string& source, const std::string& arch_in, std::vecto
   return true;
 }
 
+// ELF64 little-endian (the only code object form hipRTC emits for amdgcn): section headers -> the symbol tables -> `<kernel>.kd` -> the section that holds its
+// address -> the 64-byte kernel descriptor, whose bytes 4-7 are PRIVATE_SEGMENT_FIXED_SIZE.  Every offset is bounds-checked: the cache directory is user-writable.
+long code_object_scratch_bytes(const std::vector<char>& code, const char* kernel) {
+  const size_t N = code.size();
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(code.data());
+  auto u16 = [&](size_t o) -> uint64_t { return o + 2 <= N ? (uint64_t)p[o] | ((uint64_t)p[o + 1] << 8) : 0; };
+  auto u32 = [&](size_t o) -> uint64_t { return o + 4 <= N ? u16(o) | (u16(o + 2) << 16) : 0; };
+  auto u64 = [&](size_t o) -> uint64_t { return o + 8 <= N ? u32(o) | (u32(o + 4) << 32) : 0; };
+  if (N < 64 || memcmp(p, "\x7f" "ELF", 4) != 0 || p[4] != 2 || p[5] != 1) return -1;
+  const uint64_t shoff = u64(0x28), shentsize = u16(0x3A), shnum = u16(0x3C);
+  if (!shoff || shentsize < 64 || shnum == 0 || shoff > N || shnum * shentsize > N - shoff) return -1;
+  const std::string want = std::string(kernel) + ".kd";
+  auto sh = [&](uint64_t i, size_t field) { return shoff + i * shentsize + field; };
+  for (uint64_t i = 0; i < shnum; i++) {
+    const uint64_t type = u32(sh(i, 4));
+    if (type != 2 && type != 11) continue;                          // SHT_SYMTAB / SHT_DYNSYM
+    const uint64_t off = u64(sh(i, 0x18)), size = u64(sh(i, 0x20)), link = u32(sh(i, 0x28)), ent = u64(sh(i, 0x38));
+    if (ent < 24 || link >= shnum || off > N || size > N - off) continue;
+    const uint64_t stroff = u64(sh(link, 0x18)), strsize = u64(sh(link, 0x20));
+    if (stroff > N || strsize > N - stroff) continue;
+    for (uint64_t s = 0; s + ent <= size; s += ent) {
+      const uint64_t name = u32(off + s), value = u64(off + s + 8);
+      if (name >= strsize || strsize - name <= want.size()) continue;
+      if (memcmp(p + stroff + name, want.c_str(), want.size() + 1) != 0) continue;
+      for (uint64_t j = 0; j < shnum; j++) {                        // the section that holds the descriptor
+        const uint64_t addr = u64(sh(j, 0x10)), so = u64(sh(j, 0x18)), ss = u64(sh(j, 0x20)), st = u32(sh(j, 4));
+        if (st == 8 || value < addr || value - addr + 64 > ss) continue;      // (SHT_NOBITS has no bytes)
+        const uint64_t fo = so + (value - addr);
+        if (fo + 8 > N) return -1;
+        return (long)u32(fo + 4);
+      }
+      return -1;
+    }
+  }
+  return -1;
+}
+
 hipError_t rtc_load(const std::vector<char>& code, const char* kernel, RtcKernel* out) {
   hipError_t e = hipModuleLoadData(&out->mod, code.data());
   if (e != hipSuccess) return e;

@@ -25,6 +25,10 @@ std::string rtc_cache_dir();
 // compilation from the cache.  Returns false with the compiler log in `log`.  *cached tells where the code came from.
 bool rtc_build(const std::string& source, const std::string& arch, std::vector<char>* code, std::string* log, bool* cached = nullptr);
 
+// Bytes of scratch (private segment: register spills) per lane of `kernel` in a code object, read from its kernel descriptor (`<kernel>.kd`, bytes 4-7) — no GPU
+// needed; -1 if the ELF cannot be read.
+long code_object_scratch_bytes(const std::vector<char>& code, const char* kernel);
+
 // Load a code object on the CURRENT device and resolve `kernel`.
 hipError_t rtc_load(const std::vector<char>& code, const char* kernel, RtcKernel* out);
 void rtc_unload(RtcKernel* k);

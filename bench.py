@@ -160,12 +160,20 @@ def parity_sequence(model_path, width, height, seq):
     from oracle import oracle_py
     frames, masks, outs, bgs = seq["frames"], seq["masks"], seq["out"], seq["bg"]
     S, k = len(frames), len(frames[0])
+    # animated background through the product's source: the oracle resizes the same decoded picture itself (grab_background, app/background.cc:186) and composites over
+    # THAT; the picture the GPU handed out must be the same bytes
+    bg_steps, bg_source_identical = None, None
+    if seq.get("bg_steps") is not None:
+        bg_steps = [oracle_py.resize_linear(seq["bg_decoded"][c], width, height) for c in seq["bg_pictures"]]
+        bg_source_identical = all(np.array_equal(a_, b_) for a_, b_ in zip(bg_steps, seq["bg_steps"]))
 
     def one_stream(i):
         ious, max_abs, differing, fg, transient = [], 0, 0, 0.0, 0
         ctx = oracle_py.Ctx(model_path, width, height)
         bg = bgs[i] if bgs.ndim == 4 else bgs
         for t in range(S):
+            if bg_steps is not None:
+                bg = bg_steps[t]
             want = ctx.process(frames[t][i])
             fa, fb = masks[t][i] < 128, want < 128
             union = np.logical_or(fa, fb).sum()
@@ -191,6 +199,9 @@ def parity_sequence(model_path, width, height, seq):
            "oracle_person_fraction": [round(v, 4) for v in fg], "oracle_mask_pixels_between_0_and_255_last_step": transient}
     if seq.get("need_person") and max(fg) < 0.05:
         out["warning"] = "oracle masks contain no person: IoU is vacuous"
+    if bg_source_identical is not None:
+        out["background_pictures"] = [int(c) for c in seq["bg_pictures"]]
+        out["background_identical_to_oracle_resize_of_the_same_decoded_picture"] = bool(bg_source_identical)
     return out
 
 
@@ -404,7 +415,7 @@ def scene_ring(base, B, T, W, seed):
     return ring
 
 
-def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stream_bg=False, bg_ring=False, profile_iters=8, dump_launches="", ramp_s=0.0, coll=None,
+def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stream_bg=False, bg_ring=False, bg_source="", profile_iters=8, dump_launches="", ramp_s=0.0, coll=None,
             profile=True, moving=True, static_leg=False, parity_streams=2, parity_steps=0):
     """Run one configuration on this rank's GPU.  Returns a dict with the timed result and (rank 0) the per-launch profile and
     the samples the parity leg needs.  `coll` (backscrub_amd.dist.Collective) carries the barriers around the timed region and the one
@@ -447,9 +458,20 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
         bring = torch.from_numpy(np.stack([synth.background(480, 360, seed=100 + i) for i in range(36)])).pin_memory()
         d_small = torch.empty((1, 360, 480, 3), dtype=torch.uint8, device="cuda")
 
+    bgsrc = d_anim = None
+    if bg_source:
+        # the product's OWN background source (csrc/media.cpp + live.cpp = app/background.cc:29-104,126-194): the file is decoded when it is loaded (in-tree GIF / PNG /
+        # JPEG decoders), its pictures live on the GPU, and bsx_background_grab() — grab_background() — hands out the picture the playback clock points at, resized to
+        # the camera size, every step.  Timed inside the step like the reference's per-frame cv::resize (:186).
+        bgsrc = backscrub_amd.Background(mg, path=bg_source)
+        d_anim = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+
     def one_step(t, frames=None):
         fr = ring[t % T] if frames is None else frames
-        if bring is not None:
+        if bgsrc is not None:
+            bgsrc.grab(W, H, out=d_anim)
+            mg.step(fr, d_anim, d_out)
+        elif bring is not None:
             d_small[0].copy_(bring[t % 36], non_blocking=True)
             bg = mg.resize_bgr(d_small, W, H)[0]
             mg.step(fr, bg, d_out)
@@ -481,6 +503,12 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
     res = {"model_path": model_path, "model_name": model_name, "weights": weights, "B": B, "W": W, "H": H, "photo": photo, "ring": T,
            "fps": total_frames / max_elapsed, "ms_per_step": 1e3 * max_elapsed / steps, "checksum": checksum_all, "mg": mg, "rank_fps": rank_fps,
            "frames_ring": ring, "d_bg": d_bg, "d_out": d_out, "bg_host": bg_host, "steps": steps, "warmup": warmup}
+    if bgsrc is not None:
+        res["background_source"] = {"file": os.path.basename(bg_source), "pictures": bgsrc.n_frames, "size": "%dx%d" % (bgsrc.width, bgsrc.height), "fps": bgsrc.fps,
+                                    "animated": bgsrc.video, "what": "bsx_background_load + bsx_background_grab per step (decoded once at load, pictures resident on the GPU, "
+                                                                     "clock-indexed playback + GPU resize to the camera size inside the timed step)"}
+    if bgsrc is not None:
+        res["bgsrc"] = bgsrc
     if rank == 0 and profile:
         last_t = warmup + steps - 1
         # EVERY stream of the batch, on the GPU: streams i and i + 16 carry the same scene (and, shared background, the same temporal history), so their
@@ -488,7 +516,7 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
         if per_stream_bg:
             res["full_batch"] = None
         else:
-            if bring is not None:                # twins need ONE known background: one more step over the still image
+            if bring is not None or bgsrc is not None:                # twins need ONE known background: one more step over the still image
                 mg.step(ring[(last_t + 1) % T], d_bg, d_out)
                 last_t += 1
                 torch.cuda.synchronize()
@@ -594,8 +622,21 @@ def measure(model_key, W, H, B, steps, warmup, rank, world, local_rank, per_stre
         mg.reset()
         seq = {"frames": [], "masks": [], "out": [], "need_person": photo,
                "bg": (d_bg[:k] if per_stream_bg else d_bg).cpu().numpy()}
+        if bgsrc is not None:
+            # with the background source: every parity step composites over the picture the source handed out at that step; the oracle gets THE SAME DECODED picture
+            # (the product's host decoder, byte-equal to Pillow in tests/test_media.py) and does its own cv::resize of it (oracle resize_linear = background.cc:186)
+            seq["bg_steps"], seq["bg_pictures"] = [], []
+            decoded, _fps = backscrub_amd.media_decode(bg_source)
+            seq["bg_decoded"] = decoded
         for t in range(S):
-            mg.step(ring[t % T], d_bg, d_out)
+            if bgsrc is not None:
+                frm, _ = bgsrc.grab(W, H, out=d_anim)
+                mg.step(ring[t % T], d_anim, d_out)
+                torch.cuda.synchronize()
+                seq["bg_steps"].append(d_anim.cpu().numpy())
+                seq["bg_pictures"].append(frm - 1)
+            else:
+                mg.step(ring[t % T], d_bg, d_out)
             torch.cuda.synchronize()
             seq["frames"].append(ring[t % T][:k].cpu().numpy())
             seq["masks"].append(mg.masks()[:k].cpu().numpy())
@@ -633,7 +674,7 @@ def summarize(res, pmc):
                                    "counted_GBps": round(traffic / ms / 1e9, 1) if traffic else None, "frac_hbm_counted_traffic": round(f_cnt, 4) if f_cnt else None,
                                    "peak_hbm_GBps": HBM_PEAK_GBS, "traffic": traffic, "avg_ms": round(res["net_ms"], 4),
                                    "note": "frac_of_issuing_pipes = sum over launches of useful flops / the peak of the pipe that launch issues on (pipe_of), over the measured time"}
-    for k_ in ("mask_tiles", "static_scene", "event_overhead"):
+    for k_ in ("mask_tiles", "static_scene", "event_overhead", "background_source"):
         if res.get(k_) is not None:
             out[k_] = res[k_]
     if res.get("full_batch") is not None:
@@ -646,8 +687,10 @@ def summarize(res, pmc):
 
 def release(res):
     import torch
+    if res.get("bgsrc") is not None:
+        res["bgsrc"].close()
     res["mg"].close()
-    for k in ("mg", "frames_ring", "d_bg", "d_out", "parity_in"):
+    for k in ("mg", "frames_ring", "d_bg", "d_out", "parity_in", "bgsrc"):
         res.pop(k, None)
     torch.cuda.empty_cache()
 
@@ -773,6 +816,12 @@ def compact_config(tag, frag):
     fb = frag.get("full_batch_twin_streams")
     if isinstance(fb, dict):
         out["twins_identical"] = fb["all_identical"]
+    if isinstance(frag.get("background_source"), dict):
+        out["bg"] = "%s via bsx_background_grab" % frag["background_source"]["file"]
+        if isinstance(frag.get("parity_sample"), dict) and "background_identical_to_oracle_resize_of_the_same_decoded_picture" in frag["parity_sample"]:
+            out["bg_identical"] = frag["parity_sample"]["background_identical_to_oracle_resize_of_the_same_decoded_picture"]
+        if isinstance(frag.get("decode_elsewhere_h2d_ring"), dict) and "value" in frag["decode_elsewhere_h2d_ring"]:
+            out["h2d_ring_value"] = frag["decode_elsewhere_h2d_ring"]["value"]
     c = compact_cpu(frag.get("cpu_baseline"))
     if c:
         out["cpu"] = c
@@ -1342,8 +1391,22 @@ def main():
             ("configs[3]", dict(model_key="deeplab", W=640, H=480, B=1024), 17.0, dict(bg_ring=True, parity_steps=5)),       # animated background: per-step H2D of a 480x360 frame + GPU resize, timed
             ("configs[4]/8", dict(model_key="full", W=1280, H=720, B=1024), 3.2, {}),                          # the 8192-stream job's per-GPU slice
         ]
+        gif = os.path.join(ROOT, "models", "backgrounds", "animated.gif")       # the reference's backgrounds/animated.gif, staged as data by tools/stage_models.py
         for tag, kw, ms_guess, mkw in extra_cfgs:
             try:
+                if tag == "configs[3]" and os.path.exists(gif):
+                    # the animated background through the product's OWN background source (bsx_background_load / _grab = load_background / grab_background,
+                    # app/background.cc:126-194) is the figure; the pinned-ring H2D emulation of rounds 1-5 ("the decode happens elsewhere") stays beside it
+                    frag = run_config(tag, kw, extra_steps(ms_guess), bg_source=gif, parity_steps=5)
+                    try:
+                        r2 = measure(steps=extra_steps(ms_guess), warmup=3, rank=0, world=1, local_rank=local_rank, profile=False, ramp_s=0.5, bg_ring=True, **kw)
+                        frag["decode_elsewhere_h2d_ring"] = {"value": round(r2["fps"], 1), "ms_per_step": round(r2["ms_per_step"], 4),
+                                                             "what": "36 pre-decoded 480x360 frames in pinned host memory: per step H2D of one frame + bsx_resize_bgr"}
+                        release(r2)
+                    except Exception as e2:  # noqa: BLE001
+                        frag["decode_elsewhere_h2d_ring"] = {"error": repr(e2)}
+                    result["configs"].append(frag)
+                    continue
                 result["configs"].append(run_config(tag, kw, extra_steps(ms_guess), **mkw))
             except Exception as e:  # noqa: BLE001
                 result["configs"].append({"baseline_config": tag, "error": repr(e)})

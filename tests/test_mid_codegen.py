@@ -19,10 +19,10 @@ def api():
     return a
 
 
-# scratch bytes tolerated per architecture: 0 for the headline graph.  segm_full / MLKit keep their 88-128-channel level-3/4 tensors in HBM (they do not fit
-# one CU's LDS), and the one-row-ahead depthwise form that reads them needs ~120 registers on its own: with what stays live around it a few values
-# spill.  The bound is there so that the number can only go down.
-SCRATCH_LIMIT = {"lite": 0, "full": 512, "mlkit": 1088}
+# scratch bytes tolerated per architecture: NONE since round 6.  Rounds 3-5 tolerated 512 / 1088 bytes for segm_full / MLKit: their kernels sat
+# at 126-128 registers because the compiler kept every lane-derived value alive across the whole straight-line kernel; build_mid_kernel (bsx_api.hip) now compiles the
+# form in which each op re-derives its lane indices wherever the plain form spills, and takes it if it spills less (MLKit: 352 -> 0 bytes, 128 -> 92 registers).
+SCRATCH_LIMIT = {"lite": 0, "full": 0, "mlkit": 0}
 
 
 @pytest.mark.parametrize("key", ["lite", "full", "mlkit"])
@@ -194,8 +194,9 @@ def test_low_resolution_window_reservation_covers_every_tile(tmp_path):
 @pytest.mark.parametrize("key", ["lite", "full", "mlkit"])
 def test_zero_cell_of_the_middle_kernel(api, key, monkeypatch, debug_switches):
     """Round 5: the last 16 bytes of the middle kernel's LDS block are a zero cell — the planner's blocks end below it, the kernel's prologue zeroes it, and the
-    depthwise ops that read a planned LDS tensor take their out-of-image taps from it (traits ZC = true); the chunk-by-chunk ops keep the zeroing form
-    (profiles/r05j: the zero-cell form costs MLKit's 128-register kernel 150 bytes of spill), and BSX_RTC_NO_ZERO_CELL=1 switches the form off everywhere."""
+    depthwise ops take their out-of-image taps from it (traits ZC = true) — since round 6 also the chunk-by-chunk ops, which round 5 had to leave out
+    (profiles/r05j: the form cost MLKit's 128-register kernel 150 more bytes of spill; that kernel now needs 92 registers); BSX_RTC_NO_ZERO_CELL=1 (debug build)
+    switches the form off everywhere."""
     hdr = open(os.path.join(ROOT, "backscrub_amd", "csrc", "frame_program.hpp")).read()
     total = eval(re.search(r"constexpr int kLdsTotalFloats = ([^;]+);", hdr).group(1))            # noqa: S307 — "160 * 256"
     assert total == 160 * 256 and "kLdsZeroOff = kLdsTotalFloats - kLdsZeroFloats" in hdr and "constexpr int kLdsZeroFloats = 4;" in hdr
@@ -213,9 +214,25 @@ def test_zero_cell_of_the_middle_kernel(api, key, monkeypatch, debug_switches):
     structs = re.findall(r"struct (Op\d+(?:_\d+)?) \{\n  static constexpr int K = [^\n]+\n  static constexpr bool ZC = (true|false);\n  static constexpr int X_SP = (\d), X_OFF", src)
     assert structs, "no depthwise traits found"
     for name, zc, sp in structs:
-        chunk = "_" in name                                                                           # Op<i>_<c>: one channel chunk of a layer staged through an LDS workspace
-        assert (zc == "true") == (not chunk), (name, zc)
-    assert any(zc == "true" for _, zc, _ in structs)
+        assert zc == "true", (name, zc)                                                               # round 6: also the chunk-by-chunk ops (Op<i>_<c>) — their input is an LDS workspace
+    assert any("_" in name for name, _, _ in structs) == (key != "lite")                              # (segm_lite keeps every depthwise input resident: no chunked op)
     monkeypatch.setenv("BSX_RTC_NO_ZERO_CELL", "1")
     off = api.model_kernel_source(model_path(key))
     assert "ZC = true" not in off and off.count("ZC = false") == len(structs)
+
+
+def test_the_form_of_the_middle_kernel_is_chosen_by_its_scratch_size(api, monkeypatch, debug_switches):
+    """build_mid_kernel (bsx_api.hip): the plain form first; where its code object reports scratch (kernel descriptor bytes 4-7, read from the ELF by
+    rtc.cpp: code_object_scratch_bytes — no GPU), the form with the lane index behind an opaque asm is compiled too and taken if it spills less.  segm_lite and
+    segm_full do not spill and keep the plain form (recomputing shared values costs them issue slots: profiles/r06g); MLKit's plain form spills 352 bytes, its
+    opaque form none.  The forced forms of the debug build show the parser reads real values."""
+    for key, opaque in (("lite", False), ("full", False), ("mlkit", True)):
+        msg = api.model_precompile(model_path(key))
+        assert " 0 B of scratch" in msg and ("lane indices re-derived per op" in msg) == opaque, (key, msg)
+        assert ("#define BSXM_OPAQUE_TID 1" in api.model_kernel_source(model_path(key))) == opaque
+    monkeypatch.setenv("BSX_RTC_TID", "0")
+    plain = api.model_precompile(model_path("mlkit"))
+    m = re.search(r"(\d+) B of scratch", plain)
+    assert m and int(m.group(1)) > 0 and "re-derived" not in plain, plain
+    monkeypatch.setenv("BSX_RTC_TID", "1")
+    assert " 0 B of scratch, lane indices re-derived per op" in api.model_precompile(model_path("lite"))

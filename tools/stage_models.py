@@ -21,6 +21,15 @@ def stage():
         t = os.path.join(dst, os.path.basename(f))
         if not os.path.exists(t) or os.path.getmtime(t) < os.path.getmtime(f) or os.path.getsize(t) != os.path.getsize(f):
             shutil.copy2(f, t)
+    # the reference's animated background (a DATA file: what `-b backgrounds/animated.gif` hands to load_background, app/background.cc:126-176) next to the models, so
+    # that bench.py can time BASELINE configs[3] through the product's own background source on the GPU box
+    bsrc = os.path.join(REF, "backgrounds", "animated.gif")
+    if os.path.exists(bsrc):
+        bdst = os.path.join(dst, "backgrounds")
+        os.makedirs(bdst, exist_ok=True)
+        t = os.path.join(bdst, "animated.gif")
+        if not os.path.exists(t) or os.path.getsize(t) != os.path.getsize(bsrc):
+            shutil.copy2(bsrc, t)
     return dst
 
 
