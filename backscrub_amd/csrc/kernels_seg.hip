@@ -700,9 +700,12 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
 // ==================================================================================================================================
 // tail (decoder level 1 + output): g = gate(GAP(A), GAP(lo)); z = act(pw(A * g + up(lo))); t = z + act(dw3x3(z));
 // out = act3(Convolution2DTransposeBias 2x2 (t)) → logits (LOGITS) or straight into decode + temporal IIR on `ofinal`.
-// Tile = TR x TC (<= 14) at the A resolution = 2TR x 2TC output pixels.  Phase B lanes = (pixel of the row, channel quad): the
-// depthwise runs on the lane's 4 channels, the 4 x CO transpose-conv dot products are split over the quad and reduce-scattered so
-// that lane `quad` ends up with output position (fy, fx) = (quad >> 1, quad & 1) of its pixel.
+// Tile = TR x TC (<= 14) at the A resolution = 2TR x 2TC output pixels.  Phase B lanes = the MFMA's: lane (li, g) = (pixel li of the tile row, channel
+// quad g) runs the depthwise on its 4 channels, and its t = z + act(dw(z)) IS the B operand of the transpose convolution, one 16 x 16 MFMA tile per row
+// (A = the 2 x 2 x CO filter as 16 rows n = 4 * pos + oc): lane (li, g) ends up with output position (fy, fx) = (g >> 1, g & 1) of pixel li.
+// INVARIANT the MFMA forms here and in seg_k2_k / seg_k3_k rely on: a D column depends on the SAME B column only.  Lanes li >= TC (and LDS columns x >= BC in k2)
+// feed unwritten LDS into B; their D columns are garbage and every store / sum of an MFMA result below is guarded by the lane's own pixel being inside the tile
+// (lane_on / x2 < BC).  A new consumer of those results must carry the same guard.
 // ==================================================================================================================================
 template <int CO, bool LOGITS, bool SIGMOID, bool H16>
 __global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void seg_tail_k(const SegTail d, float* __restrict__ arena, long per_frame, float* __restrict__ net_out,
