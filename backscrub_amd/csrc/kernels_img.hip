@@ -571,7 +571,7 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
   }
 }
 
-template <bool BLEND>
+template <bool BLEND, bool YIN = false>      // YIN (BSX_STEP_YUYV_IN): `frames` is YUYV 4:2:2 — a template parameter so that the BGR instantiation carries none of the conversion
 __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                                uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                                const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
@@ -592,7 +592,8 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
   const uint8_t* src = ofinal + (long)n * outW * outH + (long)q.y * outW + q.x;
   const int tid = threadIdx.x;
   TileBlendOperands ops;
-  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 3, (yuyv & 16) != 0);
+  yuyv = YIN ? (yuyv | 16) : (yuyv & ~16);                                  // the helpers read bit 4: a compile-time constant per instantiation
+  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 3, YIN);
   if (tid == 0) { s_min = 1 << 30; s_max = -1; }
   __syncthreads();
   // 1. column / row tables
@@ -665,7 +666,10 @@ __global__ __launch_bounds__(kThreads) void mask_upscale_blur_k(const uint8_t* _
 // lane's table entries and its composite operands are all requested back to back.  Steps 2-5 then run from LDS only.
 // Used when the host verified that every tile's source block fits (ResizeTab::tile_ok); other cases take the kernel above.
 constexpr int kSrcBlockBytes = kHH * kHW;        // the raw block lives in `up` until step 3 overwrites it
-template <bool BLEND>
+// F0: the launch has no flag set (no YUYV out, no flip, mask stored, default load order) — the default step.  A template parameter like YIN because this kernel pays
+// for every wave-uniform branch it carries: with the YUYV-in conversion behind a run-time flag the BGR step's launch was 12-15 % slower (profiles/r06l: 105-111 ->
+// 94-97 us at configs[1], 1064-1114 -> 946-955 us at the configs[4] slice), code that never ran.
+template <bool BLEND, bool YIN = false, bool F0 = false>
 __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                        uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                        const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
@@ -695,8 +699,10 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   // A SHARED background (bg_stride == 0: one image for all streams, L2-resident) is requested BEFORE the tile's class is known (round 5): the class byte is a second
   // dependent round trip behind the kernel arguments, and two thirds of the tiles (uniform 255: composite = background) then need nothing else.  A per-stream
   // background is HBM traffic a uniform-0 tile must not pay: it keeps the order class -> operands.
+  if (F0) yuyv = 0;                                                                                 // flags as compile-time constants: F0 = none, YIN = bit 4 (read again by
+  yuyv = YIN ? (yuyv | 16) : (yuyv & ~16);                                                          // tile_vsum5_store)
   const bool early_bg = BLEND && bg_stride == 0 && tab.tile_class != nullptr && !(yuyv & 64);      // (bit 6: the debug build's A/B switch for this order)
-  const bool yin = (yuyv & 16) != 0;                                                                // BSX_STEP_YUYV_IN
+  constexpr bool yin = YIN;                                                                         // BSX_STEP_YUYV_IN
   TileBlendOperands ops;
   if (early_bg) tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 1, yin);
   if (tab.tile_class) {                                     // the aligned word that holds the byte: a SCALAR load (uniform address), not a vector load + readfirstlane
@@ -1104,8 +1110,15 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   if (no_early_bg) yuyv |= 64;
   static const bool plain_stores = BSX_DBG_ENV("BSX_TILE_PLAIN_STORES") != nullptr;      // A/B timing: bit 7 = the composite leaves with plain instead of nontemporal stores
   if (plain_stores) yuyv |= 128;
-  if (mask_tile_usable(tab)) mask_tile_k<true><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
-  else mask_upscale_blur_k<true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
+  const bool yin = (yuyv & 16) != 0;
+  if (mask_tile_usable(tab)) {
+    const bool f0 = (yuyv & ~16) == 0;
+#define BSX_MT(Y, F) mask_tile_k<true, Y, F><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf)
+    if (yin) { if (f0) BSX_MT(true, true); else BSX_MT(true, false); }
+    else { if (f0) BSX_MT(false, true); else BSX_MT(false, false); }
+#undef BSX_MT
+  } else if (yin) mask_upscale_blur_k<true, true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
+  else mask_upscale_blur_k<true, false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   return hipGetLastError();
 }
 
