@@ -440,7 +440,7 @@ struct TileBlendOperands { uint32_t a[kTileItems][3], b[kTileItems][3]; };
 // background before it knows the tile's class (parts = 1) and the frame after (parts = 2)
 // `yin` (wave-uniform; BSX_STEP_YUYV_IN): `frames` holds YUYV 4:2:2 — a lane's four pixels are 8 bytes (b[i][0..1]), converted where they are consumed
 // (tile_frame_bgr below); b[i][2] is then unused
-template <bool BLEND>
+template <bool BLEND, bool WHOLE = false>      // WHOLE: every tile of the launch lies inside the ROI (roi.w % 128 == 0, roi.h % 32 == 0): no per-item edge tests
 __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
                                                          int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int uniform = 0, int parts = 3, bool yin = false) {
   if constexpr (BLEND) {
@@ -453,7 +453,7 @@ __device__ __forceinline__ void tile_load_blend_operands(TileBlendOperands& o, c
     for (int i = 0; i < kTileItems; i++) {
       if (parts & 1) o.a[i][0] = o.a[i][1] = o.a[i][2] = 0;
       if (parts & 2) o.b[i][0] = o.b[i][1] = o.b[i][2] = 0;
-      if (ty0 + ly0 + 8 * i < roi.h && gx < roi.w) {
+      if (WHOLE || (ty0 + ly0 + 8 * i < roi.h && gx < roi.w)) {
         const uint32_t* ap = reinterpret_cast<const uint32_t*>(a0 + (long)(8 * i) * W * 3);
         const uint32_t* bp = reinterpret_cast<const uint32_t*>(b0 + (long)(8 * i) * W * fb);
         if ((parts & 1) && uniform != 2) { o.a[i][0] = ap[0]; o.a[i][1] = ap[1]; o.a[i][2] = ap[2]; }
@@ -518,7 +518,7 @@ __device__ __forceinline__ void reverse4px(uint32_t (&w)[3]) {
 // pixels go to the mirrored column group in reverse order, the row to the mirrored row; the persistent mask is the unflipped frame's and stays put.
 // `uniform` (wave-uniform; see mask_tile_k): 1 / 2 = every mask byte of the tile is 255 / 0 — no sums to form, and the composite IS the background / the frame
 // ((a*255 + b*0)/255 == a for every byte: the exhaustive blend test covers m = 0 and 255)
-template <bool BLEND>
+template <bool BLEND, bool WHOLE = false>
 __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __restrict__ mask, uint8_t* __restrict__ outp, const TileBlendOperands& o,
                                                  int n, int W, int H, Rect4 roi, int tx0, int ty0, int tid, int yuyv_flip, int uniform = 0) {
   const int ly0 = tid / (kTW / 4), lx = (tid % (kTW / 4)) * 4;
@@ -533,7 +533,7 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
 #pragma unroll
   for (int i = 0; i < kTileItems; i++) {
     const int ly = ly0 + 8 * i, gy = ty0 + ly;
-    if (gy >= roi.h || gx >= roi.w) continue;
+    if (!WHOLE && (gy >= roi.h || gx >= roi.w)) continue;
     uint32_t packed = uniform == 1 ? 0xFFFFFFFFu : 0u;
     if (!uniform) {
       uint2 acc = *reinterpret_cast<const uint2*>(&hs[ly * kTW + lx]);
@@ -549,7 +549,7 @@ __device__ __forceinline__ void tile_vsum5_store(const uint16_t* hs, uint8_t* __
     }
     uint8_t* dst = dst0 + (long)(8 * i) * W;
     if (BLEND && (yuyv_flip & 8)) { /* composite only (BSX_STEP_NO_MASK): the full-resolution mask stays in registers */ }
-    else if (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = packed;      // (nontemporal here: measured, no difference — profiles/r05d)
+    else if (WHOLE || (gx + 3 < roi.w && ((uintptr_t)dst & 3) == 0)) *reinterpret_cast<uint32_t*>(dst) = packed;      // (nontemporal here: measured, no difference — profiles/r05d)
     else for (int j = 0; j < 4 && gx + j < roi.w; j++) dst[j] = (uint8_t)(packed >> (8 * j));
     if constexpr (BLEND) {
       uint32_t* op = reinterpret_cast<uint32_t*>(out0 + (long)(8 * i) * orow * obpp);
@@ -669,7 +669,8 @@ constexpr int kSrcBlockBytes = kHH * kHW;        // the raw block lives in `up` 
 // F0: the launch has no flag set (no YUYV out, no flip, mask stored, default load order) — the default step.  A template parameter like YIN because this kernel pays
 // for every wave-uniform branch it carries: with the YUYV-in conversion behind a run-time flag the BGR step's launch was 12-15 % slower (profiles/r06l: 105-111 ->
 // 94-97 us at configs[1], 1064-1114 -> 946-955 us at the configs[4] slice), code that never ran.
-template <bool BLEND, bool YIN = false, bool F0 = false>
+// WH: whole tiles only (see tile_load_blend_operands) and a 4-byte aligned mask — decided by the launcher from the geometry
+template <bool BLEND, bool YIN = false, bool F0 = false, bool WH = false>
 __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                        uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                        const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
@@ -704,14 +705,14 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   const bool early_bg = BLEND && bg_stride == 0 && tab.tile_class != nullptr && !(yuyv & 64);      // (bit 6: the debug build's A/B switch for this order)
   constexpr bool yin = YIN;                                                                         // BSX_STEP_YUYV_IN
   TileBlendOperands ops;
-  if (early_bg) tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 1, yin);
+  if (early_bg) tile_load_blend_operands<BLEND, WH>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 1, yin);
   if (tab.tile_class) {                                     // the aligned word that holds the byte: a SCALAR load (uniform address), not a vector load + readfirstlane
     const uintptr_t ca = (uintptr_t)tab.tile_class + (size_t)n * (size_t)(ntx * nty) + (size_t)(tby * ntx + tbx);
     uniform = (int)((*reinterpret_cast<const uint32_t*>(ca & ~(uintptr_t)3) >> (8 * (unsigned)(ca & 3))) & 255u);
   }
   if (uniform) {                                           // wave-uniform: nothing of the general path below is even requested
-    tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, uniform, early_bg ? 2 : 3, yin);
-    tile_vsum5_store<BLEND>(hq_hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv, uniform);
+    tile_load_blend_operands<BLEND, WH>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, uniform, early_bg ? 2 : 3, yin);
+    tile_vsum5_store<BLEND, WH>(hq_hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv, uniform);
     return;
   }
   // extents of the source block: xofs / yofs are monotonic, so the extreme destination rows / columns give them
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
     t_s = tab.yofs[gy]; t_a0 = tab.ya[2 * gy]; t_a1 = tab.ya[2 * gy + 1];
   }
   // (c) composite operands (the shared background is already on its way)
-  tile_load_blend_operands<BLEND>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, early_bg ? 2 : 3, yin);
+  tile_load_blend_operands<BLEND, WH>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, early_bg ? 2 : 3, yin);
   // 1. block and tables into LDS
 #pragma unroll
   for (int j = 0; j < 3; j++) if (br + 4 * j < nsr && bc < ncol) blk[(br + 4 * j) * ncol + bc] = (uint8_t)raw[j];
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   __syncthreads();
   tile_hsum5(up, hs, tid);                                                                       // 4.
   __syncthreads();
-  tile_vsum5_store<BLEND>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv);               // 5.
+  tile_vsum5_store<BLEND, WH>(hs, mask, outp, ops, n, W, H, roi, tx0, ty0, tid, yuyv);               // 5.
 }
 
 // ---- alpha blend (deepseg.cc:108-134), stand-alone: bsx_composite_batch ---------------------------------------------------------------
@@ -1113,9 +1114,10 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   const bool yin = (yuyv & 16) != 0;
   if (mask_tile_usable(tab)) {
     const bool f0 = (yuyv & ~16) == 0;
-#define BSX_MT(Y, F) mask_tile_k<true, Y, F><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf)
-    if (yin) { if (f0) BSX_MT(true, true); else BSX_MT(true, false); }
-    else { if (f0) BSX_MT(false, true); else BSX_MT(false, false); }
+    const bool whole = f0 && roi.w % kTW == 0 && roi.h % kTH == 0 && ((uintptr_t)mask & 3) == 0;      // (W, roi.x multiples of 4: mask_blend_fusable)
+#define BSX_MT(Y, F, WHL) mask_tile_k<true, Y, F, WHL><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf)
+    if (yin) { if (whole) BSX_MT(true, true, true); else if (f0) BSX_MT(true, true, false); else BSX_MT(true, false, false); }
+    else { if (whole) BSX_MT(false, true, true); else if (f0) BSX_MT(false, true, false); else BSX_MT(false, false, false); }
 #undef BSX_MT
   } else if (yin) mask_upscale_blur_k<true, true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   else mask_upscale_blur_k<true, false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
