@@ -19,8 +19,8 @@ LIB = os.path.join(HERE, "libbsx.so")
 # out.  Test infrastructure — tests/test_gpu_switch_variants.py and the tools/ experiments load it through BSX_LIBRARY; nothing ships or measures with it.
 OBJ_DBG = os.path.join(CSRC, "build_dbg")
 LIB_DBG = os.path.join(HERE, "libbsx_dbg.so")
-SOURCES = ["tflite_model.cpp", "plan.cpp", "gen_mid.cpp", "rtc.cpp", "media.cpp", "jpeg.cpp", "live.cpp", "kernels_nn.hip", "kernels_img.hip", "kernels_frame.hip", "kernels_seg.hip", "bsx_api.hip"]
-HEADERS = ["mid_prelude.hip", "debug_switches.hpp", "gen_mid.hpp", "rtc.hpp", "media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", "roctx_ranges.hpp", os.path.join("..", "..", "include", "bsx.h")]
+SOURCES = ["tflite_model.cpp", "plan.cpp", "gen_mid.cpp", "gen_seg.cpp", "rtc.cpp", "media.cpp", "jpeg.cpp", "live.cpp", "kernels_nn.hip", "kernels_img.hip", "kernels_frame.hip", "kernels_seg.hip", "bsx_api.hip"]
+HEADERS = ["mid_prelude.hip", "debug_switches.hpp", "gen_mid.hpp", "gen_seg.hpp", "rtc.hpp", "media.hpp", "tflite_model.hpp", "plan.hpp", "kernels.hpp", "frame_program.hpp", "segments.hpp", "mfma_tile.hpp", "roctx_ranges.hpp", os.path.join("..", "..", "include", "bsx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]      # only the BSX_API entry points of include/bsx.h are exported
@@ -70,8 +70,37 @@ def embed_prelude():
                 f.write(body)
 
 
+SEG_RTC_PREAMBLE = """// hipRTC translation unit of the graph-specialised segment kernels (gen_seg.cpp puts its macros in front and the descriptors at the marker inside namespace segrtc)
+#define BSX_DBG_ENV(name) ((const char*)0)
+namespace bsx { enum Activation : int { kActNone = 0, kActRelu = 1, kActRelu6 = 3, kActHswish = 100, kActSigmoid = 101 }; }
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+"""
+
+
+def embed_seg_source():
+    """csrc/segments.hpp + mfma_tile.hpp + kernels_seg.hip → <objdir>/seg_rtc_src.inc: ONE flattened, comment-stripped text as a C++ raw string literal (gen_seg.cpp) —
+    what hipRTC compiles, with the loaded graph's descriptors as constants, when a context is created.  The files guard their host-only parts with __HIPCC_RTC__."""
+    parts = [SEG_RTC_PREAMBLE]
+    for f in ("segments.hpp", "mfma_tile.hpp", "kernels_seg.hip"):
+        t = strip_line_comments(open(os.path.join(CSRC, f)).read())
+        t = "\n".join(l for l in t.split("\n") if l.strip() != "#pragma once")
+        parts.append(t)
+    text = "\n".join(parts)
+    assert ')BSXSEG"' not in text and "BSX_SEG_CONSTANTS" in text
+    # string literals are limited in length by some compilers: cut into adjacent raw strings (concatenated by the compiler)
+    chunks = [text[i:i + 8000] for i in range(0, len(text), 8000)]
+    body = "\n".join('R"BSXSEG(' + c + ')BSXSEG"' for c in chunks) + "\n"
+    for d in (OBJ, OBJ_DBG):
+        dst = os.path.join(d, "seg_rtc_src.inc")
+        if not os.path.exists(dst) or open(dst).read() != body:
+            with open(dst, "w") as f:
+                f.write(body)
+
+
 def _build_one(objdir, lib, extra_flags, force, verbose):
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(objdir, "mid_prelude_str.inc")]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(objdir, "mid_prelude_str.inc"), os.path.join(objdir, "seg_rtc_src.inc")]
     objs = []
     procs = []
     for src in SOURCES:
@@ -105,6 +134,7 @@ def build(force=False, verbose=False, debug_lib=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(OBJ_DBG, exist_ok=True)
     embed_prelude()
+    embed_seg_source()
     rebuilt = _build_one(OBJ, LIB, [], force, verbose)
     if debug_lib:
         _build_one(OBJ_DBG, LIB_DBG, ["-DBSX_DEBUG_SWITCHES"], force, verbose)

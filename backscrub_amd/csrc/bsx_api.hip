@@ -18,6 +18,7 @@
 
 #include "../../include/bsx.h"
 #include "gen_mid.hpp"
+#include "gen_seg.hpp"
 #include "kernels.hpp"
 #include "roctx_ranges.hpp"
 #include "rtc.hpp"
@@ -121,6 +122,9 @@ struct bsx_ctx {
   MicroOp* d_program = nullptr;     // per-frame network program (kernels_frame.hip)
   bool use_program = false;
   RtcKernel mid;                    // the same program as ONE graph-specialised kernel, compiled by hipRTC when the context is created
+  RtcKernel seg_mod;                // the segment kernels specialised to this graph (gen_seg.cpp; one hipRTC module: seg_mod.fn = bsx_seg_head, seg_fn[] = k2, k3, tail)
+  hipFunction_t seg_fn[3] = {nullptr, nullptr, nullptr};
+  std::string seg_note;
   std::string mid_note;             //   (gen_mid.cpp, mid_prelude.hip); mid.fn == nullptr: the interpreter runs (BSX_NO_RTC=1, or why in mid_note)
   BilateralParams bilateral{};
   DevResizeTab tab_down, tab_up;
@@ -210,6 +214,17 @@ int upload_tab(bsx_ctx* c, const HostResizeTab& h, DevResizeTab* d) {
   BSX_HIP(c, hipMemcpy(p, h.xa.data(), b_xa, hipMemcpyHostToDevice)); d->tab.xa = (const short*)p; p += up16(b_xa);
   BSX_HIP(c, hipMemcpy(p, h.ya.data(), b_ya, hipMemcpyHostToDevice)); d->tab.ya = (const short*)p;
   return BSX_OK;
+}
+
+// The graph-specialised SEGMENT kernels of `plan` (gen_seg.cpp), compiled or fetched from the cache for `arch`: "" and the code object, or why there is none
+std::string build_seg_kernels(const Plan& plan, bool h16, bool u8in, const std::string& arch, std::vector<char>* code, bool* cached, size_t* src_bytes = nullptr) {
+  std::string why, log;
+  if (BSX_DBG_ENV("BSX_NO_SEG_RTC")) return "ahead-of-time kernels (BSX_NO_SEG_RTC)";
+  const std::string src = generate_seg_source(plan, h16, u8in, &why);
+  if (src.empty()) return "ahead-of-time kernels (" + why + ")";
+  if (src_bytes) *src_bytes = src.size();
+  if (!rtc_build(src, arch, code, &log, cached)) { if (BSX_DBG_ENV("BSX_RTC_DEBUG")) fprintf(stderr, "%s\n", log.c_str()); return "ahead-of-time kernels (hipRTC: " + log.substr(0, 600) + ")"; }
+  return "";
 }
 
 // The graph-specialised middle kernel of `plan`, compiled (or fetched from the cache) for `arch` — in the form that spills least.  The plain form lets the compiler share
@@ -303,6 +318,28 @@ int init_device_state(bsx_ctx* c) {
   // stems with a byte path take the 8-bit network input: the segmented Meet / MLKit head and DeepLab's fused head kernel
   if (BSX_DBG_ENV("BSX_NO_GRAPH")) c->graph_state = -1;
   c->in_u8 = BSX_DBG_ENV("BSX_F32_INPUT") == nullptr && ((c->use_program && c->plan.seg.on) || (!c->use_program && head0_u8_ok(c->plan)));
+  // The segment kernels specialised to this graph (gen_seg.cpp): the same source as the ahead-of-time kernels with this plan's descriptors as compile-time constants,
+  // compiled by hipRTC (cached on disk; bsx_model_precompile fills the cache without a GPU).  Anything that goes wrong leaves the ahead-of-time kernels in charge.
+  if (c->use_program && c->plan.seg.on) {
+    if (BSX_DBG_ENV("BSX_NO_RTC")) c->seg_note = "ahead-of-time kernels (BSX_NO_RTC)";
+    else {
+      hipDeviceProp_t prop;
+      std::vector<char> code;
+      bool cached = false;
+      if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) c->seg_note = "ahead-of-time kernels (no device properties)";
+      else {
+        c->seg_note = build_seg_kernels(c->plan, c->act16, c->in_u8, prop.gcnArchName, &code, &cached);
+        if (c->seg_note.empty()) {
+          if (rtc_load(code, "bsx_seg_head", &c->seg_mod) != hipSuccess || rtc_function(c->seg_mod, "bsx_seg_k2", &c->seg_fn[0]) != hipSuccess ||
+              rtc_function(c->seg_mod, "bsx_seg_k3", &c->seg_fn[1]) != hipSuccess || rtc_function(c->seg_mod, "bsx_seg_tail", &c->seg_fn[2]) != hipSuccess) {
+            rtc_unload(&c->seg_mod);
+            (void)hipGetLastError();
+            c->seg_note = "ahead-of-time kernels (code object did not load)";
+          } else c->seg_note = std::string("specialised kernels (hipRTC") + (cached ? ", from the cache)" : ", compiled now)");
+        }
+      }
+    }
+  }
   BSX_HIP(c, hipMalloc(&c->d_ofinal, N * c->outW * c->outH));
   BSX_HIP(c, hipMalloc(&c->d_masks, N * c->width * c->height));
   BSX_HIP(c, hipMemset(c->d_ofinal, 0, N * c->outW * c->outH));            // :257 leaves it uninitialised; defined as 0
@@ -385,18 +422,58 @@ int state_write_fence(bsx_ctx* c, hipStream_t s) {
   return BSX_OK;
 }
 bool infer_decodes(const bsx_ctx* c) { return (c->use_program && c->plan.seg.on && !c->keep_logits) || argmax_tail(c); }
+// the four segment launches of a step: the graph-specialised hipRTC kernels when the context has them (the decode-fused tail only: the logits-writing variant of the stage
+// tests stays with the ahead-of-time kernel), else the ahead-of-time kernels.  Same arguments, descriptor included (the specialised kernels ignore it).
+hipError_t seg_launch(hipFunction_t fn, int tiles, int n, int lds_floats, hipStream_t s, void** args) {
+  return hipModuleLaunchKernel(fn, (unsigned)tiles * (unsigned)n, 1, 1, kSegThreads, 1, 1, (unsigned)((size_t)lds_floats * sizeof(float)), s, args, nullptr);
+}
+hipError_t seg_head(bsx_ctx* c, int n, hipStream_t s) {
+  const SegPlan& sp = c->plan.seg;
+  long pf = (long)c->plan.arena_floats_per_stream;
+  if (!c->seg_mod.fn)
+    return launch_seg_head(sp.head, c->d_arena, pf, c->in_u8 ? (const void*)c->d_net_in_u8 : (const void*)c->d_net_in, c->d_weights, n, s, c->act16, c->in_u8, c->norm_scale, c->norm_offset);
+  SegHead d = sp.head; float* arena = c->d_arena; const float* in = c->in_u8 ? reinterpret_cast<const float*>(c->d_net_in_u8) : c->d_net_in; const float* w = c->d_weights;
+  float sc = c->norm_scale, of = c->norm_offset; int nf = n;
+  void* args[] = {&d, &arena, &pf, &in, &w, &sc, &of, &nf};
+  return seg_launch(c->seg_mod.fn, d.tiles_y * d.tiles_x, n, d.lds_floats, s, args);
+}
+hipError_t seg_k2(bsx_ctx* c, int n, hipStream_t s) {
+  const SegPlan& sp = c->plan.seg;
+  long pf = (long)c->plan.arena_floats_per_stream;
+  if (!c->seg_fn[0]) return launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16);
+  SegK2 d = sp.k2; float* arena = c->d_arena; const float* w = c->d_weights; int nf = n;
+  void* args[] = {&d, &arena, &pf, &w, &nf};
+  return seg_launch(c->seg_fn[0], d.tiles_y * d.tiles_x, n, d.lds_floats, s, args);
+}
+hipError_t seg_k3(bsx_ctx* c, int n, hipStream_t s) {
+  const SegPlan& sp = c->plan.seg;
+  long pf = (long)c->plan.arena_floats_per_stream;
+  if (!c->seg_fn[1]) return launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16);
+  SegK3 d = sp.k3; float* arena = c->d_arena; const float* w = c->d_weights; int nf = n;
+  void* args[] = {&d, &arena, &pf, &w, &nf};
+  return seg_launch(c->seg_fn[1], d.tiles_y * d.tiles_x, n, d.lds_floats, s, args);
+}
+hipError_t seg_tail(bsx_ctx* c, uint8_t* ofinal, bool logits, int n, hipStream_t s) {
+  const SegPlan& sp = c->plan.seg;
+  long pf = (long)c->plan.arena_floats_per_stream;
+  if (logits || !c->seg_fn[2]) return launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, ofinal, c->d_weights, logits, n, s, c->act16);
+  SegTail d = sp.tail; float* arena = c->d_arena; float* no = c->d_net_out; const float* w = c->d_weights; int nf = n;
+  void* args[] = {&d, &arena, &pf, &no, &ofinal, &w, &nf};
+  return seg_launch(c->seg_fn[2], d.tiles_y * d.tiles_x, n, d.lds_floats, s, args);
+}
+
 int run_infer(bsx_ctx* c, int n, hipStream_t s, bool logits = true, int slot = 0) {
   bsx_roctx::Range range("bsx:network");
   if (c->use_program && c->plan.seg.on) {
     const SegPlan& sp = c->plan.seg;
     const long pf = (long)c->plan.arena_floats_per_stream;
-    BSX_HIP(c, launch_seg_head(sp.head, c->d_arena, pf, c->in_u8 ? (const void*)c->d_net_in_u8 : (const void*)c->d_net_in, c->d_weights, n, s, c->act16, c->in_u8, c->norm_scale, c->norm_offset));
-    BSX_HIP(c, launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16));
+    BSX_HIP(c, seg_head(c, n, s));
+    BSX_HIP(c, seg_k2(c, n, s));
     BSX_HIP(c, launch_program(c, n, s));
-    BSX_HIP(c, launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
+    BSX_HIP(c, seg_k3(c, n, s));
     if (sp.tail.pre_gate_off >= 0) BSX_HIP(c, launch_seg_gate(sp.tail.gate, c->d_arena, pf, c->d_weights, sp.tail.pre_gate_off, n, s));
     if (!logits) { const int frc = state_write_fence(c, s); if (frc) return frc; }       // the decoding tail reads and writes d_ofinal
-    BSX_HIP(c, launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal + (size_t)slot * c->outW * c->outH, c->d_weights, logits, n, s, c->act16));
+    BSX_HIP(c, seg_tail(c, c->d_ofinal + (size_t)slot * c->outW * c->outH, logits, n, s));
     return BSX_OK;
   }
   if (c->use_program) {
@@ -544,6 +621,7 @@ bsx_ctx* bsx_new(const char* model_path, size_t threads, size_t width, size_t he
     c->plan_text += line;
     if (c->use_program) c->plan_text += "program execution: " + c->mid_note + "\n";
     if (c->use_program && c->plan.seg.on) c->plan_text += c->plan.seg_text;
+    if (c->use_program && c->plan.seg.on) c->plan_text += "segment execution: " + c->seg_note + "\n";
     if (c->use_program && c->mid.fn) c->plan_text += mid_barrier_line(c->plan, c->act16);
     for (size_t i = 0; i < c->plan.program_labels.size(); i++) { c->plan_text += "P" + std::to_string(i) + " " + c->plan.program_labels[i] + "\n"; }
   }
@@ -563,6 +641,7 @@ void bsx_delete(bsx_ctx* c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (auto& kv : c->host_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   rtc_unload(&c->mid);
+  rtc_unload(&c->seg_mod);
   void* ptrs[] = {c->d_arena, c->d_net_in, c->d_net_in_u8, c->d_net_out, c->d_weights, c->d_ofinal, c->d_masks, c->d_host_frame, c->d_bgr_scratch, c->d_bgr_scratch2, c->d_bgblur_scratch, c->d_bgr_in_scratch, c->d_color_lut, c->tab_down.mem, c->tab_up.mem, c->d_program, c->d_weights16, c->d_tile_class};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& kv : c->bg_tabs) if (kv.second.mem) (void)hipFree(kv.second.mem);
@@ -989,12 +1068,12 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     const long pf = (long)c->plan.arena_floats_per_stream;
     if (seg) {
       const SegPlan& sp = c->plan.seg;
-      BSX_TIMED(launch_seg_head(sp.head, c->d_arena, pf, c->in_u8 ? (const void*)c->d_net_in_u8 : (const void*)c->d_net_in, c->d_weights, n, s, c->act16, c->in_u8, c->norm_scale, c->norm_offset));
-      BSX_TIMED(launch_seg_k2(sp.k2, c->d_arena, pf, c->d_weights, n, s, c->act16));
+      BSX_TIMED(seg_head(c, n, s));
+      BSX_TIMED(seg_k2(c, n, s));
       BSX_TIMED(launch_program(c, n, s));
-      BSX_TIMED(launch_seg_k3(sp.k3, c->d_arena, pf, c->d_weights, n, s, c->act16));
+      BSX_TIMED(seg_k3(c, n, s));
       if (sp.tail.pre_gate_off >= 0) BSX_TIMED(launch_seg_gate(sp.tail.gate, c->d_arena, pf, c->d_weights, sp.tail.pre_gate_off, n, s));
-      BSX_TIMED(launch_seg_tail(sp.tail, c->d_arena, pf, c->d_net_out, c->d_ofinal, c->d_weights, !fused_decode, n, s, c->act16));
+      BSX_TIMED(seg_tail(c, c->d_ofinal, !fused_decode, n, s));
     } else if (c->use_program)
       BSX_TIMED(launch_program(c, n, s));
     else {
@@ -1182,8 +1261,23 @@ int bsx_model_precompile(const char* model_path, const char* arch, char* msg, si
     MidBuild mb;
     const std::string e = build_mid_kernel(p, a16 && atoi(a16) != 0 && p.seg.on, arch ? arch : "gfx950", &mb);
     if (!e.empty()) { snprintf(msg, cap, "%s", e.c_str()); return e.compare(0, 19, "interpreted (hipRTC") == 0 ? BSX_EMODEL : BSX_OK; }
-    snprintf(msg, cap, "%s (%zu bytes of source, %zu bytes of code object, %ld B of scratch%s, cache %s)", mb.cached ? "cached" : "compiled", mb.source.size(), mb.code.size(), mb.scratch,
-             mb.opaque_tid ? ", lane indices re-derived per op" : "", rtc_cache_dir().c_str());
+    // the segment kernels of the same graph (gen_seg.cpp), in the variant a context created under this environment would load
+    std::string seg_msg;
+    if (p.seg.on) {
+      std::vector<char> scode;
+      bool scached = false;
+      size_t sbytes = 0;
+      const std::string se = build_seg_kernels(p, a16 && atoi(a16) != 0, BSX_DBG_ENV("BSX_F32_INPUT") == nullptr, arch ? arch : "gfx950", &scode, &scached, &sbytes);
+      char sm[256];
+      if (se.empty()) {
+        long worst = 0;
+        for (const char* k : {"bsx_seg_head", "bsx_seg_k2", "bsx_seg_k3", "bsx_seg_tail"}) worst = std::max(worst, code_object_scratch_bytes(scode, k));
+        snprintf(sm, sizeof sm, "; segment kernels %s (%zu bytes of source, %zu bytes of code object, %ld B of scratch)", scached ? "cached" : "compiled", sbytes, scode.size(), worst);
+        seg_msg = sm;
+      } else { seg_msg = "; segment kernels: " + se; if (se.find("hipRTC:") != std::string::npos) { snprintf(msg, cap, "%s", seg_msg.c_str()); return BSX_EMODEL; } }
+    }
+    snprintf(msg, cap, "%s (%zu bytes of source, %zu bytes of code object, %ld B of scratch%s, cache %s)%s", mb.cached ? "cached" : "compiled", mb.source.size(), mb.code.size(), mb.scratch,
+             mb.opaque_tid ? ", lane indices re-derived per op" : "", rtc_cache_dir().c_str(), seg_msg.c_str());
     return BSX_OK;
   } catch (...) { snprintf(msg, cap, "exception while reading the model"); return BSX_EMODEL; }
 }

@@ -13,6 +13,14 @@
 // Reference operators covered (file:line into /root/reference): Interpreter::Invoke() lib/libbackscrub.cc:307 — CONV_2D,
 // DEPTHWISE_CONV_2D, RESIZE_BILINEAR (half-pixel), MUL/ADD gates, AVERAGE_POOL_2D (as partial sums), FULLY_CONNECTED /
 // 1x1 gate convs; Convolution2DTransposeBias lib/transpose_conv_bias.cc:37-114; decode + IIR lib/libbackscrub.cc:317-357.
+// TWO ways into this file (round 6):
+//   * hipcc, ahead of time: every kernel a template instantiation that takes its segment descriptor as a kernel argument — any graph of the family, also what runs when
+//     hipRTC is unavailable and what the stage tests' logits variant uses;
+//   * hipRTC, when a context is created (gen_seg.cpp: this text + segments.hpp + mfma_tile.hpp flattened by build.py into seg_rtc_src.inc, with BSX_SEG_RTC, the
+//     template arguments and the four descriptors of THE LOADED GRAPH as compile-time constants in front): extern "C" kernels bsx_seg_head / _k2 / _k3 / _tail in which
+//     every geometry value, weight offset and activation kind is a constant — loops get their trip counts, index arithmetic its strength reduction, dead activation
+//     branches disappear.  tools/seg_probe.sh measured that form first (profiles/r06o: head 39.7 -> 36.1 us, k2 40.2 -> 34.6, tail 44.7 -> 41.6, step -3.7 % at configs[1]).
+#ifndef __HIPCC_RTC__
 #include "debug_switches.hpp"
 #include <hip/hip_runtime.h>
 
@@ -22,9 +30,31 @@
 #include "kernels.hpp"
 #include "mfma_tile.hpp"
 #include "segments.hpp"
+#endif
+
+// Where the kernels get their descriptor `d` from: the kernel argument (ahead-of-time build), the generator's constants (BSX_SEG_RTC: kSegHEAD ... in front of this text),
+// or — tools/seg_probe.sh, the ahead-of-time experiment that preceded the hipRTC form — a dumped file of constants (-DBSX_SEG_PROBE=\"file\": one model only, never shipped).
+#if defined(BSX_SEG_RTC)
+#define BSX_SEG_D(T, NAME) constexpr T d = kSeg##NAME; (void)d_rt
+#elif defined(BSX_SEG_PROBE)
+#define BSX_SEG_D(T, NAME) constexpr T d = kProbe##NAME; (void)d_rt
+#else
+#define BSX_SEG_D(T, NAME) const T& d = d_rt
+#endif
 
 namespace bsx {
+#ifdef BSX_SEG_RTC
+namespace segrtc {               // (named: an extern "C" kernel inside an unnamed namespace would have internal linkage)
+BSX_SEG_CONSTANTS                // constexpr SegHead kSegHEAD = ...; kSegK2; kSegK3; kSegTAIL  (gen_seg.cpp)
+// the template arguments of the one variant this graph / mode needs
+constexpr bool STEM_HSWISH = BSX_SEG_HS != 0, H16 = BSX_SEG_H16 != 0, U8IN = BSX_SEG_U8 != 0, LOGITS = false, SIGMOID = BSX_SEG_SIG != 0;
+constexpr int CO = BSX_SEG_CO;
+#else
 namespace {
+#endif
+#ifdef BSX_SEG_PROBE
+#include BSX_SEG_PROBE
+#endif
 
 extern __shared__ __attribute__((aligned(16))) float seg_smem[];
 
@@ -283,9 +313,15 @@ __device__ __forceinline__ RowTile row_tile(int t, int ctiles, unsigned m_ct) {
 // ==================================================================================================================================
 // U8IN: the network input arrives as the filtered 8-bit pixels (R | G<<8 | B<<16 per pixel, prep_fused_k<2>) and is normalised here with the
 // same two roundings convertTo applies (libbackscrub.cc:302): fadd(fmul(float(q), scale), offset) — bit-identical to reading the f32 tensor.
+#ifdef BSX_SEG_RTC
+extern "C" __global__ __launch_bounds__(kSegThreads) void bsx_seg_head(
+#else
 template <bool STEM_HSWISH, bool H16, bool U8IN>
-__global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float* __restrict__ arena, long per_frame, const float* __restrict__ net_in,
+__global__ __launch_bounds__(kSegThreads) void seg_head_k(
+#endif
+    const SegHead d_rt, float* __restrict__ arena, long per_frame, const float* __restrict__ net_in,
                                                           const float* __restrict__ w, float in_scale, float in_offset, int n_frames) {
+  BSX_SEG_D(SegHead, HEAD);
   unsigned f_, t_;
   xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
   const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
@@ -455,8 +491,14 @@ __global__ __launch_bounds__(kSegThreads) void seg_head_k(const SegHead d, float
 // k2: s = gate(GAP(b0)); B = pw_a(b0 * s) (skip of decoder level 2); x = act(pw_b(B)); c0 = act(dw3x3/s2(x)).  Tile = TR x TC of c0.
 // The expanded tensor x (72 channels) exists only 16 channels at a time, in LDS.
 // ==================================================================================================================================
+#ifdef BSX_SEG_RTC
+extern "C" __global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void bsx_seg_k2(
+#else
 template <bool H16>
-__global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void seg_k2_k(const SegK2 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w, int n_frames) {
+__global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void seg_k2_k(
+#endif
+    const SegK2 d_rt, float* __restrict__ arena, long per_frame, const float* __restrict__ w, int n_frames) {
+  BSX_SEG_D(SegK2, K2);
   unsigned f_, t_;
   xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
   const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
@@ -648,8 +690,14 @@ __device__ __forceinline__ void gated_compute(const GatedPre& pre, const float* 
 // ==================================================================================================================================
 // k3 (decoder level 2): z = act(pw1(B * g + up(lo2))); t = z + act(dw3x3(z)); lo = pw2(t).  Tile = TR x TC (<= 14) at the B resolution.
 // ==================================================================================================================================
+#ifdef BSX_SEG_RTC
+extern "C" __global__ __launch_bounds__(kSegThreads) void bsx_seg_k3(
+#else
 template <bool H16>
-__global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __restrict__ arena, long per_frame, const float* __restrict__ w, int n_frames) {
+__global__ __launch_bounds__(kSegThreads) void seg_k3_k(
+#endif
+    const SegK3 d_rt, float* __restrict__ arena, long per_frame, const float* __restrict__ w, int n_frames) {
+  BSX_SEG_D(SegK3, K3);
   unsigned f_, t_;
   xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
   const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
@@ -707,9 +755,15 @@ __global__ __launch_bounds__(kSegThreads) void seg_k3_k(const SegK3 d, float* __
 // feed unwritten LDS into B; their D columns are garbage and every store / sum of an MFMA result below is guarded by the lane's own pixel being inside the tile
 // (lane_on / x2 < BC).  A new consumer of those results must carry the same guard.
 // ==================================================================================================================================
+#ifdef BSX_SEG_RTC
+extern "C" __global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void bsx_seg_tail(
+#else
 template <int CO, bool LOGITS, bool SIGMOID, bool H16>
-__global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void seg_tail_k(const SegTail d, float* __restrict__ arena, long per_frame, float* __restrict__ net_out,
+__global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void seg_tail_k(
+#endif
+    const SegTail d_rt, float* __restrict__ arena, long per_frame, float* __restrict__ net_out,
                                                           uint8_t* __restrict__ ofinal, const float* __restrict__ w, int n_frames) {
+  BSX_SEG_D(SegTail, TAIL);
   unsigned f_, t_;
   xcd_frame_tile((unsigned)(d.tiles_y * d.tiles_x), (unsigned)n_frames, &f_, &t_);
   const int f = (int)f_, ty = (int)t_ / d.tiles_x, tx = (int)t_ - ty * d.tiles_x;
@@ -790,6 +844,7 @@ __global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(5, 
   }
 }
 
+#ifndef __HIPCC_RTC__              // ---- from here on: ahead-of-time build only (the per-frame gate kernel, a 5 us launch, and the host side)
 // the gate of one decoder level, once per frame: workgroup = frame; the prologue of the tile kernels as a kernel of its own (SegTail::pre_gate_off)
 __global__ __launch_bounds__(kSegThreads) void seg_gate_k(const SegGate gt, float* __restrict__ arena, long per_frame, const float* __restrict__ w, long long out_off) {
   float* fa = arena + (size_t)blockIdx.x * (size_t)per_frame;
@@ -801,9 +856,11 @@ template <class K>
 hipError_t allow_lds(K kernel, int lds_bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
+#endif
 
 }  // namespace
 
+#ifndef __HIPCC_RTC__
 hipError_t seg_prepare() {
   const int full = 160 * 1024;     // process-global kernel attributes: always the full LDS (cf. frame_program_prepare)
   hipError_t e = hipSuccess;
@@ -877,5 +934,7 @@ hipError_t launch_seg_gate(const SegGate& gt, float* arena, long per_frame, cons
 hipError_t launch_seg_tail(const SegTail& d, float* arena, long per_frame, float* net_out, uint8_t* ofinal, const float* weights, bool logits, int n, hipStream_t s, bool h16) {
   return h16 ? launch_seg_tail_t<true>(d, arena, per_frame, net_out, ofinal, weights, logits, n, s) : launch_seg_tail_t<false>(d, arena, per_frame, net_out, ofinal, weights, logits, n, s);
 }
+
+#endif
 
 }  // namespace bsx

@@ -5,7 +5,9 @@
 // afterwards lane (g, li) holds row 4g + (li & 3), columns 4*(li >> 2) .. +3 — four consecutive channels of one pixel,
 // i.e. one 16-byte store (and one 16-byte bias / residual load) instead of four 4-byte ones.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 namespace bsx {
 

@@ -1,6 +1,7 @@
 // plan.cpp — graph → fused step list + weight packing + activation arena layout.
 #include "debug_switches.hpp"
 #include "plan.hpp"
+#include "gen_seg.hpp"
 #include "gen_mid.hpp"
 
 #include <algorithm>
@@ -753,6 +754,13 @@ static bool build_segments(Graph& g, Plan* plan) {
   if (plan->program.empty()) return seg_fail(28);
   sp.on = true;
   plan->seg = sp;
+#ifdef BSX_DEBUG_SWITCHES
+  // BSX_SEG_DUMP=<file> (debug build): the four segment descriptors of this plan as C++ constants — the input of tools/seg_probe.sh, the ahead-of-time experiment that
+  // preceded the hipRTC-specialised segment kernels (gen_seg.cpp emits the same text for them)
+  if (const char* path = BSX_DBG_ENV("BSX_SEG_DUMP")) {
+    if (FILE* f = fopen(path, "w")) { fputs(seg_constants_text(sp, "kProbe").c_str(), f); fclose(f); }
+  }
+#endif
   char line[256];
   plan->seg_text.clear();
   auto add = [&](const char* name, int TR, int TC, int ty, int tx, int lds) {

@@ -158,6 +158,11 @@ hipError_t rtc_load(const std::vector<char>& code, const char* kernel, RtcKernel
   return e;
 }
 
+hipError_t rtc_function(const RtcKernel& loaded, const char* kernel, hipFunction_t* fn) {
+  if (!loaded.mod) return hipErrorInvalidValue;
+  return hipModuleGetFunction(fn, loaded.mod, kernel);
+}
+
 void rtc_unload(RtcKernel* k) {
   if (k && k->mod) { (void)hipModuleUnload(k->mod); k->mod = nullptr; k->fn = nullptr; }
 }

@@ -32,5 +32,7 @@ long code_object_scratch_bytes(const std::vector<char>& code, const char* kernel
 // Load a code object on the CURRENT device and resolve `kernel`.
 hipError_t rtc_load(const std::vector<char>& code, const char* kernel, RtcKernel* out);
 void rtc_unload(RtcKernel* k);
+// one more kernel of a module already loaded by rtc_load (the module stays owned by the RtcKernel it was loaded into)
+hipError_t rtc_function(const RtcKernel& loaded, const char* kernel, hipFunction_t* fn);
 
 }  // namespace bsx

@@ -21,9 +21,11 @@
 // Plain PODs shared by the planner (plan.cpp) and the device code (kernels_seg.hip); passed to the kernels BY VALUE
 // (kernarg → SGPRs: no descriptor fetches on the critical path).
 #pragma once
+#ifndef __HIPCC_RTC__             // (the text of this header is also compiled by hipRTC as part of the graph-specialised segment kernels: gen_seg.cpp)
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#endif
 
 namespace bsx {
 
@@ -104,6 +106,7 @@ constexpr int kSegLoStride = 16;                 // floats per pixel of the stag
 constexpr int kSegLoTileFloats = 12 * 16 * kSegLoStride;   // staged window of the low-resolution tensor a k3 / tail tile interpolates from: <= 12 rows x 16 columns
 constexpr int kSegScratchFloats = 640;   // gate vector / means / hidden / partial-sum meeting points
 constexpr int kSegGateStageFloats = 512 + 2 * (32 * 32 + 32);   // gate prologue staging (aliases the first tile region)
+#ifndef __HIPCC_RTC__             // host-side sizing (the planner); the device code gets the results through the descriptors
 inline int seg_row_width(int cols) { return (cols + 15) / 16 * 16; }
 inline int seg_head_lds_floats(const SegHead& d) {
   const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, IR = 2 * AR + 1, IC = 2 * AC + 1;
@@ -142,6 +145,7 @@ inline int seg_lo_window_floats(int H, int W, int HL, int WL, bool half_pixel, b
 }
 inline int seg_k3_lds_floats(const SegK3& d) { return kSegScratchFloats + (d.TR + 2) * 256 + (d.lo_floats > 0 ? d.lo_floats : kSegLoTileFloats); }   // z tile + the window (t stays in registers)
 inline int seg_tail_lds_floats(const SegTail& d) { const int v = (d.TR + 2) * 256; return kSegScratchFloats + (v > kSegGateStageFloats ? v : kSegGateStageFloats) + (d.lo_floats > 0 ? d.lo_floats : kSegLoTileFloats); }
+#endif
 
 struct SegPlan {
   bool on = false;
