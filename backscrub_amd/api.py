@@ -81,6 +81,7 @@ SYMBOLS = [
     ("bsx_debug_tensor", C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_long]),
     ("bsx_model_precompile", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("bsx_model_kernel_source", C.c_long, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("bsx_model_seg_source", C.c_long, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("bsx_debug_tensor_of", C.c_long, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_long]),
     ("bsx_debug_mask_tile_stats", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_long)]),
     ("bsx_debug_program_timeline", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p]),
@@ -522,6 +523,15 @@ def model_kernel_source(path: str) -> str:
     """The generated HIP source of the specialised per-frame program ('' when the graph has none)."""
     buf = C.create_string_buffer(1 << 20)
     n = lib().bsx_model_kernel_source(os.fsencode(path), buf, len(buf))
+    if n < 0:
+        raise BsxError(buf.value.decode(errors="replace"))
+    return buf.value.decode() if n > 0 else ""
+
+
+def model_seg_source(path: str) -> str:
+    """The generated HIP source of the graph-specialised segment kernels ('' when the plan has no segment kernels)."""
+    buf = C.create_string_buffer(1 << 20)
+    n = lib().bsx_model_seg_source(os.fsencode(path), buf, len(buf))
     if n < 0:
         raise BsxError(buf.value.decode(errors="replace"))
     return buf.value.decode() if n > 0 else ""

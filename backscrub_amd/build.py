@@ -88,7 +88,9 @@ def embed_seg_source():
         t = "\n".join(l for l in t.split("\n") if l.strip() != "#pragma once")
         parts.append(t)
     text = "\n".join(parts)
-    assert ')BSXSEG"' not in text and "BSX_SEG_CONSTANTS" in text
+    # every macro of the embedded text gets its own prefix: the release library's strings carry no BSX_ name but the documented user modes (tests/test_cabi.py)
+    text = text.replace("BSX_", "BSXS_")
+    assert ')BSXSEG"' not in text and "BSXS_SEG_CONSTANTS" in text
     # string literals are limited in length by some compilers: cut into adjacent raw strings (concatenated by the compiler)
     chunks = [text[i:i + 8000] for i in range(0, len(text), 8000)]
     body = "\n".join('R"BSXSEG(' + c + ')BSXSEG"' for c in chunks) + "\n"

@@ -1250,6 +1250,20 @@ long bsx_model_kernel_source(const char* model_path, char* buf, size_t cap) {
   } catch (...) { snprintf(buf, cap, "exception while reading the model"); return BSX_EMODEL; }
 }
 
+long bsx_model_seg_source(const char* model_path, char* buf, size_t cap) {
+  if (!model_path || !buf || !cap) return BSX_EINVAL;
+  try {
+    Graph g; Plan p;
+    std::string err, why;
+    if (!load_tflite(model_path, &g, &err) || !build_plan(g, &p, &err)) { snprintf(buf, cap, "%s", err.c_str()); return BSX_EMODEL; }
+    const char* a16 = getenv("BSX_ACT16");
+    const std::string src = generate_seg_source(p, a16 && atoi(a16) != 0 && p.seg.on, BSX_DBG_ENV("BSX_F32_INPUT") == nullptr, &why);
+    if (src.empty()) { snprintf(buf, cap, "%s", why.c_str()); return 0; }
+    snprintf(buf, cap, "%s", src.c_str());
+    return (long)src.size();
+  } catch (...) { snprintf(buf, cap, "exception while reading the model"); return BSX_EMODEL; }
+}
+
 int bsx_model_precompile(const char* model_path, const char* arch, char* msg, size_t cap) {
   if (!model_path || !msg || !cap) return BSX_EINVAL;
   try {

@@ -16,7 +16,7 @@
 namespace bsx {
 namespace {
 
-// segments.hpp + mfma_tile.hpp + kernels_seg.hip, comments stripped, flattened by backscrub_amd/build.py behind a small hipRTC preamble; the line BSX_SEG_CONSTANTS
+// segments.hpp + mfma_tile.hpp + kernels_seg.hip, comments stripped, flattened by backscrub_amd/build.py behind a small hipRTC preamble; the marker line BSXS_SEG_CONSTANTS
 // marks where the constants go (inside namespace bsx::segrtc, after the descriptor structs)
 const char kSegSource[] =
 #include "seg_rtc_src.inc"
@@ -73,12 +73,12 @@ std::string generate_seg_source(const Plan& plan, bool h16, bool u8in, std::stri
   const bool sig = sp.tail.act3 == kActSigmoid;
   if (!((sp.tail.Co == 2 && !sig) || sp.tail.Co == 1)) return fail("transpose-convolution output channels");
   std::string src = kSegSource;
-  const std::string mark = "BSX_SEG_CONSTANTS";
+  const std::string mark = "BSXS_SEG_CONSTANTS";      // (build.py renames every BSX_ macro of the embedded text to BSXS_)
   const size_t at = src.find(mark);
   if (at == std::string::npos) return fail("embedded source has no constants marker");
   src.replace(at, mark.size(), seg_constants_text(sp, "kSeg"));
   char head[512];
-  snprintf(head, sizeof head, "#define BSX_SEG_RTC 1\n#define BSX_SEG_HS %d\n#define BSX_SEG_H16 %d\n#define BSX_SEG_U8 %d\n#define BSX_SEG_SIG %d\n#define BSX_SEG_CO %d\n",
+  snprintf(head, sizeof head, "#define BSXS_SEG_RTC 1\n#define BSXS_SEG_HS %d\n#define BSXS_SEG_H16 %d\n#define BSXS_SEG_U8 %d\n#define BSXS_SEG_SIG %d\n#define BSXS_SEG_CO %d\n",
            sp.head.stem.act == kActHswish ? 1 : 0, h16 ? 1 : 0, u8in ? 1 : 0, sig ? 1 : 0, sp.tail.Co);
   return std::string(head) + src;
 }

@@ -21,8 +21,10 @@
 //     every geometry value, weight offset and activation kind is a constant — loops get their trip counts, index arithmetic its strength reduction, dead activation
 //     branches disappear.  tools/seg_probe.sh measured that form first (profiles/r06o: head 39.7 -> 36.1 us, k2 40.2 -> 34.6, tail 44.7 -> 41.6, step -3.7 % at configs[1]).
 #ifndef __HIPCC_RTC__
-#include "debug_switches.hpp"
 #include <hip/hip_runtime.h>
+#endif
+#ifndef BSX_SEG_RTC               // (the flattened translation unit of gen_seg.cpp carries segments.hpp and mfma_tile.hpp in front of this text and needs nothing else)
+#include "debug_switches.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(kSegThreads) __attribute__((amdgpu_waves_per_eu(5, 
   }
 }
 
-#ifndef __HIPCC_RTC__              // ---- from here on: ahead-of-time build only (the per-frame gate kernel, a 5 us launch, and the host side)
+#ifndef BSX_SEG_RTC                // ---- from here on: ahead-of-time build only (the per-frame gate kernel, a 5 us launch, and the host side)
 // the gate of one decoder level, once per frame: workgroup = frame; the prologue of the tile kernels as a kernel of its own (SegTail::pre_gate_off)
 __global__ __launch_bounds__(kSegThreads) void seg_gate_k(const SegGate gt, float* __restrict__ arena, long per_frame, const float* __restrict__ w, long long out_off) {
   float* fa = arena + (size_t)blockIdx.x * (size_t)per_frame;
@@ -860,7 +862,7 @@ hipError_t allow_lds(K kernel, int lds_bytes) {
 
 }  // namespace
 
-#ifndef __HIPCC_RTC__
+#ifndef BSX_SEG_RTC
 hipError_t seg_prepare() {
   const int full = 160 * 1024;     // process-global kernel attributes: always the full LDS (cf. frame_program_prepare)
   hipError_t e = hipSuccess;

@@ -21,7 +21,7 @@
 // Plain PODs shared by the planner (plan.cpp) and the device code (kernels_seg.hip); passed to the kernels BY VALUE
 // (kernarg → SGPRs: no descriptor fetches on the critical path).
 #pragma once
-#ifndef __HIPCC_RTC__             // (the text of this header is also compiled by hipRTC as part of the graph-specialised segment kernels: gen_seg.cpp)
+#ifndef BSX_SEG_RTC               // (the text of this header is also part of the graph-specialised segment kernels' translation unit: gen_seg.cpp defines BSX_SEG_RTC)
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -106,7 +106,7 @@ constexpr int kSegLoStride = 16;                 // floats per pixel of the stag
 constexpr int kSegLoTileFloats = 12 * 16 * kSegLoStride;   // staged window of the low-resolution tensor a k3 / tail tile interpolates from: <= 12 rows x 16 columns
 constexpr int kSegScratchFloats = 640;   // gate vector / means / hidden / partial-sum meeting points
 constexpr int kSegGateStageFloats = 512 + 2 * (32 * 32 + 32);   // gate prologue staging (aliases the first tile region)
-#ifndef __HIPCC_RTC__             // host-side sizing (the planner); the device code gets the results through the descriptors
+#ifndef BSX_SEG_RTC               // host-side sizing (the planner); the device code gets the results through the descriptors
 inline int seg_row_width(int cols) { return (cols + 15) / 16 * 16; }
 inline int seg_head_lds_floats(const SegHead& d) {
   const int AR = 2 * d.TR + 1, AC = 2 * d.TC + 1, IR = 2 * AR + 1, IC = 2 * AC + 1;

@@ -277,12 +277,15 @@ BSX_API int bsx_debug_gauss_coeffs(int ksize, int shift, uint32_t* c4 /* 36 */, 
 BSX_API int bsx_model_describe(const char* model_path, char* buf, size_t cap);
 /* Host only, no GPU: build the plan of `model_path`, emit the kernel specialised to that graph (the per-frame program of the Meet / MLKit
  * family as straight-line code: csrc/gen_mid.cpp) and compile it with hipRTC for `arch` (NULL = "gfx950") into the code-object cache, so
- * that bsx_new on the GPU box only loads it.  This replaces what InterpreterBuilder / AllocateTensors do when the reference creates its
+ * that bsx_new on the GPU box only loads it — and the same for the graph's segment kernels (csrc/gen_seg.cpp).  This replaces what InterpreterBuilder / AllocateTensors do when the reference creates its
  * context (lib/libbackscrub.cc:205-217).  msg receives "compiled" / "cached" / why the graph stays interpreted.  Returns 0, or BSX_EMODEL. */
 BSX_API int bsx_model_precompile(const char* model_path, const char* arch, char* msg, size_t cap);
 /* The generated source itself (tests, inspection): returns its length (without NUL), copies at most cap - 1 bytes; 0 when the graph has no
  * specialised form (reason in buf), negative on a model error. */
 BSX_API long bsx_model_kernel_source(const char* model_path, char* buf, size_t cap);
+/* The same for the SEGMENT kernels of the graph (csrc/gen_seg.cpp: the high-resolution ends of the Meet / MLKit networks — the source of csrc/kernels_seg.hip with this
+ * plan's descriptors and template arguments as compile-time constants; bsx_model_precompile compiles it next to the program's kernel, bsx_new loads it). */
+BSX_API long bsx_model_seg_source(const char* model_path, char* buf, size_t cap);
 
 /* ---- measurement ---- */
 typedef struct bsx_launch_stat {

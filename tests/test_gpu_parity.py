@@ -1255,3 +1255,35 @@ def test_release_library_ignores_the_work_skipping_switches(bs, monkeypatch):
     finally:
         monkeypatch.delenv("BSX_LIBRARY", raising=False)
         api._LIB = saved
+
+
+@pytest.mark.parametrize("key,res", [("lite", VGA), ("mlkit", HD), ("full", HD)])
+def test_specialised_segment_kernels_equal_the_ahead_of_time_ones(bs, key, res, monkeypatch, debug_switches):
+    """The product path runs the segment kernels hipRTC compiled for the loaded graph (csrc/gen_seg.cpp); the ahead-of-time kernels of kernels_seg.hip — same source, the
+    descriptor a kernel argument — are the fallback.  Same arithmetic in the same order: temporal state, masks and composites identical bit for bit over three steps
+    (BSX_NO_SEG_RTC=1, debug build, selects the ahead-of-time kernels), and the plan says which ones ran."""
+    from backscrub_amd import synth
+    W, H = res
+    n = 3
+    bg = _dev(synth.background(W, H))
+    got = []
+    for aot in (False, True):
+        if aot:
+            monkeypatch.setenv("BSX_NO_SEG_RTC", "1")
+        else:
+            monkeypatch.delenv("BSX_NO_SEG_RTC", raising=False)
+        mg = bs.MaskGen(model_path(key), W, H, n_streams=n)
+        assert ("segment execution: specialised kernels (hipRTC" in mg.plan()) == (not aot), mg.plan()[-400:]
+        out = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+        snaps = []
+        for t in range(3):
+            frames = np.stack([synth.frame(W, H, i, t) for i in range(n)])
+            frames[n - 1] = synth.random_u8((H, W, 3), 50 + t)
+            mg.step(_dev(frames), bg, out)
+            snaps.append((mg.ofinal().clone(), mg.masks().clone(), out.clone()))
+        got.append(snaps)
+        mg.close()
+    monkeypatch.delenv("BSX_NO_SEG_RTC", raising=False)
+    for t in range(3):
+        for a, b in zip(got[0][t], got[1][t]):
+            assert torch.equal(a, b), "step %d" % t

@@ -236,3 +236,32 @@ def test_the_form_of_the_middle_kernel_is_chosen_by_its_scratch_size(api, monkey
     assert m and int(m.group(1)) > 0 and "re-derived" not in plain, plain
     monkeypatch.setenv("BSX_RTC_TID", "1")
     assert " 0 B of scratch, lane indices re-derived per op" in api.model_precompile(model_path("lite"))
+
+
+@pytest.mark.parametrize("key", ["lite", "full", "mlkit"])
+def test_segment_kernels_specialised_to_the_graph_compile_within_their_budgets(api, key, tmp_path):
+    """Round 6 (csrc/gen_seg.cpp): the segment kernels are compiled a second time, by hipRTC when a context is created, with the loaded graph's descriptors and template
+    arguments as compile-time constants.  Without a GPU: the source carries the plan's geometry, compiles for gfx950 (hipcc here, hipRTC through bsx_model_precompile),
+    keeps the register steps of the ahead-of-time kernels (tests/test_kernel_resources.py: occupancy is what these kernels live on) and spills nothing."""
+    src = api.model_seg_source(model_path(key))
+    assert "#define BSXS_SEG_RTC 1" in src and "constexpr SegHead kSegHEAD" in src and "constexpr SegTail kSegTAIL" in src
+    for k in ("bsx_seg_head", "bsx_seg_k2", "bsx_seg_k3", "bsx_seg_tail"):
+        assert 'extern "C" __global__' in src and k in src
+    desc = api.model_describe(model_path(key))
+    m = re.search(r"segment head  tile (\d+)x(\d+), (\d+)x(\d+) tiles", desc)
+    assert m and ("t.TR = %s; t.TC = %s; t.tiles_y = %s; t.tiles_x = %s;" % m.groups()) in src          # the constants ARE this plan's
+    p = tmp_path / "seg.hip"
+    p.write_text(src)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", str(p) + ".s", str(p)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    asm = (tmp_path / "seg.hip.s").read_text()
+    caps = {"bsx_seg_head": 88, "bsx_seg_k2": 80, "bsx_seg_k3": 104, "bsx_seg_tail": 96}
+    for k, cap in caps.items():
+        blk = asm[asm.index(".amdhsa_kernel " + k):]
+        blk = blk[:blk.index(".end_amdhsa_kernel")]
+        vg = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", blk).group(1))
+        sc = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", blk).group(1))
+        assert sc == 0 and vg <= cap, "%s of %s: %d registers (cap %d), %d B of scratch" % (k, key, vg, cap, sc)
+    msg = api.model_precompile(model_path(key))
+    assert re.search(r"segment kernels (compiled|cached) \(\d+ bytes of source, \d+ bytes of code object, 0 B of scratch\)", msg), msg
+    assert api.model_seg_source(model_path("deeplab")) == ""                                          # per-launch path: no segment kernels
