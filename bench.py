@@ -46,9 +46,11 @@ RING = 4                   # time steps per stream of the moving scene
 METRIC = "composited frames/sec at 640×480 (batch), 1/2/4/8 MI355X + mask IoU vs CPU ref"
 NAMES = {"lite": "segm_lite_v681.tflite", "full": "segm_full_v679.tflite",
          "mlkit": "selfiesegmentation_mlkit-256x256-2021_01_19-v1215.f16.tflite", "deeplab": "deeplabv3_257_mv_gpu.tflite"}
-PMC_NAMES = {"frame_program": ("bsx_mid", "frame_program_k"), "blend": "blend4x4_k", "blend(standalone)": "blend4x4_k", "mask_blend": "mask_tile_k<true>",
-             "mask_upscale_blur": "mask_tile_k<false>", "prep": "prep_fused_k", "prep_resize": "prep_resize_k", "prep_bilateral": "prep_bilateral_k", "decode_iir": "decode_k",
-             "seg_head": "seg_head_k", "seg_k2": "seg_k2_k", "seg_k3": "seg_k3_k", "seg_tail": "seg_tail_k", "seg_tail+decode": "seg_tail_k", "seg_gate": "seg_gate_k"}
+PMC_NAMES = {"frame_program": ("bsx_mid", "frame_program_k"), "blend": "blend4x4_k", "blend(standalone)": "blend4x4_k", "mask_blend": "mask_tile_k<true",
+             "mask_upscale_blur": "mask_tile_k<false", "prep": "prep_fused_k", "decode_iir": "decode_k",
+             # the segment kernels: specialised by hipRTC for the loaded graph (bsx_seg_*), or the ahead-of-time templates
+             "seg_head": ("bsx_seg_head", "seg_head_k"), "seg_k2": ("bsx_seg_k2", "seg_k2_k"), "seg_k3": ("bsx_seg_k3", "seg_k3_k"), "seg_tail": ("bsx_seg_tail", "seg_tail_k"),
+             "seg_tail+decode": ("bsx_seg_tail", "seg_tail_k"), "seg_gate": "seg_gate_k"}
 IMAGE_LAUNCHES = {"prep_resize": "prep", "prep_bilateral": "prep", "prep": "prep", "decode_iir": "decode", "mask_upscale_blur": "mask", "blend": "blend", "mask_blend": "blend"}
 
 
