@@ -674,7 +674,9 @@ template <bool BLEND, bool YIN = false, bool F0 = false, bool WH = false>
 __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restrict__ ofinal, int outW, int outH, Rect4 q, ResizeTab tab,
                                                        uint8_t* __restrict__ mask, int W, int H, Rect4 roi,
                                                        const uint8_t* __restrict__ bg, long bg_stride, const uint8_t* __restrict__ frames,
-                                                       uint8_t* __restrict__ outp, int yuyv, int ntx, int nty, int n_frames) {
+                                                       uint8_t* __restrict__ outp, int yuyv, int ntx, int nty, int n_frames, int ty_base, int nty_all) {
+  // (ty_base, nty_all: this launch covers tile rows [ty_base, ty_base + nty) of the nty_all rows of a frame — the launcher cuts a frame whose last tile row is partial
+  //  into the whole rows, run by the WH instantiation, and that last row)
   __shared__ short col_c0[kHW], col_c1[kHW], col_a0[kHW], col_a1[kHW];     // block-relative tap columns, coefficients
   __shared__ short row_r0[kHH], row_r1[kHH], row_b0[kHH], row_b1[kHH];     // block-relative tap rows, coefficients
   __shared__ __attribute__((aligned(16))) uint16_t hq_hs[kMaxSrcRows * kHW > kHH * kTW ? kMaxSrcRows * kHW : kHH * kTW];
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   // segments of neighbouring tiles share cache lines — fetched once per L2 that touches them (PMC: 1.8x the frame bytes in the plain order).
   unsigned f_, t_;
   xcd_frame_tile((unsigned)(ntx * nty), (unsigned)n_frames, &f_, &t_);
-  const int n = (int)f_, tid = threadIdx.x, tby = (int)t_ / ntx, tbx = (int)t_ - tby * ntx;
+  const int n = (int)f_, tid = threadIdx.x, tby0 = (int)t_ / ntx, tbx = (int)t_ - tby0 * ntx, tby = tby0 + ty_base;
   const int tx0 = tbx * kTW, ty0 = tby * kTH;
   // UNIFORM TILES (round 4).  In the steady state of the temporal filter the model-resolution mask is exactly 0x00 or 0xFF wherever the person's outline is not
   //     (lib/libbackscrub.cc:330-355: three equal decisions in a row), and a tile whose whole source block (taps of the halo included) holds one of those two values
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void mask_tile_k(const uint8_t* __restric
   TileBlendOperands ops;
   if (early_bg) tile_load_blend_operands<BLEND, WH>(ops, bg, bg_stride, frames, n, W, H, roi, tx0, ty0, tid, 0, 1, yin);
   if (tab.tile_class) {                                     // the aligned word that holds the byte: a SCALAR load (uniform address), not a vector load + readfirstlane
-    const uintptr_t ca = (uintptr_t)tab.tile_class + (size_t)n * (size_t)(ntx * nty) + (size_t)(tby * ntx + tbx);
+    const uintptr_t ca = (uintptr_t)tab.tile_class + (size_t)n * (size_t)(ntx * nty_all) + (size_t)(tby * ntx + tbx);
     uniform = (int)((*reinterpret_cast<const uint32_t*>(ca & ~(uintptr_t)3) >> (8 * (unsigned)(ca & 3))) & 255u);
   }
   if (uniform) {                                           // wave-uniform: nothing of the general path below is even requested
@@ -1021,7 +1023,7 @@ hipError_t launch_mask_upscale_blur(const uint8_t* ofinal, int outW, int outH, R
   const int nf = (xcd_on && shared_lines) ? n : 0;
   dim3 grid((unsigned)(ntx * nty) * (unsigned)n);
   if (hipError_t e = launch_tile_class(ofinal, outW, outH, in_roi, tab, roi, n, s)) return e;
-  if (mask_tile_usable(tab)) mask_tile_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0, ntx, nty, nf);
+  if (mask_tile_usable(tab)) mask_tile_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0, ntx, nty, nf, 0, nty);
   else mask_upscale_blur_k<false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, nullptr, 0, nullptr, nullptr, 0, ntx, nty, nf);
   return hipGetLastError();
 }
@@ -1114,10 +1116,17 @@ hipError_t launch_mask_blend(const uint8_t* ofinal, int outW, int outH, Rect4 in
   const bool yin = (yuyv & 16) != 0;
   if (mask_tile_usable(tab)) {
     const bool f0 = (yuyv & ~16) == 0;
-    const bool whole = f0 && roi.w % kTW == 0 && roi.h % kTH == 0 && ((uintptr_t)mask & 3) == 0;      // (W, roi.x multiples of 4: mask_blend_fusable)
-#define BSX_MT(Y, F, WHL) mask_tile_k<true, Y, F, WHL><<<grid, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf)
-    if (yin) { if (whole) BSX_MT(true, true, true); else if (f0) BSX_MT(true, true, false); else BSX_MT(true, false, false); }
-    else { if (whole) BSX_MT(false, true, true); else if (f0) BSX_MT(false, true, false); else BSX_MT(false, false, false); }
+    // whole tile rows (every item inside the ROI: the WH instantiation) and, where the ROI height is not a multiple of the tile height (720 = 22.5 x 32), the last,
+    // partial row as a second launch of the edge-testing instantiation
+    const bool whole_x = f0 && roi.w % kTW == 0 && ((uintptr_t)mask & 3) == 0;      // (W, roi.x multiples of 4: mask_blend_fusable)
+    const int nty_whole = whole_x ? roi.h / kTH : 0;
+#define BSX_MT(Y, F, WHL, GRID, NTY, TYB) mask_tile_k<true, Y, F, WHL><<<GRID, kThreads, (size_t)lds_pad, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, NTY, nf, TYB, nty)
+    if (nty_whole > 0) {
+      const dim3 gw((unsigned)(ntx * nty_whole) * (unsigned)n), gr((unsigned)(ntx * (nty - nty_whole)) * (unsigned)n);
+      if (yin) { BSX_MT(true, true, true, gw, nty_whole, 0); if (nty > nty_whole) BSX_MT(true, true, false, gr, nty - nty_whole, nty_whole); }
+      else { BSX_MT(false, true, true, gw, nty_whole, 0); if (nty > nty_whole) BSX_MT(false, true, false, gr, nty - nty_whole, nty_whole); }
+    } else if (yin) { if (f0) BSX_MT(true, true, false, grid, nty, 0); else BSX_MT(true, false, false, grid, nty, 0); }
+    else { if (f0) BSX_MT(false, true, false, grid, nty, 0); else BSX_MT(false, false, false, grid, nty, 0); }
 #undef BSX_MT
   } else if (yin) mask_upscale_blur_k<true, true><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);
   else mask_upscale_blur_k<true, false><<<grid, kThreads, 0, s>>>(ofinal, outW, outH, in_roi, tab, mask, W, H, roi, bg, (long)bg_stride, frames, out, yuyv, ntx, nty, nf);

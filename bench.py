@@ -297,7 +297,9 @@ def traffic_of(pmc, launch_index, n_launches, name):
     (layers that share a kernel instantiation — DeepLab's GEMMs — keep their own figure), else by kernel name."""
     seq = []
     for e in pmc.get("step_launches") or []:              # the fused mask + blend launch is two dispatches when the ROI does not cover the frame
-        if seq and seq[-1]["kernel"].startswith("outside_roi"):
+        last = seq[-1]["kernel"].split(" + ")[-1] if seq else ""
+        # ... and the tile classifier in front of it, and (last tile row partial) two instantiations of the tile kernel: all ONE launch of the step (launch_mask_blend)
+        if seq and (last.startswith("outside_roi") or last.endswith("tile_class_k") or (last.startswith("mask_tile_k") and e["kernel"].startswith("mask_tile_k"))):
             seq[-1] = {"kernel": seq[-1]["kernel"] + " + " + e["kernel"], "FETCH_SIZE_KiB": seq[-1]["FETCH_SIZE_KiB"] + e["FETCH_SIZE_KiB"],
                        "WRITE_SIZE_KiB": seq[-1]["WRITE_SIZE_KiB"] + e["WRITE_SIZE_KiB"]}
         else:
@@ -309,7 +311,12 @@ def traffic_of(pmc, launch_index, n_launches, name):
         wants = PMC_NAMES.get(name, ())
         wants = (wants,) if isinstance(wants, str) else wants          # the specialised (hipRTC) and the interpreted program are different kernels
         kern = pmc.get("kernels", {})
-        k = next((v for want in wants for n_, v in kern.items() if n_ == want or n_.startswith(want)), None)
+        for want in wants:                                    # every instantiation of the kernel the launch dispatches (the mask tiles of a frame whose last tile row is partial
+            hit = [(n_, v) for n_, v in kern.items() if n_ == want or n_.startswith(want)]      # run as two instantiations, each once per step): their sum
+            if hit:
+                k = {"kernel": " + ".join(n_ for n_, _ in hit), "FETCH_SIZE_KiB": sum(v.get("FETCH_SIZE_KiB", 0.0) for _, v in hit),
+                     "WRITE_SIZE_KiB": sum(v.get("WRITE_SIZE_KiB", 0.0) for _, v in hit)}
+                break
     if k and "FETCH_SIZE_KiB" in k and "WRITE_SIZE_KiB" in k:
         return int((2 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024), k.get("kernel")
     return None, None
