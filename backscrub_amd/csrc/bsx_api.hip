@@ -1141,6 +1141,13 @@ int bsx_profile_batch(bsx_ctx* c, const uint8_t* d_frames, const uint8_t* d_bg, 
     const bool h0 = c->plan.steps[0].fuse_head0;
     const bool h0_member = h0 && (&st == &c->plan.steps[1] || &st == &c->plan.steps[2]);
     if (h0_member || (st.fused_away && !(h0 && &st <= &c->plan.steps[2]) && ir_on)) { put(j++, st.label + " (inside the launch before)", 0, 0); continue; }   // no-op slot of a fused group
+    if (st.chain_mid >= 0 && chain3_on(c->plan, st.chain_mid, n, c->d_weights16, c->f16_terms)) { put(j++, st.label + " (inside the chained launch)", 0, 0); continue; }
+    if (st.chain_first >= 0 && chain3_on(c->plan, (int)(&st - c->plan.steps.data()), n, c->d_weights16, c->f16_terms)) {      // three 1x1 convolutions: reads the first one's input, writes the last one's output
+      const Step& ca = c->plan.steps[st.chain_first];
+      const Step& cc = c->plan.steps[st.chain_last];
+      put(j++, ca.label + "+" + st.label + "+" + cc.label, N * 4.0 * ((double)ca.H * ca.W * ca.Cin + (double)cc.OH * cc.OW * cc.Cout), N * 2.0 * (ca.macs + st.macs + cc.macs));
+      continue;
+    }
     if (st.fuse_head0 && h0) {                                   // stem + depthwise + 1x1: reads the network input, writes the 1x1's output
       const Step& d1 = c->plan.steps[1];
       const Step& p2 = c->plan.steps[2];

@@ -28,6 +28,14 @@ inline bool head0_u8_ok(const Plan& plan) {
   return st.in0 == plan.input && (long)(2 * (head0_band_rows(st.W, st.OW) + 2) + 1) * st.W <= 4 * 3 * 512;
 }
 
+// Does the chain of three 1x1 convolutions around step `mid` (Step::chain_first / chain_last) run as ONE launch for n streams?  Asked by the three steps'
+// launches and by the profile's slot labels: split-f16 MFMA mode, and enough pixels for the GEMM forms (below that the three steps run on their own).
+inline bool chain3_on(const Plan& plan, int mid, int n, const uint16_t* weights16, int f16_terms) {
+  if (mid < 0 || mid >= (int)plan.steps.size() || plan.steps[mid].chain_first < 0) return false;
+  const Step& b = plan.steps[mid];
+  return weights16 && (f16_terms & 15) == 3 && (long)n * b.OH * b.OW >= 8192;
+}
+
 // DeepLab tail: the graph's final RESIZE_BILINEAR fused with the 21-way argmax + temporal IIR (the full-resolution logits never exist)
 bool resize_argmax_fusable(const Step& st);
 // generic = the scalar first-maximum scan (what more than 24 classes take; tests force it for the 21-class graph)

@@ -778,6 +778,207 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 || (SLABS == 1 && CH == 1
 //  held across a loop over expanded-channel chunks — was parity-green and slower than this kernel + the project GEMM (spills at 128 registers, the block input
 //  re-read once per chunk); it was deleted in round 6.  docs/design/08-rejected-and-next-r1-r4.md has its measurements.)
 
+// ---- three chained 1x1 convolutions as ONE kernel (DeepLab's ASPP head: 160 → 256 relu → 256 relu, + the pooled branch as a per-frame bias → 21 classes) ---
+// As three GEMMs the two 256-channel tensors between them are written and read back: 4.4 GB of the 5.3 GB those launches move at 1024 streams, for 0.7 GB of
+// input and 0.09 GB of logits.  Here every product is formed TRANSPOSED — A = a 16-channel tile of the weights, B = 16 pixels of the activations, so the
+// accumulator of lane (li, g) holds output channels 4g .. 4g+3 of pixel li — and that is, element for element, one half of the B operand the NEXT
+// convolution wants from the same lane (pixel li, eight K values): two neighbouring 16-channel tiles give the eight halves of one 32-deep K slab once the slab's
+// K order is agreed to be {4g .. 4g+3} ∪ {16+4g .. 16+4g+3} — a permutation the planner bakes into the packed weights (plan.cpp: pack_chain3).  The
+// activations therefore go from accumulator to operand in registers (bias, clamp, the same hi/lo split as pw_gemm_f16s_k) and never touch LDS or HBM.
+// A wave owns 16 x NP pixels and ALL channels of them; what the waves of a workgroup share is the WEIGHT stream (448 KB per pass, L2-resident): one
+// 32 / 36 KB round at a time through a two-slot LDS ring, delivered by global→LDS DMA issued between the MFMAs of the round before, one barrier per round.
+//   stage 1 (S0 rounds, one K slab each):   acc1[16 tiles] += W1 tile · X slab         → bias, clamp, split → y1 (the stage-2 B operands, P1 slabs)
+//   stage 2 (P2 rounds, one output pair p): acc2[2 tiles] = Σ_s W2 tile(p, s) · y1[s]  → bias + per-frame bias, clamp, split → y2 = K slab p of stage 3
+//                                           acc3[2 tiles] += W3 tile(·, p) · y2
+// Same products as the three pw_gemm_f16s_k launches — same operand split, same term order (x_hi·w_hi, x_lo·w_hi, x_hi·w_lo), K slabs ascending; only the
+// order of the 32 products INSIDE one MFMA differs (the slab's K permutation), i.e. rounding-level differences against the unchained path.
+constexpr int kChainWaves = 4, kChainNP = 2;              // 128 pixels per workgroup, two workgroups per CU (72 KB of LDS, <= 256 registers)
+template <int WAVES, int NP, int S0, int P1, int P2, bool DT = false>      // DT: all of the next round's DMA pieces at the round top instead of one per MFMA group (A/B, debug build)
+__global__ __launch_bounds__(WAVES * 64, NP == 1 ? 4 : 2) void pw_chain3_k(const float* __restrict__ x, const _Float16* __restrict__ ws, const float* __restrict__ b1,
+                                                                            const float* __restrict__ b2, const float* __restrict__ fb2, const float* __restrict__ b3,
+                                                                            float* __restrict__ y, long M, int HW, int C3, int act1, int act2, int act3) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ch_ring[];
+  constexpr int kTile = 1024;                              // bytes of one operand tile: 64 lanes x 8 halves, in lane order
+  constexpr int kR1 = 4 * P1, kR2 = 4 * P1 + 4;            // tiles per round: stage 1 = (hi, lo) of the 2 P1 output tiles of one K slab; stage 2 = (hi, lo) x 2 tiles x P1 slabs + W3's 2 x (hi, lo)
+  constexpr int kSlot = kR2 * kTile, kRounds = S0 + P2;
+  constexpr int kC0 = 32 * S0, kC2 = 32 * P2;
+  constexpr int kNJ = (kR2 + WAVES - 1) / WAVES;           // DMA pieces per wave and round
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const long px0 = ((long)blockIdx.x * WAVES + wave) * (16 * NP);
+  int pxs[NP];                                             // (the launcher checks that M x 32 S0 fits 31 bits)
+#pragma unroll
+  for (int np = 0; np < NP; np++) pxs[np] = (int)min(px0 + 16 * np + li, M - 1);      // pixels past the end compute on the last one; their stores are dropped
+  const ClampK k1 = clamp_of(act1), k2 = clamp_of(act2), k3 = clamp_of(act3);
+  // piece j of this wave for round r (wave-uniform LDS base + lane x 16 B; the stream is stored in exactly that order)
+  auto dma = [&](int r, int j) {
+    const int t = wave + j * WAVES, nt = r < S0 ? kR1 : kR2;
+    if (r < kRounds && t < nt) {
+      const long t0 = r < S0 ? (long)r * kR1 : (long)S0 * kR1 + (long)(r - S0) * kR2;
+      __builtin_amdgcn_global_load_lds((glb_vp_t)(ws + (t0 + t) * 512 + lane * 8), (lds_vp_t)(ch_ring + (r & 1) * kSlot + t * kTile), 16, 0, 0);
+    }
+  };
+  auto mfma3 = [&](f4acc& acc, const h8v wh, const h8v wl, const h8v xh, const h8v xl) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);
+  };
+#pragma unroll
+  for (int j = 0; j < kNJ; j++) dma(0, j);
+  // ---- stage 1
+  h8v y1h[NP][P1], y1l[NP][P1];
+  {
+    f4acc acc1[NP][2 * P1];
+#pragma unroll
+    for (int np = 0; np < NP; np++)
+#pragma unroll
+      for (int t = 0; t < 2 * P1; t++) acc1[np][t] = f4acc{0.f, 0.f, 0.f, 0.f};
+    f4v xr[NP][2];
+#pragma unroll
+    for (int np = 0; np < NP; np++) {
+      xr[np][0] = *reinterpret_cast<const f4v*>(x + pxs[np] * kC0 + 8 * g);
+      xr[np][1] = *reinterpret_cast<const f4v*>(x + pxs[np] * kC0 + 8 * g + 4);
+    }
+    for (int s = 0; s < S0; s++) {
+      __syncthreads();                                     // (vmcnt(0) first) round s is in its slot for every wave, and nobody still reads the other slot
+      h8v xh[NP], xl[NP];
+#pragma unroll
+      for (int np = 0; np < NP; np++) split8<3>(xr[np][0], xr[np][1], xh[np], xl[np]);
+      if (s + 1 < S0) {
+#pragma unroll
+        for (int np = 0; np < NP; np++) {
+          xr[np][0] = *reinterpret_cast<const f4v*>(x + pxs[np] * kC0 + 32 * (s + 1) + 8 * g);
+          xr[np][1] = *reinterpret_cast<const f4v*>(x + pxs[np] * kC0 + 32 * (s + 1) + 8 * g + 4);
+        }
+      }
+      const unsigned char* slot = ch_ring + (s & 1) * kSlot + lane * 16;
+      // operand tiles one group ahead of the MFMAs that consume them; next round's DMA pieces one per group.  (A DMA between LDS reads makes hipcc wait for ALL
+      // outstanding reads — lgkmcnt(0) — at the next use of any of them; issuing the round's pieces together at the top avoids that and measured 4 % SLOWER:
+      // 636 vs 612 us, profiles/r06ab — nine back-to-back DMA issues stall the wave longer than the waits they remove.)
+      if (DT) {
+#pragma unroll
+        for (int j = 0; j < kNJ; j++) dma(s + 1, j);
+      }
+      h8v wh = *reinterpret_cast<const h8v*>(slot), wl = *reinterpret_cast<const h8v*>(slot + kTile);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int t = 0; t < 2 * P1; t++) {
+        if (!DT && t < kNJ) dma(s + 1, t);
+        h8v nh = wh, nl = wl;
+        if (t + 1 < 2 * P1) {
+          nh = *reinterpret_cast<const h8v*>(slot + (2 * (t + 1)) * kTile);
+          nl = *reinterpret_cast<const h8v*>(slot + (2 * (t + 1) + 1) * kTile);
+        }
+#pragma unroll
+        for (int np = 0; np < NP; np++) acc1[np][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[np], acc1[np][t], 0, 0, 0);
+#pragma unroll
+        for (int np = 0; np < NP; np++) acc1[np][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[np], acc1[np][t], 0, 0, 0);
+#pragma unroll
+        for (int np = 0; np < NP; np++) acc1[np][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[np], acc1[np][t], 0, 0, 0);
+        if (t + 1 < 2 * P1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NP, 0);
+        wh = nh; wl = nl;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P1; p++) {
+      const float4 ba = *reinterpret_cast<const float4*>(b1 + 32 * p + 4 * g), bb = *reinterpret_cast<const float4*>(b1 + 32 * p + 16 + 4 * g);
+#pragma unroll
+      for (int np = 0; np < NP; np++) {
+        const f4acc a = acc1[np][2 * p], b = acc1[np][2 * p + 1];
+        const f4v va{clampf(a[0] + ba.x, k1), clampf(a[1] + ba.y, k1), clampf(a[2] + ba.z, k1), clampf(a[3] + ba.w, k1)};
+        const f4v vb{clampf(b[0] + bb.x, k1), clampf(b[1] + bb.y, k1), clampf(b[2] + bb.z, k1), clampf(b[3] + bb.w, k1)};
+        split8<3>(va, vb, y1h[np][p], y1l[np][p]);
+      }
+    }
+  }
+  // ---- stages 2 and 3
+  f4acc acc3[NP][2];
+#pragma unroll
+  for (int np = 0; np < NP; np++) acc3[np][0] = acc3[np][1] = f4acc{0.f, 0.f, 0.f, 0.f};
+  int frm[NP];
+#pragma unroll
+  for (int np = 0; np < NP; np++) frm[np] = fb2 ? (pxs[np] / HW) * kC2 : 0;
+  for (int p = 0; p < P2; p++) {
+    const int r = S0 + p;
+    __syncthreads();
+    float4 ba = *reinterpret_cast<const float4*>(b2 + 32 * p + 4 * g), bb = *reinterpret_cast<const float4*>(b2 + 32 * p + 16 + 4 * g);
+    float4 fa[NP], fb[NP];
+#pragma unroll
+    for (int np = 0; np < NP; np++) { fa[np] = make_float4(0.f, 0.f, 0.f, 0.f); fb[np] = fa[np]; }
+    if (fb2) {                                             // (uniform)
+#pragma unroll
+      for (int np = 0; np < NP; np++) {
+        fa[np] = *reinterpret_cast<const float4*>(fb2 + frm[np] + 32 * p + 4 * g);
+        fb[np] = *reinterpret_cast<const float4*>(fb2 + frm[np] + 32 * p + 16 + 4 * g);
+      }
+    }
+    const unsigned char* slot = ch_ring + (r & 1) * kSlot + lane * 16;
+    f4acc acc2[NP][2];
+#pragma unroll
+    for (int np = 0; np < NP; np++) acc2[np][0] = acc2[np][1] = f4acc{0.f, 0.f, 0.f, 0.f};
+    // operand tiles one group ahead: the (hi, lo) pair of group i + 1 is requested before the six MFMAs of group i are issued — left to itself the compiler (at its
+    // register limit) requests a pair two MFMAs before it waits for it, and a wave stalls for most of an LDS round trip per group (measured: 45 % of the MFMA peak)
+    if (DT) {
+#pragma unroll
+      for (int j = 0; j < kNJ; j++) dma(r + 1, j);
+    }
+    h8v wh = *reinterpret_cast<const h8v*>(slot), wl = *reinterpret_cast<const h8v*>(slot + kTile);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    h8v w3h[2], w3l[2];
+#pragma unroll
+    for (int i = 0; i < 2 * P1; i++) {
+      const int s = i >> 1, h = i & 1;
+      if (!DT && i < kNJ) dma(r + 1, i);
+      h8v nh = wh, nl = wl;
+      if (i + 1 < 2 * P1) {
+        nh = *reinterpret_cast<const h8v*>(slot + (2 * (i + 1)) * kTile);
+        nl = *reinterpret_cast<const h8v*>(slot + (2 * (i + 1) + 1) * kTile);
+      } else {
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+          w3h[o] = *reinterpret_cast<const h8v*>(slot + (4 * P1 + 2 * o) * kTile);
+          w3l[o] = *reinterpret_cast<const h8v*>(slot + (4 * P1 + 2 * o + 1) * kTile);
+        }
+      }
+#pragma unroll
+      for (int np = 0; np < NP; np++) acc2[np][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, y1h[np][s], acc2[np][h], 0, 0, 0);
+#pragma unroll
+      for (int np = 0; np < NP; np++) acc2[np][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, y1l[np][s], acc2[np][h], 0, 0, 0);
+#pragma unroll
+      for (int np = 0; np < NP; np++) acc2[np][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, y1h[np][s], acc2[np][h], 0, 0, 0);
+      if (i + 1 < 2 * P1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * NP, 0);
+      wh = nh; wl = nl;
+    }
+#pragma unroll
+    for (int np = 0; np < NP; np++) {
+      // (the per-frame vector is added to the bias first, then the sum to the accumulator: gemm_store_tile's order)
+      const float4 sa = fb2 ? make_float4(ba.x + fa[np].x, ba.y + fa[np].y, ba.z + fa[np].z, ba.w + fa[np].w) : ba;
+      const float4 sb = fb2 ? make_float4(bb.x + fb[np].x, bb.y + fb[np].y, bb.z + fb[np].z, bb.w + fb[np].w) : bb;
+      const f4acc a = acc2[np][0], b = acc2[np][1];
+      const f4v va{clampf(a[0] + sa.x, k2), clampf(a[1] + sa.y, k2), clampf(a[2] + sa.z, k2), clampf(a[3] + sa.w, k2)};
+      const f4v vb{clampf(b[0] + sb.x, k2), clampf(b[1] + sb.y, k2), clampf(b[2] + sb.z, k2), clampf(b[3] + sb.w, k2)};
+      h8v y2h, y2l;
+      split8<3>(va, vb, y2h, y2l);
+#pragma unroll
+      for (int o = 0; o < 2; o++) mfma3(acc3[np][o], w3h[o], w3l[o], y2h, y2l);
+    }
+  }
+  // ---- logits: lane (li, g) holds classes 16 o + 4 g .. + 3 of pixel li
+#pragma unroll
+  for (int np = 0; np < NP; np++) {
+    const long px = px0 + 16 * np + li;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int cls = 16 * o + 4 * g + j;
+        if (px < M && cls < C3) y[px * C3 + cls] = clampf(acc3[np][o][j] + b3[cls], k3);
+      }
+    }
+  }
+}
+
 // ---- DeepLab's first three layers in one kernel: stem conv 3x3/s2 (3 → 16) → depthwise 3x3 → 1x1 (16 → C2 <= 16) ------------------------
 // Workgroup = (frame, band of BH output rows).  The input rows the band needs, the stem's band (+1 halo row each side: SAME padding of the
 // depthwise = zero rows outside the image) and the depthwise's band live in LDS; only the C2-channel result is written.  Unfused, the two
@@ -1512,6 +1713,7 @@ hipError_t nn_prepare() {
 #define BSX_ATTR_IR16(T, SL) BSX_ATTR((ir_expand_dw_k<T, SL, 32, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 24, true>)); BSX_ATTR((ir_expand_dw_k<T, SL, 16, true>))
   BSX_ATTR_IR16(1, 1); BSX_ATTR_IR16(1, 2); BSX_ATTR_IR16(1, 3); BSX_ATTR_IR16(3, 1); BSX_ATTR_IR16(3, 2); BSX_ATTR_IR16(3, 3);
 #undef BSX_ATTR_IR16
+  BSX_ATTR((pw_chain3_k<kChainWaves, kChainNP, kChainS0, kChainP1, kChainP2>));
   BSX_ATTR(dl_head0_k<false>);
   BSX_ATTR(dl_head0_k<true>);
   BSX_ATTR((ir_expand_dw_k<3, 1, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 2, 32, false, 1024>)); BSX_ATTR((ir_expand_dw_k<3, 3, 32, false, 1024>));
@@ -1536,6 +1738,29 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
       dim3 grid(blocks_for(M), st.cout_pad / st.cout_tile);
       int HW = st.OH * st.OW;
       if (st.fused_away && plan.steps[0].fuse_head0) break;          // ran inside dl_head0_k (the planner decides: BSX_NO_HEAD0 is read there)
+      if (st.chain_mid >= 0 && chain3_on(plan, st.chain_mid, n, weights16, f16_terms)) break;      // runs inside the chain's launch (at its middle step)
+      if (st.chain_first >= 0 && chain3_on(plan, (int)(&st - plan.steps.data()), n, weights16, f16_terms)) {
+        const Step& ca = plan.steps[st.chain_first];
+        const Step& cc = plan.steps[st.chain_last];
+        const _Float16* wsx = reinterpret_cast<const _Float16*>(weights16) + st.chain_w16_off;
+        constexpr int kW = kChainWaves, kNP = kChainNP, kPx = kW * 16 * kNP;
+        const size_t lds = 2 * (size_t)(4 * kChainP1 + 4) * 1024;
+        if (M * (32 * kChainS0) >= (1l << 31)) return hipErrorInvalidValue;      // the kernel indexes its input with 32-bit element offsets
+#ifdef BSX_DEBUG_SWITCHES
+        static const int form = BSX_DBG_ENV("BSX_CHAIN_FORM") ? atoi(BSX_DBG_ENV("BSX_CHAIN_FORM")) : 0;      // geometry A/B (profiles/r06aa, r06ab): 82 = 8 waves x 32 pixels, 161 / 1610 = 16 waves x 16 pixels, 421 = the default geometry with the DMA at the round top
+#define BSX_CHAIN_ALT(WV, NPX, DTX) { constexpr int px = WV * 16 * NPX; static bool once = false; \
+          if (!once) { once = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_chain3_k<WV, NPX, kChainS0, kChainP1, kChainP2, DTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
+          pw_chain3_k<WV, NPX, kChainS0, kChainP1, kChainP2, DTX><<<(unsigned)((M + px - 1) / px), WV * 64, lds, s>>>(P(ca.in0), wsx, weights + ca.b_off, b, P(st.out_bias), weights + cc.b_off, P(cc.out), M, HW, cc.Cout, ca.act, st.act, cc.act); break; }
+        if (form == 82) BSX_CHAIN_ALT(8, 2, true)
+        if (form == 161) BSX_CHAIN_ALT(16, 1, true)
+        if (form == 421) BSX_CHAIN_ALT(4, 2, true)
+        if (form == 1610) BSX_CHAIN_ALT(16, 1, false)
+#undef BSX_CHAIN_ALT
+#endif
+        pw_chain3_k<kW, kNP, kChainS0, kChainP1, kChainP2><<<(unsigned)((M + kPx - 1) / kPx), kW * 64, lds, s>>>(
+            P(ca.in0), wsx, weights + ca.b_off, b, P(st.out_bias), weights + cc.b_off, P(cc.out), M, HW, cc.Cout, ca.act, st.act, cc.act);
+        break;
+      }
       static const bool no_gemm = BSX_DBG_ENV("BSX_NO_PW_GEMM") != nullptr;
       if (st.fuse_dw >= 0 && weights16 && f16_terms > 0) {          // expand 1x1 + depthwise 3x3 of an inverted-residual block in one kernel
         const Step& dws = plan.steps[st.fuse_dw];

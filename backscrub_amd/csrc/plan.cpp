@@ -86,6 +86,10 @@ std::string Plan::describe() const {
              st.residual, st.in_scale, st.macs, st.in0, st.out);
     s += line;
     if (st.fuse_head0) { s += "      ^ fused with steps 1 and 2 (stem + depthwise + 1x1 in one tiled kernel)\n"; }
+    if (st.chain_first >= 0) {
+      snprintf(line, sizeof line, "      ^ chained with steps %d and %d at 8192 pixels and more (three 1x1 convolutions in one kernel: the tensors between them stay in registers)\n", st.chain_first, st.chain_last);
+      s += line;
+    }
     if (st.fuse_dw >= 0) {
       const Step& dd = steps[st.fuse_dw];
       const IrGeom ig = ir_geometry(st.OH, st.OW, st.Cout, dd.OH, dd.sh, dd.dh);
@@ -1210,6 +1214,44 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
     }
   }
 
+  // ---- chains of three 1x1 convolutions (DeepLab's ASPP head) for pw_chain3_k: a (32 S0 → 32 P1 channels) → b (→ 32 P2, may carry the folded pool branch as a
+  // per-frame bias) → c (→ at most 32), clamp activations, each intermediate read by the next step only.  The stream is appended to weights16.
+  for (size_t ia = 0; ia < steps.size() && !BSX_DBG_ENV("BSX_NO_CHAIN3"); ia++) {
+    Step& a = steps[ia];
+    auto plain_pw = [](const Step& q) { return q.kind == StepKind::PwConv && q.k16_pad > 0 && q.residual < 0 && q.in_scale < 0 && q.in2 < 0 && q.act < kActHswish; };
+    if (!plain_pw(a) || a.out_bias >= 0 || a.Cin != 32 * kChainS0 || a.Cout != 32 * kChainP1 || uses_of(a.out) != 1 || a.chain_mid >= 0) continue;
+    size_t ib = ia + 1, ic;
+    for (; ib < steps.size(); ib++) if (steps[ib].in0 == a.out) break;
+    if (ib >= steps.size()) continue;
+    Step& b = steps[ib];
+    if (!plain_pw(b) || b.Cout != 32 * kChainP2 || b.OH != a.OH || b.OW != a.OW || uses_of(b.out) != 1) continue;
+    for (ic = ib + 1; ic < steps.size(); ic++) if (steps[ic].in0 == b.out) break;
+    if (ic >= steps.size()) continue;
+    Step& c = steps[ic];
+    if (!plain_pw(c) || c.out_bias >= 0 || c.Cout > 32 || c.OH != a.OH || c.OW != a.OW) continue;
+    while (plan->weights16.size() % 8) plan->weights16.push_back(0);
+    b.chain_w16_off = plan->weights16.size();
+    b.chain_first = (int)ia; b.chain_last = (int)ic; a.chain_mid = c.chain_mid = (int)ib;
+    auto put_tile = [&](const Step& q, int tile, int slab, bool permuted, bool lo) {
+      for (int lane = 0; lane < 64; lane++) for (int i = 0; i < 8; i++) {
+        const int li = lane & 15, gq = lane >> 4, o = 16 * tile + li;
+        const int k = 32 * slab + (permuted ? (i < 4 ? 4 * gq + i : 16 + 4 * gq + (i - 4)) : 8 * gq + i);
+        uint16_t v = 0;
+        if (o < q.Cout && k < q.Cin) {
+          const float wv = W[q.w_off + (size_t)k * q.cout_pad + o];
+          const uint16_t h = f32_to_f16_rn(wv);
+          v = lo ? f32_to_f16_rn(wv - f16_to_f32(h)) : h;
+        }
+        plan->weights16.push_back(v);
+      }
+    };
+    for (int s = 0; s < kChainS0; s++) for (int t = 0; t < 2 * kChainP1; t++) { put_tile(a, t, s, false, false); put_tile(a, t, s, false, true); }
+    for (int p = 0; p < kChainP2; p++) {
+      for (int s = 0; s < kChainP1; s++) for (int h = 0; h < 2; h++) { put_tile(b, 2 * p + h, s, true, false); put_tile(b, 2 * p + h, s, true, true); }
+      for (int o = 0; o < 2; o++) { put_tile(c, o, p, true, false); put_tile(c, o, p, true, true); }
+    }
+  }
+
   // ---- activation arena: first-fit over [first def, last use] intervals, in per-stream float units
   plan->tensor_off.assign(NT, -1);
   std::vector<int> first(NT, -1), last(NT, -1);
@@ -1229,6 +1271,13 @@ bool build_plan(const Graph& g_in, Plan* plan, std::string* err, bool reuse_aren
   // green.  A convolution-type step's output therefore becomes live two steps early, i.e. from the first step any fusion can start at.
   for (int s = 0; s < NS; s++)
     if ((steps[s].kind == StepKind::DwConv || steps[s].kind == StepKind::PwConv) && first[steps[s].out] == s) first[steps[s].out] = std::max(0, s - 2);
+  // a chain runs at its middle step's place: its input stays live until then, its output is written while other workgroups still read that input
+  for (int s = 0; s < NS; s++)
+    if (steps[s].chain_first >= 0) {
+      const int tx = steps[steps[s].chain_first].in0, to = steps[steps[s].chain_last].out;
+      last[tx] = std::max(last[tx], steps[s].chain_last);
+      first[to] = std::min(first[to], std::max(0, steps[s].chain_first - 2));
+    }
   first[g.input] = -1;
   last[g.output] = NS + 1;  // keep the network output alive for the decode stage
   last[g.input] = std::max(last[g.input], 0);

@@ -54,7 +54,15 @@ struct Step {
   bool in_from_fused_dw = false;      // per-launch path, PwConv: in0 is the output of a fused expand+depthwise pair and has no other reader (may be stored as f16)
   bool fused_away = false;            // per-launch path: the step runs inside an earlier one
   bool fuse_head0 = false;            // per-launch path, stem Conv: runs together with the depthwise and the 1x1 after it (dl_head0_k)
+  // per-launch path, three chained 1x1 convolutions a → b → c as one kernel (kernels_nn.hip: pw_chain3_k), launched at b's place (b's per-frame bias exists by then):
+  int chain_first = -1, chain_last = -1;   // on b: the indices of a and c
+  int chain_mid = -1;                 // on a and c: the index of b (the step is skipped while the chain runs — chain3_on())
+  size_t chain_w16_off = 0;           // on b: Plan::weights16 offset (halves) of the chain's weight stream
 };
+// The weight stream of a chain, in the order pw_chain3_k's waves consume it: 1 KB operand tiles [64 lanes][8 halves], lane (li, g) = output channel li of the
+// tile, K values 8g .. 8g+7 of the slab (stage 1: natural order; stages 2 and 3: position i < 4 → slab channel 4g + i, i >= 4 → 16 + 4g + (i - 4)).
+constexpr int kChainS0 = 5, kChainP1 = 8, kChainP2 = 8;          // the instantiated shape: 160 → 256 → 256 → (<= 32)
+inline size_t chain3_stream_halves() { return (size_t)(kChainS0 * 4 * kChainP1 + kChainP2 * (4 * kChainP1 + 4)) * 512; }
 
 // Geometry of the fused expand + depthwise kernel (kernels_nn.hip: ir_expand_dw_k), shared by the planner (is the pair fusable?) and the
 // launcher: CH expanded channels per workgroup, BH depthwise output rows per row band; the band's expanded rows live in LDS.

@@ -377,6 +377,36 @@ def test_deeplab_batch_of_eight_uses_the_gemm_kernels_on_every_level(bs, oracle)
     mg.close()
 
 
+def test_deeplab_chained_head_equals_the_three_gemms(bs, monkeypatch, debug_switches):
+    """From 8192 pixels up the ASPP head (160 -> 256 -> 256 + per-frame pooled bias -> 21) runs as ONE kernel whose 256-channel tensors stay in registers
+    (pw_chain3_k); the planner's BSX_NO_CHAIN3 (debug build) keeps the three split-f16 GEMM launches.  Same operand split, same term order, K slabs ascending:
+    the logits differ by rounding inside one MFMA only.  9 streams of DIFFERENT frames: 9801 pixels = 76 full 128-pixel workgroups + one of 73 pixels, and
+    16-pixel tiles that straddle two frames (two per-frame bias vectors inside one tile)."""
+    from backscrub_amd import synth
+    path = model_path("deeplab")
+    W, H = VGA
+    n = 9
+    frames = np.stack([synth.frame(W, H, i % 3, 11 + i) for i in range(n)])
+    outs = {}
+    for label, env in (("chained", None), ("three launches", "1")):
+        monkeypatch.delenv("BSX_NO_CHAIN3", raising=False)
+        if env:
+            monkeypatch.setenv("BSX_NO_CHAIN3", env)
+        mg = bs.MaskGen(path, W, H, n_streams=n)
+        assert ("chained with steps" in mg.plan()) == (env is None), label
+        mg.run_stage(0, _dev(frames))
+        mg.run_stage(1, n=n)
+        outs[label] = mg.output_tensor().cpu().numpy().copy()
+        mg.close()
+    monkeypatch.delenv("BSX_NO_CHAIN3", raising=False)
+    a, b = outs["chained"], outs["three launches"]
+    assert np.isfinite(a).all()
+    err = float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
+    assert err < 2e-6, "chained vs three launches: rel err %g" % err
+    assert not np.array_equal(a[0], a[1])                      # different frames: the per-frame bias matters
+    assert (a.argmax(-1) == b.argmax(-1)).mean() > 0.9999
+
+
 def test_deeplab_f16_storage_mode_is_gated_by_iou(bs, oracle, monkeypatch):
     """BSX_F16_GEMM=fast16: plain f16 MFMA operands AND the depthwise outputs of the fused blocks stored as f16 (half the traffic of the largest
     tensors that still reach HBM).  Opt-in, IoU-gated like `fast`: the mask of the photo fixture stays within IoU 0.995 of the oracle's and the

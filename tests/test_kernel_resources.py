@@ -80,6 +80,11 @@ def test_deeplab_kernels_spill_only_where_it_is_recorded(surveys):
             assert r["scratch"] == 0, "%s spills %d bytes" % (name, r["scratch"])
     for name, r in _pick(rows, "pw_gemm_f16s_kILi3ELi4").items():
         assert r["vgpr"] <= 128, "%s: %d registers (4 workgroups per CU need <= 128)" % (name, r["vgpr"])
+    # the chained ASPP head: two 4-wave workgroups per CU = two waves per SIMD = at most 256 registers, all of them used for operands (0 scratch, asserted above)
+    chain = _pick(rows, "pw_chain3_k")
+    assert len(chain) == 1, "the release object carries ONE geometry of the chained kernel: %s" % list(chain)
+    for name, r in chain.items():
+        assert r["vgpr"] <= 256, "%s: %d registers" % (name, r["vgpr"])
 
 
 def test_no_compiler_formed_saturating_pack_in_the_product_kernels():

@@ -105,7 +105,7 @@ def test_deeplab_plan_fuses_the_head_and_every_expand_depthwise_pair(real, monke
     path = model_path("deeplab", prefer_real=real)
     if real and "synthetic" in os.path.basename(path):
         pytest.skip("reference model not staged on this box")
-    for k in ("BSX_NO_IR_FUSE", "BSX_NO_HEAD0", "BSX_IR_GEOM", "BSX_H0_BH"):
+    for k in ("BSX_NO_IR_FUSE", "BSX_NO_HEAD0", "BSX_IR_GEOM", "BSX_H0_BH", "BSX_NO_CHAIN3"):
         monkeypatch.delenv(k, raising=False)
     text = backscrub_amd.model_describe(path)
     assert "fused with steps 1 and 2 (stem + depthwise + 1x1 in one tiled kernel)" in text
@@ -121,10 +121,20 @@ def test_deeplab_plan_fuses_the_head_and_every_expand_depthwise_pair(real, monke
         rows = min(H, S * (bh - 1) + 2 * d + 1)
         lds = rows * W * ch * 4
         assert lds <= (150 if nb == 1 else 78) * 1024, (dw_step, lds)
+    # the ASPP head — 160 -> 256 (relu) -> 256 (relu, the pooled branch as its per-frame bias) -> 21 — is marked as one chained launch (pw_chain3_k), at the
+    # middle convolution (the per-frame bias exists by then); the pool-branch GEMV sits between the first and the middle step
+    m = re.search(r"\^ chained with steps (\d+) and (\d+)", text)
+    assert m and text.count("chained with steps") == 1, text
+    first, last = int(m.group(1)), int(m.group(2))
+    mid = [i for i in steps if first < i < last and "-pool " in steps[i].group(0)]
+    assert len(mid) == 1 and last == mid[0] + 1 and first == mid[0] - 2
+    shape = lambda i: (int(steps[i].group(5)), int(steps[i].group(8)))
+    assert [shape(i) for i in (first, mid[0], last)] == [(160, 256), (256, 256), (256, 21)]
     monkeypatch.setenv("BSX_NO_IR_FUSE", "1")
     monkeypatch.setenv("BSX_NO_HEAD0", "1")
+    monkeypatch.setenv("BSX_NO_CHAIN3", "1")
     plain = backscrub_amd.model_describe(path)
-    assert "fused with" not in plain and len(plain.splitlines()) < len(text.splitlines())
+    assert "fused with" not in plain and "chained with" not in plain and len(plain.splitlines()) < len(text.splitlines())
 
 
 # ---- hostile / unsupported files: an error string, never a crash, an exception across the C ABI or a wrong network ----
