@@ -33,7 +33,8 @@ inline bool head0_u8_ok(const Plan& plan) {
 inline bool chain3_on(const Plan& plan, int mid, int n, const uint16_t* weights16, int f16_terms) {
   if (mid < 0 || mid >= (int)plan.steps.size() || plan.steps[mid].chain_first < 0) return false;
   const Step& b = plan.steps[mid];
-  return weights16 && (f16_terms & 15) == 3 && (long)n * b.OH * b.OW >= 8192;
+  const long M = (long)n * b.OH * b.OW;                 // (the kernel indexes its input with 32-bit element offsets: past 2^31 elements the three steps run on their own)
+  return weights16 && (f16_terms & 15) == 3 && M >= 8192 && M * plan.steps[b.chain_first].Cin < (1l << 31);
 }
 
 // DeepLab tail: the graph's final RESIZE_BILINEAR fused with the 21-way argmax + temporal IIR (the full-resolution logits never exist)

@@ -504,9 +504,6 @@ __global__ __launch_bounds__(kThreads, NTW > 4 ? 3 : 4) void pw_gemm_f16s_k(cons
 typedef __attribute__((address_space(3))) void* lds_vp_t;
 typedef const __attribute__((address_space(1))) void* glb_vp_t;
 __device__ __forceinline__ int asw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
-template <int OFF> __device__ __forceinline__ f4v lds_rd_f4(unsigned addr) { f4v v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); return v; }
-template <int OFF> __device__ __forceinline__ h8v lds_rd_h8(unsigned addr) { h8v v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory"); return v; }
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ---- inverted-residual front half: expand 1x1 (+act) → depthwise 3x3 (+act) as ONE kernel ----------------------------------------------
 // Workgroup = (frame, row band, chunk of CH expanded channels).  Phase 1: the chunk of the expanded tensor for the band's rows (+ the rows
@@ -805,7 +802,7 @@ __global__ __launch_bounds__(WAVES * 64, NP == 1 ? 4 : 2) void pw_chain3_k(const
   constexpr int kNJ = (kR2 + WAVES - 1) / WAVES;           // DMA pieces per wave and round
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const long px0 = ((long)blockIdx.x * WAVES + wave) * (16 * NP);
-  int pxs[NP];                                             // (the launcher checks that M x 32 S0 fits 31 bits)
+  int pxs[NP];                                             // (chain3_on() keeps M x 32 S0 below 2^31)
 #pragma unroll
   for (int np = 0; np < NP; np++) pxs[np] = (int)min(px0 + 16 * np + li, M - 1);      // pixels past the end compute on the last one; their stores are dropped
   const ClampK k1 = clamp_of(act1), k2 = clamp_of(act2), k3 = clamp_of(act3);
@@ -1745,7 +1742,6 @@ hipError_t launch_step(const Step& st, const Plan& plan, float* arena, float* ne
         const _Float16* wsx = reinterpret_cast<const _Float16*>(weights16) + st.chain_w16_off;
         constexpr int kW = kChainWaves, kNP = kChainNP, kPx = kW * 16 * kNP;
         const size_t lds = 2 * (size_t)(4 * kChainP1 + 4) * 1024;
-        if (M * (32 * kChainS0) >= (1l << 31)) return hipErrorInvalidValue;      // the kernel indexes its input with 32-bit element offsets
 #ifdef BSX_DEBUG_SWITCHES
         static const int form = BSX_DBG_ENV("BSX_CHAIN_FORM") ? atoi(BSX_DBG_ENV("BSX_CHAIN_FORM")) : 0;      // geometry A/B (profiles/r06aa, r06ab): 82 = 8 waves x 32 pixels, 161 / 1610 = 16 waves x 16 pixels, 421 = the default geometry with the DMA at the round top
 #define BSX_CHAIN_ALT(WV, NPX, DTX) { constexpr int px = WV * 16 * NPX; static bool once = false; \
