@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$TAG -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-extra-configs --no-side-probes --profile-iters 4 --ramp-seconds 1.0 > $ROOT/gpurun_out/prof_$TAG.log 2>&1
 cd $ROOT
 python tools/rocpd_summary.py gpurun_out/prof_$TAG/bench_results.db > gpurun_out/${TAG}_kernel_stats.md; rm -rf gpurun_out/prof_$TAG
-tail -1 gpurun_out/prof_$TAG.log > gpurun_out/${TAG}_kernel_stats_bench_line.json
+grep '^{' gpurun_out/prof_$TAG.log | tail -1 > gpurun_out/${TAG}_kernel_stats_bench_line.json      # (the log's last line is rocprofv3's own)
 # SQ counters
 timeout 300 bash tools/pmc_sq2.sh ${TAG}_lite > /dev/null 2>&1; cp gpurun_out/pmc_sq2_${TAG}_lite.md gpurun_out/${TAG}_pmc_sq_lite.md
 timeout 300 bash tools/pmc_sq2.sh ${TAG}_mlkit --model mlkit --batch 256 --width 1280 --height 720 > /dev/null 2>&1; cp gpurun_out/pmc_sq2_${TAG}_mlkit.md gpurun_out/${TAG}_pmc_sq_mlkit_hd.md
